@@ -1,0 +1,74 @@
+"""ctypes binding of libtt_hip.so (include/tt_hip.h).  Fails loudly when the HIP
+library has not been built -- there is deliberately no fallback path."""
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_NAME = "libtt_hip.so"
+_lock = threading.Lock()
+_lib = None
+
+
+class LibraryNotBuiltError(RuntimeError):
+    pass
+
+
+class TTError(RuntimeError):
+    """A libtt_hip.so call returned a non-zero status."""
+
+
+def lib_path() -> str:
+    return os.path.join(_HERE, _LIB_NAME)
+
+
+_F32P = ctypes.POINTER(c_float)
+_I32P = ctypes.POINTER(c_int32)
+
+# name -> (restype, argtypes); must list every symbol include/tt_hip.h declares
+SIGNATURES = {
+    "tt_version": (c_int, []),
+    "tt_arch": (c_char_p, []),
+    "tt_last_error": (c_char_p, []),
+    "tt_device_cu_count": (c_int, []),
+    "tt_scan_workspace_bytes": (c_size_t, [c_int64, c_int, c_int, c_int]),
+    "tt_scan_topk": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_int, c_int32, c_void_p, c_void_p,
+                             c_void_p, c_size_t, c_void_p, c_void_p]),
+    "tt_scan_exact_workspace_bytes": (c_size_t, [c_int64, c_int, c_int, c_int]),
+    "tt_scan_topk_exact": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_int, c_int32, c_void_p, c_void_p,
+                                   c_void_p, c_size_t, c_void_p]),
+    "tt_topk_merge": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+}
+
+
+def load_library():
+    """Load (once) and return the ctypes handle; raises LibraryNotBuiltError."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        path = lib_path()
+        if not os.path.exists(path):
+            raise LibraryNotBuiltError(
+                f"{path} not found. Build it first: `python -c 'import __graft_entry__ as g; g.build()'` "
+                f"or `make -C {os.path.join(_HERE, 'csrc')}` (needs hipcc, --offload-arch=gfx950). "
+                "tensor_truth_amd has no CPU fallback."
+            )
+        lib = ctypes.CDLL(path)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the .so is stale
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+        return _lib
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        msg = load_library().tt_last_error().decode("utf-8", "replace")
+        raise TTError(f"{what} failed with status {status}: {msg}")

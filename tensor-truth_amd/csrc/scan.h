@@ -1,0 +1,43 @@
+// Internal interface between scan.hip (kernels), select.hip and scan_api.cpp.
+#pragma once
+#include "common.h"
+
+struct ScanParams {
+    const uint16_t* corpus;   // [N][D] bf16, shard base
+    const uint16_t* queries;  // [Q][D] bf16
+    int64_t row_lo, row_hi;   // rows of the shard this launch covers
+    int n_queries;
+    int32_t idx_base;         // emitted index = idx_base + shard row
+    // DENSE=true: every score -> dense[q * dense_stride + (row - row_lo)]
+    float* dense;
+    int64_t dense_stride;     // >= round_up(row_hi - row_lo, 32), multiple of 4
+    // DENSE=false: scores >= thr[q] are appended to the candidate lists
+    const float* thr;         // [Qpad]
+    int32_t* cnt;             // [Qpad] running candidate counts (may exceed cap)
+    float* cand_scores;       // [Qpad][cap]
+    int32_t* cand_idx;        // [Qpad][cap]
+    int cap;
+};
+
+// mode 0: A fragments loaded directly from global; mode 1: full-line loads
+// transposed through wave-private LDS.  blocks = grid.x (clamped to the work).
+int tt_scan_launch(const ScanParams& p, int dim, int mode, bool dense, int blocks, hipStream_t stream);
+
+struct SelectParams {
+    const float* scores;      // per query: scores + q * stride
+    const int32_t* idx;       // per query: idx + q * stride; NULL => implicit position + idx_base
+    int64_t stride;
+    const int32_t* cnt;       // per-query candidate count (device), NULL => m_fixed
+    int m_fixed;
+    int cap;                  // cnt is clamped to cap; cnt > cap raises *overflow_flag
+    int32_t idx_base;         // added to implicit indices only
+    int k;
+    float* out_scores;        // [Q][out_stride]
+    int32_t* out_idx;         // [Q][out_stride]
+    int64_t out_stride;
+    float* thr_out;           // optional [Q]: k-th best score (or -inf if fewer than k valid)
+    int32_t* cnt_out;         // optional [Q]: number of valid outputs (<= k)
+    int32_t* overflow_flag;   // optional
+};
+
+int tt_select_launch(const SelectParams& p, int n_queries, hipStream_t stream);

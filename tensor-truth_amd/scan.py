@@ -1,0 +1,133 @@
+"""Exact similarity scan + top-k on MI355X (host side of include/tt_hip.h's scan API).
+
+Stands in for the vector search the reference reaches through
+``index.as_retriever(similarity_top_k=...)`` (``src/tensortruth/rag_engine.py:639``)
+-> ``ChromaVectorStore.query``: given L2-normalised query embeddings it returns,
+per query, the ``k`` corpus rows with the largest dot product, ordered by
+(score desc, row index asc).  The corpus is a row-major bf16 matrix resident in
+HBM (a shard of it under multi-GPU row sharding, see ``sharded.py``).
+"""
+from __future__ import annotations
+
+import threading
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+
+
+def _require_cuda(t: torch.Tensor, name: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"{name} must live on a HIP device (got {t.device}); tensor_truth_amd has no CPU path"
+        )
+
+
+class _Workspace(threading.local):
+    """Per-thread scratch buffers, so concurrent retrieve() calls from the
+    reference's executor threads (rag_engine.py:420-424) never share scratch."""
+
+    def __init__(self):
+        self.bufs = {}
+
+    def get(self, device: torch.device, nbytes: int) -> torch.Tensor:
+        key = (device.type, device.index)
+        buf = self.bufs.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
+            self.bufs[key] = buf
+        return buf
+
+
+_ws = _Workspace()
+
+
+def _stream_ptr(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def scan_topk(
+    corpus: torch.Tensor,
+    queries: torch.Tensor,
+    k: int,
+    idx_base: int = 0,
+    exact_dense: bool = False,
+    check_overflow: bool = True,
+) -> Tuple[torch.Tensor, torch.Tensor]:
+    """corpus [N,D] bf16, queries [Q,D] bf16 (same HIP device) ->
+    (scores [Q,k] fp32, idx [Q,k] int32), idx = idx_base + row, padding (-inf, -1).
+
+    ``exact_dense`` forces the dense-score path (N*Q*4 bytes of scratch).
+    ``check_overflow`` reads the device status word (one sync) and transparently
+    re-runs through the dense path if a candidate list overflowed.
+    """
+    lib = _lib.load_library()
+    _require_cuda(corpus, "corpus")
+    _require_cuda(queries, "queries")
+    if corpus.dtype != torch.bfloat16 or queries.dtype != torch.bfloat16:
+        raise TypeError("corpus and queries must be torch.bfloat16")
+    if corpus.dim() != 2 or queries.dim() != 2 or corpus.shape[1] != queries.shape[1]:
+        raise ValueError(f"shape mismatch: corpus {tuple(corpus.shape)} queries {tuple(queries.shape)}")
+    if corpus.device != queries.device:
+        raise ValueError("corpus and queries must be on the same device")
+    if not corpus.is_contiguous() or not queries.is_contiguous():
+        raise ValueError("corpus and queries must be contiguous row-major")
+    n, d = corpus.shape
+    q = queries.shape[0]
+    dev = corpus.device
+    out_s = torch.empty((q, k), dtype=torch.float32, device=dev)
+    out_i = torch.empty((q, k), dtype=torch.int32, device=dev)
+    if q == 0:
+        return out_s, out_i
+    with torch.cuda.device(dev):
+        st = _stream_ptr(dev)
+        if exact_dense:
+            need = lib.tt_scan_exact_workspace_bytes(n, d, q, k)
+            ws = _ws.get(dev, need)
+            rc = lib.tt_scan_topk_exact(corpus.data_ptr(), n, d, queries.data_ptr(), q, k, idx_base,
+                                        out_s.data_ptr(), out_i.data_ptr(), ws.data_ptr(), ws.numel(), st)
+            _lib.check(rc, "tt_scan_topk_exact")
+            return out_s, out_i
+        need = lib.tt_scan_workspace_bytes(n, d, q, k)
+        ws = _ws.get(dev, need + 256)
+        base = (ws.data_ptr() + 255) // 256 * 256
+        flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        rc = lib.tt_scan_topk(corpus.data_ptr(), n, d, queries.data_ptr(), q, k, idx_base,
+                              out_s.data_ptr(), out_i.data_ptr(), base, ws.numel() - (base - ws.data_ptr()),
+                              flag.data_ptr(), st)
+        _lib.check(rc, "tt_scan_topk")
+        if check_overflow and int(flag.item()) != 0:
+            return scan_topk(corpus, queries, k, idx_base, exact_dense=True)
+    return out_s, out_i
+
+
+def topk_merge(scores: torch.Tensor, idx: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Merge candidate lists [Q, M] (fp32 scores, int32 global indices, idx<0 =
+    padding) into the top-k by (score desc, idx asc)."""
+    lib = _lib.load_library()
+    _require_cuda(scores, "scores")
+    _require_cuda(idx, "idx")
+    if scores.dtype != torch.float32 or idx.dtype != torch.int32:
+        raise TypeError("scores must be float32 and idx int32")
+    if scores.shape != idx.shape or scores.dim() != 2:
+        raise ValueError("scores/idx must both be [Q, M]")
+    scores = scores.contiguous()
+    idx = idx.contiguous()
+    q, m = scores.shape
+    dev = scores.device
+    out_s = torch.empty((q, k), dtype=torch.float32, device=dev)
+    out_i = torch.empty((q, k), dtype=torch.int32, device=dev)
+    if q == 0:
+        return out_s, out_i
+    with torch.cuda.device(dev):
+        rc = lib.tt_topk_merge(scores.data_ptr(), idx.data_ptr(), q, m, k, out_s.data_ptr(), out_i.data_ptr(),
+                               _stream_ptr(dev))
+        _lib.check(rc, "tt_topk_merge")
+    return out_s, out_i
+
+
+def similarity_from_cosine(cos: torch.Tensor) -> torch.Tensor:
+    """Reference score mapping for NodeWithScore.score: ChromaVectorStore returns
+    exp(-squared_L2) and squared_L2 = 2 - 2 cos for unit vectors."""
+    return torch.exp(-(2.0 - 2.0 * cos))

@@ -1,0 +1,40 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN
+
+
+@pytest.fixture(scope="session")
+def built_lib():
+    """Path of libtt_hip.so, building it if this checkout has not been built yet."""
+    from tensor_truth_amd import _lib
+
+    if not os.path.exists(_lib.lib_path()):
+        import __graft_entry__
+
+        __graft_entry__.build()
+    return _lib.lib_path()
+
+
+@pytest.fixture(scope="session")
+def dev():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.fail("gpu-marked test selected but no HIP device is visible")
+    return torch.device("cuda:0")
