@@ -8,20 +8,30 @@ struct ScanParams {
     int64_t row_lo, row_hi;   // rows of the shard this launch covers
     int n_queries;
     int32_t idx_base;         // emitted index = idx_base + shard row
-    // DENSE=true: every score -> dense[q * dense_stride + (row - row_lo)]
+    // out=1: every score -> dense[q * dense_stride + (row - row_lo)]; out=2: group maxima
     float* dense;
     int64_t dense_stride;     // >= round_up(row_hi - row_lo, 32), multiple of 4
-    // DENSE=false: scores >= thr[q] are appended to the candidate lists
+    // out=0: scores >= thr[q] are appended to the candidate lists
     const float* thr;         // [Qpad]
     int32_t* cnt;             // [Qpad] running candidate counts (may exceed cap)
     float* cand_scores;       // [Qpad][cap]
     int32_t* cand_idx;        // [Qpad][cap]
     int cap;
+    // private (atomic-free) candidate lists written by the filter pass:
+    // priv[(q * n_sub + sub) * TT_SCAN_PRIV_SLOTS + j] = {score bits, index},
+    // priv_cnt[q * n_sub + sub] = fill count, n_sub = grid.x * 16 (wave, lane half)
+    uint2* priv;
+    int32_t* priv_cnt;
 };
+
+#define TT_SCAN_PRIV_SLOTS 16
+#define TT_SCAN_WAVES_PER_BLOCK 8
 
 // mode 0: A fragments loaded directly from global; mode 1: full-line loads
 // transposed through wave-private LDS.  blocks = grid.x (clamped to the work).
-int tt_scan_launch(const ScanParams& p, int dim, int mode, bool dense, int blocks, hipStream_t stream);
+// out: 0 = threshold filter into the candidate lists, 1 = dense scores,
+// 2 = one max per (32-row group, query) into dense[q * dense_stride + group].
+int tt_scan_launch(const ScanParams& p, int dim, int mode, int out, int blocks, hipStream_t stream);
 
 struct SelectParams {
     const float* scores;      // per query: scores + q * stride
@@ -35,6 +45,10 @@ struct SelectParams {
     float* out_scores;        // [Q][out_stride]
     int32_t* out_idx;         // [Q][out_stride]
     int64_t out_stride;
+    // optional second source: private sub-lists of the filter pass (see ScanParams)
+    const uint2* priv;
+    const int32_t* priv_cnt;
+    int n_sub;
     float* thr_out;           // optional [Q]: k-th best score (or -inf if fewer than k valid)
     int32_t* cnt_out;         // optional [Q]: number of valid outputs (<= k)
     int32_t* overflow_flag;   // optional

@@ -22,7 +22,8 @@
 //     compare; survivors are appended to a per-query candidate list in global
 //     memory (rare: the threshold comes from an exact top-k over a sample of
 //     the first n0 rows, see scan_api.cpp).
-//   * DENSE=true writes every score instead (sample phase / small shards).
+//   * OUT=1 writes every score instead (small shards), OUT=2 writes one max per
+//     (32-row group, query): the sample phase that produces the thresholds.
 //
 // Roofline: HBM-bound; algorithmic bytes = rows * D * 2 per launch.
 #include "common.h"
@@ -35,6 +36,7 @@ constexpr int kWaves = kThreads / TT_WAVE;
 constexpr int kBM = 64;            // queries per block
 constexpr int kNG = kBM / 32;      // 32-query groups per block
 constexpr int kScratchPerWave = 4096;
+constexpr int kPrivSlots = TT_SCAN_PRIV_SLOTS;  // private candidate slots per (wave, lane, query group)
 
 template <int D>
 struct Cfg {
@@ -52,16 +54,42 @@ __device__ __forceinline__ uint4 ldg16(const uint16_t* p) {
     return *reinterpret_cast<const uint4*>(p);
 }
 
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+template <bool NT>
+__device__ __forceinline__ uint4 ldg16c(const uint16_t* p) {
+    if constexpr (NT) {
+        const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+        return make_uint4(v[0], v[1], v[2], v[3]);
+    } else {
+        return *reinterpret_cast<const uint4*>(p);
+    }
+}
+
 // ---- epilogue: dense store or threshold filter + candidate append ---------------
-template <bool DENSE>
+// Survivors of the threshold filter go to a list PRIVATE to this lane (one per wave,
+// lane and query group: kPrivSlots entries in global memory, fill count in a register),
+// so the hot loop issues no atomic: a returning global atomic sits in the in-order
+// vmcnt queue and stalls the whole prefetch ring for its (long) latency -- measured
+// ~2.4 us per event, +65 % kernel time at 3 survivors per row group.  Only a lane
+// whose private list is full (heavily clustered hits) falls back to the shared
+// per-query overflow list, which is allocated with an atomic.
+template <int OUT>
 __device__ __forceinline__ void scan_epilogue(const ScanParams& p, f32x16 (&acc)[2], const float (&thr)[2],
-                                              const bool (&qvalid)[2], int q0, int ql, int half, int64_t grp) {
+                                              const bool (&qvalid)[2], int q0, int ql, int half, int64_t grp,
+                                              int (&pcnt)[2], uint2* const (&pbase)[2]) {
     const int64_t row0 = p.row_lo + grp * 32;         // first row of this group
     const bool tail = row0 + 32 > p.row_hi;           // wave-uniform
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
         const int q = q0 + g * 32 + ql;
-        if constexpr (DENSE) {
+        if constexpr (OUT == 2) {
+            // max over this lane's 16 rows, then over the other half's 16 rows
+            float mx = acc[g][0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[g][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            if (qvalid[g] && half == 0) p.dense[(size_t)q * p.dense_stride + (size_t)grp] = mx;
+        } else if constexpr (OUT == 1) {
             if (qvalid[g]) {
                 float* dst = p.dense + (size_t)q * p.dense_stride + (size_t)(row0 - p.row_lo);
 #pragma unroll
@@ -73,28 +101,27 @@ __device__ __forceinline__ void scan_epilogue(const ScanParams& p, f32x16 (&acc)
             }
         } else {
             const float t = thr[g];
-            int npass = 0;
+            float mx = acc[g][0];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t row = row0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                bool ok = acc[g][r] >= t;
-                if (tail) ok = ok && (row < p.row_hi);
-                npass += ok ? 1 : 0;
-            }
-            if (__any(npass > 0)) {
-                int pos = 0;
-                if (npass > 0) pos = atomicAdd(p.cnt + q, npass);
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[g][r]);
+            if (__any(mx >= t)) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int64_t row = row0 + (r & 3) + 8 * (r >> 2) + 4 * half;
                     bool ok = acc[g][r] >= t;
                     if (tail) ok = ok && (row < p.row_hi);
                     if (ok) {
-                        if (pos < p.cap) {
-                            p.cand_scores[(size_t)q * p.cap + pos] = acc[g][r];
-                            p.cand_idx[(size_t)q * p.cap + pos] = (int32_t)(p.idx_base + row);
+                        const uint2 e = make_uint2(__float_as_uint(acc[g][r]), (uint32_t)(p.idx_base + (int32_t)row));
+                        if (pcnt[g] < kPrivSlots) {
+                            pbase[g][pcnt[g]] = e;
+                        } else {
+                            const int pos = atomicAdd(p.cnt + q, 1);
+                            if (pos < p.cap) {
+                                p.cand_scores[(size_t)q * p.cap + pos] = acc[g][r];
+                                p.cand_idx[(size_t)q * p.cap + pos] = (int32_t)e.y;
+                            }
                         }
-                        ++pos;
+                        ++pcnt[g];
                     }
                 }
             }
@@ -104,7 +131,10 @@ __device__ __forceinline__ void scan_epilogue(const ScanParams& p, f32x16 (&acc)
     }
 }
 
-template <int D, int MODE, bool DENSE>
+// VAR bits (ablation / tuning knobs, D=1024 filter kernels only): 1 = default-policy corpus
+// loads instead of the non-temporal ones every shipped variant uses (+11 % kernel time), 2 = loads only (no LDS, no MFMA), 4 = loads + LDS transpose writes only,
+// 8 = everything but the MFMAs, 16 = MFMAs without the query-image reads.
+template <int D, int MODE, int OUT, int VAR>
 __global__ __launch_bounds__(kThreads) void scan_kernel(ScanParams p) {
     using C = Cfg<D>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -141,7 +171,7 @@ __global__ __launch_bounds__(kThreads) void scan_kernel(ScanParams p) {
         const int q = q0 + g * 32 + ql;
         qvalid[g] = q < p.n_queries;
         thr[g] = __builtin_inff();
-        if (!DENSE && qvalid[g]) thr[g] = p.thr[q];
+        if (OUT == 0 && qvalid[g]) thr[g] = p.thr[q];
     }
     // byte offset of this lane's B fragment slot base in the Q image
     int qoff[kNG];
@@ -167,6 +197,17 @@ __global__ __launch_bounds__(kThreads) void scan_kernel(ScanParams p) {
         for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
 
     int64_t grp = g_lo + wave;
+    // private candidate lists: sub-list id = (global wave, half), one per query
+    const int n_sub = gridDim.x * kWaves * 2;
+    const int sub = (blockIdx.x * kWaves + wave) * 2 + half;
+    int pcnt[kNG];
+    uint2* pbase[kNG];
+#pragma unroll
+    for (int g = 0; g < kNG; ++g) {
+        pcnt[g] = 0;
+        pbase[g] = nullptr;
+        if (OUT == 0) pbase[g] = p.priv + ((size_t)(q0 + g * 32 + ql) * n_sub + sub) * kPrivSlots;
+    }
 
     if constexpr (MODE == 1) {
         constexpr int P = C::P1;
@@ -178,7 +219,7 @@ __global__ __launch_bounds__(kThreads) void scan_kernel(ScanParams p) {
             for (int j = 0; j < 4; ++j) {
                 int64_t row = p.row_lo + g * 32 + 8 * j + lrow;
                 row = row < last_row ? row : last_row;
-                dst[j] = ldg16(corpus + (size_t)row * D + c * 64 + lpiece * 8);
+                dst[j] = ldg16c<(VAR & 1) == 0>(corpus + (size_t)row * D + c * 64 + lpiece * 8);
             }
         };
         // scratch write offsets (row = 8j + lrow): slot = piece ^ ((row>>1)&7)
@@ -202,9 +243,16 @@ __global__ __launch_bounds__(kThreads) void scan_kernel(ScanParams p) {
 #pragma unroll
             for (int c = 0; c < C::NCH; ++c) {
                 const int s = c % P;
+                if constexpr ((VAR & 2) == 0) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    *reinterpret_cast<uint4*>(scratch + woff[j]) = ring[s][j];
+                    for (int j = 0; j < 4; ++j)
+                        *reinterpret_cast<uint4*>(scratch + woff[j]) = ring[s][j];
+                } else {
+                    // ablation: keep the loads alive without touching LDS
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        asm volatile("" ::"v"(ring[s][j].x), "v"(ring[s][j].y), "v"(ring[s][j].z), "v"(ring[s][j].w));
+                }
                 // pin the refill of this ring slot right behind its drain: without the
                 // barriers hipcc sinks the loads next to their use and the prefetch
                 // depth collapses to zero
@@ -215,6 +263,7 @@ __global__ __launch_bounds__(kThreads) void scan_kernel(ScanParams p) {
                     issue(ring[s], nxt, c + P - C::NCH);
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                if constexpr ((VAR & 6) == 0)
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
                     const int piece = 2 * ks + half;
@@ -223,12 +272,20 @@ __global__ __launch_bounds__(kThreads) void scan_kernel(ScanParams p) {
                     const int kc = c * 8 + piece;  // 16-B slot index inside the query row
 #pragma unroll
                     for (int g = 0; g < kNG; ++g) {
-                        const uint4 bv = *reinterpret_cast<const uint4*>(q_img + qoff[g] + ((kc ^ qswz) << 4));
-                        acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, bv), acc[g], 0, 0, 0);
+                        if constexpr ((VAR & 16) != 0) {  // ablation: no Q-image reads
+                            acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, a, acc[g], 0, 0, 0);
+                        } else {
+                            const uint4 bv = *reinterpret_cast<const uint4*>(q_img + qoff[g] + ((kc ^ qswz) << 4));
+                            if constexpr ((VAR & 8) != 0) {  // ablation: LDS reads, no MFMA
+                                asm volatile("" ::"v"(bv.x), "v"(bv.y), "v"(bv.z), "v"(bv.w), "v"(av.x), "v"(av.w));
+                            } else {
+                                acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, bv), acc[g], 0, 0, 0);
+                            }
+                        }
                     }
                 }
             }
-            scan_epilogue<DENSE>(p, acc, thr, qvalid, q0, ql, half, grp);
+            scan_epilogue<OUT>(p, acc, thr, qvalid, q0, ql, half, grp, pcnt, pbase);
             grp = nxt;
         }
     } else {
@@ -237,7 +294,7 @@ __global__ __launch_bounds__(kThreads) void scan_kernel(ScanParams p) {
         auto issue = [&](uint4& dst, int64_t g, int ks) {
             int64_t row = p.row_lo + g * 32 + ql;
             row = row < last_row ? row : last_row;
-            dst = ldg16(corpus + (size_t)row * D + ks * 16 + half * 8);
+            dst = ldg16c<(VAR & 1) == 0>(corpus + (size_t)row * D + ks * 16 + half * 8);
         };
         if (grp < g_hi) {
 #pragma unroll
@@ -268,20 +325,25 @@ __global__ __launch_bounds__(kThreads) void scan_kernel(ScanParams p) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            scan_epilogue<DENSE>(p, acc, thr, qvalid, q0, ql, half, grp);
+            scan_epilogue<OUT>(p, acc, thr, qvalid, q0, ql, half, grp, pcnt, pbase);
             grp = nxt;
         }
+    }
+    if constexpr (OUT == 0) {
+#pragma unroll
+        for (int g = 0; g < kNG; ++g)
+            p.priv_cnt[(size_t)(q0 + g * 32 + ql) * n_sub + sub] = pcnt[g] < kPrivSlots ? pcnt[g] : kPrivSlots;
     }
 }
 
 }  // namespace
 
 // ---- host-side launcher ---------------------------------------------------------
-template <int D, int MODE, bool DENSE>
+template <int D, int MODE, int OUT, int VAR>
 static int launch_one(const ScanParams& p, int blocks, int q_tiles, hipStream_t stream) {
     using C = Cfg<D>;
     const size_t lds = (size_t)C::kQImageBytes + (MODE == 1 ? (size_t)kWaves * kScratchPerWave : 0);
-    auto kern = scan_kernel<D, MODE, DENSE>;
+    auto kern = scan_kernel<D, MODE, OUT, VAR>;
     static thread_local bool attr_set = false;  // per instantiation, per thread: cheap & race-free
     if (!attr_set) {
         TT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -294,29 +356,51 @@ static int launch_one(const ScanParams& p, int blocks, int q_tiles, hipStream_t 
 }
 
 template <int D>
-static int launch_d(const ScanParams& p, int mode, bool dense, int blocks, int q_tiles, hipStream_t stream) {
-    if (mode == 1) {
-        return dense ? launch_one<D, 1, true>(p, blocks, q_tiles, stream)
-                     : launch_one<D, 1, false>(p, blocks, q_tiles, stream);
+static int launch_d(const ScanParams& p, int mode, int out, int blocks, int q_tiles, hipStream_t stream) {
+    const int load_mode = mode & 15;
+    const int var = mode >> 4;
+    if constexpr (D == 1024) {
+        // tuning / ablation variants exist for the headline shape only
+        if (out == 0 && load_mode == 1) {
+            switch (var) {
+                case 1: return launch_one<D, 1, 0, 1>(p, blocks, q_tiles, stream);
+                case 2: return launch_one<D, 1, 0, 2>(p, blocks, q_tiles, stream);
+                case 4: return launch_one<D, 1, 0, 4>(p, blocks, q_tiles, stream);
+                case 8: return launch_one<D, 1, 0, 8>(p, blocks, q_tiles, stream);
+                default: break;
+            }
+        }
     }
-    return dense ? launch_one<D, 0, true>(p, blocks, q_tiles, stream)
-                 : launch_one<D, 0, false>(p, blocks, q_tiles, stream);
+    if (load_mode == 1) {
+        switch (out) {
+            case 0: return launch_one<D, 1, 0, 0>(p, blocks, q_tiles, stream);
+            case 1: return launch_one<D, 1, 1, 0>(p, blocks, q_tiles, stream);
+            default: return launch_one<D, 1, 2, 0>(p, blocks, q_tiles, stream);
+        }
+    }
+    switch (out) {
+        case 0: return launch_one<D, 0, 0, 0>(p, blocks, q_tiles, stream);
+        case 1: return launch_one<D, 0, 1, 0>(p, blocks, q_tiles, stream);
+        default: return launch_one<D, 0, 2, 0>(p, blocks, q_tiles, stream);
+    }
 }
 
-int tt_scan_launch(const ScanParams& p, int dim, int mode, bool dense, int blocks, hipStream_t stream) {
+int tt_scan_launch(const ScanParams& p, int dim, int mode, int out, int blocks, hipStream_t stream) {
     const int q_tiles = (p.n_queries + kBM - 1) / kBM;
     if (p.row_hi <= p.row_lo || q_tiles == 0) return TT_OK;
     const int64_t n_groups = (p.row_hi - p.row_lo + 31) / 32;
-    const int64_t max_blocks = (n_groups + kWaves - 1) / kWaves;
+    // dense / group-max launches are short: spread the row groups over every CU;
+    // the long filter pass keeps 8 waves per CU busy
+    const int64_t max_blocks = out != 0 ? n_groups : (n_groups + kWaves - 1) / kWaves;
     if (blocks > max_blocks) blocks = (int)max_blocks;
     if (blocks < 1) blocks = 1;
     switch (dim) {
-        case 128: return launch_d<128>(p, mode, dense, blocks, q_tiles, stream);
-        case 256: return launch_d<256>(p, mode, dense, blocks, q_tiles, stream);
-        case 384: return launch_d<384>(p, mode, dense, blocks, q_tiles, stream);
-        case 512: return launch_d<512>(p, mode, dense, blocks, q_tiles, stream);
-        case 768: return launch_d<768>(p, mode, dense, blocks, q_tiles, stream);
-        case 1024: return launch_d<1024>(p, mode, dense, blocks, q_tiles, stream);
+        case 128: return launch_d<128>(p, mode, out, blocks, q_tiles, stream);
+        case 256: return launch_d<256>(p, mode, out, blocks, q_tiles, stream);
+        case 384: return launch_d<384>(p, mode, out, blocks, q_tiles, stream);
+        case 512: return launch_d<512>(p, mode, out, blocks, q_tiles, stream);
+        case 768: return launch_d<768>(p, mode, out, blocks, q_tiles, stream);
+        case 1024: return launch_d<1024>(p, mode, out, blocks, q_tiles, stream);
         default:
             tt_set_error("tt_scan: dim %d not in the compiled set {128,256,384,512,768,1024}", dim);
             return TT_E_UNSUPPORTED;

@@ -1,16 +1,18 @@
 // C-ABI entry points for the similarity scan (see include/tt_hip.h).
 //
 // Pipeline of tt_scan_topk for a shard of N rows (all launches on one stream):
-//   1. sample : dense scores of rows [0, n0)                    (scan_kernel DENSE)
-//   2. select : exact top-k of the sample -> seeds the candidate lists,
-//               thr[q] = k-th best sample score                 (select_kernel)
-//   3. main   : rows [n0, N), append scores >= thr[q]           (scan_kernel filter)
-//   4. select : exact top-k of the candidates                   (select_kernel)
-// Exactness: every true top-k row either lies in the sample's top-k or has a
-// score >= thr[q] (thr is the k-th best of a subset, hence <= the true k-th
-// best).  The expected candidate volume is k * N / n0 per query; n0 is sized so
-// that this is <= cap/4, and an overflow (adversarial score order) is reported
-// through status_flag rather than silently truncated.
+//   1. sample : one max per (32-row group, query) over rows [0, n0)    (scan_kernel OUT=2)
+//   2. select : thr[q] = k-th best group maximum                        (select_kernel)
+//   3. filter : all N rows, scores >= thr[q] go to atomic-free private lists
+//               (overflowing lanes: shared per-query list)               (scan_kernel OUT=0)
+//   4. select : exact top-k of the candidates                           (select_kernel)
+// Exactness: the k best group maxima are k distinct rows scoring >= thr, so thr is a
+// lower bound of the true k-th best score and every true top-k row passes the filter
+// (the sample rows are simply scanned again: n0/N extra traffic, 3 % at N = 1M).
+// Expected candidate volume ~ k * N / n0 per query.  An overflow of the shared list
+// (adversarial score order AND clustering) is reported through status_flag, never
+// silently truncated.  Shards with fewer than ~4k groups take the dense path
+// (every score written, exact selection).
 #include <limits.h>
 #include <string.h>
 
@@ -42,42 +44,55 @@ int tt_cu_count_cached() {
 
 namespace {
 
-constexpr int kCap = 16384;            // candidate slots per query
-constexpr int64_t kDenseMaxRows = 65536;  // shards up to this size take the dense-only path
-constexpr int64_t kSampleMin = 16384;
-constexpr int64_t kSampleMax = 262144;
+constexpr int kCap = 16384;              // shared overflow-list slots per query
+constexpr int64_t kSampleRows = 32768;   // default sample size (1024 group maxima per query)
 
 struct Plan {
     bool dense_only;
-    int64_t n0;        // sample rows (== n_rows when dense_only)
-    int64_t stride;    // dense row stride (floats)
+    int64_t n0;        // sample rows (dense_only: all rows)
+    int64_t stride;    // floats per query in the dense / group-max buffer
     int qpad;
-    size_t off_dense, off_cs, off_ci, off_cnt, off_thr, total;
+    int main_blocks;   // grid.x of the filter pass (fixes the private-list geometry)
+    int n_sub;         // private sub-lists per query = main_blocks * waves * 2
+    size_t off_dense, off_cs, off_ci, off_cnt, off_thr, off_priv, off_pcnt, total;
 };
 
-Plan make_plan(int64_t n_rows, int n_queries, int k) {
+int filter_blocks(int64_t rows, int cus) {
+    const int64_t groups = (rows + 31) / 32;
+    const int64_t mb = (groups + TT_SCAN_WAVES_PER_BLOCK - 1) / TT_SCAN_WAVES_PER_BLOCK;
+    int64_t b = cus > 0 ? cus : 256;
+    if (b > mb) b = mb;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+Plan make_plan(int64_t n_rows, int n_queries, int k, int cus) {
     Plan pl{};
     pl.qpad = (n_queries + 63) / 64 * 64;
-    if (n_rows <= kDenseMaxRows) {
+    // the sample needs >= 4k groups for a useful threshold
+    int64_t n0 = kSampleRows;
+    if (n0 < (int64_t)128 * k) n0 = (int64_t)128 * k;
+    if (n_rows < (int64_t)128 * k || n_rows <= 8192) {
         pl.dense_only = true;
         pl.n0 = n_rows;
+        pl.stride = (n_rows + 31) / 32 * 32;
     } else {
         pl.dense_only = false;
-        // expected candidates/query = k * N / n0  <= cap / 4
-        int64_t need = (4 * (int64_t)k * n_rows + kCap - 1) / kCap;
-        need = (need + 8191) / 8192 * 8192;
-        if (need < kSampleMin) need = kSampleMin;
-        if (need > kSampleMax) need = kSampleMax;
-        if (need > n_rows) need = n_rows;
-        pl.n0 = need;
+        pl.n0 = n0 < n_rows ? n0 : n_rows;
+        pl.stride = ((pl.n0 + 31) / 32 + 31) / 32 * 32;
     }
-    pl.stride = (pl.n0 + 31) / 32 * 32;
     size_t off = 0;
     pl.off_dense = off; off += tt_align_up((size_t)pl.qpad * pl.stride * sizeof(float), 256);
     pl.off_cs = off;    off += tt_align_up((size_t)pl.qpad * kCap * sizeof(float), 256);
     pl.off_ci = off;    off += tt_align_up((size_t)pl.qpad * kCap * sizeof(int32_t), 256);
     pl.off_cnt = off;   off += tt_align_up((size_t)pl.qpad * sizeof(int32_t), 256);
     pl.off_thr = off;   off += tt_align_up((size_t)pl.qpad * sizeof(float), 256);
+    if (!pl.dense_only) {
+        pl.main_blocks = filter_blocks(n_rows, cus);
+        pl.n_sub = pl.main_blocks * TT_SCAN_WAVES_PER_BLOCK * 2;
+        pl.off_priv = off; off += tt_align_up((size_t)pl.qpad * pl.n_sub * TT_SCAN_PRIV_SLOTS * sizeof(uint2), 256);
+        pl.off_pcnt = off; off += tt_align_up((size_t)pl.qpad * pl.n_sub * sizeof(int32_t), 256);
+    }
     pl.total = off;
     return pl;
 }
@@ -104,10 +119,11 @@ __global__ void fill_pad_kernel(float* s, int32_t* ix, int64_t n) {
 }
 
 int scan_mode_from_env() {
-    // TT_SCAN_MODE=0|1 selects the corpus load path (bench/ablation knob); default 1.
+    // TT_SCAN_MODE = load path (0 direct fragments | 1 LDS transpose) + 16 * variant; default 1
+    // (bench/ablation knob, see scan.hip).
     const char* e = getenv("TT_SCAN_MODE");
-    if (e && e[0] == '0') return 0;
-    return 1;
+    if (e && e[0]) return atoi(e);
+    return 1;  // LDS-transpose load path (non-temporal corpus loads)
 }
 
 }  // namespace
@@ -122,7 +138,10 @@ int tt_device_cu_count(void) { return tt_cu_count_cached(); }
 size_t tt_scan_workspace_bytes(int64_t n_rows, int dim, int n_queries, int k) {
     (void)dim;
     if (n_rows < 0 || n_queries <= 0 || k < 1) return 0;
-    return make_plan(n_rows, n_queries, k).total;
+    // sized for the largest grid the filter pass can use on any gfx950 part (256 CUs)
+    int cus = tt_cu_count_cached();
+    if (cus <= 0) cus = 256;
+    return make_plan(n_rows, n_queries, k, cus).total;
 }
 
 size_t tt_scan_exact_workspace_bytes(int64_t n_rows, int dim, int n_queries, int k) {
@@ -145,7 +164,7 @@ static int scan_dense_select(const void* corpus, int64_t n_rows, int dim, const 
     sp.idx_base = idx_base;
     sp.dense = dense;
     sp.dense_stride = stride;
-    int rc = tt_scan_launch(sp, dim, scan_mode_from_env(), true, tt_cu_count_cached(), st);
+    int rc = tt_scan_launch(sp, dim, scan_mode_from_env(), 1, tt_cu_count_cached(), st);
     if (rc) return rc;
     SelectParams se{};
     se.scores = dense;
@@ -199,7 +218,9 @@ int tt_scan_topk(const void* corpus_bf16, int64_t n_rows, int dim, const void* q
         TT_CHECK_LAUNCH();
         return TT_OK;
     }
-    const Plan pl = make_plan(n_rows, n_queries, k);
+    int cus_plan = tt_cu_count_cached();
+    if (cus_plan <= 0) cus_plan = 256;
+    const Plan pl = make_plan(n_rows, n_queries, k, cus_plan);
     if (!workspace || workspace_bytes < pl.total) {
         tt_set_error("tt_scan_topk: workspace %zu < required %zu bytes", workspace_bytes, pl.total);
         return TT_E_WORKSPACE;
@@ -218,7 +239,7 @@ int tt_scan_topk(const void* corpus_bf16, int64_t n_rows, int dim, const void* q
     const int mode = scan_mode_from_env();
     const int cus = tt_cu_count_cached();
 
-    // 1. sample: dense scores of rows [0, n0)
+    // 1. sample: group maxima of rows [0, n0)
     ScanParams sp{};
     sp.corpus = (const uint16_t*)corpus_bf16;
     sp.queries = (const uint16_t*)queries_bf16;
@@ -228,30 +249,32 @@ int tt_scan_topk(const void* corpus_bf16, int64_t n_rows, int dim, const void* q
     sp.idx_base = idx_base;
     sp.dense = dense;
     sp.dense_stride = pl.stride;
-    rc = tt_scan_launch(sp, dim, mode, true, cus, st);
+    rc = tt_scan_launch(sp, dim, mode, 2, cus, st);
     if (rc) return rc;
 
-    // 2. exact top-k of the sample seeds the candidate lists and the thresholds
+    // 2. thr[q] = k-th best group maximum (the selected rows themselves are re-found by
+    //    the filter pass, so the outputs of this selection are scratch)
     SelectParams s1{};
     s1.scores = dense;
     s1.idx = nullptr;
     s1.stride = pl.stride;
     s1.cnt = nullptr;
-    s1.m_fixed = (int)pl.n0;
+    s1.m_fixed = (int)((pl.n0 + 31) / 32);
     s1.cap = INT_MAX;
-    s1.idx_base = idx_base;
+    s1.idx_base = 0;
     s1.k = k;
     s1.out_scores = cs;
     s1.out_idx = ci;
     s1.out_stride = kCap;
     s1.thr_out = thr;
-    s1.cnt_out = cnt;
+    s1.cnt_out = nullptr;
     rc = tt_select_launch(s1, n_queries, st);
     if (rc) return rc;
+    TT_CHECK_HIP(hipMemsetAsync(cnt, 0, (size_t)pl.qpad * sizeof(int32_t), st));
 
-    // 3. main pass over rows [n0, N): append scores >= thr[q]
+    // 3. filter pass over ALL rows: scores >= thr[q] -> private lists (+ shared overflow list)
     ScanParams mp = sp;
-    mp.row_lo = pl.n0;
+    mp.row_lo = 0;
     mp.row_hi = n_rows;
     mp.dense = nullptr;
     mp.thr = thr;
@@ -259,7 +282,9 @@ int tt_scan_topk(const void* corpus_bf16, int64_t n_rows, int dim, const void* q
     mp.cand_scores = cs;
     mp.cand_idx = ci;
     mp.cap = kCap;
-    rc = tt_scan_launch(mp, dim, mode, false, cus, st);
+    mp.priv = (uint2*)(ws + pl.off_priv);
+    mp.priv_cnt = (int32_t*)(ws + pl.off_pcnt);
+    rc = tt_scan_launch(mp, dim, mode, 0, pl.main_blocks, st);
     if (rc) return rc;
 
     // 4. exact top-k of the candidates
@@ -275,6 +300,9 @@ int tt_scan_topk(const void* corpus_bf16, int64_t n_rows, int dim, const void* q
     s2.out_idx = out_idx;
     s2.out_stride = k;
     s2.overflow_flag = status_flag;
+    s2.priv = mp.priv;
+    s2.priv_cnt = mp.priv_cnt;
+    s2.n_sub = pl.n_sub;
     return tt_select_launch(s2, n_queries, st);
 }
 

@@ -1,12 +1,14 @@
 // Exact top-k selection over a per-query candidate list, gfx950.
 //
-// One 256-thread workgroup per query.  MSB-first radix select (4 x 8-bit passes
-// over an order-preserving 32-bit key of the fp32 score) finds the k-th largest
-// score; ties on that score are resolved by a second radix select on the row
-// index (smallest first), so the result is the exact top-k under the total
-// order (score desc, index asc) whatever the input order -- which is what makes
-// the atomically-appended candidate lists of scan.hip deterministic.  The
-// survivors (<= 1024) are bitonic-sorted in LDS on a 64-bit composite key.
+// One 1024-thread workgroup per query; everything happens in a 128-KiB LDS buffer
+// of 64-bit composite keys  (order-preserving score key << 32 | ~index), so a plain
+// unsigned compare IS the total order (score desc, index asc) and the result is
+// exact and deterministic whatever order the candidates were appended in.
+// Network: bitonic-sort every group of kpad (= pow2 >= k) keys, then log2(n/kpad)
+// rounds of "elementwise max of A[i] and B[kpad-1-i]" (the top kpad of two sorted
+// groups, as a bitonic sequence) + a log2(kpad)-stage bitonic merge.  O(n log^2 k)
+// compare-exchanges, no atomics, no data-dependent control flow.  Inputs longer
+// than the buffer are streamed in chunks with the running top-k carried along.
 //
 // Used for: (1) the sample phase of the scan (dense scores, implicit indices),
 // (2) the final pass over the filtered candidates, (3) the multi-GPU / multi-
@@ -17,8 +19,12 @@
 
 namespace {
 
-constexpr int kSelThreads = 256;
+constexpr int kSelThreads = 1024;
 constexpr int kMaxK = 1024;
+constexpr int kChunk = 8192;   // composite keys staged in LDS per round (64 KiB)
+constexpr int kAux = 1024;     // per-thread maxima of the prefilter (8 KiB)
+constexpr int kAux2 = 4096;    // prefilter survivors (32 KiB)
+typedef unsigned long long u64;
 
 __device__ __forceinline__ uint32_t score_key(float f) {
     if (f != f) return 0u;           // NaN: never selected
@@ -32,50 +38,135 @@ __device__ __forceinline__ float key_score(uint32_t k) {
     return __uint_as_float(u);
 }
 
-// Finds the digit (searching from `from_top ? 255 : 0`) where the running count
-// reaches `need`.  hist[] in LDS; returns via LDS words sel[0]=digit,
-// sel[1]=count strictly before the digit, sel[2]=count in the digit.
-__device__ __forceinline__ void pick_digit(const uint32_t* hist, uint32_t need, bool from_top, uint32_t* sel) {
-    // 256 bins; a single wave does an inclusive scan with shuffles (4 bins per lane)
+__device__ __forceinline__ u64 make_key(float s, int32_t id) {
+    const uint32_t k = score_key(s);
+    if (k == 0u || id < 0) return 0ull;
+    return ((u64)k << 32) | (u64)(0xFFFFFFFFu - (uint32_t)id);
+}
+
+// One compare-exchange stage over n_ce pairs.  Pairs are processed in batches of kU per
+// thread with all LDS reads issued before the first write, so the reads pipeline
+// instead of paying one LDS round trip per pair (4-8x faster than the naive loop).
+constexpr int kU = 4;
+
+template <typename PairFn>
+__device__ __forceinline__ void ce_stage(u64* buf, int n_ce, PairFn pair) {
     const int tid = threadIdx.x;
-    if (tid < 64) {
-        uint32_t v[4];
-        uint32_t s = 0;
+    const int wave_first = tid & ~63;  // first thread id of this wave (wave-uniform)
+    for (int base = 0; base + wave_first < n_ce; base += kU * kSelThreads) {
+        int lo[kU], hi[kU];
+        bool desc[kU];
+        u64 a[kU], b[kU];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int bin = from_top ? 255 - (tid * 4 + i) : tid * 4 + i;
-            v[i] = hist[bin];
-            s += v[i];
-        }
-        uint32_t incl = s;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t o = __shfl_up(incl, off, 64);
-            if (tid >= off) incl += o;
-        }
-        uint32_t run = incl - s;  // exclusive prefix of this lane's 4 bins
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if (run < need && run + v[i] >= need) {
-                const int bin = from_top ? 255 - (tid * 4 + i) : tid * 4 + i;
-                sel[0] = (uint32_t)bin;
-                sel[1] = run;
-                sel[2] = v[i];
+        for (int u = 0; u < kU; ++u) {
+            const int t = base + u * kSelThreads + tid;
+            lo[u] = -1;
+            if (t < n_ce) {
+                pair(t, lo[u], hi[u], desc[u]);
+                a[u] = buf[lo[u]];
+                b[u] = buf[hi[u]];
             }
-            run += v[i];
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            if (lo[u] >= 0 && ((a[u] < b[u]) == desc[u])) {
+                buf[lo[u]] = b[u];
+                buf[hi[u]] = a[u];
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// top-kpad of buf[0..n_act) -> buf[0..kpad) sorted descending.  n_act, kpad powers of two,
+// n_act >= 2*kpad.  lk = log2(kpad).
+__device__ __forceinline__ void topk_network(u64* buf, int n_act, int kpad, int lk) {
+    const int tid = threadIdx.x;
+    // 1) sort each kpad-group (last stage descending for every group)
+    for (int size = 2; size <= kpad; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            ce_stage(buf, n_act >> 1, [=](int i, int& lo, int& hi, bool& desc) {
+                lo = 2 * i - (i & (stride - 1));
+                hi = lo + stride;
+                desc = ((lo & size) == 0) || (size == kpad);
+            });
+        }
+    }
+    // 2) merge-and-halve rounds
+    for (int span = kpad; span < n_act; span <<= 1) {
+        const int npairs = n_act / (2 * span);
+        for (int t = tid; t < npairs * kpad; t += kSelThreads) {
+            const int pr = t >> lk, i = t & (kpad - 1);
+            const int a0 = pr * 2 * span;
+            const u64 a = buf[a0 + i], b = buf[a0 + span + kpad - 1 - i];
+            buf[a0 + i] = a > b ? a : b;
+        }
+        __syncthreads();
+        for (int stride = kpad >> 1; stride > 0; stride >>= 1) {
+            ce_stage(buf, npairs * (kpad >> 1), [=](int t, int& lo, int& hi, bool& desc) {
+                const int pr = t >> (lk - 1), i = t & ((kpad >> 1) - 1);
+                lo = pr * 2 * span + 2 * i - (i & (stride - 1));
+                hi = lo + stride;
+                desc = true;
+            });
         }
     }
 }
 
-__global__ __launch_bounds__(kSelThreads) void select_kernel(SelectParams p) {
-    __shared__ uint32_t hist[256];
-    __shared__ uint32_t sel[4];
-    __shared__ uint32_t n_out;
-    __shared__ unsigned long long buf[kMaxK];
+// Fold the `filled` keys staged at buf[kpad ..) into the running top-k at buf[0 .. kpad).
+//
+// Prefilter (when many keys are staged): thread t takes the max of its strided share;
+// the kpad-th best of those 1024 maxima, thr, is a lower bound of the kpad-th best staged
+// key (kpad distinct keys are >= thr), and every key >= thr lies in one of the <= kpad
+// shares whose max is >= thr -- at most kpad * ceil(filled/1024) survivors, which then
+// go through the exact network instead of all `filled` keys.  Keys are unique (they
+// embed the row index), so there are no ties to reason about.
+__device__ __forceinline__ void flush_staged(u64* buf, int filled, int kpad, int lk) {
+    u64* aux = buf + kChunk;
+    u64* aux2 = aux + kAux;
+    int* ctr = reinterpret_cast<int*>(aux2 + kAux2);
+    const int tid = threadIdx.x;
+    const int per_thread = (filled + kSelThreads - 1) / kSelThreads;
+    if (filled >= 2048 && per_thread * kpad <= kAux2) {
+        u64 mx = 0ull;
+        for (int j = tid; j < filled; j += kSelThreads) {
+            const u64 key = buf[kpad + j];
+            mx = key > mx ? key : mx;
+        }
+        aux[tid] = mx;
+        __syncthreads();
+        topk_network(aux, kAux, kpad, lk);
+        const u64 thr = aux[kpad - 1];
+        if (tid == 0) ctr[2] = 0;
+        __syncthreads();
+        for (int j = tid; j < filled; j += kSelThreads) {
+            const u64 key = buf[kpad + j];
+            if (key != 0ull && key >= thr) {
+                const int pos = atomicAdd(&ctr[2], 1);
+                if (pos < kAux2) aux2[pos] = key;
+            }
+        }
+        __syncthreads();
+        const int ns = ctr[2];
+        if (ns <= kAux2) {
+            for (int j = tid; j < ns; j += kSelThreads) buf[kpad + j] = aux2[j];
+            filled = ns;
+        }
+        __syncthreads();
+    }
+    int n_act = 2 * kpad;
+    while (n_act < kpad + filled) n_act <<= 1;
+    for (int i = kpad + filled + tid; i < n_act; i += kSelThreads) buf[i] = 0ull;
+    __syncthreads();
+    topk_network(buf, n_act, kpad, lk);
+}
 
+__global__ __launch_bounds__(kSelThreads) void select_kernel(SelectParams p) {
+    extern __shared__ __attribute__((aligned(16))) u64 buf[];
+    int* lds_ctr = reinterpret_cast<int*>(buf + kChunk + kAux + kAux2);  // 4 ints behind the key buffers
     const int q = blockIdx.x;
     const int tid = threadIdx.x;
-    const float* sc = p.scores + (size_t)q * p.stride;
+    const float* sc = p.scores ? p.scores + (size_t)q * p.stride : nullptr;
     const int32_t* ix = p.idx ? p.idx + (size_t)q * p.stride : nullptr;
     int m = p.m_fixed;
     if (p.cnt) {
@@ -83,114 +174,143 @@ __global__ __launch_bounds__(kSelThreads) void select_kernel(SelectParams p) {
         m = c < p.cap ? c : p.cap;
         if (c > p.cap && p.overflow_flag && tid == 0) atomicOr(p.overflow_flag, 1);
     }
+    if (!sc) m = 0;
     const int k = p.k;
+    int kpad = 2, lk = 1;
+    while (kpad < k) { kpad <<= 1; ++lk; }
+    const int room = kChunk - kpad;
 
-    // ---- count valid entries ---------------------------------------------------
-    if (tid == 0) { sel[3] = 0; n_out = 0; }
-    __syncthreads();
-    {
-        uint32_t local = 0;
-        for (int i = tid; i < m; i += kSelThreads) {
-            const bool ok = score_key(sc[i]) != 0u && (!ix || ix[i] >= 0);
-            local += ok ? 1u : 0u;
-        }
+    for (int i = tid; i < kpad; i += kSelThreads) buf[i] = 0ull;
+    int filled = 0;
+
+    // ---- source 1: a flat list (dense scores with implicit indices, or score/index pairs)
+    // Loads are issued kLd at a time per thread before the first use: this kernel runs on
+    // 64 CUs with one block each, so memory-level parallelism has to come from the unroll.
+    constexpr int kLd = 8;
+    int pos = 0;
+    while (pos < m) {
+        const int n = (m - pos) < (room - filled) ? (m - pos) : (room - filled);
+        for (int i0 = tid; i0 < n; i0 += kLd * kSelThreads) {
+            float v[kLd];
+            int32_t id[kLd];
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
-        if ((tid & 63) == 0 && local) atomicAdd(&sel[3], local);
-    }
-    __syncthreads();
-    const uint32_t n_valid = sel[3];
-    const uint32_t k_eff = n_valid < (uint32_t)k ? n_valid : (uint32_t)k;
-
-    uint32_t pivot = 0, idx_pivot = 0x7FFFFFFFu;
-    if (k_eff > 0) {
-        // ---- radix select on the score key: k_eff-th largest ------------------------
-        uint32_t prefix = 0, mask = 0, need = k_eff, eq_count = 0;
-        for (int pass = 0; pass < 4; ++pass) {
-            const int shift = 24 - 8 * pass;
-            hist[tid] = 0;
-            __syncthreads();
-            for (int i = tid; i < m; i += kSelThreads) {
-                const uint32_t key = score_key(sc[i]);
-                if (key != 0u && (!ix || ix[i] >= 0) && (key & mask) == prefix)
-                    atomicAdd(&hist[(key >> shift) & 255u], 1u);
-            }
-            __syncthreads();
-            pick_digit(hist, need, true, sel);
-            __syncthreads();
-            prefix |= sel[0] << shift;
-            mask |= 255u << shift;
-            need -= sel[1];
-            eq_count = sel[2];
-            __syncthreads();
-        }
-        pivot = prefix;
-        // `need` entries with key == pivot are wanted out of eq_count
-        if (eq_count > need) {
-            // ---- radix select on the index among the ties: need-th smallest -------------
-            uint32_t iprefix = 0, imask = 0, ineed = need;
-            for (int pass = 0; pass < 4; ++pass) {
-                const int shift = 24 - 8 * pass;
-                hist[tid] = 0;
-                __syncthreads();
-                for (int i = tid; i < m; i += kSelThreads) {
-                    if (score_key(sc[i]) != pivot) continue;
-                    const int32_t id = ix ? ix[i] : i;
-                    if (id < 0) continue;
-                    if (((uint32_t)id & imask) == iprefix) atomicAdd(&hist[((uint32_t)id >> shift) & 255u], 1u);
-                }
-                __syncthreads();
-                pick_digit(hist, ineed, false, sel);
-                __syncthreads();
-                iprefix |= sel[0] << shift;
-                imask |= 255u << shift;
-                ineed -= sel[1];
-                __syncthreads();
-            }
-            idx_pivot = iprefix;
-        }
-        // ---- collect survivors ----------------------------------------------------------
-        for (int i = tid; i < m; i += kSelThreads) {
-            const uint32_t key = score_key(sc[i]);
-            const int32_t id = ix ? ix[i] : i;
-            if (key == 0u || id < 0) continue;
-            if (key > pivot || (key == pivot && (uint32_t)id <= idx_pivot)) {
-                const uint32_t pos = atomicAdd(&n_out, 1u);
-                if (pos < (uint32_t)kMaxK)
-                    buf[pos] = ((unsigned long long)key << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)id);
-            }
-        }
-    }
-    __syncthreads();
-
-    // ---- bitonic sort (descending) of the composite keys, padded with 0 ----------------
-    int kpad = 1;
-    while (kpad < (int)k_eff) kpad <<= 1;
-    for (int i = tid; i < kpad; i += kSelThreads)
-        if (i >= (int)k_eff) buf[i] = 0ull;
-    __syncthreads();
-    for (int size = 2; size <= kpad; size <<= 1) {
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int i = tid; i < kpad / 2; i += kSelThreads) {
-                const int lo = 2 * i - (i & (stride - 1));  // index with bit `stride` clear
-                const int hi = lo + stride;
-                const bool desc = ((lo & size) == 0);
-                const unsigned long long a = buf[lo], b2 = buf[hi];
-                if ((a < b2) == desc) {
-                    buf[lo] = b2;
-                    buf[hi] = a;
+            for (int u = 0; u < kLd; ++u) {
+                const int i = i0 + u * kSelThreads;
+                v[u] = 0.f;
+                id[u] = -1;
+                if (i < n) {
+                    v[u] = sc[pos + i];
+                    id[u] = ix ? ix[pos + i] : pos + i;
                 }
             }
-            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < kLd; ++u) {
+                const int i = i0 + u * kSelThreads;
+                if (i < n) buf[kpad + filled + i] = make_key(v[u], id[u]);
+            }
+        }
+        filled += n;
+        pos += n;
+        if (filled == room) {
+            flush_staged(buf, filled, kpad, lk);
+            filled = 0;
         }
     }
 
-    // ---- write results -----------------------------------------------------------------
+    // ---- source 2: the filter pass's private sub-lists -------------------------------
+    if (p.priv) {
+        const uint2* pv = p.priv + (size_t)q * p.n_sub * TT_SCAN_PRIV_SLOTS;
+        const int32_t* pc = p.priv_cnt + (size_t)q * p.n_sub;
+        // rounds of kSub sub-lists per thread; all fill counts of a round are loaded at once,
+        // then the entries in groups of kGrp per sub-list
+        constexpr int kSub = 4, kGrp = 4;
+        for (int b0 = 0; b0 < p.n_sub; b0 += kSub * kSelThreads) {
+            int c[kSub], off[kSub];
+#pragma unroll
+            for (int u = 0; u < kSub; ++u) {
+                const int sidx = b0 + u * kSelThreads + tid;
+                c[u] = sidx < p.n_sub ? pc[sidx] : 0;
+            }
+            int mine = 0;
+#pragma unroll
+            for (int u = 0; u < kSub; ++u) {
+                c[u] = c[u] < TT_SCAN_PRIV_SLOTS ? c[u] : TT_SCAN_PRIV_SLOTS;
+                mine += c[u];
+            }
+            if (tid == 0) lds_ctr[0] = 0;
+            __syncthreads();
+            int my_off = mine ? atomicAdd(&lds_ctr[0], mine) : 0;
+            __syncthreads();
+            const int total = lds_ctr[0];
+            if (total > room) {
+                // pathological round (heavily clustered hits): stage it sub-list by sub-list
+#pragma unroll
+                for (int u = 0; u < kSub; ++u) {
+                    const int sidx = b0 + u * kSelThreads + tid;
+                    for (int quarter = 0; quarter < 4; ++quarter) {
+                        const bool on = (tid >> 8) == quarter;  // 256 threads * 16 <= room
+                        if (tid == 0) lds_ctr[0] = 0;
+                        __syncthreads();
+                        const int o = (on && c[u]) ? atomicAdd(&lds_ctr[0], c[u]) : 0;
+                        __syncthreads();
+                        const int tot = lds_ctr[0];
+                        if (filled + tot > room) {
+                            flush_staged(buf, filled, kpad, lk);
+                            filled = 0;
+                        }
+                        if (on)
+                            for (int j = 0; j < c[u]; ++j) {
+                                const uint2 e = pv[(size_t)sidx * TT_SCAN_PRIV_SLOTS + j];
+                                buf[kpad + filled + o + j] = make_key(__uint_as_float(e.x), (int32_t)e.y);
+                            }
+                        filled += tot;
+                        __syncthreads();
+                    }
+                }
+                continue;
+            }
+            if (filled + total > room) {  // block-uniform
+                flush_staged(buf, filled, kpad, lk);
+                filled = 0;
+            }
+#pragma unroll
+            for (int u = 0; u < kSub; ++u) {
+                off[u] = my_off;
+                my_off += c[u];
+            }
+            for (int j0 = 0; j0 < TT_SCAN_PRIV_SLOTS; j0 += kGrp) {
+                bool any = false;
+#pragma unroll
+                for (int u = 0; u < kSub; ++u) any = any || (c[u] > j0);
+                if (!__syncthreads_or(any ? 1 : 0)) break;
+                uint2 e[kSub][kGrp];
+#pragma unroll
+                for (int u = 0; u < kSub; ++u) {
+                    const int sidx = b0 + u * kSelThreads + tid;
+#pragma unroll
+                    for (int j = 0; j < kGrp; ++j)
+                        if (j0 + j < c[u]) e[u][j] = pv[(size_t)sidx * TT_SCAN_PRIV_SLOTS + j0 + j];
+                }
+#pragma unroll
+                for (int u = 0; u < kSub; ++u)
+#pragma unroll
+                    for (int j = 0; j < kGrp; ++j)
+                        if (j0 + j < c[u])
+                            buf[kpad + filled + off[u] + j0 + j] =
+                                make_key(__uint_as_float(e[u][j].x), (int32_t)e[u][j].y);
+            }
+            filled += total;
+            __syncthreads();
+        }
+    }
+    if (filled > 0) flush_staged(buf, filled, kpad, lk);
+    __syncthreads();
+
     for (int i = tid; i < k; i += kSelThreads) {
+        const u64 e = buf[i];
         float s = -__builtin_inff();
         int32_t id = -1;
-        if (i < (int)k_eff) {
-            const unsigned long long e = buf[i];
+        if (e != 0ull) {
             s = key_score((uint32_t)(e >> 32));
             id = (int32_t)(0xFFFFFFFFu - (uint32_t)(e & 0xFFFFFFFFull));
             if (!ix) id += p.idx_base;
@@ -198,9 +318,18 @@ __global__ __launch_bounds__(kSelThreads) void select_kernel(SelectParams p) {
         p.out_scores[(size_t)q * p.out_stride + i] = s;
         p.out_idx[(size_t)q * p.out_stride + i] = id;
     }
-    if (tid == 0) {
-        if (p.thr_out) p.thr_out[q] = (k_eff == (uint32_t)k) ? key_score(pivot) : -__builtin_inff();
-        if (p.cnt_out) p.cnt_out[q] = (int32_t)k_eff;
+    if (p.thr_out || p.cnt_out) {
+        if (tid == 0) lds_ctr[1] = 0;
+        __syncthreads();
+        int local = 0;
+        for (int i = tid; i < k; i += kSelThreads) local += buf[i] != 0ull ? 1 : 0;
+        if (local) atomicAdd(&lds_ctr[1], local);
+        __syncthreads();
+        if (tid == 0) {
+            const u64 e = buf[k - 1];
+            if (p.thr_out) p.thr_out[q] = (e != 0ull) ? key_score((uint32_t)(e >> 32)) : -__builtin_inff();
+            if (p.cnt_out) p.cnt_out[q] = lds_ctr[1];
+        }
     }
 }
 
@@ -212,7 +341,14 @@ int tt_select_launch(const SelectParams& p, int n_queries, hipStream_t stream) {
         tt_set_error("top-k: k=%d outside [1,%d]", p.k, kMaxK);
         return TT_E_INVALID;
     }
-    hipLaunchKernelGGL(select_kernel, dim3(n_queries), dim3(kSelThreads), 0, stream, p);
+    const size_t lds = (size_t)(kChunk + kAux + kAux2) * sizeof(u64) + 16;
+    static thread_local bool attr_set = false;
+    if (!attr_set) {
+        TT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(select_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(select_kernel, dim3(n_queries), dim3(kSelThreads), lds, stream, p);
     TT_CHECK_LAUNCH();
     return TT_OK;
 }

@@ -69,8 +69,14 @@ int main(int argc, char** argv) {
     printf("scan_bench: N=%lld D=%d Q=%d K=%d iters=%d ws=%.1f MB CUs=%d\n", (long long)n, d, q, k, iters,
            ws_bytes / 1e6, tt_device_cu_count());
     std::vector<int32_t> ref_idx;
-    for (int mode = 1; mode >= 0; --mode) {
-        setenv("TT_SCAN_MODE", mode ? "1" : "0", 1);
+    const char* modes_env = getenv("SCAN_BENCH_MODES");
+    std::vector<int> modes;
+    if (modes_env) {
+        for (const char* c = modes_env; *c;) { modes.push_back(atoi(c)); while (*c && *c != ',') ++c; if (*c == ',') ++c; }
+    } else { modes = {1, 0}; }
+    for (int mode : modes) {
+        char mbuf[16]; snprintf(mbuf, sizeof mbuf, "%d", mode);
+        setenv("TT_SCAN_MODE", mbuf, 1);
         for (int w = 0; w < 3; ++w) {
             int rc = tt_scan_topk(corpus, n, d, queries, q, k, 0, out_s, out_i, ws, ws_bytes, flag, st);
             if (rc) { fprintf(stderr, "tt_scan_topk rc=%d: %s\n", rc, tt_last_error()); return 1; }
@@ -98,7 +104,7 @@ int main(int argc, char** argv) {
         else {
             size_t diff = 0;
             for (size_t i = 0; i < idx.size(); ++i) diff += idx[i] != ref_idx[i];
-            printf("mode 0 vs mode 1 index mismatches: %zu / %zu\n", diff, idx.size());
+            printf("mode %d vs first mode index mismatches: %zu / %zu\n", mode, diff, idx.size());
         }
     }
     return 0;
