@@ -81,6 +81,89 @@ int tt_topk_merge(const float* in_scores, const int32_t* in_idx,
                   int n_queries, int n_candidates, int k_out,
                   float* out_scores, int32_t* out_idx, void* stream);
 
+
+/* ---- encoder (bi-encoder embedder / cross-encoder reranker) --------------------
+ * Replaces the transformer forward the reference reaches through
+ *   HuggingFaceEmbedding(...)       src/tensortruth/services/model_manager.py:254-260,
+ *                                   src/tensortruth/indexing/builder.py:146-152
+ *   SentenceTransformerRerank(...)  src/tensortruth/services/model_manager.py:333-337
+ * (upstream: sentence-transformers over transformers XLMRobertaModel / BertModel /
+ * XLMRobertaForSequenceClassification).
+ *
+ * Token layout: sequences are PACKED (no padding tokens are computed): token rows
+ * [seq_start[b], seq_start[b] + seq_len[b]) belong to sequence b, seq_start[b] is a
+ * multiple of 8, and the row count n_rows (>= last start + len) is a multiple of 128;
+ * rows that belong to no sequence are computed but never read.
+ * All weights are bf16 [out][in] (nn.Linear layout), biases / LayerNorm parameters fp32.
+ * The structs below hold DEVICE pointers but live in HOST memory.
+ */
+typedef struct tt_layer_weights {
+    const void* qkv_w;   /* [3H][H]  query, key, value rows concatenated */
+    const float* qkv_b;  /* [3H] */
+    const void* o_w;     /* [H][H]   attention.output.dense */
+    const float* o_b;
+    const float* ln1_g;  /* attention.output.LayerNorm */
+    const float* ln1_b;
+    const void* ffn1_w;  /* [F][H]   intermediate.dense (GELU-erf) */
+    const float* ffn1_b;
+    const void* ffn2_w;  /* [H][F]   output.dense */
+    const float* ffn2_b;
+    const float* ln2_g;  /* output.LayerNorm */
+    const float* ln2_b;
+} tt_layer_weights;
+
+typedef struct tt_encoder_weights {
+    int32_t hidden, layers, heads, ffn, vocab, max_pos, type_vocab;
+    float ln_eps;
+    const void* word_emb;  /* [vocab][H] bf16 */
+    const void* pos_emb;   /* [max_pos][H] bf16 */
+    const void* type_emb;  /* [type_vocab][H] bf16 */
+    const float* emb_ln_g;
+    const float* emb_ln_b;
+    const tt_layer_weights* layer; /* host array [layers] */
+    const void* cls_dense_w;  /* [H][H] bf16 or NULL (no classification head) */
+    const float* cls_dense_b;
+    const void* cls_out_w;    /* [1][H] bf16 */
+    const float* cls_out_b;   /* [1] */
+} tt_encoder_weights;
+
+size_t tt_encoder_workspace_bytes(const tt_encoder_weights* w, int n_rows);
+
+/* ids/pos/type_ids: [n_rows] int32 (type_ids may be NULL = all zero); hidden_out:
+ * [n_rows][H] bf16 last hidden state.  max_len = longest sequence (host value). */
+int tt_encoder_forward(const tt_encoder_weights* w, const int32_t* ids, const int32_t* pos,
+                       const int32_t* type_ids, const int32_t* seq_start, const int32_t* seq_len,
+                       int n_seq, int n_rows, int max_len, void* hidden_out,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* sentence-transformers Pooling(cls) + Normalize: out[b] = h[rows[b]] / ||h[rows[b]]||_2.
+ * out_bf16 (optional) is the same vector rounded to bf16, ready to be a scan query. */
+int tt_embed_pool(const void* hidden_bf16, int ld, const int32_t* rows, int n_seq, int hidden,
+                  float* out_f32, void* out_bf16, void* stream);
+
+/* XLMRobertaClassificationHead + CrossEncoder sigmoid on the CLS rows:
+ * scores[b] = sigmoid(out_proj(tanh(dense(h[rows[b]])))) ; logits optional.
+ * workspace >= 2 * round_up(n_seq,128) * H * 2 bytes. */
+int tt_rerank_head(const tt_encoder_weights* w, const void* hidden_bf16, const int32_t* rows, int n_seq,
+                   float* scores, float* logits, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Building blocks, exported for the parity tests (same kernels the forward uses). */
+int tt_gemm_bf16(const void* a, const void* w, const float* bias, const void* residual, void* c,
+                 int m, int n, int k, int epilogue /*0 bias,1 gelu,2 +residual,3 tanh*/, void* stream);
+int tt_layernorm_bf16(const void* in, void* out, const float* gamma, const float* beta, int rows, int hidden,
+                      float eps, void* stream);
+int tt_attention_varlen(const void* qk, int ld_qk, int q_col0, int k_col0, const void* vt, int ldvt, void* out,
+                        int ld_out, const int32_t* seq_start, const int32_t* seq_len, int n_seq, int heads,
+                        int head_dim, int max_len, void* stream);
+
+/* Per-kernel device timing (HIP events on the launch stream), for bench.py's roofline leg.
+ * tt_prof_enable(1) starts recording one event pair per launch of the tracked kernels on the
+ * calling thread; tt_prof_read() synchronises those events and returns total milliseconds
+ * and launch count for kernel id `which` since the last enable, then keeps recording.
+ * ids: 1 scan filter pass, 2 scan sample pass, 3 top-k select, 4 gemm, 5 attention, 6 row ops */
+int tt_prof_enable(int on);
+int tt_prof_read(int which, double* total_ms_host, int* launches_host);
+
 #ifdef __cplusplus
 }
 #endif

@@ -41,6 +41,17 @@ SIGNATURES = {
     "tt_scan_topk_exact": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_int, c_int32, c_void_p, c_void_p,
                                    c_void_p, c_size_t, c_void_p]),
     "tt_topk_merge": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "tt_encoder_workspace_bytes": (c_size_t, [c_void_p, c_int]),
+    "tt_encoder_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                   c_void_p, c_void_p, c_size_t, c_void_p]),
+    "tt_embed_pool": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "tt_rerank_head": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "tt_gemm_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "tt_layernorm_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
+    "tt_attention_varlen": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p,
+                                    c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "tt_prof_enable": (c_int, [c_int]),
+    "tt_prof_read": (c_int, [c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int)]),
 }
 
 

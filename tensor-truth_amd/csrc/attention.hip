@@ -1,0 +1,206 @@
+// Variable-length bidirectional self-attention (flash-style, online softmax), gfx950 MFMA.
+//
+//   ctx[t][h*dh + d] = sum_k softmax_k(Q[t].K[k] / sqrt(dh)) V[k][d]   over the keys of t's sequence
+//
+// Replaces the scaled-dot-product attention inside the reference's XLM-R / BERT encoder
+// layers (additive -inf key-padding mask == attending only to the sequence's own tokens
+// in the packed varlen layout).
+//
+// One workgroup = 4 waves = 128 query rows of one (sequence, head); keys stream through LDS
+// in tiles of 64.  Both products run "swapped" on v_mfma_f32_32x32x16_bf16 so that the
+// QUERY sits on the lane for the whole kernel:
+//   S^T[key][q] = K . Q^T      A = K fragment (ds_read_b128, XOR-swizzled), B = Q fragment (registers)
+//   O^T[d][q]  += V^T . P^T    A = V^T fragment (2 x ds_read_b64 from a padded [d][key] image),
+//                              B = the S^T accumulator itself, converted to bf16 in place
+// so the softmax row statistics are lane-local (one cross-half exchange per tile), P never
+// goes through LDS, and V is consumed from the transposed copy the QKV GEMM epilogue wrote.
+#include "common.h"
+#include "encoder.h"
+
+namespace {
+
+constexpr int kAttThreads = 256;
+constexpr int kQTile = 128;   // query rows per workgroup (32 per wave)
+constexpr int kKTile = 64;    // keys per LDS tile
+constexpr int kVtStride = kKTile * 2 + 8;  // bytes per V^T row in LDS (padded: conflict-free ds_read_b64)
+
+template <int DH>
+__global__ __launch_bounds__(kAttThreads) void attention_kernel(AttnParams p) {
+    constexpr int RB = DH * 2;              // bytes per K row
+    constexpr int CH = RB / 16;             // 16-B chunks per K row
+    constexpr int RPB = 256 / RB;           // K rows per 256-B bank row
+    constexpr int KS = DH / 16;             // k-steps of Q.K
+    constexpr int DT = DH / 32;             // 32-row d tiles of O^T
+    __shared__ __attribute__((aligned(16))) char k_lds[kKTile * RB];
+    __shared__ __attribute__((aligned(16))) char vt_lds[DH * kVtStride];
+
+    const int seq = blockIdx.z, head = blockIdx.y, qt = blockIdx.x;
+    const int len = p.seq_len[seq];
+    if (qt * kQTile >= len) return;
+    const int t0 = p.seq_start[seq];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ql = lane & 31, hh = lane >> 5;
+
+    // ---- Q fragments (B operand), straight from global ---------------------------------
+    const int q_row = qt * kQTile + wave * 32 + ql;        // row inside the sequence
+    const int q_row_c = q_row < len ? q_row : len - 1;     // clamp: result discarded
+    const uint16_t* qp = p.qk + (size_t)(t0 + q_row_c) * p.ld_qk + p.q_col0 + head * DH + hh * 8;
+    bf16x8 qf[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + s * 16);
+
+    f32x16 acc_o[DT];
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc_o[d][r] = 0.f;
+    float m_run = -__builtin_inff();
+    float l_run = 0.f;
+    const float sc = p.scale * 1.4426950408889634f;  // fold log2(e): softmax via exp2
+
+    const int n_kt = (len + kKTile - 1) / kKTile;
+    for (int kt = 0; kt < n_kt; ++kt) {
+        const int k0 = kt * kKTile;
+        if (kt > 0) __syncthreads();
+        // ---- stage K tile [64 keys][DH] (swizzled 16-B chunks) ----------------------------
+        {
+            constexpr int LPR = CH;                       // lanes per row
+            constexpr int RPP = kAttThreads / LPR;        // rows per pass
+            const int c = tid % LPR;
+#pragma unroll
+            for (int r0 = 0; r0 < kKTile; r0 += RPP) {
+                const int r = r0 + tid / LPR;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (k0 + r < len)
+                    v = *reinterpret_cast<const uint4*>(p.qk + (size_t)(t0 + k0 + r) * p.ld_qk + p.k_col0 + head * DH + c * 8);
+                *reinterpret_cast<uint4*>(k_lds + r * RB + ((c ^ ((r / RPB) & (CH - 1))) << 4)) = v;
+            }
+        }
+        // ---- stage V^T tile [DH][64 keys] (rows padded to kVtStride) -----------------------
+        {
+            constexpr int LPR = kKTile / 8;               // 8 lanes x 16 B per row
+            constexpr int RPP = kAttThreads / LPR;        // 32 rows per pass
+            const int c = tid % LPR;
+#pragma unroll
+            for (int r0 = 0; r0 < DH; r0 += RPP) {
+                const int d = r0 + tid / LPR;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (k0 + c * 8 < len)
+                    v = *reinterpret_cast<const uint4*>(p.vt + (size_t)(head * DH + d) * p.ldvt + t0 + k0 + c * 8);
+                uint2* dst = reinterpret_cast<uint2*>(vt_lds + d * kVtStride + c * 16);
+                dst[0] = make_uint2(v.x, v.y);
+                dst[1] = make_uint2(v.z, v.w);
+            }
+        }
+        __syncthreads();
+
+        // ---- S^T = K . Q^T for two 32-key tiles -------------------------------------------------
+        f32x16 acc_s[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc_s[j][r] = 0.f;
+            const int key = 32 * j + ql;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const int chunk = 2 * s + hh;
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(k_lds + key * RB + ((chunk ^ ((key / RPB) & (CH - 1))) << 4));
+                acc_s[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], acc_s[j], 0, 0, 0);
+            }
+        }
+        // ---- scale, mask the tail, running max ----------------------------------------------------
+        const bool tail = k0 + kKTile > len;  // wave-uniform
+        float mx = -__builtin_inff();
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc_s[j][r] * sc;
+                if (tail) {
+                    const int key = k0 + 32 * j + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    if (key >= len) v = -__builtin_inff();
+                }
+                acc_s[j][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);            // finite: every tile holds >= 1 valid key
+        const float alpha = exp2f(m_run - m_new);        // first tile: exp2(-inf) = 0
+        m_run = m_new;
+        float psum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e = exp2f(acc_s[j][r] - m_new);
+                acc_s[j][r] = e;
+                psum += e;
+            }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc_o[d][r] *= alpha;
+
+        // ---- O^T += V^T . P^T ----------------------------------------------------------------------
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                uint4 pb;
+                pb.x = pack_bf16x2(acc_s[j][8 * s2 + 0], acc_s[j][8 * s2 + 1]);
+                pb.y = pack_bf16x2(acc_s[j][8 * s2 + 2], acc_s[j][8 * s2 + 3]);
+                pb.z = pack_bf16x2(acc_s[j][8 * s2 + 4], acc_s[j][8 * s2 + 5]);
+                pb.w = pack_bf16x2(acc_s[j][8 * s2 + 6], acc_s[j][8 * s2 + 7]);
+                const bf16x8 pf = __builtin_bit_cast(bf16x8, pb);
+                const int kb = 32 * j + 16 * s2 + 4 * hh;   // keys kb..kb+3 and kb+8..kb+11
+#pragma unroll
+                for (int d = 0; d < DT; ++d) {
+                    const char* vrow = vt_lds + (32 * d + ql) * kVtStride + kb * 2;
+                    const uint2 lo = *reinterpret_cast<const uint2*>(vrow);
+                    const uint2 hi = *reinterpret_cast<const uint2*>(vrow + 16);
+                    const uint4 vv = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                    acc_o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf, acc_o[d], 0, 0, 0);
+                }
+            }
+    }
+
+    // ---- normalise and store: lane = query row, registers = 4 consecutive d ------------------
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    if (q_row < len) {
+        uint16_t* op = p.out + (size_t)(t0 + q_row) * p.ld_out + head * DH;
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                uint2 o;
+                o.x = pack_bf16x2(acc_o[d][4 * g + 0] * inv, acc_o[d][4 * g + 1] * inv);
+                o.y = pack_bf16x2(acc_o[d][4 * g + 2] * inv, acc_o[d][4 * g + 3] * inv);
+                *reinterpret_cast<uint2*>(op + 32 * d + 8 * g + 4 * hh) = o;
+            }
+    }
+}
+
+}  // namespace
+
+int tt_attention_launch(const AttnParams& p, hipStream_t st) {
+    if (p.n_seq <= 0 || p.max_len <= 0) return TT_OK;
+    if ((p.ld_qk % 8) || (p.q_col0 % 8) || (p.k_col0 % 8) || (p.ldvt % 8) || (p.ld_out % 4)) {
+        tt_set_error("attention: leading dimensions / column offsets must keep 16-byte alignment");
+        return TT_E_INVALID;
+    }
+    const dim3 grid((p.max_len + kQTile - 1) / kQTile, p.heads, p.n_seq);
+    TtProfScope prof(TT_K_ATTENTION, st);
+    if (p.head_dim == 64) {
+        hipLaunchKernelGGL(attention_kernel<64>, grid, dim3(kAttThreads), 0, st, p);
+    } else if (p.head_dim == 32) {
+        hipLaunchKernelGGL(attention_kernel<32>, grid, dim3(kAttThreads), 0, st, p);
+    } else {
+        tt_set_error("attention: head_dim %d not in {32, 64}", p.head_dim);
+        return TT_E_UNSUPPORTED;
+    }
+    TT_CHECK_LAUNCH();
+    return TT_OK;
+}

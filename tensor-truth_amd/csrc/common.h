@@ -60,3 +60,15 @@ __device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) {
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
     return (uint32_t)f32_to_bf16_bits(lo) | ((uint32_t)f32_to_bf16_bits(hi) << 16);
 }
+
+// ---- per-kernel device timing (tt_prof_enable / tt_prof_read) -----------------------------
+enum { TT_K_SCAN_FILTER = 1, TT_K_SCAN_SAMPLE = 2, TT_K_SELECT = 3, TT_K_GEMM = 4, TT_K_ATTENTION = 5, TT_K_ROWOPS = 6 };
+bool tt_prof_on();
+void tt_prof_begin(int id, hipStream_t st);
+void tt_prof_end(hipStream_t st);
+struct TtProfScope {
+    hipStream_t st;
+    bool on;
+    TtProfScope(int id, hipStream_t s) : st(s), on(tt_prof_on()) { if (on) tt_prof_begin(id, st); }
+    ~TtProfScope() { if (on) tt_prof_end(st); }
+};

@@ -1,0 +1,59 @@
+// Internal interfaces of the encoder kernels (gemm.hip, attention.hip, rowops.hip, encoder_api.hip).
+#pragma once
+#include "common.h"
+
+enum { TT_EPI_BIAS = 0, TT_EPI_GELU = 1, TT_EPI_RESIDUAL = 2, TT_EPI_TANH = 3, TT_EPI_QKV = 4 };
+
+struct GemmParams {
+    const uint16_t* A;        // [M][lda] bf16
+    const uint16_t* W;        // [N][K] bf16 (nn.Linear weight)
+    const float* bias;        // [N] fp32
+    const uint16_t* residual; // [M][ldr] bf16 (TT_EPI_RESIDUAL)
+    uint16_t* C;              // [M][ldc] bf16
+    uint16_t* vt;             // TT_EPI_QKV: columns >= vt_col0 go to vt[n - vt_col0][m] (ldvt)
+    int M, N, K, lda, ldc, ldr, ldvt, vt_col0;
+};
+int tt_gemm_launch(const GemmParams& p, int epilogue, hipStream_t st);
+
+struct AttnParams {
+    const uint16_t* qk;       // [T][ld_qk] bf16: Q at column q_col0 + h*dh, K at k_col0 + h*dh
+    const uint16_t* vt;       // [heads*dh][ldvt] bf16 (V transposed: feature-major, token-minor)
+    uint16_t* out;            // [T][ld_out] bf16, context at column h*dh
+    const int32_t* seq_start; // [B] first token row of each sequence (multiple of 8)
+    const int32_t* seq_len;   // [B]
+    int n_seq, heads, head_dim, max_len;
+    int ld_qk, q_col0, k_col0, ldvt, ld_out;
+    float scale;              // 1/sqrt(head_dim)
+};
+int tt_attention_launch(const AttnParams& p, hipStream_t st);
+
+struct EmbedParams {
+    const int32_t* ids;       // [T]
+    const int32_t* pos;       // [T]
+    const int32_t* type;      // [T] or null (=> type 0)
+    const uint16_t* word;     // [vocab][H] bf16
+    const uint16_t* posemb;   // [max_pos][H] bf16
+    const uint16_t* typeemb;  // [type_vocab][H] bf16
+    const float* gamma;
+    const float* beta;
+    uint16_t* out;            // [T][H] bf16
+    int T, H, vocab, max_pos, type_vocab;
+    float eps;
+};
+int tt_embed_ln_launch(const EmbedParams& p, hipStream_t st);
+
+// out = LayerNorm(in) * gamma + beta, rows of H bf16
+int tt_layernorm_launch(const uint16_t* in, uint16_t* out, const float* gamma, const float* beta, int rows, int H,
+                        float eps, hipStream_t st);
+
+// out_f32[b] = x[row[b]] / max(||x[row[b]]||, 1e-12); optional bf16 copy
+int tt_cls_pool_l2norm_launch(const uint16_t* hidden, int ld, const int32_t* rows, int n, int H, float* out_f32,
+                              uint16_t* out_bf16, hipStream_t st);
+
+// gather rows: dst[b][:] = src[rows[b]][:]  (bf16, H elements), rows beyond n zero-filled up to n_pad
+int tt_gather_rows_launch(const uint16_t* src, int ld, const int32_t* rows, int n, int n_pad, int H, uint16_t* dst,
+                          hipStream_t st);
+
+// score[b] = sigmoid(dot(t[b][:], w) + bias)   (t bf16 [n][ld], w bf16 [H]); logits optional
+int tt_head_out_sigmoid_launch(const uint16_t* t, int ld, const uint16_t* w, const float* bias, int n, int H,
+                               float* scores, float* logits, hipStream_t st);

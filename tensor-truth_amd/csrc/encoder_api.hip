@@ -1,0 +1,218 @@
+// C-ABI entry points of the encoder (see include/tt_hip.h): whole-model forward, pooling,
+// rerank head, and the building blocks exported for the parity tests.
+//
+// Layer schedule (post-LN BERT / XLM-R block; one rounding to bf16 per fused kernel output):
+//   qk, vT = QKV-GEMM(x)                       [T][2H] + transposed V [H][T]
+//   ctx    = attention(qk, vT)                 [T][H]
+//   y      = GEMM(ctx, Wo) + bo + x            residual fused in the epilogue
+//   x1     = LayerNorm(y)
+//   f      = GELU(GEMM(x1, W1) + b1)           [T][F]
+//   y      = GEMM(f, W2) + b2 + x1
+//   x      = LayerNorm(y)
+#include "common.h"
+#include "encoder.h"
+
+namespace {
+
+struct EncWs {
+    size_t off_xa, off_xb, off_y, off_qk, off_vt, off_ctx, off_ffn, total;
+};
+
+EncWs enc_plan(const tt_encoder_weights* w, int n_rows) {
+    EncWs e{};
+    const size_t H = (size_t)w->hidden, F = (size_t)w->ffn, T = (size_t)n_rows;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += tt_align_up(bytes, 256); return o; };
+    e.off_xa = take(T * H * 2);
+    e.off_xb = take(T * H * 2);
+    e.off_y = take(T * H * 2);
+    e.off_qk = take(T * 2 * H * 2);
+    e.off_vt = take(H * T * 2);
+    e.off_ctx = take(T * H * 2);
+    e.off_ffn = take(T * F * 2);
+    e.total = off;
+    return e;
+}
+
+int check_weights(const tt_encoder_weights* w) {
+    TT_CHECK_ARG(w != nullptr, "null weights");
+    TT_CHECK_ARG(w->hidden > 0 && w->hidden % 128 == 0 && w->hidden <= 1024, "hidden=%d unsupported", w->hidden);
+    TT_CHECK_ARG(w->heads > 0 && w->hidden % w->heads == 0, "heads=%d", w->heads);
+    const int dh = w->hidden / w->heads;
+    TT_CHECK_ARG(dh == 64 || dh == 32, "head_dim=%d not in {32,64}", dh);
+    TT_CHECK_ARG(w->ffn > 0 && w->ffn % 128 == 0, "ffn=%d must be a multiple of 128", w->ffn);
+    TT_CHECK_ARG(w->layers >= 0 && (w->layers == 0 || w->layer != nullptr), "layer array missing");
+    TT_CHECK_ARG(w->word_emb && w->pos_emb && w->type_emb && w->emb_ln_g && w->emb_ln_b, "embedding tables missing");
+    return TT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t tt_encoder_workspace_bytes(const tt_encoder_weights* w, int n_rows) {
+    if (!w || n_rows <= 0) return 0;
+    return enc_plan(w, n_rows).total;
+}
+
+int tt_encoder_forward(const tt_encoder_weights* w, const int32_t* ids, const int32_t* pos,
+                       const int32_t* type_ids, const int32_t* seq_start, const int32_t* seq_len, int n_seq,
+                       int n_rows, int max_len, void* hidden_out, void* workspace, size_t workspace_bytes,
+                       void* stream) {
+    if (int rc = check_weights(w)) return rc;
+    TT_CHECK_ARG(n_rows > 0 && n_rows % 128 == 0, "n_rows=%d must be a positive multiple of 128", n_rows);
+    TT_CHECK_ARG(n_seq > 0 && max_len > 0, "n_seq=%d max_len=%d", n_seq, max_len);
+    TT_CHECK_ARG(ids && pos && seq_start && seq_len && hidden_out, "null pointer");
+    const EncWs e = enc_plan(w, n_rows);
+    if (!workspace || workspace_bytes < e.total) {
+        tt_set_error("tt_encoder_forward: workspace %zu < required %zu bytes", workspace_bytes, e.total);
+        return TT_E_WORKSPACE;
+    }
+    TT_CHECK_ARG(((uintptr_t)workspace % 256) == 0, "workspace must be 256-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    const int H = w->hidden, F = w->ffn, T = n_rows;
+    uint16_t* xa = (uint16_t*)(ws + e.off_xa);
+    uint16_t* xb = (uint16_t*)(ws + e.off_xb);
+    uint16_t* y = (uint16_t*)(ws + e.off_y);
+    uint16_t* qk = (uint16_t*)(ws + e.off_qk);
+    uint16_t* vt = (uint16_t*)(ws + e.off_vt);
+    uint16_t* ctx = (uint16_t*)(ws + e.off_ctx);
+    uint16_t* ffn = (uint16_t*)(ws + e.off_ffn);
+    // rows that belong to no sequence are never written by the attention kernel
+    TT_CHECK_HIP(hipMemsetAsync(ctx, 0, (size_t)T * H * 2, st));
+
+    EmbedParams ep{};
+    ep.ids = ids; ep.pos = pos; ep.type = type_ids;
+    ep.word = (const uint16_t*)w->word_emb; ep.posemb = (const uint16_t*)w->pos_emb;
+    ep.typeemb = (const uint16_t*)w->type_emb;
+    ep.gamma = w->emb_ln_g; ep.beta = w->emb_ln_b;
+    ep.T = T; ep.H = H; ep.vocab = w->vocab; ep.max_pos = w->max_pos; ep.type_vocab = w->type_vocab;
+    ep.eps = w->ln_eps;
+    uint16_t* x = w->layers == 0 ? (uint16_t*)hidden_out : xa;
+    ep.out = x;
+    {
+        TtProfScope prof(TT_K_ROWOPS, st);
+        if (int rc = tt_embed_ln_launch(ep, st)) return rc;
+    }
+
+    const int dh = H / w->heads;
+    for (int l = 0; l < w->layers; ++l) {
+        const tt_layer_weights& lw = w->layer[l];
+        TT_CHECK_ARG(lw.qkv_w && lw.qkv_b && lw.o_w && lw.o_b && lw.ln1_g && lw.ln1_b && lw.ffn1_w && lw.ffn1_b &&
+                         lw.ffn2_w && lw.ffn2_b && lw.ln2_g && lw.ln2_b,
+                     "layer %d has a null weight pointer", l);
+        uint16_t* x_out = (l == w->layers - 1) ? (uint16_t*)hidden_out : (x == xa ? xb : xa);
+        // QKV projection
+        GemmParams g{};
+        g.A = x; g.lda = H; g.W = (const uint16_t*)lw.qkv_w; g.bias = lw.qkv_b;
+        g.C = qk; g.ldc = 2 * H; g.vt = vt; g.ldvt = T; g.vt_col0 = 2 * H;
+        g.M = T; g.N = 3 * H; g.K = H;
+        if (int rc = tt_gemm_launch(g, TT_EPI_QKV, st)) return rc;
+        // attention
+        AttnParams a{};
+        a.qk = qk; a.ld_qk = 2 * H; a.q_col0 = 0; a.k_col0 = H; a.vt = vt; a.ldvt = T;
+        a.out = ctx; a.ld_out = H; a.seq_start = seq_start; a.seq_len = seq_len;
+        a.n_seq = n_seq; a.heads = w->heads; a.head_dim = dh; a.max_len = max_len;
+        a.scale = 1.0f / sqrtf((float)dh);
+        if (int rc = tt_attention_launch(a, st)) return rc;
+        // attention output projection + residual, LayerNorm
+        GemmParams go{};
+        go.A = ctx; go.lda = H; go.W = (const uint16_t*)lw.o_w; go.bias = lw.o_b;
+        go.residual = x; go.ldr = H; go.C = y; go.ldc = H; go.M = T; go.N = H; go.K = H;
+        if (int rc = tt_gemm_launch(go, TT_EPI_RESIDUAL, st)) return rc;
+        uint16_t* x1 = (x == xa) ? xb : xa;
+        {
+            TtProfScope prof(TT_K_ROWOPS, st);
+            if (int rc = tt_layernorm_launch(y, x1, lw.ln1_g, lw.ln1_b, T, H, w->ln_eps, st)) return rc;
+        }
+        // FFN
+        GemmParams g1{};
+        g1.A = x1; g1.lda = H; g1.W = (const uint16_t*)lw.ffn1_w; g1.bias = lw.ffn1_b;
+        g1.C = ffn; g1.ldc = F; g1.M = T; g1.N = F; g1.K = H;
+        if (int rc = tt_gemm_launch(g1, TT_EPI_GELU, st)) return rc;
+        GemmParams g2{};
+        g2.A = ffn; g2.lda = F; g2.W = (const uint16_t*)lw.ffn2_w; g2.bias = lw.ffn2_b;
+        g2.residual = x1; g2.ldr = H; g2.C = y; g2.ldc = H; g2.M = T; g2.N = H; g2.K = F;
+        if (int rc = tt_gemm_launch(g2, TT_EPI_RESIDUAL, st)) return rc;
+        // x1 is free again after the FFN-down GEMM has consumed it as residual; the LN output
+        // goes to the other hidden buffer (or straight to hidden_out on the last layer)
+        uint16_t* dst = (l == w->layers - 1) ? (uint16_t*)hidden_out : x;
+        (void)x_out;
+        {
+            TtProfScope prof(TT_K_ROWOPS, st);
+            if (int rc = tt_layernorm_launch(y, dst, lw.ln2_g, lw.ln2_b, T, H, w->ln_eps, st)) return rc;
+        }
+        x = dst;
+    }
+    return TT_OK;
+}
+
+int tt_embed_pool(const void* hidden_bf16, int ld, const int32_t* rows, int n_seq, int hidden, float* out_f32,
+                  void* out_bf16, void* stream) {
+    TT_CHECK_ARG(n_seq >= 0, "n_seq=%d", n_seq);
+    if (n_seq == 0) return TT_OK;
+    TT_CHECK_ARG(hidden_bf16 && rows && out_f32 && ld >= hidden && ld % 8 == 0, "bad argument");
+    TtProfScope prof(TT_K_ROWOPS, (hipStream_t)stream);
+    return tt_cls_pool_l2norm_launch((const uint16_t*)hidden_bf16, ld, rows, n_seq, hidden, out_f32,
+                                     (uint16_t*)out_bf16, (hipStream_t)stream);
+}
+
+int tt_rerank_head(const tt_encoder_weights* w, const void* hidden_bf16, const int32_t* rows, int n_seq,
+                   float* scores, float* logits, void* workspace, size_t workspace_bytes, void* stream) {
+    if (int rc = check_weights(w)) return rc;
+    TT_CHECK_ARG(w->cls_dense_w && w->cls_dense_b && w->cls_out_w && w->cls_out_b, "weights carry no classification head");
+    TT_CHECK_ARG(n_seq >= 0, "n_seq=%d", n_seq);
+    if (n_seq == 0) return TT_OK;
+    TT_CHECK_ARG(hidden_bf16 && rows && scores, "null pointer");
+    const int H = w->hidden;
+    const int n_pad = (n_seq + 127) / 128 * 128;
+    const size_t need = 2 * tt_align_up((size_t)n_pad * H * 2, 256);
+    if (!workspace || workspace_bytes < need) {
+        tt_set_error("tt_rerank_head: workspace %zu < required %zu bytes", workspace_bytes, need);
+        return TT_E_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    uint16_t* cls = (uint16_t*)workspace;
+    uint16_t* t = (uint16_t*)((char*)workspace + tt_align_up((size_t)n_pad * H * 2, 256));
+    {
+        TtProfScope prof(TT_K_ROWOPS, st);
+        if (int rc = tt_gather_rows_launch((const uint16_t*)hidden_bf16, H, rows, n_seq, n_pad, H, cls, st)) return rc;
+    }
+    GemmParams g{};
+    g.A = cls; g.lda = H; g.W = (const uint16_t*)w->cls_dense_w; g.bias = w->cls_dense_b;
+    g.C = t; g.ldc = H; g.M = n_pad; g.N = H; g.K = H;
+    if (int rc = tt_gemm_launch(g, TT_EPI_TANH, st)) return rc;
+    TtProfScope prof(TT_K_ROWOPS, st);
+    return tt_head_out_sigmoid_launch(t, H, (const uint16_t*)w->cls_out_w, w->cls_out_b, n_seq, H, scores, logits, st);
+}
+
+int tt_gemm_bf16(const void* a, const void* w, const float* bias, const void* residual, void* c, int m, int n,
+                 int k, int epilogue, void* stream) {
+    TT_CHECK_ARG(epilogue >= TT_EPI_BIAS && epilogue <= TT_EPI_TANH, "epilogue %d", epilogue);
+    GemmParams g{};
+    g.A = (const uint16_t*)a; g.lda = k; g.W = (const uint16_t*)w; g.bias = bias;
+    g.residual = (const uint16_t*)residual; g.ldr = n; g.C = (uint16_t*)c; g.ldc = n;
+    g.M = m; g.N = n; g.K = k;
+    return tt_gemm_launch(g, epilogue, (hipStream_t)stream);
+}
+
+int tt_layernorm_bf16(const void* in, void* out, const float* gamma, const float* beta, int rows, int hidden,
+                      float eps, void* stream) {
+    TT_CHECK_ARG(in && out && gamma && beta, "null pointer");
+    return tt_layernorm_launch((const uint16_t*)in, (uint16_t*)out, gamma, beta, rows, hidden, eps, (hipStream_t)stream);
+}
+
+int tt_attention_varlen(const void* qk, int ld_qk, int q_col0, int k_col0, const void* vt, int ldvt, void* out,
+                        int ld_out, const int32_t* seq_start, const int32_t* seq_len, int n_seq, int heads,
+                        int head_dim, int max_len, void* stream) {
+    TT_CHECK_ARG(qk && vt && out && seq_start && seq_len, "null pointer");
+    AttnParams a{};
+    a.qk = (const uint16_t*)qk; a.ld_qk = ld_qk; a.q_col0 = q_col0; a.k_col0 = k_col0;
+    a.vt = (const uint16_t*)vt; a.ldvt = ldvt; a.out = (uint16_t*)out; a.ld_out = ld_out;
+    a.seq_start = seq_start; a.seq_len = seq_len; a.n_seq = n_seq; a.heads = heads; a.head_dim = head_dim;
+    a.max_len = max_len; a.scale = 1.0f / sqrtf((float)head_dim);
+    return tt_attention_launch(a, (hipStream_t)stream);
+}
+
+}  // extern "C"

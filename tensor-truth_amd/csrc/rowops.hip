@@ -1,0 +1,243 @@
+// Row-wise (HBM-bound) encoder kernels: embedding gather + LayerNorm, LayerNorm, CLS pooling +
+// L2 normalisation, row gather, classifier output projection + sigmoid.  One 64-lane wave
+// per row, 16-byte bf16x8 accesses, fp32 statistics (mean, then centred variance -- the
+// same two-pass formula as the oracle / torch.nn.LayerNorm).
+//
+// Reference arithmetic: XLM-R / BERT embeddings
+// LN(word[id] + pos[p] + type[t]); post-LN residual blocks; sentence-transformers
+// Pooling(cls) + Normalize; XLMRobertaClassificationHead out_proj + CrossEncoder sigmoid.
+#include "common.h"
+#include "encoder.h"
+
+namespace {
+
+constexpr int kRowThreads = 256;  // 4 rows per block
+constexpr int kMaxChunks = 2;     // H <= 1024: at most 2 x (8 bf16) per lane
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__device__ __forceinline__ void unpack8(const uint4& u, float (&f)[8]) {
+    f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xFFFF0000u);
+    f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xFFFF0000u);
+    f[4] = __uint_as_float(u.z << 16); f[5] = __uint_as_float(u.z & 0xFFFF0000u);
+    f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xFFFF0000u);
+}
+
+__device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
+    uint4 u;
+    u.x = pack_bf16x2(f[0], f[1]); u.y = pack_bf16x2(f[2], f[3]);
+    u.z = pack_bf16x2(f[4], f[5]); u.w = pack_bf16x2(f[6], f[7]);
+    return u;
+}
+
+// normalise x[kMaxChunks][8] (this lane's share of a row of H values) and store bf16
+__device__ __forceinline__ void ln_finish(float (&x)[kMaxChunks][8], int nchunk_total, int lane, int H, float eps,
+                                          const float* gamma, const float* beta, uint16_t* out_row) {
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < kMaxChunks; ++c)
+        if (lane + 64 * c < nchunk_total)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s += x[c][i];
+    const float mean = wave_sum(s) / (float)H;
+    float v = 0.f;
+#pragma unroll
+    for (int c = 0; c < kMaxChunks; ++c)
+        if (lane + 64 * c < nchunk_total)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float d = x[c][i] - mean;
+                v += d * d;
+            }
+    const float rstd = rsqrtf(wave_sum(v) / (float)H + eps);
+#pragma unroll
+    for (int c = 0; c < kMaxChunks; ++c) {
+        const int ch = lane + 64 * c;
+        if (ch < nchunk_total) {
+            const float4 g0 = *reinterpret_cast<const float4*>(gamma + ch * 8);
+            const float4 g1 = *reinterpret_cast<const float4*>(gamma + ch * 8 + 4);
+            const float4 b0 = *reinterpret_cast<const float4*>(beta + ch * 8);
+            const float4 b1 = *reinterpret_cast<const float4*>(beta + ch * 8 + 4);
+            const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+            const float b[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+            float y[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) y[i] = (x[c][i] - mean) * rstd * g[i] + b[i];
+            *reinterpret_cast<uint4*>(out_row + ch * 8) = pack8(y);
+        }
+    }
+}
+
+__global__ __launch_bounds__(kRowThreads) void layernorm_kernel(const uint16_t* in, uint16_t* out, const float* gamma,
+                                                               const float* beta, int rows, int H, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (kRowThreads / 64) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nch = H / 8;
+    float x[kMaxChunks][8];
+#pragma unroll
+    for (int c = 0; c < kMaxChunks; ++c) {
+        const int ch = lane + 64 * c;
+        if (ch < nch) {
+            const uint4 u = *reinterpret_cast<const uint4*>(in + (size_t)row * H + ch * 8);
+            unpack8(u, x[c]);
+        }
+    }
+    ln_finish(x, nch, lane, H, eps, gamma, beta, out + (size_t)row * H);
+}
+
+__global__ __launch_bounds__(kRowThreads) void embed_ln_kernel(EmbedParams p) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (kRowThreads / 64) + (threadIdx.x >> 6);
+    if (row >= p.T) return;
+    int id = p.ids[row], ps = p.pos[row], ty = p.type ? p.type[row] : 0;
+    // out-of-range ids would read outside the tables: clamp (the host validates too)
+    id = id < 0 ? 0 : (id >= p.vocab ? p.vocab - 1 : id);
+    ps = ps < 0 ? 0 : (ps >= p.max_pos ? p.max_pos - 1 : ps);
+    ty = ty < 0 ? 0 : (ty >= p.type_vocab ? p.type_vocab - 1 : ty);
+    const int nch = p.H / 8;
+    float x[kMaxChunks][8];
+#pragma unroll
+    for (int c = 0; c < kMaxChunks; ++c) {
+        const int ch = lane + 64 * c;
+        if (ch < nch) {
+            float a[8], b[8], t[8];
+            unpack8(*reinterpret_cast<const uint4*>(p.word + (size_t)id * p.H + ch * 8), a);
+            unpack8(*reinterpret_cast<const uint4*>(p.posemb + (size_t)ps * p.H + ch * 8), b);
+            unpack8(*reinterpret_cast<const uint4*>(p.typeemb + (size_t)ty * p.H + ch * 8), t);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) x[c][i] = a[i] + b[i] + t[i];
+        }
+    }
+    ln_finish(x, nch, lane, p.H, p.eps, p.gamma, p.beta, p.out + (size_t)row * p.H);
+}
+
+__global__ __launch_bounds__(kRowThreads) void cls_pool_kernel(const uint16_t* hidden, int ld, const int32_t* rows, int n,
+                                                              int H, float* out_f32, uint16_t* out_bf16) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * (kRowThreads / 64) + (threadIdx.x >> 6);
+    if (b >= n) return;
+    const int nch = H / 8;
+    const uint16_t* src = hidden + (size_t)rows[b] * ld;
+    float x[kMaxChunks][8];
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < kMaxChunks; ++c) {
+        const int ch = lane + 64 * c;
+        if (ch < nch) {
+            unpack8(*reinterpret_cast<const uint4*>(src + ch * 8), x[c]);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ss += x[c][i] * x[c][i];
+        }
+    }
+    const float nrm = fmaxf(sqrtf(wave_sum(ss)), 1e-12f);
+    const float inv = 1.0f / nrm;
+#pragma unroll
+    for (int c = 0; c < kMaxChunks; ++c) {
+        const int ch = lane + 64 * c;
+        if (ch < nch) {
+            float y[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) y[i] = x[c][i] * inv;
+            float* o = out_f32 + (size_t)b * H + ch * 8;
+            *reinterpret_cast<float4*>(o) = make_float4(y[0], y[1], y[2], y[3]);
+            *reinterpret_cast<float4*>(o + 4) = make_float4(y[4], y[5], y[6], y[7]);
+            if (out_bf16) *reinterpret_cast<uint4*>(out_bf16 + (size_t)b * H + ch * 8) = pack8(y);
+        }
+    }
+}
+
+__global__ __launch_bounds__(kRowThreads) void gather_rows_kernel(const uint16_t* src, int ld, const int32_t* rows, int n,
+                                                                 int n_pad, int H, uint16_t* dst) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * (kRowThreads / 64) + (threadIdx.x >> 6);
+    if (b >= n_pad) return;
+    const int nch = H / 8;
+    for (int ch = lane; ch < nch; ch += 64) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (b < n) v = *reinterpret_cast<const uint4*>(src + (size_t)rows[b] * ld + ch * 8);
+        *reinterpret_cast<uint4*>(dst + (size_t)b * H + ch * 8) = v;
+    }
+}
+
+__global__ __launch_bounds__(kRowThreads) void head_out_kernel(const uint16_t* t, int ld, const uint16_t* w,
+                                                              const float* bias, int n, int H, float* scores,
+                                                              float* logits) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * (kRowThreads / 64) + (threadIdx.x >> 6);
+    if (b >= n) return;
+    const int nch = H / 8;
+    float acc = 0.f;
+    for (int ch = lane; ch < nch; ch += 64) {
+        float a[8], ww[8];
+        unpack8(*reinterpret_cast<const uint4*>(t + (size_t)b * ld + ch * 8), a);
+        unpack8(*reinterpret_cast<const uint4*>(w + ch * 8), ww);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc += a[i] * ww[i];
+    }
+    acc = wave_sum(acc) + bias[0];
+    if (lane == 0) {
+        if (logits) logits[b] = acc;
+        scores[b] = 1.0f / (1.0f + expf(-acc));
+    }
+}
+
+int check_h(int H) {
+    if (H <= 0 || H % 8 || H > 64 * 8 * kMaxChunks) {
+        tt_set_error("row op: hidden size %d unsupported (multiple of 8, <= %d)", H, 64 * 8 * kMaxChunks);
+        return TT_E_UNSUPPORTED;
+    }
+    return TT_OK;
+}
+
+inline dim3 row_grid(int rows) { return dim3((rows + kRowThreads / 64 - 1) / (kRowThreads / 64)); }
+
+}  // namespace
+
+int tt_layernorm_launch(const uint16_t* in, uint16_t* out, const float* gamma, const float* beta, int rows, int H,
+                        float eps, hipStream_t st) {
+    if (rows <= 0) return TT_OK;
+    if (int rc = check_h(H)) return rc;
+    hipLaunchKernelGGL(layernorm_kernel, row_grid(rows), dim3(kRowThreads), 0, st, in, out, gamma, beta, rows, H, eps);
+    TT_CHECK_LAUNCH();
+    return TT_OK;
+}
+
+int tt_embed_ln_launch(const EmbedParams& p, hipStream_t st) {
+    if (p.T <= 0) return TT_OK;
+    if (int rc = check_h(p.H)) return rc;
+    hipLaunchKernelGGL(embed_ln_kernel, row_grid(p.T), dim3(kRowThreads), 0, st, p);
+    TT_CHECK_LAUNCH();
+    return TT_OK;
+}
+
+int tt_cls_pool_l2norm_launch(const uint16_t* hidden, int ld, const int32_t* rows, int n, int H, float* out_f32,
+                              uint16_t* out_bf16, hipStream_t st) {
+    if (n <= 0) return TT_OK;
+    if (int rc = check_h(H)) return rc;
+    hipLaunchKernelGGL(cls_pool_kernel, row_grid(n), dim3(kRowThreads), 0, st, hidden, ld, rows, n, H, out_f32, out_bf16);
+    TT_CHECK_LAUNCH();
+    return TT_OK;
+}
+
+int tt_gather_rows_launch(const uint16_t* src, int ld, const int32_t* rows, int n, int n_pad, int H, uint16_t* dst,
+                          hipStream_t st) {
+    if (n_pad <= 0) return TT_OK;
+    if (int rc = check_h(H)) return rc;
+    hipLaunchKernelGGL(gather_rows_kernel, row_grid(n_pad), dim3(kRowThreads), 0, st, src, ld, rows, n, n_pad, H, dst);
+    TT_CHECK_LAUNCH();
+    return TT_OK;
+}
+
+int tt_head_out_sigmoid_launch(const uint16_t* t, int ld, const uint16_t* w, const float* bias, int n, int H,
+                               float* scores, float* logits, hipStream_t st) {
+    if (n <= 0) return TT_OK;
+    if (int rc = check_h(H)) return rc;
+    hipLaunchKernelGGL(head_out_kernel, row_grid(n), dim3(kRowThreads), 0, st, t, ld, w, bias, n, H, scores, logits);
+    TT_CHECK_LAUNCH();
+    return TT_OK;
+}

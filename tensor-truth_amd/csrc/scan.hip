@@ -350,7 +350,10 @@ static int launch_one(const ScanParams& p, int blocks, int q_tiles, hipStream_t 
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(blocks, q_tiles), dim3(kThreads), lds, stream, p);
+    {
+        TtProfScope prof(OUT == 0 ? TT_K_SCAN_FILTER : TT_K_SCAN_SAMPLE, stream);
+        hipLaunchKernelGGL(kern, dim3(blocks, q_tiles), dim3(kThreads), lds, stream, p);
+    }
     TT_CHECK_LAUNCH();
     return TT_OK;
 }

@@ -348,7 +348,10 @@ int tt_select_launch(const SelectParams& p, int n_queries, hipStream_t stream) {
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL(select_kernel, dim3(n_queries), dim3(kSelThreads), lds, stream, p);
+    {
+        TtProfScope prof(TT_K_SELECT, stream);
+        hipLaunchKernelGGL(select_kernel, dim3(n_queries), dim3(kSelThreads), lds, stream, p);
+    }
     TT_CHECK_LAUNCH();
     return TT_OK;
 }

@@ -1,0 +1,360 @@
+"""Encoder (bi-encoder / cross-encoder) host side: weight packing, varlen token packing and
+the ctypes calls into libtt_hip.so's ``tt_encoder_forward`` / ``tt_embed_pool`` /
+``tt_rerank_head``.
+
+Mirrors what the reference obtains from ``HuggingFaceEmbedding`` (built at
+``src/tensortruth/services/model_manager.py:254-260``) and ``SentenceTransformerRerank``
+(``model_manager.py:333-337``): XLM-R / BERT encoder forward -> CLS pooling + L2
+normalisation (embeddings), or -> classification head + sigmoid (rerank scores).
+Computation is bf16 with fp32 accumulation (the reference's ``torch_dtype: bfloat16``
+option, ``model_manager.py:218-229``); there is no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes
+import threading
+from ctypes import POINTER, Structure, c_float, c_int32, c_void_p
+from dataclasses import dataclass
+from typing import Dict, Iterable, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+@dataclass(frozen=True)
+class EncoderConfig:
+    """The HF config fields the hot path reads."""
+
+    arch: str = "xlmr"  # "xlmr" | "bert"
+    vocab_size: int = 250002
+    hidden: int = 1024
+    layers: int = 24
+    heads: int = 16
+    ffn: int = 4096
+    max_pos: int = 8194
+    type_vocab: int = 1
+    pad_id: int = 1
+    ln_eps: float = 1e-5
+    num_labels: int = 0
+
+    @property
+    def max_seq_len(self) -> int:
+        # XLM-R reserves positions 0..pad_id for padding
+        return self.max_pos - (self.pad_id + 1) if self.arch == "xlmr" else self.max_pos
+
+
+BGE_M3 = EncoderConfig()
+BGE_RERANKER_V2_M3 = EncoderConfig(num_labels=1)
+BGE_SMALL_EN_V15 = EncoderConfig(arch="bert", vocab_size=30522, hidden=384, layers=12, heads=12, ffn=1536,
+                                 max_pos=512, type_vocab=2, pad_id=0, ln_eps=1e-12)
+
+KNOWN_CONFIGS = {
+    "BAAI/bge-m3": BGE_M3,
+    "BAAI/bge-reranker-v2-m3": BGE_RERANKER_V2_M3,
+    "BAAI/bge-small-en-v1.5": BGE_SMALL_EN_V15,
+}
+
+
+class _LayerW(Structure):
+    _fields_ = [(n, c_void_p) for n in ("qkv_w", "qkv_b", "o_w", "o_b", "ln1_g", "ln1_b", "ffn1_w", "ffn1_b",
+                                        "ffn2_w", "ffn2_b", "ln2_g", "ln2_b")]
+
+
+class _EncW(Structure):
+    _fields_ = [
+        ("hidden", c_int32), ("layers", c_int32), ("heads", c_int32), ("ffn", c_int32), ("vocab", c_int32),
+        ("max_pos", c_int32), ("type_vocab", c_int32), ("ln_eps", c_float),
+        ("word_emb", c_void_p), ("pos_emb", c_void_p), ("type_emb", c_void_p), ("emb_ln_g", c_void_p),
+        ("emb_ln_b", c_void_p), ("layer", POINTER(_LayerW)),
+        ("cls_dense_w", c_void_p), ("cls_dense_b", c_void_p), ("cls_out_w", c_void_p), ("cls_out_b", c_void_p),
+    ]
+
+
+def _strip_prefix(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    out = {}
+    for k, v in sd.items():
+        for pre in ("roberta.", "bert.", "model.", "0.auto_model."):
+            if k.startswith(pre):
+                k = k[len(pre):]
+                break
+        out[k] = v
+    return out
+
+
+class EncoderWeights:
+    """Device-resident weights in the layout libtt_hip.so expects.
+
+    ``state`` maps HF checkpoint names (``embeddings.word_embeddings.weight``,
+    ``encoder.layer.{i}.attention.self.query.weight`` ... optional ``roberta.``/``bert.``
+    prefix, ``classifier.dense`` / ``classifier.out_proj`` for the reranker) to tensors.
+    Matrices are stored bf16, biases and LayerNorm parameters fp32.
+    """
+
+    def __init__(self, cfg: EncoderConfig, state: Dict[str, torch.Tensor], device: torch.device):
+        if device.type != "cuda":
+            raise RuntimeError("EncoderWeights need a HIP device; tensor_truth_amd has no CPU path")
+        self.cfg = cfg
+        self.device = device
+        sd = _strip_prefix(state)
+        self._keep: List[torch.Tensor] = []
+
+        def mat(name):
+            t = sd[name].to(device=device, dtype=torch.bfloat16).contiguous()
+            self._keep.append(t)
+            return t
+
+        def vec(name):
+            t = sd[name].to(device=device, dtype=torch.float32).contiguous()
+            self._keep.append(t)
+            return t
+
+        H = cfg.hidden
+        self.word = mat("embeddings.word_embeddings.weight")
+        self.pos = mat("embeddings.position_embeddings.weight")
+        self.type = mat("embeddings.token_type_embeddings.weight")
+        self.emb_g = vec("embeddings.LayerNorm.weight")
+        self.emb_b = vec("embeddings.LayerNorm.bias")
+        if self.word.shape != (cfg.vocab_size, H) or self.pos.shape != (cfg.max_pos, H):
+            raise ValueError(f"embedding tables {tuple(self.word.shape)} / {tuple(self.pos.shape)} do not match {cfg}")
+        self._layers = (_LayerW * max(cfg.layers, 1))()
+        for i in range(cfg.layers):
+            p = f"encoder.layer.{i}."
+            qkv_w = torch.cat([sd[p + f"attention.self.{n}.weight"] for n in ("query", "key", "value")], 0)
+            qkv_b = torch.cat([sd[p + f"attention.self.{n}.bias"] for n in ("query", "key", "value")], 0)
+            qkv_w = qkv_w.to(device=device, dtype=torch.bfloat16).contiguous()
+            qkv_b = qkv_b.to(device=device, dtype=torch.float32).contiguous()
+            self._keep += [qkv_w, qkv_b]
+            L = self._layers[i]
+            L.qkv_w, L.qkv_b = qkv_w.data_ptr(), qkv_b.data_ptr()
+            L.o_w, L.o_b = mat(p + "attention.output.dense.weight").data_ptr(), vec(p + "attention.output.dense.bias").data_ptr()
+            L.ln1_g = vec(p + "attention.output.LayerNorm.weight").data_ptr()
+            L.ln1_b = vec(p + "attention.output.LayerNorm.bias").data_ptr()
+            L.ffn1_w, L.ffn1_b = mat(p + "intermediate.dense.weight").data_ptr(), vec(p + "intermediate.dense.bias").data_ptr()
+            L.ffn2_w, L.ffn2_b = mat(p + "output.dense.weight").data_ptr(), vec(p + "output.dense.bias").data_ptr()
+            L.ln2_g = vec(p + "output.LayerNorm.weight").data_ptr()
+            L.ln2_b = vec(p + "output.LayerNorm.bias").data_ptr()
+        w = _EncW()
+        w.hidden, w.layers, w.heads, w.ffn = H, cfg.layers, cfg.heads, cfg.ffn
+        w.vocab, w.max_pos, w.type_vocab, w.ln_eps = cfg.vocab_size, cfg.max_pos, cfg.type_vocab, cfg.ln_eps
+        w.word_emb, w.pos_emb, w.type_emb = self.word.data_ptr(), self.pos.data_ptr(), self.type.data_ptr()
+        w.emb_ln_g, w.emb_ln_b = self.emb_g.data_ptr(), self.emb_b.data_ptr()
+        w.layer = ctypes.cast(self._layers, POINTER(_LayerW))
+        if cfg.num_labels:
+            if cfg.num_labels != 1:
+                raise ValueError("only single-label (sigmoid) cross-encoder heads are supported")
+            w.cls_dense_w = mat("classifier.dense.weight").data_ptr()
+            w.cls_dense_b = vec("classifier.dense.bias").data_ptr()
+            w.cls_out_w = mat("classifier.out_proj.weight").data_ptr()
+            w.cls_out_b = vec("classifier.out_proj.bias").data_ptr()
+        self.struct = w
+
+    def parameters(self) -> Iterable[torch.Tensor]:
+        """For ModelManager-style memory accounting (reference model_manager.py:477-507)."""
+        return iter(self._keep)
+
+    def nbytes(self) -> int:
+        return sum(t.numel() * t.element_size() for t in self._keep)
+
+
+def synthetic_state(cfg: EncoderConfig, seed: int = 0) -> Dict[str, torch.Tensor]:
+    """Seeded random-init weights of the given architecture (HF init: normal(0, 0.02);
+    LayerNorm gamma/beta perturbed).  Same generator sequence as the test oracle's
+    ``synth_weights`` so parity tests can rebuild identical weights from a seed."""
+    g = torch.Generator().manual_seed(seed)
+    n = lambda *s, std=0.02: (torch.randn(*s, generator=g) * std)  # noqa: E731
+    H, F = cfg.hidden, cfg.ffn
+    W = {
+        "embeddings.word_embeddings.weight": n(cfg.vocab_size, H),
+        "embeddings.position_embeddings.weight": n(cfg.max_pos, H),
+        "embeddings.token_type_embeddings.weight": n(cfg.type_vocab, H),
+        "embeddings.LayerNorm.weight": 1.0 + n(H, std=0.1),
+        "embeddings.LayerNorm.bias": n(H, std=0.05),
+    }
+    for i in range(cfg.layers):
+        p = f"encoder.layer.{i}."
+        for nm in ("query", "key", "value"):
+            W[p + f"attention.self.{nm}.weight"] = n(H, H)
+            W[p + f"attention.self.{nm}.bias"] = n(H)
+        W[p + "attention.output.dense.weight"] = n(H, H)
+        W[p + "attention.output.dense.bias"] = n(H)
+        W[p + "attention.output.LayerNorm.weight"] = 1.0 + n(H, std=0.1)
+        W[p + "attention.output.LayerNorm.bias"] = n(H, std=0.05)
+        W[p + "intermediate.dense.weight"] = n(F, H)
+        W[p + "intermediate.dense.bias"] = n(F)
+        W[p + "output.dense.weight"] = n(H, F)
+        W[p + "output.dense.bias"] = n(H)
+        W[p + "output.LayerNorm.weight"] = 1.0 + n(H, std=0.1)
+        W[p + "output.LayerNorm.bias"] = n(H, std=0.05)
+    if cfg.num_labels:
+        W["classifier.dense.weight"] = n(H, H)
+        W["classifier.dense.bias"] = n(H)
+        W["classifier.out_proj.weight"] = n(cfg.num_labels, H, std=0.2)
+        W["classifier.out_proj.bias"] = n(cfg.num_labels)
+    return W
+
+
+def synthetic_state_device(cfg: EncoderConfig, device: torch.device, seed: int = 0) -> Dict[str, torch.Tensor]:
+    """Random-init weights generated directly on the device (benchmarks: avoids building a
+    2.3 GB fp32 model on the host).  Not reproducible against the CPU oracle."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    n = lambda *s, std=0.02: (torch.randn(*s, generator=g, device=device) * std).to(torch.bfloat16)  # noqa: E731
+    H, F = cfg.hidden, cfg.ffn
+    W = {
+        "embeddings.word_embeddings.weight": n(cfg.vocab_size, H),
+        "embeddings.position_embeddings.weight": n(cfg.max_pos, H),
+        "embeddings.token_type_embeddings.weight": n(cfg.type_vocab, H),
+        "embeddings.LayerNorm.weight": 1.0 + n(H, std=0.1).float(),
+        "embeddings.LayerNorm.bias": n(H, std=0.05).float(),
+    }
+    for i in range(cfg.layers):
+        p = f"encoder.layer.{i}."
+        for nm in ("query", "key", "value"):
+            W[p + f"attention.self.{nm}.weight"] = n(H, H)
+            W[p + f"attention.self.{nm}.bias"] = n(H).float()
+        W[p + "attention.output.dense.weight"] = n(H, H)
+        W[p + "attention.output.dense.bias"] = n(H).float()
+        W[p + "attention.output.LayerNorm.weight"] = 1.0 + n(H, std=0.1).float()
+        W[p + "attention.output.LayerNorm.bias"] = n(H, std=0.05).float()
+        W[p + "intermediate.dense.weight"] = n(F, H)
+        W[p + "intermediate.dense.bias"] = n(F).float()
+        W[p + "output.dense.weight"] = n(H, F)
+        W[p + "output.dense.bias"] = n(H).float()
+        W[p + "output.LayerNorm.weight"] = 1.0 + n(H, std=0.1).float()
+        W[p + "output.LayerNorm.bias"] = n(H, std=0.05).float()
+    if cfg.num_labels:
+        W["classifier.dense.weight"] = n(H, H)
+        W["classifier.dense.bias"] = n(H).float()
+        W["classifier.out_proj.weight"] = n(cfg.num_labels, H, std=0.2)
+        W["classifier.out_proj.bias"] = n(cfg.num_labels).float()
+    return W
+
+
+@dataclass
+class PackedBatch:
+    """Varlen packed token batch (host arrays): see include/tt_hip.h 'Token layout'."""
+
+    ids: np.ndarray        # [n_rows] int32
+    pos: np.ndarray        # [n_rows] int32
+    types: Optional[np.ndarray]
+    seq_start: np.ndarray  # [B] int32, multiples of 8
+    seq_len: np.ndarray    # [B] int32
+    n_rows: int            # multiple of 128
+    max_len: int
+    n_tokens: int          # real tokens (sum of seq_len)
+
+
+def pack_tokens(seqs: Sequence[Sequence[int]], cfg: EncoderConfig,
+                type_ids: Optional[Sequence[Sequence[int]]] = None, max_len: Optional[int] = None) -> PackedBatch:
+    """Pack token-id sequences (already carrying their special tokens) without padding
+    tokens: sequence starts are aligned to 8 rows, the total to 128 rows.  Sequences longer
+    than ``max_len`` (default: the model's limit) are truncated on the right, as the
+    reference's tokenizer call does (``truncation=True``)."""
+    limit = cfg.max_seq_len if max_len is None else min(max_len, cfg.max_seq_len)
+    lens = np.array([min(len(s), limit) for s in seqs], dtype=np.int64)
+    if (lens <= 0).any():
+        raise ValueError("empty token sequence")
+    starts = np.zeros(len(seqs), dtype=np.int64)
+    off = 0
+    for i, n in enumerate(lens):
+        starts[i] = off
+        off += (int(n) + 7) // 8 * 8
+    n_rows = max(128, (off + 127) // 128 * 128)
+    ids = np.full(n_rows, cfg.pad_id, dtype=np.int32)
+    pos = np.zeros(n_rows, dtype=np.int32)
+    types = np.zeros(n_rows, dtype=np.int32) if type_ids is not None else None
+    pos_off = cfg.pad_id + 1 if cfg.arch == "xlmr" else 0
+    for i, s in enumerate(seqs):
+        n, st = int(lens[i]), int(starts[i])
+        ids[st:st + n] = np.asarray(s[:n], dtype=np.int32)
+        pos[st:st + n] = np.arange(n, dtype=np.int32) + pos_off
+        if types is not None:
+            types[st:st + n] = np.asarray(type_ids[i][:n], dtype=np.int32)
+    if ids.min() < 0 or ids.max() >= cfg.vocab_size:
+        raise ValueError("token id outside the vocabulary")
+    return PackedBatch(ids, pos, types, starts.astype(np.int32), lens.astype(np.int32), int(n_rows),
+                       int(lens.max()), int(lens.sum()))
+
+
+class _Scratch(threading.local):
+    def __init__(self):
+        self.bufs = {}
+
+    def get(self, key, device, nbytes):
+        buf = self.bufs.get(key)
+        if buf is None or buf.numel() < nbytes + 256 or buf.device != device:
+            buf = torch.empty(nbytes + 256, dtype=torch.uint8, device=device)
+            self.bufs[key] = buf
+        base = (buf.data_ptr() + 255) // 256 * 256
+        return buf, base
+
+
+_scratch = _Scratch()
+
+
+class Encoder:
+    """Runs the HIP encoder for one set of weights."""
+
+    def __init__(self, weights: EncoderWeights):
+        self.w = weights
+        self.cfg = weights.cfg
+        self.device = weights.device
+        self.lib = _lib.load_library()
+
+    def _to_dev(self, arr: np.ndarray) -> torch.Tensor:
+        return torch.from_numpy(arr).to(self.device, non_blocking=True)
+
+    def forward_packed(self, batch: PackedBatch) -> Tuple[torch.Tensor, torch.Tensor]:
+        """-> (hidden [n_rows, H] bf16, cls_rows [B] int32 device tensor)."""
+        lib, dev, H = self.lib, self.device, self.cfg.hidden
+        ids, pos = self._to_dev(batch.ids), self._to_dev(batch.pos)
+        types = self._to_dev(batch.types) if batch.types is not None else None
+        starts, lens = self._to_dev(batch.seq_start), self._to_dev(batch.seq_len)
+        hidden = torch.empty((batch.n_rows, H), dtype=torch.bfloat16, device=dev)
+        need = lib.tt_encoder_workspace_bytes(ctypes.byref(self.w.struct), batch.n_rows)
+        ws, base = _scratch.get("enc", dev, need)
+        with torch.cuda.device(dev):
+            rc = lib.tt_encoder_forward(ctypes.byref(self.w.struct), ids.data_ptr(), pos.data_ptr(),
+                                        types.data_ptr() if types is not None else None, starts.data_ptr(),
+                                        lens.data_ptr(), len(batch.seq_len), batch.n_rows, batch.max_len,
+                                        hidden.data_ptr(), base, need, torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(rc, "tt_encoder_forward")
+        return hidden, starts
+
+    def embed_packed(self, batch: PackedBatch) -> Tuple[torch.Tensor, torch.Tensor]:
+        """-> (embeddings fp32 [B, H] L2-normalised, same rounded to bf16)."""
+        hidden, cls_rows = self.forward_packed(batch)
+        B, H = len(batch.seq_len), self.cfg.hidden
+        out = torch.empty((B, H), dtype=torch.float32, device=self.device)
+        out16 = torch.empty((B, H), dtype=torch.bfloat16, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = self.lib.tt_embed_pool(hidden.data_ptr(), H, cls_rows.data_ptr(), B, H, out.data_ptr(), out16.data_ptr(),
+                                        torch.cuda.current_stream(self.device).cuda_stream)
+        _lib.check(rc, "tt_embed_pool")
+        return out, out16
+
+    def rerank_packed(self, batch: PackedBatch, want_logits: bool = False):
+        """-> sigmoid scores fp32 [B] (and logits)."""
+        if not self.cfg.num_labels:
+            raise RuntimeError("these weights carry no classification head")
+        hidden, cls_rows = self.forward_packed(batch)
+        B, H = len(batch.seq_len), self.cfg.hidden
+        scores = torch.empty(B, dtype=torch.float32, device=self.device)
+        logits = torch.empty(B, dtype=torch.float32, device=self.device) if want_logits else None
+        n_pad = (B + 127) // 128 * 128
+        need = 2 * ((n_pad * H * 2 + 255) // 256 * 256)
+        ws, base = _scratch.get("head", self.device, need)
+        with torch.cuda.device(self.device):
+            rc = self.lib.tt_rerank_head(ctypes.byref(self.w.struct), hidden.data_ptr(), cls_rows.data_ptr(), B,
+                                         scores.data_ptr(), logits.data_ptr() if want_logits else None, base, need,
+                                         torch.cuda.current_stream(self.device).cuda_stream)
+        _lib.check(rc, "tt_rerank_head")
+        return (scores, logits) if want_logits else scores
+
+    # -- convenience over python lists -------------------------------------------------------
+    def embed(self, seqs, type_ids=None, max_len=None):
+        return self.embed_packed(pack_tokens(seqs, self.cfg, type_ids, max_len))
+
+    def rerank(self, seqs, max_len: Optional[int] = 512, want_logits: bool = False):
+        return self.rerank_packed(pack_tokens(seqs, self.cfg, None, max_len), want_logits)

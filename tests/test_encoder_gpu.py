@@ -1,0 +1,239 @@
+"""GPU parity: encoder kernels (GEMM, LayerNorm, attention, full forward, pooling, rerank head)
+through the C ABI against the CPU oracle.
+
+Tolerances (bf16 compute, fp32 accumulate -- the reference's ``torch_dtype: bfloat16`` mode):
+  * single kernels: one bf16 rounding of the fp32 reference -> |err| <= 2^-7 |ref| + 2e-3;
+  * whole forward vs the oracle emulating the same bf16 rounding points: hidden within
+    2^-5 |ref| + 3e-2 for >= 99.9 % of the elements (a few bf16 ulps), max 0.25, mean abs error < 6e-3, embeddings cosine >= 0.9995;
+  * embeddings vs the fp32 oracle / transformers golden: cosine >= 0.999, max-abs <= 2e-3 per
+    unit-norm component;
+  * rerank sigmoid scores: |err| <= 1.5e-2 absolute vs fp32 (looser bound stated for bf16).
+"""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import encoder as oe
+
+pytestmark = pytest.mark.gpu
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _bf(x):
+    return x.to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("m,n,k", [(128, 128, 64), (256, 384, 384), (384, 1152, 384), (128, 1536, 384),
+                                   (512, 1024, 1024), (256, 4096, 1024), (256, 1024, 4096)])
+@pytest.mark.parametrize("epi", [0, 1, 2, 3])
+def test_gemm_epilogues(dev, built_lib, m, n, k, epi):
+    from tensor_truth_amd import _lib
+
+    lib = _lib.load_library()
+    g = torch.Generator().manual_seed(m + n + k + epi)
+    a = _bf(torch.randn(m, k, generator=g))
+    w = _bf(torch.randn(n, k, generator=g) * 0.05)
+    bias = torch.randn(n, generator=g) * 0.1
+    res = _bf(torch.randn(m, n, generator=g))
+    ref = a.float() @ w.float().T + bias
+    if epi == 1:
+        ref = oe.gelu_erf(ref)
+    elif epi == 2:
+        ref = ref + res.float()
+    elif epi == 3:
+        ref = torch.tanh(ref)
+    a_d, w_d, b_d, r_d = a.to(dev), w.to(dev), bias.to(dev), res.to(dev)
+    c_d = torch.empty(m, n, dtype=torch.bfloat16, device=dev)
+    rc = lib.tt_gemm_bf16(a_d.data_ptr(), w_d.data_ptr(), b_d.data_ptr(), r_d.data_ptr() if epi == 2 else None,
+                          c_d.data_ptr(), m, n, k, epi, _stream())
+    _lib.check(rc, "tt_gemm_bf16")
+    torch.cuda.synchronize()
+    got = c_d.float().cpu()
+    err = (got - ref).abs()
+    assert (err <= 2 ** -7 * ref.abs() + 2e-3).all(), f"max err {err.max().item()}"
+
+
+def test_gemm_rejects_bad_shapes(dev, built_lib):
+    from tensor_truth_amd import _lib
+
+    lib = _lib.load_library()
+    t = torch.zeros(128, 128, dtype=torch.bfloat16, device=dev)
+    b = torch.zeros(128, device=dev)
+    rc = lib.tt_gemm_bf16(t.data_ptr(), t.data_ptr(), b.data_ptr(), None, t.data_ptr(), 100, 128, 128, 0, _stream())
+    assert rc != 0 and b"multiples" in lib.tt_last_error()
+
+
+@pytest.mark.parametrize("rows,h,eps", [(5, 384, 1e-12), (1000, 1024, 1e-5), (129, 128, 1e-5)])
+def test_layernorm(dev, built_lib, rows, h, eps):
+    from tensor_truth_amd import _lib
+
+    lib = _lib.load_library()
+    g = torch.Generator().manual_seed(rows)
+    x = _bf(torch.randn(rows, h, generator=g) * 3 + 0.5)
+    gamma = 1 + 0.1 * torch.randn(h, generator=g)
+    beta = 0.1 * torch.randn(h, generator=g)
+    ref = oe.layer_norm(x.float(), gamma, beta, eps)
+    x_d, g_d, b_d = x.to(dev), gamma.to(dev), beta.to(dev)
+    y_d = torch.empty_like(x_d)
+    _lib.check(lib.tt_layernorm_bf16(x_d.data_ptr(), y_d.data_ptr(), g_d.data_ptr(), b_d.data_ptr(), rows, h, eps,
+                                     _stream()), "ln")
+    torch.cuda.synchronize()
+    err = (y_d.float().cpu() - ref).abs()
+    assert (err <= 2 ** -7 * ref.abs() + 2e-3).all(), err.max().item()
+
+
+@pytest.mark.parametrize("heads,dh,lens", [(16, 64, [16, 9, 5, 12]), (12, 32, [16, 7, 11, 3]),
+                                           (4, 64, [300, 64, 65, 129, 1]), (2, 32, [513, 128]),
+                                           (2, 64, [1100])])
+def test_attention_varlen(dev, built_lib, heads, dh, lens):
+    from tensor_truth_amd import _lib
+
+    lib = _lib.load_library()
+    H = heads * dh
+    g = torch.Generator().manual_seed(sum(lens) + heads)
+    starts, off = [], 0
+    for n in lens:
+        starts.append(off)
+        off += (n + 7) // 8 * 8
+    T = (off + 127) // 128 * 128
+    q = _bf(torch.randn(T, H, generator=g))
+    k = _bf(torch.randn(T, H, generator=g))
+    v = _bf(torch.randn(T, H, generator=g))
+    qk = torch.cat([q, k], 1).contiguous()
+    vt = v.T.contiguous()
+    out = torch.zeros(T, H, dtype=torch.bfloat16, device=dev)
+    st_d = torch.tensor(starts, dtype=torch.int32, device=dev)
+    ln_d = torch.tensor(lens, dtype=torch.int32, device=dev)
+    qk_d, vt_d = qk.to(dev), vt.to(dev)
+    _lib.check(lib.tt_attention_varlen(qk_d.data_ptr(), 2 * H, 0, H, vt_d.data_ptr(), T, out.data_ptr(), H,
+                                       st_d.data_ptr(), ln_d.data_ptr(), len(lens), heads, dh, max(lens), _stream()),
+               "attention")
+    torch.cuda.synchronize()
+    got = out.float().cpu()
+    for s0, n in zip(starts, lens):
+        qq = q[s0:s0 + n].float().view(n, heads, dh).transpose(0, 1)
+        kk = k[s0:s0 + n].float().view(n, heads, dh).transpose(0, 1)
+        vv = v[s0:s0 + n].float().view(n, heads, dh).transpose(0, 1)
+        p = torch.softmax(qq @ kk.transpose(-1, -2) / math.sqrt(dh), dim=-1)
+        ref = (p @ vv).transpose(0, 1).reshape(n, H)
+        err = (got[s0:s0 + n] - ref).abs()
+        # P is rounded to bf16 before the PV product: error ~ 2^-8 * sum|p v|
+        assert err.max().item() < 2e-2, f"len {n}: max err {err.max().item()}"
+        assert err.mean().item() < 2e-3
+
+
+def _load_golden(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, name))
+    cfg_o = oe.EncoderConfig(**json.loads(str(z["cfg"])))
+    return z, cfg_o
+
+
+def _product_cfg(cfg_o):
+    from tensor_truth_amd.encoder import EncoderConfig
+
+    return EncoderConfig(**cfg_o.__dict__)
+
+
+def _seqs_from_padded(ids, mask):
+    return [ids[b, : int(mask[b].sum())].tolist() for b in range(ids.shape[0])]
+
+
+@pytest.mark.parametrize("name", ["xlmr_encoder.npz", "bert_encoder.npz"])
+def test_encoder_forward_vs_golden_and_oracle(dev, built_lib, golden_dir, name):
+    from tensor_truth_amd.encoder import Encoder, EncoderWeights, pack_tokens
+
+    z, cfg_o = _load_golden(golden_dir, name)
+    W = oe.synth_weights(cfg_o, seed=int(z["seed"]))
+    Wb = {k: v.to(torch.bfloat16) for k, v in W.items()}
+    ids, mask = torch.from_numpy(z["ids"]), torch.from_numpy(z["mask"])
+    type_ids = torch.from_numpy(z["type_ids"]) if "type_ids" in z.files else None
+    seqs = _seqs_from_padded(ids, mask)
+    types = None if type_ids is None else [type_ids[b, : len(s)].tolist() for b, s in enumerate(seqs)]
+    cfg = _product_cfg(cfg_o)
+    enc = Encoder(EncoderWeights(cfg, W, dev))
+    batch = pack_tokens(seqs, cfg, types)
+    hidden, _ = enc.forward_packed(batch)
+    emb, emb16 = enc.embed_packed(batch)
+    torch.cuda.synchronize()
+    hidden, emb = hidden.float().cpu(), emb.cpu()
+    # (1) vs the oracle emulating the kernel's bf16 rounding points, bf16 weights
+    want_h = oe.encoder_forward(ids, mask, Wb, cfg_o, emulate_bf16=True, type_ids=type_ids)
+    for b, s in enumerate(seqs):
+        st = int(batch.seq_start[b])
+        ref = want_h[b, : len(s)]
+        err = (hidden[st:st + len(s)] - ref).abs()
+        # a few bf16 ulps of the value (ulp = 2^-8 |x|) plus an absolute floor
+        # (a value sitting on a bf16 rounding boundary before a LayerNorm can flip by one
+        # ulp of the pre-LN magnitude, so the bound is on the 99.9th percentile + a hard cap)
+        bad = (err > 2 ** -5 * ref.abs() + 3e-2).float().mean().item()
+        assert bad < 1e-3 and err.max().item() < 0.25, f"seq {b}: {bad:.2e} outliers, max err {err.max().item()}"
+        assert err.mean().item() < 6e-3
+    want_e = oe.cls_pool_normalize(want_h)
+    assert ((emb * want_e).sum(1) >= 0.9995).all()
+    # (2) vs the transformers golden (fp32 weights and math)
+    gold = torch.from_numpy(z["emb"])
+    cos = (emb * gold).sum(1)
+    assert (cos >= 0.999).all(), cos
+    assert (emb - gold).abs().max().item() <= 2e-3 * math.sqrt(1024 / cfg.hidden) * 2
+    assert torch.allclose(emb.norm(dim=1), torch.ones(emb.shape[0]), atol=1e-3)
+    assert torch.equal(emb16.cpu(), emb.to(torch.bfloat16))
+
+
+def test_rerank_head_vs_golden(dev, built_lib, golden_dir):
+    from tensor_truth_amd.encoder import Encoder, EncoderWeights, pack_tokens
+
+    z, cfg_o = _load_golden(golden_dir, "xenc_head.npz")
+    W = oe.synth_weights(cfg_o, seed=int(z["seed"]))
+    ids, mask = torch.from_numpy(z["ids"]), torch.from_numpy(z["mask"])
+    seqs = _seqs_from_padded(ids, mask)
+    cfg = _product_cfg(cfg_o)
+    enc = Encoder(EncoderWeights(cfg, W, dev))
+    scores, logits = enc.rerank(seqs, want_logits=True)
+    torch.cuda.synchronize()
+    scores, logits = scores.cpu(), logits.cpu()
+    Wb = {k: v.to(torch.bfloat16) for k, v in W.items()}
+    want_emul = oe.rerank_logits(ids, mask, Wb, cfg_o, emulate_bf16=True)
+    # the synthetic head (out_proj std 0.2 over 1024 inputs) amplifies bf16 noise ~6x
+    assert (logits - want_emul).abs().max().item() < 1e-1
+    gold_s = torch.from_numpy(z["scores"])
+    assert (scores - gold_s).abs().max().item() < 1.5e-2  # stated bf16 bound
+    assert torch.allclose(scores, torch.sigmoid(logits), atol=1e-6)
+    # order of the pairs is preserved wherever the fp32 scores are separated by the tolerance
+    order_g = torch.argsort(gold_s, descending=True)
+    gaps = (gold_s[order_g][:-1] - gold_s[order_g][1:])
+    if (gaps > 2e-2).all():
+        assert torch.equal(torch.argsort(scores, descending=True), order_g)
+
+
+def test_encoder_longer_sequences_and_truncation(dev, built_lib):
+    """Ragged 4-layer XLM-R-shaped model with sequences crossing the 64/128 tile sizes."""
+    from tensor_truth_amd.encoder import Encoder, EncoderConfig, EncoderWeights, pack_tokens
+
+    cfg_o = oe.EncoderConfig(arch="xlmr", vocab_size=2000, hidden=256, layers=3, heads=4, ffn=512, max_pos=300,
+                             type_vocab=1, pad_id=1, ln_eps=1e-5)
+    cfg = EncoderConfig(**cfg_o.__dict__)
+    W = oe.synth_weights(cfg_o, seed=5)
+    Wb = {k: v.to(torch.bfloat16) for k, v in W.items()}
+    lens = [200, 65, 1 + 128, 33, 298, 400]  # the last one is truncated to max_seq_len = 298
+    g = torch.Generator().manual_seed(1)
+    seqs = [torch.randint(4, 2000, (n,), generator=g).tolist() for n in lens]
+    enc = Encoder(EncoderWeights(cfg, W, dev))
+    emb, _ = enc.embed(seqs)
+    torch.cuda.synchronize()
+    L = cfg.max_seq_len
+    ids = torch.full((len(seqs), L), cfg.pad_id, dtype=torch.int64)
+    mask = torch.zeros(len(seqs), L, dtype=torch.int64)
+    for b, s in enumerate(seqs):
+        n = min(len(s), L)
+        ids[b, :n] = torch.tensor(s[:n])
+        mask[b, :n] = 1
+    want = oe.embed(ids, mask, Wb, cfg_o, emulate_bf16=True)
+    cos = (emb.cpu() * want).sum(1)
+    assert (cos >= 0.9995).all(), cos

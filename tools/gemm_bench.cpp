@@ -1,0 +1,61 @@
+// Standalone timing of tt_gemm_bf16 on the encoder-layer shapes (no torch).
+//   ./gemm_bench [M] [iters]
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "../include/tt_hip.h"
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+__device__ inline uint32_t hash32(uint64_t x) {
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+    return (uint32_t)x;
+}
+__global__ void fill_bf16(uint16_t* p, size_t n, uint64_t seed, float scale) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        uint32_t h = hash32(i * 2654435761ULL + seed);
+        float u = ((h & 0xFFFF) + (h >> 16)) * (1.0f / 65536.0f) - 1.0f;   // [-1, 1) triangular
+        uint32_t b = __float_as_uint(u * scale);
+        b += 0x7FFF + ((b >> 16) & 1);
+        p[i] = (uint16_t)(b >> 16);
+    }
+}
+
+int main(int argc, char** argv) {
+    int M = argc > 1 ? atoi(argv[1]) : 16384;
+    int iters = argc > 2 ? atoi(argv[2]) : 20;
+    struct Shape { int n, k, epi; const char* name; } shapes[] = {
+        {3072, 1024, 0, "qkv(bias)"}, {1024, 1024, 2, "o-proj(+res)"}, {4096, 1024, 1, "ffn-up(gelu)"},
+        {1024, 4096, 2, "ffn-down(+res)"}, {1152, 384, 0, "small qkv"}, {1536, 384, 1, "small ffn-up"}};
+    uint16_t *a, *w, *c, *r;
+    float* bias;
+    size_t maxA = (size_t)M * 4096, maxW = (size_t)4096 * 4096, maxC = (size_t)M * 4096;
+    CK(hipMalloc(&a, maxA * 2)); CK(hipMalloc(&w, maxW * 2)); CK(hipMalloc(&c, maxC * 2)); CK(hipMalloc(&r, maxC * 2));
+    CK(hipMalloc(&bias, 4096 * 4));
+    fill_bf16<<<2048, 256>>>(a, maxA, 1, 1.0f);
+    fill_bf16<<<2048, 256>>>(w, maxW, 2, 0.05f);
+    fill_bf16<<<2048, 256>>>(r, maxC, 3, 1.0f);
+    CK(hipMemset(bias, 0, 4096 * 4));
+    CK(hipDeviceSynchronize());
+    hipStream_t st; CK(hipStreamCreate(&st));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    printf("gemm_bench: M=%d iters=%d (uniform random operands)\n", M, iters);
+    for (auto& s : shapes) {
+        for (int i = 0; i < 3; ++i) {
+            int rc = tt_gemm_bf16(a, w, bias, s.epi == 2 ? r : nullptr, c, M, s.n, s.k, s.epi, st);
+            if (rc) { fprintf(stderr, "rc=%d %s\n", rc, tt_last_error()); return 1; }
+        }
+        CK(hipStreamSynchronize(st));
+        CK(hipEventRecord(e0, st));
+        for (int i = 0; i < iters; ++i) tt_gemm_bf16(a, w, bias, s.epi == 2 ? r : nullptr, c, M, s.n, s.k, s.epi, st);
+        CK(hipEventRecord(e1, st));
+        CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= iters;
+        double fl = 2.0 * M * s.n * s.k;
+        printf("%-16s M=%d N=%d K=%d  %.3f ms  %.1f TF/s\n", s.name, M, s.n, s.k, ms, fl / (ms * 1e-3) / 1e12);
+    }
+    return 0;
+}
