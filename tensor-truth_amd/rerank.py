@@ -1,0 +1,82 @@
+"""Cross-encoder rerank postprocessor with the ``SentenceTransformerRerank`` surface.
+
+Stands in for the object built at ``src/tensortruth/services/model_manager.py:333-337`` and
+called at ``services/rag_service.py:343-346,617-620`` (keyword ``query_bundle``) and
+``utils/web_search.py:155,222`` (positional).  Behaviour restated from llama-index /
+sentence-transformers: pairs ``(query_str, node.get_content(EMBED))``,
+truncation to 512, sigmoid scores, ``node.score = float(score)``, sort desc, ``[:top_n]``;
+empty input -> ``[]``; missing query -> ``ValueError``.
+"""
+from __future__ import annotations
+
+from typing import Any, Dict, List, Optional, Sequence
+
+import torch
+
+from . import weights as _weights
+from .encoder import Encoder, EncoderWeights, pack_tokens
+from .schema import MetadataMode, NodeWithScore
+from .tokenization import load_tokenizer
+
+
+class HipSentenceTransformerRerank:
+    def __init__(self, model: str = "BAAI/bge-reranker-v2-m3", top_n: int = 2, device: Optional[str] = None,
+                 keep_retrieval_score: bool = False, model_kwargs: Optional[Dict[str, Any]] = None,
+                 max_length: int = 512, batch_pairs: int = 1024, **_ignored):
+        dev = torch.device("cuda" if device in (None, "cuda") else device)
+        if dev.type != "cuda":
+            raise RuntimeError(f"device '{device}': tensor_truth_amd runs on HIP devices only (no CPU path)")
+        if dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+        self.model_name = model
+        self.top_n = top_n
+        self.device = dev
+        self.keep_retrieval_score = keep_retrieval_score
+        self.max_length = max_length
+        self.batch_pairs = batch_pairs
+        cfg, state, mdir = _weights.resolve(model, model_kwargs, dev, want_head=True)
+        if not cfg.num_labels:
+            raise ValueError(f"'{model}' has no classification head (not a cross-encoder)")
+        self.config = cfg
+        self.model = EncoderWeights(cfg, state, dev)    # `.model` is what the reference's memory accounting reads
+        self._encoder = Encoder(self.model)
+        self._tokenizer = (model_kwargs or {}).get("tokenizer") or load_tokenizer(mdir, cfg.arch, cfg.vocab_size)
+
+    # ---- token-id level ---------------------------------------------------------------------------
+    def score_token_pairs(self, pair_ids: Sequence[Sequence[int]]) -> torch.Tensor:
+        """Sigmoid relevance of already tokenised ``<s> q </s></s> p </s>`` sequences, fp32 [n] (device)."""
+        outs = []
+        for lo in range(0, len(pair_ids), self.batch_pairs):
+            outs.append(self._encoder.rerank_packed(pack_tokens(pair_ids[lo:lo + self.batch_pairs], self.config,
+                                                                None, self.max_length)))
+        return torch.cat(outs) if outs else torch.empty(0, device=self.device)
+
+    def predict(self, pairs: Sequence[Sequence[str]]) -> List[float]:
+        """CrossEncoder.predict: [(query, passage), ...] -> sigmoid scores."""
+        ids = [self._tokenizer.encode_pair(q, p, self.max_length)[0] for q, p in pairs]
+        return self.score_token_pairs(ids).cpu().tolist()
+
+    # ---- postprocessor surface ------------------------------------------------------------------------
+    def postprocess_nodes(self, nodes: List[NodeWithScore], query_bundle=None, query_str: Optional[str] = None):
+        if query_bundle is None and query_str is None:
+            raise ValueError("Missing query bundle in extra info.")
+        q = query_str if query_bundle is None else query_bundle.query_str
+        if len(nodes) == 0:
+            return []
+        texts = [n.node.get_content(metadata_mode=MetadataMode.EMBED) for n in nodes]
+        scores = self.predict([(q, t) for t in texts])
+        for n, s in zip(nodes, scores):
+            if self.keep_retrieval_score:
+                n.node.metadata["retrieval_score"] = n.score
+            n.score = float(s)
+        return sorted(nodes, key=lambda x: -x.score if x.score else 0)[: self.top_n]
+
+    _postprocess_nodes = postprocess_nodes
+
+    # ---- core/ranking.py Reranker protocol (reference: core/ranking.py:16-32) ---------------------------
+    def rerank(self, query: str, documents: Sequence[str], top_n: Optional[int] = None):
+        scores = self.predict([(query, d) for d in documents])
+        order = sorted(range(len(documents)), key=lambda i: -scores[i])
+        if top_n is not None:
+            order = order[:top_n]
+        return [{"index": i, "relevance_score": float(scores[i])} for i in order]

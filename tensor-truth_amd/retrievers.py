@@ -1,0 +1,189 @@
+"""Host-side retriever logic around the GPU retriever: multi-index fan-out + balancing,
+auto-merging, similarity cutoff.  Pure Python (lists of at most a few hundred nodes) -- these
+restate the reference's control flow so the HIP retriever drops into the same pipeline.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict, defaultdict
+from concurrent.futures import ThreadPoolExecutor, as_completed
+from functools import lru_cache
+from typing import Dict, List, Optional
+
+from .schema import NodeWithScore, QueryBundle, TextNode, as_query_bundle
+
+
+def similarity_top_k_for(reranker_top_n: int) -> int:
+    """Candidate-pool size per index (reference: rag_engine.py:592-593)."""
+    return max(5, reranker_top_n * 2)
+
+
+def _node_metadata(node):
+    inner = getattr(node, "node", None)
+    if inner is not None and isinstance(getattr(inner, "metadata", None), dict):
+        return inner.metadata
+    md = getattr(node, "metadata", None)
+    return md if isinstance(md, dict) else None
+
+
+class MultiIndexRetriever:
+    """Queries several index retrievers concurrently and balances their contributions.
+
+    Behaviour of the reference class (``src/tensortruth/rag_engine.py:368-527``): one task per
+    retriever on a thread pool (``min(len, 8)`` workers), results concatenated in completion
+    order, every node tagged ``metadata["_source_index"] = idx``; a failing retriever is
+    reported and skipped; with more than one retriever and ``balance_strategy ==
+    "top_k_per_index"`` each index keeps its first ``max(1, total // n_indexes)`` nodes and
+    the union is re-sorted by score (missing score = 0.0) descending; an LRU cache keyed on
+    the query string (default 128 entries) short-circuits repeated queries.
+    """
+
+    def __init__(self, retrievers: List, max_workers: Optional[int] = None, enable_cache: bool = True,
+                 cache_size: int = 128, balance_strategy: str = "top_k_per_index") -> None:
+        self.retrievers = retrievers
+        self.max_workers = max_workers or min(len(retrievers), 8)
+        self.enable_cache = enable_cache
+        self.balance_strategy = balance_strategy
+        if enable_cache:
+            self._retrieve_cached = lru_cache(maxsize=cache_size)(self._retrieve_impl)
+        else:
+            self._retrieve_cached = self._retrieve_impl
+
+    def _retrieve_impl(self, query_text: str):
+        bundle = QueryBundle(query_str=query_text)
+        combined = []
+        with ThreadPoolExecutor(max_workers=max(1, self.max_workers)) as pool:
+            futures = {pool.submit(r.retrieve, bundle): i for i, r in enumerate(self.retrievers)}
+            for fut in as_completed(futures):
+                try:
+                    nodes = fut.result()
+                except Exception as exc:  # noqa: BLE001 - degrade like the reference (rag_engine.py:453-455)
+                    print(f"Retriever failed: {exc}")
+                    continue
+                for n in nodes:
+                    md = _node_metadata(n)
+                    if md is not None:
+                        md["_source_index"] = futures[fut]
+                combined.extend(nodes)
+        if len(self.retrievers) > 1 and self.balance_strategy == "top_k_per_index":
+            combined = self._balance_top_k_per_index(combined)
+        return combined
+
+    def _balance_top_k_per_index(self, nodes: List[NodeWithScore]) -> List[NodeWithScore]:
+        groups: Dict[int, list] = defaultdict(list)
+        for n in nodes:
+            md = _node_metadata(n)
+            groups[md.get("_source_index", 0) if md else 0].append(n)
+        if not groups:
+            return []
+        limit = max(1, len(nodes) // len(groups))
+        kept = []
+        for members in groups.values():
+            kept.extend(members[:limit])
+        kept.sort(key=lambda n: n.score if n.score else 0.0, reverse=True)
+        return kept
+
+    def retrieve(self, query) -> List[NodeWithScore]:
+        return self._retrieve(as_query_bundle(query))
+
+    def _retrieve(self, query_bundle) -> List[NodeWithScore]:
+        return self._retrieve_cached(query_bundle.query_str)
+
+    def clear_cache(self) -> None:
+        if self.enable_cache and hasattr(self._retrieve_cached, "cache_clear"):
+            self._retrieve_cached.cache_clear()
+
+
+class AutoMergingRetriever:
+    """Merges retrieved leaves into their parent when most of the parent's children were hit.
+
+    Restates llama-index ``AutoMergingRetriever`` as the reference builds it
+    (``rag_engine.py:641-643``): ``simple_ratio_thresh = 0.5``; loop
+    {fill in single gaps between retrieved neighbours (score = mean of the two), replace
+    children by their parent when ``hits / len(parent.children) > ratio`` (score = mean of the
+    children)} until nothing changes; final sort by score descending.  ``docstore`` maps node id
+    -> node with ``parent_id / child_ids / prev_id / next_id`` links.
+    """
+
+    def __init__(self, vector_retriever, docstore, simple_ratio_thresh: float = 0.5, verbose: bool = False):
+        self._vector_retriever = vector_retriever
+        self._docstore = docstore.docstore if hasattr(docstore, "docstore") and isinstance(
+            getattr(docstore, "docstore"), dict) else docstore
+        self._ratio = simple_ratio_thresh
+        self._verbose = verbose
+
+    def _get(self, node_id):
+        ds = self._docstore
+        return ds.get(node_id) if hasattr(ds, "get") else ds[node_id]
+
+    def _merge_parents(self, nodes: List[NodeWithScore]):
+        by_parent: Dict[str, List[NodeWithScore]] = OrderedDict()
+        for n in nodes:
+            pid = getattr(n.node, "parent_id", None)
+            if pid is not None:
+                by_parent.setdefault(pid, []).append(n)
+        drop, add, changed = set(), [], False
+        for pid, hits in by_parent.items():
+            parent = self._get(pid)
+            if parent is None:
+                continue
+            children = list(getattr(parent, "child_ids", []) or [])
+            if not children:
+                continue
+            if len(hits) / len(children) > self._ratio:
+                drop.update(h.node.id_ for h in hits)
+                score = sum((h.score or 0.0) for h in hits) / len(hits)
+                add.append(NodeWithScore(node=parent, score=score))
+                changed = True
+        out = [n for n in nodes if n.node.id_ not in drop]
+        present = {n.node.id_ for n in out}
+        for a in add:
+            if a.node.id_ not in present:
+                out.append(a)
+                present.add(a.node.id_)
+        return out, changed
+
+    def _fill_in(self, nodes: List[NodeWithScore]):
+        out, changed = [], False
+        present = {n.node.id_ for n in nodes}
+        for i, cur in enumerate(nodes):
+            out.append(cur)
+            if i + 1 >= len(nodes):
+                continue
+            nxt = nodes[i + 1]
+            gap = getattr(cur.node, "next_id", None)
+            if gap is not None and gap == getattr(nxt.node, "prev_id", None) and gap not in present:
+                mid = self._get(gap)
+                if mid is not None:
+                    out.append(NodeWithScore(node=mid, score=((cur.score or 0.0) + (nxt.score or 0.0)) / 2))
+                    present.add(gap)
+                    changed = True
+        return out, changed
+
+    def _try_merging(self, nodes):
+        nodes, c1 = self._fill_in(nodes)
+        nodes, c2 = self._merge_parents(nodes)
+        return nodes, (c1 or c2)
+
+    def retrieve(self, query) -> List[NodeWithScore]:
+        nodes = self._vector_retriever.retrieve(as_query_bundle(query))
+        nodes, changed = self._try_merging(nodes)
+        while changed:
+            nodes, changed = self._try_merging(nodes)
+        nodes.sort(key=lambda n: n.score if n.score is not None else 0.0, reverse=True)
+        return nodes
+
+    _retrieve = retrieve
+
+
+class SimilarityPostprocessor:
+    """Drops nodes scoring below ``similarity_cutoff`` (reference wiring: rag_engine.py:717-726)."""
+
+    def __init__(self, similarity_cutoff: Optional[float] = None):
+        self.similarity_cutoff = similarity_cutoff
+
+    def postprocess_nodes(self, nodes, query_bundle=None, query_str=None):
+        if self.similarity_cutoff is None:
+            return list(nodes)
+        return [n for n in nodes if n.score is not None and n.score >= self.similarity_cutoff]
+
+    _postprocess_nodes = postprocess_nodes

@@ -1,0 +1,95 @@
+"""Tokenizer adapters for the encoders.
+
+The reference tokenizes inside sentence-transformers with the model's HF tokenizer
+(Rust ``tokenizers``).  ``HFTokenizer`` wraps a local ``tokenizer.json`` when
+one exists; ``HashTokenizer`` is a deterministic stand-in for environments without tokenizer
+files (the build container and the benchmark box have no network): it produces ids in the
+model's vocabulary range with the model's special-token layout, which is all the kernels
+and the parity tests need.  The kernel boundary itself is token-ids-in.
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import re
+from typing import List, Optional, Sequence, Tuple
+
+_WORD = re.compile(r"\w+|[^\w\s]", re.UNICODE)
+
+
+class SpecialTokens:
+    def __init__(self, arch: str):
+        if arch == "xlmr":
+            self.bos, self.pad, self.eos, self.unk, self.first_free = 0, 1, 2, 3, 4
+            self.pair_sep = [2, 2]          # <s> A </s></s> B </s>
+        else:
+            self.bos, self.pad, self.eos, self.unk, self.first_free = 101, 0, 102, 100, 1000
+            self.pair_sep = [102]           # [CLS] A [SEP] B [SEP]
+
+
+class HashTokenizer:
+    """Word-level hashing tokenizer (deterministic, vocabulary-range ids)."""
+
+    def __init__(self, arch: str, vocab_size: int):
+        self.arch = arch
+        self.vocab_size = vocab_size
+        self.sp = SpecialTokens(arch)
+
+    def _ids(self, text: str) -> List[int]:
+        lo = self.sp.first_free
+        span = self.vocab_size - lo
+        out = []
+        for w in _WORD.findall(text):
+            h = int.from_bytes(hashlib.blake2b(w.encode("utf-8"), digest_size=8).digest(), "little")
+            out.append(lo + h % span)
+        return out
+
+    def encode(self, text: str, max_length: Optional[int] = None) -> List[int]:
+        body = self._ids(text)
+        if max_length is not None:
+            body = body[: max(0, max_length - 2)]
+        return [self.sp.bos] + body + [self.sp.eos]
+
+    def encode_pair(self, a: str, b: str, max_length: int = 512) -> Tuple[List[int], List[int]]:
+        """-> (ids, token_type_ids); truncation 'longest_first' like CrossEncoder's tokenizer call."""
+        ia, ib = self._ids(a), self._ids(b)
+        budget = max_length - 2 - len(self.sp.pair_sep)
+        while len(ia) + len(ib) > budget and (ia or ib):
+            if len(ia) > len(ib):
+                ia.pop()
+            else:
+                ib.pop()
+        ids = [self.sp.bos] + ia + self.sp.pair_sep + ib + [self.sp.eos]
+        n_a = 1 + len(ia) + (1 if self.arch != "xlmr" else len(self.sp.pair_sep))
+        types = [0] * n_a + [1] * (len(ids) - n_a) if self.arch != "xlmr" else [0] * len(ids)
+        return ids, types
+
+
+class HFTokenizer:
+    """Adapter over a local HF ``tokenizer.json`` (``tokenizers`` library)."""
+
+    def __init__(self, tokenizer_json: str, arch: str):
+        from tokenizers import Tokenizer  # local import: optional dependency
+
+        self.tk = Tokenizer.from_file(tokenizer_json)
+        self.arch = arch
+        self.sp = SpecialTokens(arch)
+
+    def encode(self, text: str, max_length: Optional[int] = None) -> List[int]:
+        ids = self.tk.encode(text).ids
+        if max_length is not None and len(ids) > max_length:
+            ids = ids[: max_length - 1] + [ids[-1]]
+        return ids
+
+    def encode_pair(self, a: str, b: str, max_length: int = 512):
+        self.tk.enable_truncation(max_length=max_length, strategy="longest_first")
+        enc = self.tk.encode(a, b)
+        return enc.ids, enc.type_ids
+
+
+def load_tokenizer(model_dir: Optional[str], arch: str, vocab_size: int):
+    if model_dir:
+        tj = os.path.join(model_dir, "tokenizer.json")
+        if os.path.exists(tj):
+            return HFTokenizer(tj, arch)
+    return HashTokenizer(arch, vocab_size)

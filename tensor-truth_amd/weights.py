@@ -1,0 +1,86 @@
+"""Locating model weights for the HIP encoders.
+
+Order of resolution (first hit wins):
+  1. ``model_kwargs["state_dict"]``      -- tensors handed over directly (tests);
+  2. a local model directory             -- ``model_kwargs["model_dir"]``, ``$TT_AMD_MODEL_DIR/<org>/<name>``
+                                            or the HF hub cache, holding ``model.safetensors``
+                                            (HF checkpoint names) + ``config.json``;
+  3. ``model_kwargs["synthetic_seed"]``  -- seeded random init of the known architecture
+                                            (benchmarks / parity tests; no network here).
+Anything else raises, like the reference does when a model cannot be loaded
+(``model_manager.py:265-272``: the caller wraps it in ``RuntimeError("Failed to load ...")``).
+"""
+from __future__ import annotations
+
+import json
+import os
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from .encoder import KNOWN_CONFIGS, EncoderConfig, synthetic_state, synthetic_state_device
+
+
+def _config_from_hf(d: dict, num_labels_default: int = 0) -> EncoderConfig:
+    mt = d.get("model_type", "xlm-roberta")
+    arch = "bert" if mt == "bert" else "xlmr"
+    archs = " ".join(d.get("architectures", []))
+    num_labels = 1 if "SequenceClassification" in archs else num_labels_default
+    return EncoderConfig(
+        arch=arch, vocab_size=d["vocab_size"], hidden=d["hidden_size"], layers=d["num_hidden_layers"],
+        heads=d["num_attention_heads"], ffn=d["intermediate_size"], max_pos=d["max_position_embeddings"],
+        type_vocab=d.get("type_vocab_size", 1), pad_id=d.get("pad_token_id", 1 if arch == "xlmr" else 0),
+        ln_eps=d.get("layer_norm_eps", 1e-5), num_labels=num_labels)
+
+
+def find_model_dir(model_name: str, model_kwargs: Optional[dict]) -> Optional[str]:
+    mk = model_kwargs or {}
+    cands = []
+    if mk.get("model_dir"):
+        cands.append(mk["model_dir"])
+    if os.path.isdir(model_name):
+        cands.append(model_name)
+    root = os.environ.get("TT_AMD_MODEL_DIR")
+    if root:
+        cands += [os.path.join(root, model_name), os.path.join(root, model_name.split("/")[-1])]
+    for c in cands:
+        if os.path.exists(os.path.join(c, "model.safetensors")):
+            return c
+    try:  # HF hub cache, offline
+        from huggingface_hub import try_to_load_from_cache
+
+        p = try_to_load_from_cache(model_name, "model.safetensors")
+        if isinstance(p, str) and os.path.exists(p):
+            return os.path.dirname(p)
+    except Exception:  # noqa: BLE001
+        pass
+    return None
+
+
+def resolve(model_name: str, model_kwargs: Optional[dict], device: torch.device,
+            want_head: bool) -> Tuple[EncoderConfig, Dict[str, torch.Tensor], Optional[str]]:
+    """-> (config, state dict, model_dir or None)."""
+    mk = model_kwargs or {}
+    cfg = mk.get("encoder_config") or KNOWN_CONFIGS.get(model_name)
+    if "state_dict" in mk:
+        if cfg is None:
+            raise ValueError(f"no architecture known for '{model_name}': pass model_kwargs['encoder_config']")
+        return cfg, mk["state_dict"], None
+    mdir = find_model_dir(model_name, mk)
+    if mdir is not None:
+        from safetensors.torch import load_file
+
+        with open(os.path.join(mdir, "config.json")) as f:
+            cfg = _config_from_hf(json.load(f), 1 if want_head else 0)
+        return cfg, load_file(os.path.join(mdir, "model.safetensors")), mdir
+    if "synthetic_seed" in mk:
+        if cfg is None:
+            raise ValueError(f"no architecture known for '{model_name}': pass model_kwargs['encoder_config']")
+        seed = int(mk["synthetic_seed"])
+        if mk.get("synthetic_on_device", cfg.layers * cfg.hidden >= 12 * 768):
+            return cfg, synthetic_state_device(cfg, device, seed), None
+        return cfg, synthetic_state(cfg, seed), None
+    raise FileNotFoundError(
+        f"weights for '{model_name}' not found: no model.safetensors under model_kwargs['model_dir'], "
+        f"$TT_AMD_MODEL_DIR or the HF cache, and this environment has no network. "
+        f"(Benchmarks/tests: pass model_kwargs={{'synthetic_seed': N}}.)")

@@ -1,0 +1,265 @@
+"""CPU: host-side logic of the plugin surface (no GPU, no HIP calls).
+
+Mirrors the behaviours the reference's own unit tests pin with mocks
+(``tests/unit/test_rag_engine.py``, ``tests/unit/test_rag_service.py``,
+``tests/unit/test_embedding_model_selection.py``,
+``tests/unit/services/test_retrieval_metrics.py``) plus the golden outputs of the reference's
+``compute_retrieval_metrics`` (tests/golden/metrics_golden.json).
+"""
+import json
+import math
+import os
+from unittest.mock import MagicMock, patch
+
+import numpy as np
+import pytest
+
+from tensor_truth_amd import model_manager as mm
+from tensor_truth_amd import quality_metrics as qm
+from tensor_truth_amd import retrievers as rt
+from tensor_truth_amd.retrieval_service import RetrievalService
+from tensor_truth_amd.schema import NodeWithScore, QueryBundle, TextNode
+
+
+def _nws(score, text="t", **md):
+    return NodeWithScore(node=TextNode(text=text, metadata=dict(md)), score=score)
+
+
+# ---- retrieval metrics ------------------------------------------------------------------------
+def test_metrics_match_reference_golden(golden_dir):
+    gold = json.load(open(os.path.join(golden_dir, "metrics_golden.json")))
+    for name, case in gold.items():
+        if name == "entropy":
+            for e in case:
+                assert qm.calculate_entropy(e["counts"]) == pytest.approx(e["expected"], abs=1e-12)
+            continue
+        nodes = [_nws(s, t, **m) for s, t, m in case["nodes"]]
+        got = qm.compute_retrieval_metrics(nodes).to_dict()
+        want = case["expected"]
+        for section in want:
+            for key, val in want[section].items():
+                if isinstance(val, float):
+                    assert got[section][key] == pytest.approx(val, rel=1e-12, abs=1e-12), (name, section, key)
+                else:
+                    assert got[section][key] == val, (name, section, key)
+
+
+def test_metrics_known_answers():
+    # known answers restated from the reference's tests/unit/services/test_retrieval_metrics.py
+    m = qm.compute_retrieval_metrics([_nws(s) for s in (0.9, 0.8, 0.7, 0.6)])
+    assert m.score_mean == pytest.approx(0.75) and m.score_median == pytest.approx(0.75)
+    assert m.score_q1 == pytest.approx(0.65) and m.score_q3 == pytest.approx(0.85)
+    assert m.high_confidence_ratio == pytest.approx(0.75) and m.low_confidence_ratio == 0.0
+    assert qm.calculate_entropy([1, 1]) == pytest.approx(1.0)
+    assert qm.calculate_entropy([2, 2, 2, 2]) == pytest.approx(2.0)
+    assert qm.compute_retrieval_metrics([]).to_dict()["coverage"]["total_chunks"] == 0
+
+
+# ---- similarity_top_k, multi-index retriever ------------------------------------------------------
+def test_similarity_top_k_formula():
+    assert [rt.similarity_top_k_for(n) for n in (1, 2, 3, 5, 10)] == [5, 5, 6, 10, 20]
+
+
+def test_multi_index_balancing_and_tagging():
+    n1 = [MagicMock(score=s, metadata={}) for s in (0.9, 0.8, 0.7)]
+    n2 = [MagicMock(score=s, metadata={}) for s in (0.6, 0.5, 0.4)]
+    r1, r2 = MagicMock(), MagicMock()
+    r1.retrieve.return_value, r2.retrieve.return_value = n1, n2
+    multi = rt.MultiIndexRetriever([r1, r2], balance_strategy="top_k_per_index")
+    res = multi._retrieve(QueryBundle(query_str="test"))
+    assert all("_source_index" in n.metadata for n in res)
+    assert sum(n.metadata["_source_index"] == 0 for n in res) == 3
+    assert sum(n.metadata["_source_index"] == 1 for n in res) == 3
+    assert [n.score for n in res] == sorted((n.score for n in res), reverse=True)
+
+
+def test_multi_index_uneven_limit_and_sort():
+    # 5 + 1 nodes over 2 indexes -> per-index limit max(1, 6 // 2) = 3
+    a = [_nws(s) for s in (0.9, 0.8, 0.7, 0.6, 0.5)]
+    b = [_nws(0.95)]
+    r1, r2 = MagicMock(), MagicMock()
+    r1.retrieve.return_value, r2.retrieve.return_value = a, b
+    res = rt.MultiIndexRetriever([r1, r2]).retrieve("q")
+    assert [n.score for n in res] == [0.95, 0.9, 0.8, 0.7]
+    assert [n.node.metadata["_source_index"] for n in res] == [1, 0, 0, 0]
+
+
+def test_multi_index_no_balance_single_and_failure(capsys):
+    r1, r2, bad = MagicMock(), MagicMock(), MagicMock()
+    r1.retrieve.return_value = [_nws(0.9)]
+    r2.retrieve.return_value = [_nws(0.6)]
+    bad.retrieve.side_effect = RuntimeError("index offline")
+    assert len(rt.MultiIndexRetriever([r1, r2], balance_strategy="none").retrieve("q")) == 2
+    assert len(rt.MultiIndexRetriever([r1]).retrieve("q")) == 1
+    res = rt.MultiIndexRetriever([r1, bad], balance_strategy="none").retrieve("q")
+    assert len(res) == 1 and "Retriever failed" in capsys.readouterr().out
+
+
+def test_multi_index_cache_and_clear():
+    r = MagicMock()
+    r.retrieve.return_value = [_nws(0.5)]
+    multi = rt.MultiIndexRetriever([r], enable_cache=True)
+    multi.retrieve("same")
+    multi.retrieve("same")
+    assert r.retrieve.call_count == 1
+    multi.clear_cache()
+    multi.clear_cache()
+    multi.retrieve("same")
+    assert r.retrieve.call_count == 2
+    nocache = rt.MultiIndexRetriever([r], enable_cache=False)
+    nocache.retrieve("x")
+    nocache.retrieve("x")
+    assert r.retrieve.call_count == 4
+
+
+# ---- auto-merging -------------------------------------------------------------------------------------
+def _hierarchy():
+    parent = TextNode(text="P", id_="p", child_ids=["c0", "c1", "c2", "c3"])
+    kids = [TextNode(text=f"c{i}", id_=f"c{i}", parent_id="p",
+                     prev_id=f"c{i-1}" if i else None, next_id=f"c{i+1}" if i < 3 else None) for i in range(4)]
+    lone = TextNode(text="x", id_="x")
+    ds = {n.id_: n for n in [parent, lone] + kids}
+    return ds, kids, lone
+
+
+def test_auto_merge_replaces_children_by_parent():
+    ds, kids, lone = _hierarchy()
+    base = MagicMock()
+    base.retrieve.return_value = [NodeWithScore(kids[0], 0.9), NodeWithScore(kids[1], 0.7), NodeWithScore(kids[2], 0.5),
+                                  NodeWithScore(lone, 0.6)]
+    out = rt.AutoMergingRetriever(base, ds).retrieve("q")
+    assert [n.node.id_ for n in out] == ["p", "x"]
+    assert out[0].score == pytest.approx((0.9 + 0.7 + 0.5) / 3)
+
+
+def test_auto_merge_threshold_is_strict_and_fills_gaps():
+    ds, kids, lone = _hierarchy()
+    base = MagicMock()
+    # 2 of 4 children: ratio 0.5 is NOT > 0.5 -> no merge
+    base.retrieve.return_value = [NodeWithScore(kids[0], 0.9), NodeWithScore(kids[3], 0.5)]
+    out = rt.AutoMergingRetriever(base, ds).retrieve("q")
+    assert sorted(n.node.id_ for n in out) == ["c0", "c3"]
+    # c0 and c2 retrieved: the single gap c1 is filled with the mean score, then 3/4 > 0.5 merges
+    base.retrieve.return_value = [NodeWithScore(kids[0], 0.8), NodeWithScore(kids[2], 0.4)]
+    out = rt.AutoMergingRetriever(base, ds).retrieve("q")
+    assert [n.node.id_ for n in out] == ["p"]
+    assert out[0].score == pytest.approx((0.8 + 0.6 + 0.4) / 3)
+
+
+def test_similarity_postprocessor():
+    nodes = [_nws(0.9), _nws(0.04), _nws(None)]
+    assert [n.score for n in rt.SimilarityPostprocessor(0.05).postprocess_nodes(nodes)] == [0.9]
+    assert len(rt.SimilarityPostprocessor(None).postprocess_nodes(nodes)) == 3
+
+
+# ---- retrieval service ---------------------------------------------------------------------------------
+def test_retrieve_contract_confidence_and_progress():
+    retr = MagicMock()
+    retr.retrieve.return_value = [_nws(0.2, "aaaa", filename="a"), _nws(0.3, "bb", filename="b"), _nws(0.1)]
+    rer = MagicMock()
+    rer.postprocess_nodes.side_effect = lambda nodes, query_bundle=None: sorted(nodes, key=lambda n: -n.score)
+    svc = RetrievalService(retr, [rer], {"reranker_top_n": 2, "confidence_cutoff": 0.35})
+    phases = []
+    res = svc.retrieve("what?", progress_callback=lambda p: phases.append(p.phase))
+    assert phases == ["retrieving", "reranking"]
+    assert res.num_sources == 2 and [n.score for n in res.source_nodes] == [0.3, 0.2]
+    assert res.confidence_level == "low" and res.condensed_query == "what?"
+    assert res.metrics["configuration"]["configured_top_n"] == 2
+    assert rer.postprocess_nodes.call_args.kwargs["query_bundle"].query_str == "what?"
+    svc2 = RetrievalService(retr, [rer], {"reranker_top_n": 2, "confidence_cutoff": 0.25})
+    assert svc2.retrieve("q").confidence_level == "normal"
+    retr.retrieve.return_value = []
+    assert svc.retrieve("q").confidence_level == "none"
+    assert RetrievalService().retrieve("q").confidence_level == "none"
+
+
+def test_retrieve_postprocessor_failure_keeps_unprocessed_nodes():
+    retr = MagicMock()
+    retr.retrieve.return_value = [_nws(0.5), _nws(0.6)]
+    boom = MagicMock()
+    boom.postprocess_nodes.side_effect = RuntimeError("reranker down")
+    res = RetrievalService(retr, [boom], {}).retrieve("q")
+    assert [n.score for n in res.source_nodes] == [0.5, 0.6]
+
+
+# ---- model manager ------------------------------------------------------------------------------------------
+def test_model_id_helpers():
+    assert mm.sanitize_model_id("BAAI/bge-m3") == "bge-m3"
+    assert mm.sanitize_model_id("sentence-transformers/all-MiniLM-L6-v2") == "all-minilm-l6-v2"
+    assert mm.sanitize_model_id("Org/My Model!!v2") == "my-model-v2"
+    assert mm.resolve_embedding_model_name("bge-m3") == "BAAI/bge-m3"
+    assert mm.resolve_embedding_model_name("BAAI/bge-m3") == "BAAI/bge-m3"
+    assert mm.resolve_embedding_model_name("unknown-model") == "unknown-model"
+
+
+def test_model_manager_swap_semantics():
+    mm.ModelManager.reset_instance()
+    mgr = mm.ModelManager.get_instance()
+    assert mgr is mm.ModelManager()
+    made = []
+
+    def fake_emb(**kw):
+        made.append(kw)
+        return MagicMock(name="emb", **{"model_name": kw["model_name"]})
+
+    with patch("tensor_truth_amd.embedding.HipHuggingFaceEmbedding", side_effect=fake_emb):
+        e1 = mgr.get_embedder("BAAI/bge-m3", "cuda")
+        assert mgr.get_embedder("bge-m3", "cuda") is e1              # healed name, same (model, device) -> reuse
+        assert made[0]["embed_batch_size"] == 128 and made[0]["tokenizer_kwargs"] is None
+        e2 = mgr.get_embedder("BAAI/bge-small-en-v1.5", "cuda")      # model change -> reload
+        assert e2 is not e1 and len(made) == 2
+        mgr.get_embedder("BAAI/bge-small-en-v1.5", "cpu")            # device change -> reload, CPU batch size
+        assert len(made) == 3 and made[2]["embed_batch_size"] == 16
+    rr = []
+
+    def fake_rr(**kw):
+        rr.append(kw)
+        return MagicMock(name="rr")
+
+    with patch("tensor_truth_amd.rerank.HipSentenceTransformerRerank", side_effect=fake_rr):
+        a = mgr.get_reranker(top_n=3, device="cuda")
+        assert rr[0]["model"] == "BAAI/bge-reranker-v2-m3" and rr[0]["top_n"] == 3
+        assert mgr.get_reranker(top_n=3, device="cuda") is a
+        assert mgr.get_reranker(top_n=5, device="cuda") is not a     # top_n change -> reload
+        assert len(rr) == 2
+    st = mgr.get_status()
+    assert st["embedder"]["loaded"] and st["reranker"]["top_n"] == 5
+    mgr.unload_all()
+    assert not mgr.get_status()["embedder"]["loaded"]
+    with patch("tensor_truth_amd.embedding.HipHuggingFaceEmbedding", side_effect=OSError("no weights")):
+        with pytest.raises(RuntimeError, match="Failed to load embedding model"):
+            mgr.get_embedder("BAAI/bge-m3", "cuda")
+        assert mgr._embedder is None and mgr._embedder_model_name is None
+    mm.ModelManager.reset_instance()
+
+
+# ---- token packing / tokenizer --------------------------------------------------------------------------------------
+def test_pack_tokens_layout():
+    from tensor_truth_amd.encoder import BGE_M3, BGE_SMALL_EN_V15, pack_tokens
+
+    b = pack_tokens([[0, 5, 6, 2], [0, 9, 2], list(range(4, 24))], BGE_M3)
+    assert b.n_rows % 128 == 0 and (b.seq_start % 8 == 0).all()
+    assert b.seq_len.tolist() == [4, 3, 20] and b.seq_start.tolist() == [0, 8, 16]
+    assert b.pos[:4].tolist() == [2, 3, 4, 5]                 # XLM-R positions start at pad_id + 1
+    assert b.ids[4] == 1 and b.n_tokens == 27 and b.max_len == 20
+    s = pack_tokens([[101, 7, 102]], BGE_SMALL_EN_V15, type_ids=[[0, 0, 0]])
+    assert s.pos[:3].tolist() == [0, 1, 2] and s.types is not None
+    long = pack_tokens([list(range(4, 4 + 9000))], BGE_M3)
+    assert long.seq_len[0] == 8192                             # truncated to the model limit
+    with pytest.raises(ValueError):
+        pack_tokens([[]], BGE_M3)
+    with pytest.raises(ValueError):
+        pack_tokens([[0, 999999, 2]], BGE_M3)
+
+
+def test_hash_tokenizer_pairs():
+    from tensor_truth_amd.tokenization import HashTokenizer
+
+    tk = HashTokenizer("xlmr", 250002)
+    a = tk.encode("hello world")
+    assert a[0] == 0 and a[-1] == 2 and len(a) == 4 and tk.encode("hello world") == a
+    ids, types = tk.encode_pair("q " * 10, "p " * 600, max_length=512)
+    assert len(ids) == 512 and ids[0] == 0 and ids[-1] == 2 and ids[11:13] == [2, 2] and set(types) == {0}
+    bt = HashTokenizer("bert", 30522)
+    ids, types = bt.encode_pair("a b", "c d e")
+    assert ids[0] == 101 and ids[-1] == 102 and types == [0, 0, 0, 0, 1, 1, 1, 1]

@@ -1,0 +1,163 @@
+"""GPU: the plugin surface end to end (embedding model -> index/retriever -> rerank postprocessor
+-> retrieval service) against the CPU oracle on the same token ids."""
+import math
+
+import pytest
+import torch
+
+from oracle import encoder as oe
+from oracle import scan as osc
+
+pytestmark = pytest.mark.gpu
+
+SMALL = dict(arch="bert", vocab_size=3000, hidden=384, layers=2, heads=12, ffn=1536, max_pos=128, type_vocab=2,
+             pad_id=0, ln_eps=1e-12)
+XENC = dict(arch="xlmr", vocab_size=3000, hidden=256, layers=2, heads=4, ffn=512, max_pos=130, type_vocab=1,
+            pad_id=1, ln_eps=1e-5, num_labels=1)
+
+
+def _texts(n):
+    words = ["tensor", "kernel", "wave", "matrix", "retrieval", "index", "corpus", "query", "rerank", "chunk",
+             "gradient", "vector", "cache", "stream", "shard", "token", "layer", "norm", "attention", "softmax"]
+    g = torch.Generator().manual_seed(3)
+    out = []
+    for i in range(n):
+        k = int(torch.randint(5, 40, (1,), generator=g))
+        idx = torch.randint(0, len(words), (k,), generator=g).tolist()
+        out.append(" ".join(words[j] for j in idx) + f" doc{i}")
+    return out
+
+
+def _pad(seqs, pad):
+    L = max(len(s) for s in seqs)
+    ids = torch.full((len(seqs), L), pad, dtype=torch.int64)
+    mask = torch.zeros(len(seqs), L, dtype=torch.int64)
+    for b, s in enumerate(seqs):
+        ids[b, : len(s)] = torch.tensor(s)
+        mask[b, : len(s)] = 1
+    return ids, mask
+
+
+def test_embedding_index_retriever_roundtrip(dev, built_lib, tmp_path):
+    from tensor_truth_amd.embedding import HipHuggingFaceEmbedding
+    from tensor_truth_amd.encoder import EncoderConfig
+    from tensor_truth_amd.schema import TextNode
+    from tensor_truth_amd.vector_index import HipVectorIndex
+
+    cfg = EncoderConfig(**SMALL)
+    ocfg = oe.EncoderConfig(**SMALL)
+    emb = HipHuggingFaceEmbedding("test/bge-small-shaped", device="cuda",
+                                  model_kwargs={"encoder_config": cfg, "synthetic_seed": 21}, embed_batch_size=64)
+    assert emb.embed_batch_size == 64 and emb.query_instruction == ""
+    texts = _texts(300)
+    nodes = [TextNode(text=t, id_=f"n{i}", metadata={"filename": f"f{i % 7}.md", "doc_type": "library"})
+             for i, t in enumerate(texts)]
+    for nd in nodes:
+        nd.excluded_embed_metadata_keys = ["filename", "doc_type"]
+    index = HipVectorIndex(cfg.hidden, embed_model=emb, score_mode="cosine")
+    index.add(nodes)
+    assert index.n == 300
+
+    # oracle embeddings of the very same token ids (bf16 weights, bf16 rounding emulated)
+    W = {k: v.to(torch.bfloat16) for k, v in oe.synth_weights(ocfg, seed=21).items()}
+    seqs = [emb._tokenizer.encode(t, emb.max_length) for t in texts]
+    ids, mask = _pad(seqs, cfg.pad_id)
+    want = oe.embed(ids, mask, W, ocfg, emulate_bf16=True)
+    got = torch.tensor(emb.get_text_embedding_batch(texts))
+    assert ((got * want).sum(1) >= 0.9995).all()
+    one = torch.tensor(emb.get_text_embedding(texts[5]))
+    assert torch.allclose(one, got[5], atol=2e-3)
+    assert abs(HipHuggingFaceEmbedding.similarity(got[0].tolist(), got[0].tolist()) - 1.0) < 1e-5
+
+    # retrieval: same neighbours as the oracle scan over the oracle's embeddings wherever tie-free
+    query = texts[17]
+    res = index.as_retriever(similarity_top_k=10).retrieve(query)
+    assert len(res) == 10 and res[0].node.id_ == "n17" and res[0].score > 0.99
+    assert [r.score for r in res] == sorted((r.score for r in res), reverse=True)
+    qv = got[17:18].to(torch.bfloat16)
+    w_s, w_i, gap = osc.scan_topk(index.matrix.cpu(), qv, 10)
+    if gap[0] > 1e-4:
+        assert [r.node.id_ for r in res] == [f"n{int(j)}" for j in w_i[0]]
+    res[0].node.metadata["_source_index"] = 3            # mutable per-hit metadata, not shared
+    assert "_source_index" not in index.docstore["n17"].metadata
+
+    # persist / load / delete
+    index.persist(str(tmp_path / "indexes" / "bge-small" / "library_x"), embedding_model="test/bge-small-shaped")
+    loaded = HipVectorIndex.load(str(tmp_path / "indexes" / "bge-small" / "library_x"), embed_model=emb,
+                                 score_mode="cosine")
+    assert loaded.n == 300 and torch.equal(loaded.matrix.cpu().view(torch.int16), index.matrix.cpu().view(torch.int16))
+    assert [r.node.id_ for r in loaded.as_retriever(10).retrieve(query)] == [r.node.id_ for r in res]
+    assert loaded.delete(["n17"]) == 1 and loaded.n == 299
+    assert loaded.as_retriever(10).retrieve(query)[0].node.id_ != "n17"
+    # chroma-style score mapping
+    chroma = HipVectorIndex.load(str(tmp_path / "indexes" / "bge-small" / "library_x"), embed_model=emb)
+    top = chroma.as_retriever(3).retrieve(query)[0]
+    assert top.score == pytest.approx(math.exp(-(2 - 2 * res[0].score)), rel=1e-5)
+
+
+def test_rerank_postprocessor_and_service(dev, built_lib):
+    from tensor_truth_amd import model_manager as mm
+    from tensor_truth_amd.encoder import EncoderConfig
+    from tensor_truth_amd.rerank import HipSentenceTransformerRerank
+    from tensor_truth_amd.retrieval_service import build_retrieval_service
+    from tensor_truth_amd.schema import NodeWithScore, QueryBundle, TextNode
+    from tensor_truth_amd.vector_index import HipVectorIndex
+
+    cfg = EncoderConfig(**XENC)
+    ocfg = oe.EncoderConfig(**XENC)
+    rr = HipSentenceTransformerRerank(model="test/xenc", top_n=3, device="cuda",
+                                      model_kwargs={"encoder_config": cfg, "synthetic_seed": 31})
+    texts = _texts(12)
+    nodes = [NodeWithScore(node=TextNode(text=t, id_=f"n{i}"), score=0.5) for i, t in enumerate(texts)]
+    query = "which kernel streams the corpus"
+    out = rr.postprocess_nodes(list(nodes), query_bundle=QueryBundle(query_str=query))
+    assert len(out) == 3 and all(isinstance(n.score, float) for n in out)
+    assert [n.score for n in out] == sorted((n.score for n in out), reverse=True)
+    assert rr.postprocess_nodes([], QueryBundle(query_str=query)) == []           # positional bundle, empty input
+    with pytest.raises(ValueError):
+        rr.postprocess_nodes(list(nodes))
+    # scores vs the oracle on the same token ids
+    W = {k: v.to(torch.bfloat16) for k, v in oe.synth_weights(ocfg, seed=31).items()}
+    pair_ids = [rr._tokenizer.encode_pair(query, t, 512)[0] for t in texts]
+    ids, mask = _pad(pair_ids, cfg.pad_id)
+    want = oe.rerank_scores(ids, mask, W, ocfg, emulate_bf16=True)
+    got = torch.tensor(rr.predict([(query, t) for t in texts]))
+    assert (got - want).abs().max().item() < 1.5e-2
+    ranked = rr.rerank(query, texts, top_n=4)
+    assert len(ranked) == 4 and ranked[0]["relevance_score"] == pytest.approx(got.max().item())
+    order = torch.argsort(want, descending=True)
+    gaps = want[order][:-1] - want[order][1:]
+    if (gaps[:3] > 3e-2).all():
+        assert [int(n.node.id_[1:]) for n in out] == order[:3].tolist()
+
+    # whole service through the ModelManager (weights resolved from per-model overrides)
+    mm.ModelManager.reset_instance()
+    mgr = mm.ModelManager.get_instance()
+    small = EncoderConfig(**SMALL)
+    mgr.model_kwargs_overrides["test/bge-small-shaped"] = {"encoder_config": small, "synthetic_seed": 21}
+    mgr.model_kwargs_overrides["test/xenc"] = {"encoder_config": cfg, "synthetic_seed": 31}
+    emb = mgr.get_embedder("test/bge-small-shaped", "cuda")
+    assert mgr.get_embedder("test/bge-small-shaped", "cuda") is emb
+    indexes = []
+    for part in range(2):
+        ix = HipVectorIndex(small.hidden, embed_model=emb)
+        ix.add([TextNode(text=t, id_=f"i{part}_{j}", metadata={"filename": f"p{part}.md"})
+                for j, t in enumerate(_texts(60)[part * 30:(part + 1) * 30])])
+        indexes.append(ix)
+    params = {"reranker_model": "test/xenc", "reranker_top_n": 4, "confidence_cutoff": 0.35,
+              "confidence_cutoff_hard": 0.05, "balance_strategy": "top_k_per_index"}
+    svc = build_retrieval_service(indexes, params, device="cuda", manager=mgr)
+    res = svc.retrieve("attention softmax kernel")
+    assert 0 < res.num_sources <= 4 and res.confidence_level in ("normal", "low")
+    assert res.metrics["coverage"]["total_chunks"] == res.num_sources
+    assert {n.node.metadata["_source_index"] for n in res.source_nodes} <= {0, 1}
+    usage = mgr.get_memory_usage()
+    assert usage["embedder_bytes"] > 0 and usage["reranker_bytes"] > 0
+    mm.ModelManager.reset_instance()
+
+
+def test_devices_other_than_hip_are_refused(built_lib):
+    from tensor_truth_amd.embedding import HipHuggingFaceEmbedding
+
+    with pytest.raises(RuntimeError, match="HIP devices only"):
+        HipHuggingFaceEmbedding("BAAI/bge-m3", device="cpu", model_kwargs={"synthetic_seed": 1})
