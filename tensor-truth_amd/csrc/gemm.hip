@@ -17,6 +17,8 @@
 //
 // Roofline: MFMA-bound; 2*M*N*K flops per launch.
 #include "common.h"
+#include <type_traits>
+
 #include "encoder.h"
 
 namespace {
@@ -27,7 +29,136 @@ constexpr int kTileBytes = BM * BK * 2;          // 16 KiB per operand tile
 constexpr int kStageBytes = 2 * kTileBytes;      // A + W
 constexpr int kGemmLds = 2 * kStageBytes;        // 64 KiB
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// GELU(x) = 0.5 x (1 + erf(x / sqrt 2)), exact-erf form (HF "gelu").  erf by Abramowitz-Stegun 7.1.26
+// (|abs err| <= 1.5e-7, far below the bf16 output resolution) -- the libm erff costs ~3x the
+// instructions and made the FFN-up epilogue a quarter of that GEMM's time.
+__device__ __forceinline__ float gelu_erf(float x) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    poly *= t;
+    const float e = __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f);
+    const float erf_abs = fmaf(-poly, e, 1.0f);               // erf(|x|/sqrt2)
+    const float erf_v = copysignf(erf_abs, x);
+    return 0.5f * x * (1.0f + erf_v);
+}
+
+// ---- epilogue of one wave's 64x64 tile: lane holds C[m][n..n+3], m = tile row (l&15), n = 4*(l>>4)
+template <int EPI, int NT, int MT>
+__device__ __forceinline__ void gemm_epilogue_tile(const GemmParams& p, f32x4 (&acc)[NT][MT], int mw, int nw, int lane) {
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const int n = nw + i * 16 + (lane >> 4) * 4;
+        const float4 b4 = *reinterpret_cast<const float4*>(p.bias + n);
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+            const int m = mw + j * 16 + (lane & 15);
+            float v0 = acc[i][j][0] + b4.x, v1 = acc[i][j][1] + b4.y, v2 = acc[i][j][2] + b4.z, v3 = acc[i][j][3] + b4.w;
+            if constexpr (EPI == TT_EPI_GELU) {
+                v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3);
+            } else if constexpr (EPI == TT_EPI_TANH) {
+                v0 = tanhf(v0); v1 = tanhf(v1); v2 = tanhf(v2); v3 = tanhf(v3);
+            } else if constexpr (EPI == TT_EPI_RESIDUAL) {
+                const uint2 r = *reinterpret_cast<const uint2*>(p.residual + (size_t)m * p.ldr + n);
+                v0 += __uint_as_float(r.x << 16);
+                v1 += __uint_as_float(r.x & 0xFFFF0000u);
+                v2 += __uint_as_float(r.y << 16);
+                v3 += __uint_as_float(r.y & 0xFFFF0000u);
+            }
+            if constexpr (EPI == TT_EPI_QKV) {
+                if (n >= p.vt_col0) {
+                    // V third: store transposed, VT[n - vt_col0][m]
+                    uint16_t* vt = p.vt + (size_t)(n - p.vt_col0) * p.ldvt + m;
+                    vt[0] = f32_to_bf16_bits(v0);
+                    vt[p.ldvt] = f32_to_bf16_bits(v1);
+                    vt[2 * (size_t)p.ldvt] = f32_to_bf16_bits(v2);
+                    vt[3 * (size_t)p.ldvt] = f32_to_bf16_bits(v3);
+                    continue;
+                }
+            }
+            uint2 o;
+            o.x = pack_bf16x2(v0, v1);
+            o.y = pack_bf16x2(v2, v3);
+            *reinterpret_cast<uint2*>(p.C + (size_t)m * p.ldc + n) = o;
+        }
+    }
+}
+
+template <int EPI>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[4][4], int mw, int nw, int lane) {
+    gemm_epilogue_tile<EPI, 4, 4>(p, acc, mw, nw, lane);
+}
+
+// ---- wide epilogue: 16-byte stores -----------------------------------------------------------
+// In the swapped accumulator layout a lane holds 4 consecutive columns of one row (8-B stores, and a
+// row-per-lane store tail is store-ISSUE bound: 32 dwordx2 per lane cost ~10 us per 256x256 tile).
+// v_permlane16_swap between the register of m-tile 2j (vdst) and of m-tile 2j+1 (src) hands the
+// lanes of even 16-lane rows their right-hand neighbour's 4 columns of m-tile 2j and the lanes of
+// odd rows their left-hand neighbour's 4 columns of m-tile 2j+1: every lane then owns 8 consecutive
+// columns of ONE row -> one 16-B store (and 16-B residual load) per pair of tiles.
+template <int EPI, int NT, int MT>
+__device__ __forceinline__ void gemm_epilogue_wide(const GemmParams& p, f32x4 (&acc)[NT][MT], int mw, int nw, int lane) {
+    static_assert(MT % 2 == 0, "m-tiles are processed in pairs");
+    const int g = lane >> 4;           // 16-lane row: columns 4g..4g+3 of the tile before the swap
+    const bool odd = (g & 1) != 0;
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        if constexpr (EPI == TT_EPI_QKV) {
+            if (nw + i * 16 >= p.vt_col0) {   // V third (block-uniform): transposed 2-byte stores, narrow path
+#pragma unroll
+                for (int j = 0; j < MT; ++j) {
+                    const int n = nw + i * 16 + g * 4;
+                    const int m = mw + j * 16 + (lane & 15);
+                    const float4 b4 = *reinterpret_cast<const float4*>(p.bias + n);
+                    uint16_t* vt = p.vt + (size_t)(n - p.vt_col0) * p.ldvt + m;
+                    vt[0] = f32_to_bf16_bits(acc[i][j][0] + b4.x);
+                    vt[p.ldvt] = f32_to_bf16_bits(acc[i][j][1] + b4.y);
+                    vt[2 * (size_t)p.ldvt] = f32_to_bf16_bits(acc[i][j][2] + b4.z);
+                    vt[3 * (size_t)p.ldvt] = f32_to_bf16_bits(acc[i][j][3] + b4.w);
+                }
+                continue;
+            }
+        }
+        const int n = nw + i * 16 + (g & ~1) * 4;             // first of this lane's 8 columns
+        const float4 ba = *reinterpret_cast<const float4*>(p.bias + n);
+        const float4 bb = *reinterpret_cast<const float4*>(p.bias + n + 4);
+        const float bias8[8] = {ba.x, ba.y, ba.z, ba.w, bb.x, bb.y, bb.z, bb.w};
+#pragma unroll
+        for (int j = 0; j < MT; j += 2) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[i][j][k]),
+                                                                __float_as_uint(acc[i][j + 1][k]), false, false);
+                v[k] = __uint_as_float(r[0]);
+                v[4 + k] = __uint_as_float(r[1]);
+            }
+            const int m = mw + (odd ? j + 1 : j) * 16 + (lane & 15);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] += bias8[k];
+            if constexpr (EPI == TT_EPI_GELU) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = gelu_erf(v[k]);
+            } else if constexpr (EPI == TT_EPI_TANH) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = tanhf(v[k]);
+            } else if constexpr (EPI == TT_EPI_RESIDUAL) {
+                const uint4 r = *reinterpret_cast<const uint4*>(p.residual + (size_t)m * p.ldr + n);
+                v[0] += __uint_as_float(r.x << 16); v[1] += __uint_as_float(r.x & 0xFFFF0000u);
+                v[2] += __uint_as_float(r.y << 16); v[3] += __uint_as_float(r.y & 0xFFFF0000u);
+                v[4] += __uint_as_float(r.z << 16); v[5] += __uint_as_float(r.z & 0xFFFF0000u);
+                v[6] += __uint_as_float(r.w << 16); v[7] += __uint_as_float(r.w & 0xFFFF0000u);
+            }
+            uint4 o;
+            o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
+            o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
+            *reinterpret_cast<uint4*>(p.C + (size_t)m * p.ldc + n) = o;
+        }
+    }
+}
 
 // issue the global->LDS copies of one K-step (both operand tiles) for this wave
 __device__ __forceinline__ void stage_tile(const GemmParams& p, char* stage, int wave, int lane, int m0, int n0, int k0) {
@@ -118,47 +249,399 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_kernel(GemmParams p) {
         __syncthreads();
     }
 
-    // ---- epilogue: lane holds C[m][n..n+3], m = tile row (l&15), n = 4*(l>>4) -----------
+    gemm_epilogue<EPI>(p, acc, m0 + wm * 64, n0 + wn * 64, lane);
+}
+
+// ---------------------------------------------------------------------------------------------
+// v2: 256x128x64 block tile, 8 waves (4 along M x 2 along N, 64x64 each), THREE-deep LDS ring.
+// The global->LDS copies of K-step kt+2 are issued while kt is computed and are waited for with
+// a COUNTED s_waitcnt vmcnt(6) (one stage = 6 glds per wave stays in flight) in front of a raw
+// s_barrier -- __syncthreads() would drain the LDS-DMA queue (vmcnt(0)) every K-step, which is
+// what caps v1 (36 % MFMA busy, 36 % of wave time in s_waitcnt/barrier by SQ counters).
+namespace v2 {
+constexpr int BM2 = 256, BN2 = 128;
+constexpr int kThreads2 = 512;
+constexpr int kATile = BM2 * BK * 2;            // 32 KiB
+constexpr int kWTile = BN2 * BK * 2;            // 16 KiB
+constexpr int kStage = kATile + kWTile;         // 48 KiB
+constexpr int kStages = 3;
+constexpr int kLds2 = kStages * kStage;         // 144 KiB
+
+__device__ __forceinline__ void stage_tile2(const GemmParams& p, char* stage, int wave, int lane, int m0, int n0, int k0) {
+    const int lrow = lane >> 3;
+    const int slot = lane & 7;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int n = n0 + wn * 64 + i * 16 + (lane >> 4) * 4;
-        const float4 b4 = *reinterpret_cast<const float4*>(p.bias + n);
+    for (int j = 0; j < 4; ++j) {
+        const int row = 32 * wave + 8 * j + lrow;
+        const int chunk = slot ^ ((row >> 1) & 7);
+        const uint16_t* src = p.A + (size_t)(m0 + row) * p.lda + k0 + chunk * 8;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(stage + (32 * wave + 8 * j) * 128),
+                                         16, 0, 0);
+    }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int m = m0 + wm * 64 + j * 16 + (lane & 15);
-            float v0 = acc[i][j][0] + b4.x, v1 = acc[i][j][1] + b4.y, v2 = acc[i][j][2] + b4.z, v3 = acc[i][j][3] + b4.w;
-            if constexpr (EPI == TT_EPI_GELU) {
-                v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3);
-            } else if constexpr (EPI == TT_EPI_TANH) {
-                v0 = tanhf(v0); v1 = tanhf(v1); v2 = tanhf(v2); v3 = tanhf(v3);
-            } else if constexpr (EPI == TT_EPI_RESIDUAL) {
-                const uint2 r = *reinterpret_cast<const uint2*>(p.residual + (size_t)m * p.ldr + n);
-                v0 += __uint_as_float(r.x << 16);
-                v1 += __uint_as_float(r.x & 0xFFFF0000u);
-                v2 += __uint_as_float(r.y << 16);
-                v3 += __uint_as_float(r.y & 0xFFFF0000u);
-            }
-            if constexpr (EPI == TT_EPI_QKV) {
-                if (n >= p.vt_col0) {
-                    // V third: store transposed, VT[n - vt_col0][m]
-                    uint16_t* vt = p.vt + (size_t)(n - p.vt_col0) * p.ldvt + m;
-                    vt[0] = f32_to_bf16_bits(v0);
-                    vt[p.ldvt] = f32_to_bf16_bits(v1);
-                    vt[2 * (size_t)p.ldvt] = f32_to_bf16_bits(v2);
-                    vt[3 * (size_t)p.ldvt] = f32_to_bf16_bits(v3);
-                    continue;
-                }
-            }
-            uint2 o;
-            o.x = pack_bf16x2(v0, v1);
-            o.y = pack_bf16x2(v2, v3);
-            *reinterpret_cast<uint2*>(p.C + (size_t)m * p.ldc + n) = o;
-        }
+    for (int j = 0; j < 2; ++j) {
+        const int row = 16 * wave + 8 * j + lrow;
+        const int chunk = slot ^ ((row >> 1) & 7);
+        const uint16_t* src = p.W + (size_t)(n0 + row) * p.K + k0 + chunk * 8;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(stage + kATile + (16 * wave + 8 * j) * 128),
+                                         16, 0, 0);
     }
 }
 
 template <int EPI>
+__global__ __launch_bounds__(kThreads2, 2) void gemm_kernel_v2(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int mt_n = p.M / BM2, nt_n = p.N / BN2;
+    int L = blockIdx.x;
+    {
+        const int nwg = gridDim.x;
+        if ((nwg & 7) == 0) L = (L & 7) * (nwg >> 3) + (L >> 3);
+    }
+    const int SN = nt_n < 8 ? nt_n : 8;
+    const int SM = 4;
+    const int per_super = SM * SN;
+    const int supers_n = (nt_n + SN - 1) / SN;
+    const int s = L / per_super, w = L % per_super;
+    const int tm = (s / supers_n) * SM + w / SN;
+    const int tn = (s % supers_n) * SN + w % SN;
+    if (tm >= mt_n || tn >= nt_n) return;
+    const int m0 = tm * BM2, n0 = tn * BN2;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / BK;
+    stage_tile2(p, smem, wave, lane, m0, n0, 0);
+    if (nk > 1) stage_tile2(p, smem + kStage, wave, lane, m0, n0, BK);
+
+    const int frow = lane & 15;
+    const int fchk = lane >> 4;
+
+    for (int kt = 0; kt < nk; ++kt) {
+        // stage kt has landed once at most the 6 copies of stage kt+1 are still in flight
+        if (kt + 1 < nk) {
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // every wave is past its reads of stage kt-1: its slot can take stage kt+2
+        if (kt + 2 < nk) stage_tile2(p, smem + ((kt + 2) % kStages) * kStage, wave, lane, m0, n0, (kt + 2) * BK);
+        const char* tA = smem + (kt % kStages) * kStage;
+        const char* tW = tA + kATile;
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss) {
+            bf16x8 wf[4], xf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int rw = wn * 64 + i * 16 + frow;
+                wf[i] = *reinterpret_cast<const bf16x8*>(tW + rw * 128 + (((4 * ss + fchk) ^ ((rw >> 1) & 7)) << 4));
+                const int ra = wm * 64 + i * 16 + frow;
+                xf[i] = *reinterpret_cast<const bf16x8*>(tA + ra * 128 + (((4 * ss + fchk) ^ ((ra >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    gemm_epilogue<EPI>(p, acc, m0 + wm * 64, n0 + wn * 64, lane);
+}
+}  // namespace v2
+
+// ---------------------------------------------------------------------------------------------
+// v3: 256x256x64 block tile, 8 waves of 128x64, "ping-pong" schedule.
+//
+// LDS image: 8 half-tile slots of 16 KiB = {A,W} x {lo,hi 128 rows} x {even,odd K-tile}.  Wave w
+// (wm = w>>2, wn = w&3) owns rows wm*64+[0,64) of BOTH A halves and columns wn*32+[0,32) of BOTH W
+// halves, so quadrant (qm,qn) of its 128x64 output needs exactly half-tiles A[qm], W[qn].
+// Per K-tile every wave runs  L1 C1 L2 C2 L3 C3 L4 C4  with a raw s_barrier after each slot:
+//   L = LDS fragment reads for the next C + 2 global->LDS copies (one half-tile per L, all waves)
+//   C = 16 MFMAs (one quadrant x K=64)
+// Waves 4-7 run ONE SLOT BEHIND waves 0-3 (one extra barrier up front), and each SIMD hosts one
+// wave of either group: while one group's waves are in a C slot (matrix pipe) the other group's
+// are in an L slot (LDS + DMA issue), so LDS traffic overlaps the MFMAs instead of adding to them
+// (v1/v2 spend as many CU cycles on LDS as on MFMA and do not overlap them: 36 % MFMA busy).
+// Quadrant order (0,0) (0,1) (1,1) (1,0); fragments: A-sub 8 reads in L1/L3, W-sub1 4 reads in L2,
+// W-sub0 4 reads in L1 and kept in registers for C4.  A half-tile slot is re-staged as soon as
+// both groups are past its last read (two K-tiles ahead):
+//   L1(t): A-hi(t+1)   L2(t): A-lo(t+2)   L3(t): W-lo(t+2)   L4(t): W-hi(t+2)
+// so >= 11 slots pass between a copy's issue and its first read; every L ends with a counted
+// s_waitcnt vmcnt(10) (the five youngest half-tile copies may still be in flight) + lgkmcnt(0).
+namespace v3 {
+constexpr int BM3 = 256, BN3 = 256;
+constexpr int kThreads3 = 512;
+constexpr int kHalf = 128 * BK * 2;   // 16 KiB half-tile
+constexpr int kLds3 = 8 * kHalf;      // 128 KiB
+// slot offsets: [operand A=0/W=1][half][buf]
+__device__ __forceinline__ constexpr int slot_off(int operand, int half, int buf) { return ((operand * 2 + half) * 2 + buf) * kHalf; }
+
+template <int OPERAND>
+__device__ __forceinline__ void stage_half(const GemmParams& p, char* smem, int half, int buf, int tile, int wave, int lane,
+                                           int m0, int n0) {
+    const int lrow = lane >> 3, slot = lane & 7;
+    char* dst = smem + slot_off(OPERAND, half, buf);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = 16 * wave + 8 * j + lrow;
+        const int chunk = slot ^ ((r >> 1) & 7);
+        const uint16_t* src;
+        if constexpr (OPERAND == 0) src = p.A + (size_t)(m0 + half * 128 + r) * p.lda + tile * BK + chunk * 8;
+        else src = p.W + (size_t)(n0 + half * 128 + r) * p.K + tile * BK + chunk * 8;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(dst + (16 * wave + 8 * j) * 128),
+                                         16, 0, 0);
+    }
+}
+
+#define TT_SLOT_END()                                         \
+    do {                                                      \
+        __builtin_amdgcn_sched_barrier(0);                    \
+        __builtin_amdgcn_s_barrier();                         \
+        __builtin_amdgcn_sched_barrier(0);                    \
+    } while (0)
+
+template <int EPI, int SLOTS>
+__global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+
+    const int mt_n = p.M / BM3, nt_n = p.N / BN3;
+    int L = blockIdx.x;
+    {
+        const int nwg = gridDim.x;
+        if ((nwg & 7) == 0) L = (L & 7) * (nwg >> 3) + (L >> 3);
+    }
+    const int SN = nt_n < 4 ? nt_n : 4;
+    const int SM = 8;
+    const int per_super = SM * SN;
+    const int supers_n = (nt_n + SN - 1) / SN;
+    const int sidx = L / per_super, widx = L % per_super;
+    const int tm = (sidx / supers_n) * SM + widx / SN;
+    const int tn = (sidx % supers_n) * SN + widx % SN;
+    if (tm >= mt_n || tn >= nt_n) return;
+    const int m0 = tm * BM3, n0 = tn * BN3;
+    const int nk = p.K / BK;
+
+    f32x4 acc[2][2][2][4];  // [qm][qn][n-tile][m-tile]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int d = 0; d < 4; ++d) acc[a][b][c][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // per-lane fragment offsets inside a half-tile (row frow of a 16-row tile, k-substep 0 / 1)
+    const int frow = lane & 15, fchk = lane >> 4, sw = (frow >> 1) & 7;
+    const int off0 = frow * 128 + ((fchk ^ sw) << 4);
+    const int off1 = frow * 128 + (((4 + fchk) ^ sw) << 4);
+    const int a_row0 = wm * 64 * 128;   // byte offset of this wave's first A row inside a half-tile
+    const int w_row0 = wn * 32 * 128;
+
+    // ---- prologue: tile 0 complete, tile 1 without its A-hi (issued in L1(0)); same order as steady state
+    stage_half<0>(p, smem, 0, 0, 0, wave, lane, m0, n0);
+    stage_half<1>(p, smem, 0, 0, 0, wave, lane, m0, n0);
+    stage_half<1>(p, smem, 1, 0, 0, wave, lane, m0, n0);
+    stage_half<0>(p, smem, 1, 0, 0, wave, lane, m0, n0);
+    if (nk > 1) {
+        stage_half<0>(p, smem, 0, 1, 1, wave, lane, m0, n0);
+        stage_half<1>(p, smem, 0, 1, 1, wave, lane, m0, n0);
+        if constexpr (SLOTS == 8) stage_half<1>(p, smem, 1, 1, 1, wave, lane, m0, n0);
+    }
+    if (SLOTS == 8 && nk > 2) {
+        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    } else if (SLOTS == 4 && nk > 1) {
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // A-hi(0), A-lo(1), W-lo(1) may be in flight
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    TT_SLOT_END();
+    if (wave >= 4) TT_SLOT_END();   // waves 4-7 run one slot behind
+
+    bf16x8 xf[4][2], wf0[2][2], wf1[2][2];
+
+    auto read_a = [&](const char* base) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            xf[mt][0] = *reinterpret_cast<const bf16x8*>(base + a_row0 + mt * 2048 + off0);
+            xf[mt][1] = *reinterpret_cast<const bf16x8*>(base + a_row0 + mt * 2048 + off1);
+        }
+    };
+    auto read_w = [&](bf16x8(&wf)[2][2], const char* base) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            wf[nt][0] = *reinterpret_cast<const bf16x8*>(base + w_row0 + nt * 2048 + off0);
+            wf[nt][1] = *reinterpret_cast<const bf16x8*>(base + w_row0 + nt * 2048 + off1);
+        }
+    };
+    auto mma = [&](f32x4(&c)[2][4], const bf16x8(&wf)[2][2]) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+                    c[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt][ss], xf[mt][ss], c[nt][mt], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto l_end = [&](bool steady) {
+        if (steady) {
+            asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        }
+        TT_SLOT_END();
+    };
+
+    auto tile = [&](int t, auto bufc) {
+        constexpr int B = decltype(bufc)::value;
+        const bool steady = t + 2 < nk;
+        // L1: A-hi(t+1) -> (A,hi,B^1); fragments A-lo, W-lo of tile t
+        if (t + 1 < nk) stage_half<0>(p, smem, 1, B ^ 1, t + 1, wave, lane, m0, n0);
+        read_a(smem + slot_off(0, 0, B));
+        read_w(wf0, smem + slot_off(1, 0, B));
+        l_end(steady);
+        mma(acc[0][0], wf0);                       // C1
+        TT_SLOT_END();
+        // L2: A-lo(t+2) -> (A,lo,B); fragments W-hi
+        if (t + 2 < nk) stage_half<0>(p, smem, 0, B, t + 2, wave, lane, m0, n0);
+        read_w(wf1, smem + slot_off(1, 1, B));
+        l_end(steady);
+        mma(acc[0][1], wf1);                       // C2
+        TT_SLOT_END();
+        // L3: W-lo(t+2) -> (W,lo,B); fragments A-hi
+        if (t + 2 < nk) stage_half<1>(p, smem, 0, B, t + 2, wave, lane, m0, n0);
+        read_a(smem + slot_off(0, 1, B));
+        l_end(steady);
+        mma(acc[1][1], wf1);                       // C3
+        TT_SLOT_END();
+        // L4: W-hi(t+2) -> (W,hi,B)
+        if (t + 2 < nk) stage_half<1>(p, smem, 1, B, t + 2, wave, lane, m0, n0);
+        l_end(steady);
+        mma(acc[1][0], wf0);                       // C4
+        TT_SLOT_END();
+    };
+
+    // 4-slot variant: La (A-lo, W-lo, W-hi fragments) | Ca (quadrants 00, 01) | Lb (A-hi) | Cb (11, 10):
+    // half as many barriers per MFMA.  Copies: La(t): W-hi(t+1), A-hi(t+1);  Lb(t): A-lo(t+2), W-lo(t+2).
+    auto wait_n = [&](int n) {
+        if (n == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        else if (n == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        TT_SLOT_END();
+    };
+    auto tile4 = [&](int t, auto bufc) {
+        constexpr int B = decltype(bufc)::value;
+        // La
+        if (t + 1 < nk) {
+            stage_half<1>(p, smem, 1, B ^ 1, t + 1, wave, lane, m0, n0);
+            stage_half<0>(p, smem, 1, B ^ 1, t + 1, wave, lane, m0, n0);
+        }
+        read_a(smem + slot_off(0, 0, B));
+        read_w(wf0, smem + slot_off(1, 0, B));
+        read_w(wf1, smem + slot_off(1, 1, B));
+        wait_n(t + 1 < nk ? 8 : 0);
+        mma(acc[0][0], wf0);                       // Ca
+        mma(acc[0][1], wf1);
+        TT_SLOT_END();
+        // Lb
+        if (t + 2 < nk) {
+            stage_half<0>(p, smem, 0, B, t + 2, wave, lane, m0, n0);
+            stage_half<1>(p, smem, 0, B, t + 2, wave, lane, m0, n0);
+        }
+        read_a(smem + slot_off(0, 1, B));
+        wait_n(t + 2 < nk ? 6 : 0);
+        mma(acc[1][1], wf1);                       // Cb
+        mma(acc[1][0], wf0);
+        TT_SLOT_END();
+    };
+
+    for (int t = 0; t < nk; t += 2) {
+        if constexpr (SLOTS == 8) {
+            tile(t, std::integral_constant<int, 0>{});
+            if (t + 1 < nk) tile(t + 1, std::integral_constant<int, 1>{});
+        } else {
+            tile4(t, std::integral_constant<int, 0>{});
+            if (t + 1 < nk) tile4(t + 1, std::integral_constant<int, 1>{});
+        }
+    }
+    if (wave < 4) TT_SLOT_END();   // match the extra barrier waves 4-7 took up front
+
+    // ---- epilogue ---------------------------------------------------------------------------------
+#pragma unroll
+    for (int qm = 0; qm < 2; ++qm)
+#pragma unroll
+        for (int qn = 0; qn < 2; ++qn)
+            gemm_epilogue_wide<EPI, 2, 4>(p, acc[qm][qn], m0 + qm * 128 + wm * 64, n0 + qn * 128 + wn * 32, lane);
+}
+#undef TT_SLOT_END
+}  // namespace v3
+
+template <int EPI>
 int launch(const GemmParams& p, hipStream_t st) {
+    static const int variant = [] { const char* e = getenv("TT_GEMM_VARIANT"); return e && e[0] ? atoi(e) : 4; }();
+    if ((variant == 3 || variant == 4) && p.M % v3::BM3 == 0 && p.N % v3::BN3 == 0 && p.ldc % 8 == 0 &&
+        (EPI != TT_EPI_RESIDUAL || p.ldr % 8 == 0)) {
+        const int mt_n = p.M / v3::BM3, nt_n = p.N / v3::BN3;
+        const int SN = nt_n < 4 ? nt_n : 4, SM = 8;
+        const int supers = ((mt_n + SM - 1) / SM) * ((nt_n + SN - 1) / SN);
+        int blocks = supers * SM * SN;
+        blocks = (blocks + 7) / 8 * 8;
+        auto kern = variant == 4 ? v3::gemm_kernel_v3<EPI, 4> : v3::gemm_kernel_v3<EPI, 8>;
+        static thread_local bool attr3 = false;
+        if (!attr3) {
+            TT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(v3::gemm_kernel_v3<EPI, 4>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, v3::kLds3));
+            TT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(v3::gemm_kernel_v3<EPI, 8>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, v3::kLds3));
+            attr3 = true;
+        }
+        {
+            TtProfScope prof(TT_K_GEMM, st);
+            hipLaunchKernelGGL(kern, dim3(blocks), dim3(v3::kThreads3), v3::kLds3, st, p);
+        }
+        TT_CHECK_LAUNCH();
+        return TT_OK;
+    }
+    if (variant == 2 && p.M % v2::BM2 == 0) {
+        const int mt_n = p.M / v2::BM2, nt_n = p.N / v2::BN2;
+        const int SN = nt_n < 8 ? nt_n : 8, SM = 4;
+        const int supers = ((mt_n + SM - 1) / SM) * ((nt_n + SN - 1) / SN);
+        int blocks = supers * SM * SN;
+        blocks = (blocks + 7) / 8 * 8;
+        auto kern = v2::gemm_kernel_v2<EPI>;
+        static thread_local bool attr2 = false;
+        if (!attr2) {
+            TT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, v2::kLds2));
+            attr2 = true;
+        }
+        {
+            TtProfScope prof(TT_K_GEMM, st);
+            hipLaunchKernelGGL(kern, dim3(blocks), dim3(v2::kThreads2), v2::kLds2, st, p);
+        }
+        TT_CHECK_LAUNCH();
+        return TT_OK;
+    }
     const int mt_n = p.M / BM, nt_n = p.N / BN;
     const int SN = nt_n < 8 ? nt_n : 8, SM = 8;
     const int supers = ((mt_n + SM - 1) / SM) * ((nt_n + SN - 1) / SN);

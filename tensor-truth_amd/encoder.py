@@ -260,7 +260,7 @@ def pack_tokens(seqs: Sequence[Sequence[int]], cfg: EncoderConfig,
     for i, n in enumerate(lens):
         starts[i] = off
         off += (int(n) + 7) // 8 * 8
-    n_rows = max(128, (off + 127) // 128 * 128)
+    n_rows = max(256, (off + 255) // 256 * 256)   # multiple of 256: the 256-row GEMM tile
     ids = np.full(n_rows, cfg.pad_id, dtype=np.int32)
     pos = np.zeros(n_rows, dtype=np.int32)
     types = np.zeros(n_rows, dtype=np.int32) if type_ids is not None else None
