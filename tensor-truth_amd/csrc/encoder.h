@@ -2,7 +2,8 @@
 #pragma once
 #include "common.h"
 
-enum { TT_EPI_BIAS = 0, TT_EPI_GELU = 1, TT_EPI_RESIDUAL = 2, TT_EPI_TANH = 3, TT_EPI_QKV = 4 };
+enum { TT_EPI_BIAS = 0, TT_EPI_GELU = 1, TT_EPI_RESIDUAL = 2, TT_EPI_TANH = 3, TT_EPI_QKV = 4,
+       TT_EPI_VT = 5 /* internal: whole output stored transposed into vt (the V third of a QKV projection) */ };
 
 struct GemmParams {
     const uint16_t* A;        // [M][lda] bf16

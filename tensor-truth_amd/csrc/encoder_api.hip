@@ -197,6 +197,15 @@ int tt_gemm_bf16(const void* a, const void* w, const float* bias, const void* re
     return tt_gemm_launch(g, epilogue, (hipStream_t)stream);
 }
 
+// diagnostic only (not in tt_hip.h): run the bias GEMM with a stamp buffer in GemmParams.vt
+int tt_gemm_debug_stamps(const void* a, const void* w, const float* bias, void* c, int m, int n, int k, void* stamps,
+                         void* stream) {
+    GemmParams g{};
+    g.A = (const uint16_t*)a; g.lda = k; g.W = (const uint16_t*)w; g.bias = bias; g.C = (uint16_t*)c; g.ldc = n;
+    g.M = m; g.N = n; g.K = k; g.vt = (uint16_t*)stamps;
+    return tt_gemm_launch(g, TT_EPI_BIAS, (hipStream_t)stream);
+}
+
 int tt_layernorm_bf16(const void* in, void* out, const float* gamma, const float* beta, int rows, int hidden,
                       float eps, void* stream) {
     TT_CHECK_ARG(in && out && gamma && beta, "null pointer");

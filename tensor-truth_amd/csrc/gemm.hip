@@ -160,6 +160,38 @@ __device__ __forceinline__ void gemm_epilogue_wide(const GemmParams& p, f32x4 (&
     }
 }
 
+// ---- V^T epilogue (un-swapped accumulators: lane = feature column l&15, registers = 4 consecutive tokens)
+// permlane16_swap between the registers of n-tile 2i and 2i+1 gives every lane 8 consecutive tokens of one
+// feature: one 16-B store into the transposed V buffer instead of eight 2-byte stores.
+template <int NT, int MT>
+__device__ __forceinline__ void gemm_epilogue_vt(const GemmParams& p, f32x4 (&acc)[NT][MT], int mw, int nw, int lane) {
+    static_assert(NT % 2 == 0, "n-tiles are processed in pairs");
+    const int g = lane >> 4;
+    const bool odd = (g & 1) != 0;
+#pragma unroll
+    for (int i = 0; i < NT; i += 2) {
+        const int n = nw + (odd ? i + 1 : i) * 16 + (lane & 15);
+        const float b = p.bias[n];
+        uint16_t* row = p.vt + (size_t)(n - p.vt_col0) * p.ldvt;
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[i][j][k]),
+                                                                __float_as_uint(acc[i + 1][j][k]), false, false);
+                v[k] = __uint_as_float(r[0]) + b;
+                v[4 + k] = __uint_as_float(r[1]) + b;
+            }
+            const int m = mw + j * 16 + (g & ~1) * 4;
+            uint4 o;
+            o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
+            o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
+            *reinterpret_cast<uint4*>(row + m) = o;
+        }
+    }
+}
+
 // issue the global->LDS copies of one K-step (both operand tiles) for this wave
 __device__ __forceinline__ void stage_tile(const GemmParams& p, char* stage, int wave, int lane, int m0, int n0, int k0) {
     const int lrow = lane >> 3;   // row inside the 8-row piece
@@ -389,19 +421,25 @@ constexpr int kLds3 = 8 * kHalf;      // 128 KiB
 // slot offsets: [operand A=0/W=1][half][buf]
 __device__ __forceinline__ constexpr int slot_off(int operand, int half, int buf) { return ((operand * 2 + half) * 2 + buf) * kHalf; }
 
+// One half-tile = 2 global->LDS copies per wave.  The source is addressed as a wave-uniform base
+// (SGPR pair: operand + first row of the half + K offset) plus a per-lane 32-bit byte offset that is
+// constant for the whole kernel (voff[j]), so a copy costs no vector address arithmetic.
 template <int OPERAND>
-__device__ __forceinline__ void stage_half(const GemmParams& p, char* smem, int half, int buf, int tile, int wave, int lane,
-                                           int m0, int n0) {
-    const int lrow = lane >> 3, slot = lane & 7;
+__device__ __forceinline__ void stage_half(const GemmParams& p, char* smem, int half, int buf, int tile, int wave,
+                                           const uint32_t (&voff)[2], int m0, int n0) {
     char* dst = smem + slot_off(OPERAND, half, buf);
+    const char* base;
+    if constexpr (OPERAND == 0) base = reinterpret_cast<const char*>(p.A + (size_t)(m0 + half * 128) * p.lda + tile * BK);
+    else base = reinterpret_cast<const char*>(p.W + (size_t)(n0 + half * 128) * p.K + tile * BK);
+    // keep the base in SGPRs (otherwise hipcc folds it into per-lane 64-bit VGPR addresses and
+    // pays two 64-bit vector adds per copy)
+    const unsigned long long b64 = reinterpret_cast<unsigned long long>(base);
+    const unsigned int blo = __builtin_amdgcn_readfirstlane((unsigned int)b64);
+    const unsigned int bhi = __builtin_amdgcn_readfirstlane((unsigned int)(b64 >> 32));
+    base = reinterpret_cast<const char*>(((unsigned long long)bhi << 32) | blo);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int r = 16 * wave + 8 * j + lrow;
-        const int chunk = slot ^ ((r >> 1) & 7);
-        const uint16_t* src;
-        if constexpr (OPERAND == 0) src = p.A + (size_t)(m0 + half * 128 + r) * p.lda + tile * BK + chunk * 8;
-        else src = p.W + (size_t)(n0 + half * 128 + r) * p.K + tile * BK + chunk * 8;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + voff[j]),
                                          (__attribute__((address_space(3))) void*)(dst + (16 * wave + 8 * j) * 128),
                                          16, 0, 0);
     }
@@ -456,25 +494,37 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
     const int a_row0 = wm * 64 * 128;   // byte offset of this wave's first A row inside a half-tile
     const int w_row0 = wn * 32 * 128;
 
+    // per-lane source byte offsets of this wave's two copies inside a half-tile (rows 16w+8j+lane/8,
+    // 16-B chunk (lane&7) ^ swizzle(row))
+    uint32_t voffA[2], voffW[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = 16 * wave + 8 * j + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((r >> 1) & 7);
+        voffA[j] = (uint32_t)r * (uint32_t)p.lda * 2u + (uint32_t)chunk * 16u;
+        voffW[j] = (uint32_t)r * (uint32_t)p.K * 2u + (uint32_t)chunk * 16u;
+    }
+
     // ---- prologue: tile 0 complete, tile 1 without its A-hi (issued in L1(0)); same order as steady state
-    stage_half<0>(p, smem, 0, 0, 0, wave, lane, m0, n0);
-    stage_half<1>(p, smem, 0, 0, 0, wave, lane, m0, n0);
-    stage_half<1>(p, smem, 1, 0, 0, wave, lane, m0, n0);
-    stage_half<0>(p, smem, 1, 0, 0, wave, lane, m0, n0);
+    stage_half<0>(p, smem, 0, 0, 0, wave, voffA, m0, n0);
+    stage_half<1>(p, smem, 0, 0, 0, wave, voffW, m0, n0);
+    stage_half<1>(p, smem, 1, 0, 0, wave, voffW, m0, n0);
+    stage_half<0>(p, smem, 1, 0, 0, wave, voffA, m0, n0);
     if (nk > 1) {
-        stage_half<0>(p, smem, 0, 1, 1, wave, lane, m0, n0);
-        stage_half<1>(p, smem, 0, 1, 1, wave, lane, m0, n0);
-        if constexpr (SLOTS == 8) stage_half<1>(p, smem, 1, 1, 1, wave, lane, m0, n0);
+        stage_half<0>(p, smem, 0, 1, 1, wave, voffA, m0, n0);
+        stage_half<1>(p, smem, 0, 1, 1, wave, voffW, m0, n0);
+        if constexpr (SLOTS == 8) stage_half<1>(p, smem, 1, 1, 1, wave, voffW, m0, n0);
     }
     if (SLOTS == 8 && nk > 2) {
         asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-    } else if (SLOTS == 4 && nk > 1) {
+    } else if (SLOTS != 8 && nk > 1) {
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // A-hi(0), A-lo(1), W-lo(1) may be in flight
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     TT_SLOT_END();
-    if (wave >= 4) TT_SLOT_END();   // waves 4-7 run one slot behind
+    const bool late = (SLOTS == 45) ? ((wave & 1) != 0) : (wave >= 4);
+    if (late) TT_SLOT_END();   // waves 4-7 run one slot behind
 
     bf16x8 xf[4][2], wf0[2][2], wf1[2][2];
 
@@ -492,16 +542,30 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
             wf[nt][1] = *reinterpret_cast<const bf16x8*>(base + w_row0 + nt * 2048 + off1);
         }
     };
+    // Tiles of the V third of a QKV projection are produced un-swapped (a = X, b = W): a lane then holds 4
+    // consecutive TOKENS of one feature, which is what the transposed V^T store wants.
+    constexpr bool vblk = (EPI == TT_EPI_VT);
     auto mma = [&](f32x4(&c)[2][4], const bf16x8(&wf)[2][2]) {
-        __builtin_amdgcn_s_setprio(1);
+        if constexpr (SLOTS == 43) return;
+        if constexpr (SLOTS != 44) __builtin_amdgcn_s_setprio(1);
+        if constexpr (vblk) {
 #pragma unroll
-        for (int ss = 0; ss < 2; ++ss)
+            for (int ss = 0; ss < 2; ++ss)
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
+                for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
-                    c[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt][ss], xf[mt][ss], c[nt][mt], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
+                    for (int mt = 0; mt < 4; ++mt)
+                        c[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[mt][ss], wf[nt][ss], c[nt][mt], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int ss = 0; ss < 2; ++ss)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt)
+                        c[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt][ss], xf[mt][ss], c[nt][mt], 0, 0, 0);
+        }
+        if constexpr (SLOTS != 44) __builtin_amdgcn_s_setprio(0);
     };
     auto l_end = [&](bool steady) {
         if (steady) {
@@ -516,63 +580,97 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
         constexpr int B = decltype(bufc)::value;
         const bool steady = t + 2 < nk;
         // L1: A-hi(t+1) -> (A,hi,B^1); fragments A-lo, W-lo of tile t
-        if (t + 1 < nk) stage_half<0>(p, smem, 1, B ^ 1, t + 1, wave, lane, m0, n0);
+        if (t + 1 < nk) stage_half<0>(p, smem, 1, B ^ 1, t + 1, wave, voffA, m0, n0);
         read_a(smem + slot_off(0, 0, B));
         read_w(wf0, smem + slot_off(1, 0, B));
         l_end(steady);
         mma(acc[0][0], wf0);                       // C1
         TT_SLOT_END();
         // L2: A-lo(t+2) -> (A,lo,B); fragments W-hi
-        if (t + 2 < nk) stage_half<0>(p, smem, 0, B, t + 2, wave, lane, m0, n0);
+        if (t + 2 < nk) stage_half<0>(p, smem, 0, B, t + 2, wave, voffA, m0, n0);
         read_w(wf1, smem + slot_off(1, 1, B));
         l_end(steady);
         mma(acc[0][1], wf1);                       // C2
         TT_SLOT_END();
         // L3: W-lo(t+2) -> (W,lo,B); fragments A-hi
-        if (t + 2 < nk) stage_half<1>(p, smem, 0, B, t + 2, wave, lane, m0, n0);
+        if (t + 2 < nk) stage_half<1>(p, smem, 0, B, t + 2, wave, voffW, m0, n0);
         read_a(smem + slot_off(0, 1, B));
         l_end(steady);
         mma(acc[1][1], wf1);                       // C3
         TT_SLOT_END();
         // L4: W-hi(t+2) -> (W,hi,B)
-        if (t + 2 < nk) stage_half<1>(p, smem, 1, B, t + 2, wave, lane, m0, n0);
+        if (t + 2 < nk) stage_half<1>(p, smem, 1, B, t + 2, wave, voffW, m0, n0);
         l_end(steady);
         mma(acc[1][0], wf0);                       // C4
         TT_SLOT_END();
     };
 
     // 4-slot variant: La (A-lo, W-lo, W-hi fragments) | Ca (quadrants 00, 01) | Lb (A-hi) | Cb (11, 10):
-    // half as many barriers per MFMA.  Copies: La(t): W-hi(t+1), A-hi(t+1);  Lb(t): A-lo(t+2), W-lo(t+2).
+    // half as many barriers per MFMA.
+    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(p.vt);
+    int dbg_i = 0;
+    auto stamp = [&](int t) {
+        if constexpr (SLOTS == 46) {
+            if (blockIdx.x == 0 && t == 6 && (lane == 0) && dbg) {
+                __builtin_amdgcn_sched_barrier(0);
+                dbg[wave * 32 + dbg_i] = __builtin_amdgcn_s_memtime();
+                ++dbg_i;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
     auto wait_n = [&](int n) {
         if (n == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
         else if (n == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         TT_SLOT_END();
     };
+    constexpr bool kNoGlds = SLOTS == 41, kNoReads = SLOTS == 42;
+    // Copy schedule:  La(t): W-hi(t+1), A-hi(t+1)   Lb(t): A-lo(t+2), W-lo(t+2).
+    // (Moving half of the copies into the C slots was measured neutral-to-worse: an LDS-DMA issue
+    // costs ~100 cycles wherever it sits, and the C slot is then as long as the L slot.)
     auto tile4 = [&](int t, auto bufc) {
         constexpr int B = decltype(bufc)::value;
+        const bool more1 = !kNoGlds && t + 1 < nk, more2 = !kNoGlds && t + 2 < nk;
         // La
-        if (t + 1 < nk) {
-            stage_half<1>(p, smem, 1, B ^ 1, t + 1, wave, lane, m0, n0);
-            stage_half<0>(p, smem, 1, B ^ 1, t + 1, wave, lane, m0, n0);
+        stamp(t);                                  // 0: La start
+        if (more1) {
+            stage_half<1>(p, smem, 1, B ^ 1, t + 1, wave, voffW, m0, n0);
+            stage_half<0>(p, smem, 1, B ^ 1, t + 1, wave, voffA, m0, n0);
         }
-        read_a(smem + slot_off(0, 0, B));
-        read_w(wf0, smem + slot_off(1, 0, B));
-        read_w(wf1, smem + slot_off(1, 1, B));
-        wait_n(t + 1 < nk ? 8 : 0);
+        stamp(t);                                  // 1: copies issued
+        if (!kNoReads) {
+            read_a(smem + slot_off(0, 0, B));
+            read_w(wf0, smem + slot_off(1, 0, B));
+            read_w(wf1, smem + slot_off(1, 1, B));
+        }
+        stamp(t);                                  // 2: reads issued
+        if (SLOTS == 46) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        stamp(t);                                  // 3: reads returned
+        wait_n(kNoGlds ? 0 : (t + 1 < nk ? 8 : 0));
+        stamp(t);                                  // 4: past barrier (Ca start)
         mma(acc[0][0], wf0);                       // Ca
         mma(acc[0][1], wf1);
+        stamp(t);                                  // 5: MFMAs issued
         TT_SLOT_END();
         // Lb
-        if (t + 2 < nk) {
-            stage_half<0>(p, smem, 0, B, t + 2, wave, lane, m0, n0);
-            stage_half<1>(p, smem, 0, B, t + 2, wave, lane, m0, n0);
+        stamp(t);                                  // 6: Lb start
+        if (more2) {
+            stage_half<0>(p, smem, 0, B, t + 2, wave, voffA, m0, n0);
+            stage_half<1>(p, smem, 0, B, t + 2, wave, voffW, m0, n0);
         }
-        read_a(smem + slot_off(0, 1, B));
-        wait_n(t + 2 < nk ? 6 : 0);
+        stamp(t);                                  // 7
+        if (!kNoReads) read_a(smem + slot_off(0, 1, B));
+        stamp(t);                                  // 8
+        if (SLOTS == 46) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        stamp(t);                                  // 9
+        wait_n(kNoGlds ? 0 : (t + 2 < nk ? 6 : 0));
+        stamp(t);                                  // 10: Cb start
         mma(acc[1][1], wf1);                       // Cb
         mma(acc[1][0], wf0);
+        stamp(t);                                  // 11
         TT_SLOT_END();
+        stamp(t);                                  // 12
     };
 
     for (int t = 0; t < nk; t += 2) {
@@ -584,14 +682,19 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
             if (t + 1 < nk) tile4(t + 1, std::integral_constant<int, 1>{});
         }
     }
-    if (wave < 4) TT_SLOT_END();   // match the extra barrier waves 4-7 took up front
+    if (!late) TT_SLOT_END();   // match the extra barrier the late group took up front
 
     // ---- epilogue ---------------------------------------------------------------------------------
 #pragma unroll
     for (int qm = 0; qm < 2; ++qm)
 #pragma unroll
         for (int qn = 0; qn < 2; ++qn)
-            gemm_epilogue_wide<EPI, 2, 4>(p, acc[qm][qn], m0 + qm * 128 + wm * 64, n0 + qn * 128 + wn * 32, lane);
+        {
+            if constexpr (vblk)
+                gemm_epilogue_vt<2, 4>(p, acc[qm][qn], m0 + qm * 128 + wm * 64, n0 + qn * 128 + wn * 32, lane);
+            else
+                gemm_epilogue_wide<EPI, 2, 4>(p, acc[qm][qn], m0 + qm * 128 + wm * 64, n0 + qn * 128 + wn * 32, lane);
+        }
 }
 #undef TT_SLOT_END
 }  // namespace v3
@@ -607,6 +710,16 @@ int launch(const GemmParams& p, hipStream_t st) {
         int blocks = supers * SM * SN;
         blocks = (blocks + 7) / 8 * 8;
         auto kern = variant == 4 ? v3::gemm_kernel_v3<EPI, 4> : v3::gemm_kernel_v3<EPI, 8>;
+        if constexpr (EPI == TT_EPI_BIAS) {   // timing-only ablations of the 4-slot loop (wrong results)
+            static const int abl = [] { const char* e = getenv("TT_GEMM_ABLATE"); return e && e[0] ? atoi(e) : 0; }();
+            if (abl == 1) kern = v3::gemm_kernel_v3<EPI, 41>;
+            if (abl == 2) kern = v3::gemm_kernel_v3<EPI, 42>;
+            if (abl == 3) kern = v3::gemm_kernel_v3<EPI, 43>;
+            if (abl == 4) kern = v3::gemm_kernel_v3<EPI, 44>;
+            if (abl == 5) kern = v3::gemm_kernel_v3<EPI, 45>;
+            if (abl == 6) kern = v3::gemm_kernel_v3<EPI, 46>;
+            if (abl) TT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, v3::kLds3));
+        }
         static thread_local bool attr3 = false;
         if (!attr3) {
             TT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(v3::gemm_kernel_v3<EPI, 4>),
@@ -621,6 +734,10 @@ int launch(const GemmParams& p, hipStream_t st) {
         }
         TT_CHECK_LAUNCH();
         return TT_OK;
+    }
+    if constexpr (EPI == TT_EPI_VT) {
+        tt_set_error("gemm: internal V^T epilogue needs the 256x256 kernel");
+        return TT_E_UNSUPPORTED;
     }
     if (variant == 2 && p.M % v2::BM2 == 0) {
         const int mt_n = p.M / v2::BM2, nt_n = p.N / v2::BN2;
@@ -681,9 +798,26 @@ int tt_gemm_launch(const GemmParams& p, int epilogue, hipStream_t st) {
             if (!p.residual) { tt_set_error("gemm: residual epilogue without residual"); return TT_E_INVALID; }
             return launch<TT_EPI_RESIDUAL>(p, st);
         case TT_EPI_TANH: return launch<TT_EPI_TANH>(p, st);
-        case TT_EPI_QKV:
+        case TT_EPI_QKV: {
             if (!p.vt) { tt_set_error("gemm: qkv epilogue without vt"); return TT_E_INVALID; }
+            static const int variant = [] { const char* e = getenv("TT_GEMM_VARIANT"); return e && e[0] ? atoi(e) : 4; }();
+            const int nv = p.N - p.vt_col0;
+            if ((variant == 3 || variant == 4) && p.M % v3::BM3 == 0 && p.vt_col0 % v3::BN3 == 0 && nv % v3::BN3 == 0 &&
+                nv > 0 && p.ldc % 8 == 0 && p.ldvt % 8 == 0) {
+                // Q,K columns: plain bias GEMM; V columns: un-swapped tiles stored transposed (two launches,
+                // same number of tile rounds as one)
+                GemmParams a = p;
+                a.N = p.vt_col0;
+                if (int rc = launch<TT_EPI_BIAS>(a, st)) return rc;
+                GemmParams b = p;
+                b.W = p.W + (size_t)p.vt_col0 * p.K;
+                b.bias = p.bias + p.vt_col0;
+                b.N = nv;
+                b.vt_col0 = 0;
+                return launch<TT_EPI_VT>(b, st);
+            }
             return launch<TT_EPI_QKV>(p, st);
+        }
         default: tt_set_error("gemm: unknown epilogue %d", epilogue); return TT_E_INVALID;
     }
 }

@@ -1,11 +1,7 @@
 #!/bin/bash
-set -x
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-./tools/gemm_bench 16384 20 > gpurun_out/gemm_bench.log 2>&1
-cat gpurun_out/gemm_bench.log
 rm -rf gpurun_out/gpmc1 gpurun_out/gpmc2
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_LDS SQ_INSTS_VALU GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/gpmc1 -- ./tools/gemm_bench 16384 3 > gpurun_out/gpmc1.log 2>&1
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_INSTS_MFMA SQ_INSTS_SALU SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM --kernel-trace --output-format csv -d gpurun_out/gpmc2 -- ./tools/gemm_bench 16384 3 > gpurun_out/gpmc2.log 2>&1
-ls gpurun_out/gpmc1/*/ gpurun_out/gpmc2/*/
