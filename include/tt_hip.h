@@ -147,7 +147,10 @@ int tt_embed_pool(const void* hidden_bf16, int ld, const int32_t* rows, int n_se
 int tt_rerank_head(const tt_encoder_weights* w, const void* hidden_bf16, const int32_t* rows, int n_seq,
                    float* scores, float* logits, void* workspace, size_t workspace_bytes, void* stream);
 
-/* Building blocks, exported for the parity tests (same kernels the forward uses). */
+/* Building blocks, exported for the parity tests (same kernels the forward uses).
+ * tt_attention_varlen: Q and K are row-major [rows][ld_qk] at column offsets q_col0 / k_col0;
+ * V is passed in the token-blocked transposed layout the QKV GEMM epilogue writes,
+ * vt[(row / 8) * ldvt + feature * 8 + row % 8] with ldvt = 8 * heads * head_dim. */
 int tt_gemm_bf16(const void* a, const void* w, const float* bias, const void* residual, void* c,
                  int m, int n, int k, int epilogue /*0 bias,1 gelu,2 +residual,3 tanh*/, void* stream);
 int tt_layernorm_bf16(const void* in, void* out, const float* gamma, const float* beta, int rows, int hidden,

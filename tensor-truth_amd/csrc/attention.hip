@@ -13,7 +13,8 @@
 //   O^T[d][q]  += V^T . P^T    A = V^T fragment (2 x ds_read_b64 from a padded [d][key] image),
 //                              B = the S^T accumulator itself, converted to bf16 in place
 // so the softmax row statistics are lane-local (one cross-half exchange per tile), P never
-// goes through LDS, and V is consumed from the transposed copy the QKV GEMM epilogue wrote.
+// goes through LDS, and V is consumed from the token-blocked transposed copy the QKV GEMM
+// epilogue wrote (V8: [token/8][feature][8]: a 64-key x dh tile is 8 contiguous 1-KiB runs).
 #include "common.h"
 #include "encoder.h"
 
@@ -60,41 +61,60 @@ __global__ __launch_bounds__(kAttThreads) void attention_kernel(AttnParams p) {
     const float sc = p.scale * 1.4426950408889634f;  // fold log2(e): softmax via exp2
 
     const int n_kt = (len + kKTile - 1) / kKTile;
+    // waves whose 32 query rows all lie beyond the sequence only help staging the tiles
+    const bool wave_active = qt * kQTile + wave * 32 < len;   // wave-uniform
+
+    // ---- staging: each thread moves KPT 16-B pieces of the K tile and VPT of the V^T tile;
+    // the NEXT tile's pieces are loaded into registers before the current tile is computed and
+    // written to LDS after it (global latency hidden behind the MFMA / softmax work).
+    constexpr int KPT = kKTile * CH / kAttThreads;          // 2 (dh 64) or 1 (dh 32)
+    constexpr int VPT = DH * (kKTile / 8) / kAttThreads;    // 2 (dh 64) or 1 (dh 32)
+    uint4 kreg[KPT], vreg[VPT];
+    auto load_tile = [&](int kt) {
+        const int k0 = kt * kKTile;
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            const int piece = tid + i * kAttThreads;
+            const int r = piece / CH, c = piece % CH;
+            kreg[i] = make_uint4(0, 0, 0, 0);
+            if (k0 + r < len)
+                kreg[i] = *reinterpret_cast<const uint4*>(p.qk + (size_t)(t0 + k0 + r) * p.ld_qk + p.k_col0 + head * DH + c * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const int piece = tid + i * kAttThreads;
+            const int d = piece % DH, c = piece / DH;       // consecutive threads -> consecutive features (16 B apart)
+            vreg[i] = make_uint4(0, 0, 0, 0);
+            if (k0 + c * 8 < len)
+                vreg[i] = *reinterpret_cast<const uint4*>(p.vt + (size_t)((t0 + k0) / 8 + c) * p.ldvt + (size_t)(head * DH + d) * 8);
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            const int piece = tid + i * kAttThreads;
+            const int r = piece / CH, c = piece % CH;
+            *reinterpret_cast<uint4*>(k_lds + r * RB + ((c ^ ((r / RPB) & (CH - 1))) << 4)) = kreg[i];
+        }
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const int piece = tid + i * kAttThreads;
+            const int d = piece % DH, c = piece / DH;
+            uint2* dst = reinterpret_cast<uint2*>(vt_lds + d * kVtStride + c * 16);
+            dst[0] = make_uint2(vreg[i].x, vreg[i].y);
+            dst[1] = make_uint2(vreg[i].z, vreg[i].w);
+        }
+    };
+
+    load_tile(0);
     for (int kt = 0; kt < n_kt; ++kt) {
         const int k0 = kt * kKTile;
-        if (kt > 0) __syncthreads();
-        // ---- stage K tile [64 keys][DH] (swizzled 16-B chunks) ----------------------------
-        {
-            constexpr int LPR = CH;                       // lanes per row
-            constexpr int RPP = kAttThreads / LPR;        // rows per pass
-            const int c = tid % LPR;
-#pragma unroll
-            for (int r0 = 0; r0 < kKTile; r0 += RPP) {
-                const int r = r0 + tid / LPR;
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (k0 + r < len)
-                    v = *reinterpret_cast<const uint4*>(p.qk + (size_t)(t0 + k0 + r) * p.ld_qk + p.k_col0 + head * DH + c * 8);
-                *reinterpret_cast<uint4*>(k_lds + r * RB + ((c ^ ((r / RPB) & (CH - 1))) << 4)) = v;
-            }
-        }
-        // ---- stage V^T tile [DH][64 keys] (rows padded to kVtStride) -----------------------
-        {
-            constexpr int LPR = kKTile / 8;               // 8 lanes x 16 B per row
-            constexpr int RPP = kAttThreads / LPR;        // 32 rows per pass
-            const int c = tid % LPR;
-#pragma unroll
-            for (int r0 = 0; r0 < DH; r0 += RPP) {
-                const int d = r0 + tid / LPR;
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (k0 + c * 8 < len)
-                    v = *reinterpret_cast<const uint4*>(p.vt + (size_t)(head * DH + d) * p.ldvt + t0 + k0 + c * 8);
-                uint2* dst = reinterpret_cast<uint2*>(vt_lds + d * kVtStride + c * 16);
-                dst[0] = make_uint2(v.x, v.y);
-                dst[1] = make_uint2(v.z, v.w);
-            }
-        }
+        if (kt > 0) __syncthreads();          // everyone is done reading the previous tile
+        store_tile();
+        if (kt + 1 < n_kt) load_tile(kt + 1);  // in flight while this tile is computed
         __syncthreads();
 
+        if (!wave_active) continue;
         // ---- S^T = K . Q^T for two 32-key tiles -------------------------------------------------
         f32x16 acc_s[2];
 #pragma unroll
@@ -109,39 +129,42 @@ __global__ __launch_bounds__(kAttThreads) void attention_kernel(AttnParams p) {
                 acc_s[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], acc_s[j], 0, 0, 0);
             }
         }
-        // ---- scale, mask the tail, running max ----------------------------------------------------
+        // ---- mask the tail, running max, exponentials --------------------------------------------
+        // The softmax scale (and log2 e) is folded into one FMA per score: p = 2^(s*sc - m), with m
+        // tracked in the scaled domain; v_exp_f32 is used raw (arguments are <= 0, a result that
+        // underflows is 0 either way), the libm exp2f wraps it in 5 more instructions per value.
         const bool tail = k0 + kKTile > len;  // wave-uniform
         float mx = -__builtin_inff();
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float v = acc_s[j][r] * sc;
                 if (tail) {
                     const int key = k0 + 32 * j + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                    if (key >= len) v = -__builtin_inff();
+                    if (key >= len) acc_s[j][r] = -__builtin_inff();
                 }
-                acc_s[j][r] = v;
-                mx = fmaxf(mx, v);
+                mx = fmaxf(mx, acc_s[j][r]);
             }
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);            // finite: every tile holds >= 1 valid key
-        const float alpha = exp2f(m_run - m_new);        // first tile: exp2(-inf) = 0
+        const float m_new = fmaxf(m_run, mx * sc);       // finite: every tile holds >= 1 valid key
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // first tile: 2^-inf = 0
         m_run = m_new;
         float psum = 0.f;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float e = exp2f(acc_s[j][r] - m_new);
+                const float e = __builtin_amdgcn_exp2f(fmaf(acc_s[j][r], sc, -m_new));
                 acc_s[j][r] = e;
                 psum += e;
             }
         l_run = l_run * alpha + psum;
+        if (!__all(alpha == 1.0f)) {          // the running max rarely moves after the first tiles
 #pragma unroll
-        for (int d = 0; d < DT; ++d)
+            for (int d = 0; d < DT; ++d)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc_o[d][r] *= alpha;
+                for (int r = 0; r < 16; ++r) acc_o[d][r] *= alpha;
+        }
 
         // ---- O^T += V^T . P^T ----------------------------------------------------------------------
 #pragma unroll

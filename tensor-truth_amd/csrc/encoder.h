@@ -11,14 +11,16 @@ struct GemmParams {
     const float* bias;        // [N] fp32
     const uint16_t* residual; // [M][ldr] bf16 (TT_EPI_RESIDUAL)
     uint16_t* C;              // [M][ldc] bf16
-    uint16_t* vt;             // TT_EPI_QKV: columns >= vt_col0 go to vt[n - vt_col0][m] (ldvt)
+    uint16_t* vt;             // TT_EPI_QKV: columns >= vt_col0 go to the V8 buffer:
+                              //   vt[(m / 8) * ldvt + (n - vt_col0) * 8 + m % 8],  ldvt = 8 * (N - vt_col0)
     int M, N, K, lda, ldc, ldr, ldvt, vt_col0;
 };
 int tt_gemm_launch(const GemmParams& p, int epilogue, hipStream_t st);
 
 struct AttnParams {
     const uint16_t* qk;       // [T][ld_qk] bf16: Q at column q_col0 + h*dh, K at k_col0 + h*dh
-    const uint16_t* vt;       // [heads*dh][ldvt] bf16 (V transposed: feature-major, token-minor)
+    const uint16_t* vt;       // V8 layout [T/8][heads*dh][8] bf16: 8 consecutive tokens of one feature = 16 B;
+                              // ldvt = elements per 8-token group = 8 * heads*dh
     uint16_t* out;            // [T][ld_out] bf16, context at column h*dh
     const int32_t* seq_start; // [B] first token row of each sequence (multiple of 8)
     const int32_t* seq_len;   // [B]

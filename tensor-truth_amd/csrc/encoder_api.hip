@@ -2,7 +2,7 @@
 // rerank head, and the building blocks exported for the parity tests.
 //
 // Layer schedule (post-LN BERT / XLM-R block; one rounding to bf16 per fused kernel output):
-//   qk, vT = QKV-GEMM(x)                       [T][2H] + transposed V [H][T]
+//   qk, vT = QKV-GEMM(x)                       [T][2H] + token-blocked transposed V [T/8][H][8]
 //   ctx    = attention(qk, vT)                 [T][H]
 //   y      = GEMM(ctx, Wo) + bo + x            residual fused in the epilogue
 //   x1     = LayerNorm(y)
@@ -106,12 +106,12 @@ int tt_encoder_forward(const tt_encoder_weights* w, const int32_t* ids, const in
         // QKV projection
         GemmParams g{};
         g.A = x; g.lda = H; g.W = (const uint16_t*)lw.qkv_w; g.bias = lw.qkv_b;
-        g.C = qk; g.ldc = 2 * H; g.vt = vt; g.ldvt = T; g.vt_col0 = 2 * H;
+        g.C = qk; g.ldc = 2 * H; g.vt = vt; g.ldvt = 8 * H; g.vt_col0 = 2 * H;
         g.M = T; g.N = 3 * H; g.K = H;
         if (int rc = tt_gemm_launch(g, TT_EPI_QKV, st)) return rc;
         // attention
         AttnParams a{};
-        a.qk = qk; a.ld_qk = 2 * H; a.q_col0 = 0; a.k_col0 = H; a.vt = vt; a.ldvt = T;
+        a.qk = qk; a.ld_qk = 2 * H; a.q_col0 = 0; a.k_col0 = H; a.vt = vt; a.ldvt = 8 * H;
         a.out = ctx; a.ld_out = H; a.seq_start = seq_start; a.seq_len = seq_len;
         a.n_seq = n_seq; a.heads = w->heads; a.head_dim = dh; a.max_len = max_len;
         a.scale = 1.0f / sqrtf((float)dh);

@@ -71,11 +71,12 @@ __device__ __forceinline__ void gemm_epilogue_tile(const GemmParams& p, f32x4 (&
             if constexpr (EPI == TT_EPI_QKV) {
                 if (n >= p.vt_col0) {
                     // V third: store transposed, VT[n - vt_col0][m]
-                    uint16_t* vt = p.vt + (size_t)(n - p.vt_col0) * p.ldvt + m;
+                    // V8 layout: vt[(m / 8) * ldvt + feature * 8 + m % 8]
+                    uint16_t* vt = p.vt + (size_t)(m >> 3) * p.ldvt + (size_t)(n - p.vt_col0) * 8 + (m & 7);
                     vt[0] = f32_to_bf16_bits(v0);
-                    vt[p.ldvt] = f32_to_bf16_bits(v1);
-                    vt[2 * (size_t)p.ldvt] = f32_to_bf16_bits(v2);
-                    vt[3 * (size_t)p.ldvt] = f32_to_bf16_bits(v3);
+                    vt[8] = f32_to_bf16_bits(v1);
+                    vt[16] = f32_to_bf16_bits(v2);
+                    vt[24] = f32_to_bf16_bits(v3);
                     continue;
                 }
             }
@@ -113,11 +114,11 @@ __device__ __forceinline__ void gemm_epilogue_wide(const GemmParams& p, f32x4 (&
                     const int n = nw + i * 16 + g * 4;
                     const int m = mw + j * 16 + (lane & 15);
                     const float4 b4 = *reinterpret_cast<const float4*>(p.bias + n);
-                    uint16_t* vt = p.vt + (size_t)(n - p.vt_col0) * p.ldvt + m;
+                    uint16_t* vt = p.vt + (size_t)(m >> 3) * p.ldvt + (size_t)(n - p.vt_col0) * 8 + (m & 7);
                     vt[0] = f32_to_bf16_bits(acc[i][j][0] + b4.x);
-                    vt[p.ldvt] = f32_to_bf16_bits(acc[i][j][1] + b4.y);
-                    vt[2 * (size_t)p.ldvt] = f32_to_bf16_bits(acc[i][j][2] + b4.z);
-                    vt[3 * (size_t)p.ldvt] = f32_to_bf16_bits(acc[i][j][3] + b4.w);
+                    vt[8] = f32_to_bf16_bits(acc[i][j][1] + b4.y);
+                    vt[16] = f32_to_bf16_bits(acc[i][j][2] + b4.z);
+                    vt[24] = f32_to_bf16_bits(acc[i][j][3] + b4.w);
                 }
                 continue;
             }
@@ -162,7 +163,7 @@ __device__ __forceinline__ void gemm_epilogue_wide(const GemmParams& p, f32x4 (&
 
 // ---- V^T epilogue (un-swapped accumulators: lane = feature column l&15, registers = 4 consecutive tokens)
 // permlane16_swap between the registers of n-tile 2i and 2i+1 gives every lane 8 consecutive tokens of one
-// feature: one 16-B store into the transposed V buffer instead of eight 2-byte stores.
+// feature: one 16-B store into the V8 buffer ([token/8][feature][8 tokens]) instead of eight 2-byte stores.
 template <int NT, int MT>
 __device__ __forceinline__ void gemm_epilogue_vt(const GemmParams& p, f32x4 (&acc)[NT][MT], int mw, int nw, int lane) {
     static_assert(NT % 2 == 0, "n-tiles are processed in pairs");
@@ -172,7 +173,7 @@ __device__ __forceinline__ void gemm_epilogue_vt(const GemmParams& p, f32x4 (&ac
     for (int i = 0; i < NT; i += 2) {
         const int n = nw + (odd ? i + 1 : i) * 16 + (lane & 15);
         const float b = p.bias[n];
-        uint16_t* row = p.vt + (size_t)(n - p.vt_col0) * p.ldvt;
+        uint16_t* col = p.vt + (size_t)(n - p.vt_col0) * 8;   // V8 layout: + (m / 8) * ldvt
 #pragma unroll
         for (int j = 0; j < MT; ++j) {
             float v[8];
@@ -187,7 +188,7 @@ __device__ __forceinline__ void gemm_epilogue_vt(const GemmParams& p, f32x4 (&ac
             uint4 o;
             o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
             o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
-            *reinterpret_cast<uint4*>(row + m) = o;
+            *reinterpret_cast<uint4*>(col + (size_t)(m >> 3) * p.ldvt) = o;
         }
     }
 }

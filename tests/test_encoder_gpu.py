@@ -107,12 +107,12 @@ def test_attention_varlen(dev, built_lib, heads, dh, lens):
     k = _bf(torch.randn(T, H, generator=g))
     v = _bf(torch.randn(T, H, generator=g))
     qk = torch.cat([q, k], 1).contiguous()
-    vt = v.T.contiguous()
+    vt = v.view(T // 8, 8, H).permute(0, 2, 1).contiguous()   # V8 layout [T/8][H][8]
     out = torch.zeros(T, H, dtype=torch.bfloat16, device=dev)
     st_d = torch.tensor(starts, dtype=torch.int32, device=dev)
     ln_d = torch.tensor(lens, dtype=torch.int32, device=dev)
     qk_d, vt_d = qk.to(dev), vt.to(dev)
-    _lib.check(lib.tt_attention_varlen(qk_d.data_ptr(), 2 * H, 0, H, vt_d.data_ptr(), T, out.data_ptr(), H,
+    _lib.check(lib.tt_attention_varlen(qk_d.data_ptr(), 2 * H, 0, H, vt_d.data_ptr(), 8 * H, out.data_ptr(), H,
                                        st_d.data_ptr(), ln_d.data_ptr(), len(lens), heads, dh, max(lens), _stream()),
                "attention")
     torch.cuda.synchronize()
