@@ -201,6 +201,18 @@ def main():
     scan_bytes = (hi - lo) * D * 2 * q_tiles                                    # per launch: shard read once per 64 queries
     scan_gbs = scan_bytes * scan_n / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
 
+    # HBM traffic per launch: PMC counters cannot be read from inside this process; the committed
+    # profiles/r01_pmc_traffic.json holds them for exactly this default single-GPU command
+    # (tools/gpu_pmc_bench.sh + tools/pmc_to_traffic.py), otherwise null.
+    traffic = {"gemm": None, "scan_filter": None}
+    default_cfg = (world == 1 and args.corpus_rows == 10_000_000 and D == 1024 and Bq == 16 and K == 50
+                   and args.chunk_len == 256 and args.query_len == 32 and L == 24)
+    tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if default_cfg and os.path.exists(tpath):
+        with open(tpath) as f:
+            tj = json.load(f)
+        traffic = {k: tj[k]["hbm_bytes_per_launch"] for k in traffic if k in tj}
+
     out = {
         "metric": "queries/sec (embed+top-k+rerank) over 10M x 1024 corpus",
         "value": world * Bq * args.steps / dt,
@@ -228,13 +240,13 @@ def main():
         "roofline": {
             "kernel": "gemm_kernel (encoder GEMMs, bf16 MFMA)",
             "bound": "mfma", "achieved": gemm_tf, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
-            "frac": gemm_tf / MFMA_BF16_PEAK_TF, "traffic": None,
+            "frac": gemm_tf / MFMA_BF16_PEAK_TF, "traffic": traffic.get("gemm"),
             "launches": gemm_n, "avg_launch_ms": gemm_ms / max(gemm_n, 1),
         },
         "roofline_scan": {
             "kernel": "scan_kernel (filter pass over the corpus shard)",
             "bound": "hbm", "achieved": scan_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": scan_gbs / HBM_PEAK_GBS, "traffic": None,
+            "frac": scan_gbs / HBM_PEAK_GBS, "traffic": traffic.get("scan_filter"),
             "launches": scan_n, "avg_launch_ms": scan_ms / max(scan_n, 1),
         },
         "stage_ms_per_step": {k: v[0] / args.steps for k, v in prof.items()},

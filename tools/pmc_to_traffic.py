@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Turn the two rocprofv3 --pmc passes of `bench.py --steps 1 --warmup 1` (FETCH_SIZE, WRITE_SIZE; see
+tools/gpu_pmc_bench.sh) into per-launch HBM traffic of the kernels bench.py reports rooflines for.
+
+gfx950 corrections (MI355X_MICROARCH.md, HBM section): counters are in KiB; FETCH_SIZE reports exactly half
+of the bytes of a wide (16 B/lane) coalesced streaming read, so it is doubled; WRITE_SIZE is exact.
+Only the dispatches of the TIMED step are used (the warm-up step and the ingest leg are skipped)."""
+import csv
+import glob
+import json
+import sys
+
+
+def load(dirname, counter):
+    f = glob.glob(f"{dirname}/*/*counter_collection.csv")[0]
+    rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter]
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    return rows
+
+
+def main(fetch_dir, write_dir, out):
+    res = {}
+    for kind, match in (("gemm", "gemm_kernel"), ("scan_filter", "scan_kernel<1024, 1, 0")):
+        fr = [r for r in load(fetch_dir, "FETCH_SIZE") if match in r["Kernel_Name"]]
+        wr = [r for r in load(write_dir, "WRITE_SIZE") if match in r["Kernel_Name"]]
+        if kind == "gemm":
+            per_step = 241  # 2 forwards x 24 layers x 5 GEMM launches + the rerank-head GEMM
+            fr, wr = fr[per_step:2 * per_step], wr[per_step:2 * per_step]
+        else:
+            fr, wr = fr[1:2], wr[1:2]
+        fetch = sum(float(r["Counter_Value"]) for r in fr) * 1024 * 2
+        write = sum(float(r["Counter_Value"]) for r in wr) * 1024
+        res[kind] = {"launches": len(fr), "fetch_bytes_per_launch": fetch / len(fr),
+                     "write_bytes_per_launch": write / len(wr), "hbm_bytes_per_launch": (fetch + write) / len(fr)}
+    res["source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline`"
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2], sys.argv[3])
