@@ -96,7 +96,7 @@ def main():
 
     from tensor_truth_amd import _lib, scan as tscan
     from tensor_truth_amd.encoder import (BGE_M3, BGE_RERANKER_V2_M3, Encoder, EncoderConfig, EncoderWeights,
-                                          pack_tokens, synthetic_state_device)
+                                          pack_token_matrix, pack_tokens, synthetic_state_device)
     from tensor_truth_amd.sharded import ShardedCorpus, gather_queries, shard_bounds
 
     lib = _lib.load_library()
@@ -121,8 +121,9 @@ def main():
 
     def step(q_tok):
         # 1. embed this rank's queries: <s> q </s>
-        seqs = [np.concatenate(([0], q, [2])) for q in q_tok]
-        batch = pack_tokens(seqs, emb_cfg)
+        q_ids = np.empty((Bq, args.query_len + 2), dtype=np.int32)
+        q_ids[:, 0], q_ids[:, 1:-1], q_ids[:, -1] = 0, q_tok, 2
+        batch = pack_token_matrix(q_ids, emb_cfg)
         _, q16 = embedder.embed_packed(batch)
         tokens_step["embed"] = batch.n_tokens
         # 2.-4. every shard scans the gathered query batch; partial top-k all-gathered + merged
@@ -132,12 +133,14 @@ def main():
         # 5. rerank: <s> q </s></s> chunk </s>, 50 pairs per query
         flat = mine.reshape(-1)
         ptok = passage_tokens(np.maximum(flat, 0), args.chunk_len, vocab)
-        pairs = []
-        for qi in range(Bq):
-            head = np.concatenate(([0], q_tok[qi], [2, 2]))
-            for c in range(K):
-                pairs.append(np.concatenate((head, ptok[qi * K + c], [2])))
-        rb = pack_tokens(pairs, rr_cfg, max_len=512)
+        QL = args.query_len
+        pair_ids = np.empty((Bq * K, QL + args.chunk_len + 4), dtype=np.int32)
+        pair_ids[:, 0] = 0
+        pair_ids[:, 1:1 + QL] = np.repeat(q_tok, K, axis=0)
+        pair_ids[:, 1 + QL:3 + QL] = 2
+        pair_ids[:, 3 + QL:-1] = ptok
+        pair_ids[:, -1] = 2
+        rb = pack_token_matrix(pair_ids, rr_cfg)
         tokens_step["rerank"] = rb.n_tokens
         scores = reranker.rerank_packed(rb).view(Bq, K)
         # 6. top-n by rerank score (host-visible result, as the postprocessor returns it)

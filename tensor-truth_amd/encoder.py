@@ -277,6 +277,35 @@ def pack_tokens(seqs: Sequence[Sequence[int]], cfg: EncoderConfig,
                        int(lens.max()), int(lens.sum()))
 
 
+def pack_token_matrix(ids2d: np.ndarray, cfg: EncoderConfig, type_ids2d: Optional[np.ndarray] = None) -> PackedBatch:
+    """Vectorised ``pack_tokens`` for sequences of one common length (rows of ``ids2d``): no Python
+    loop, so host packing of a few thousand rerank pairs stays in the 100-microsecond range."""
+    ids2d = np.ascontiguousarray(ids2d, dtype=np.int32)
+    n, length = ids2d.shape
+    if n == 0 or length == 0:
+        raise ValueError("empty token matrix")
+    if length > cfg.max_seq_len:
+        ids2d = ids2d[:, : cfg.max_seq_len]
+        length = cfg.max_seq_len
+    stride = (length + 7) // 8 * 8
+    n_rows = max(256, (n * stride + 255) // 256 * 256)
+    ids = np.full(n_rows, cfg.pad_id, dtype=np.int32)
+    pos = np.zeros(n_rows, dtype=np.int32)
+    pos_off = cfg.pad_id + 1 if cfg.arch == "xlmr" else 0
+    view = ids[: n * stride].reshape(n, stride)
+    view[:, :length] = ids2d
+    pos[: n * stride].reshape(n, stride)[:, :length] = np.arange(length, dtype=np.int32) + pos_off
+    types = None
+    if type_ids2d is not None:
+        types = np.zeros(n_rows, dtype=np.int32)
+        types[: n * stride].reshape(n, stride)[:, :length] = np.asarray(type_ids2d, dtype=np.int32)[:, :length]
+    if ids2d.min() < 0 or ids2d.max() >= cfg.vocab_size:
+        raise ValueError("token id outside the vocabulary")
+    starts = (np.arange(n, dtype=np.int64) * stride).astype(np.int32)
+    lens = np.full(n, length, dtype=np.int32)
+    return PackedBatch(ids, pos, types, starts, lens, int(n_rows), int(length), int(n * length))
+
+
 class _Scratch(threading.local):
     def __init__(self):
         self.bufs = {}
