@@ -446,6 +446,83 @@ __device__ __forceinline__ void stage_half(const GemmParams& p, char* smem, int 
     }
 }
 
+// Whole-wave epilogue of the 256x256 kernel (acc[qm][qn][nt][mt], wide 16-B layout after permlane16_swap).
+// All bias vectors (and, for the residual epilogue, all 16 residual vectors) are loaded UP FRONT: with the
+// loads inside the per-tile loop every iteration paid a full global-load latency and the epilogue took
+// 11 k cycles per 256x256 tile (20 % of a K=1024 GEMM) by in-kernel stamps.
+template <int EPI>
+__device__ __forceinline__ void epilogue_all(const GemmParams& p, f32x4 (&acc)[2][2][2][4], int m0, int n0, int wm, int wn,
+                                             int lane) {
+    const int g = lane >> 4;
+    const bool odd = (g & 1) != 0;
+    const int ncol = wn * 32 + (g & ~1) * 4;           // + qn*128 + nt*16: first of this lane's 8 columns
+    const int mrow = wm * 64 + (lane & 15);            // + qm*128 + (pair*2 + odd)*16
+    float4 bias[2][2][2];
+#pragma unroll
+    for (int qn = 0; qn < 2; ++qn)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const float* bp = p.bias + n0 + qn * 128 + nt * 16 + ncol;
+            bias[qn][nt][0] = *reinterpret_cast<const float4*>(bp);
+            bias[qn][nt][1] = *reinterpret_cast<const float4*>(bp + 4);
+        }
+    uint4 res[2][2][2][2];
+    if constexpr (EPI == TT_EPI_RESIDUAL) {
+#pragma unroll
+        for (int qm = 0; qm < 2; ++qm)
+#pragma unroll
+            for (int qn = 0; qn < 2; ++qn)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int pr = 0; pr < 2; ++pr) {
+                        const int m = m0 + qm * 128 + mrow + (pr * 2 + (odd ? 1 : 0)) * 16;
+                        const int n = n0 + qn * 128 + nt * 16 + ncol;
+                        res[qm][qn][nt][pr] = *reinterpret_cast<const uint4*>(p.residual + (size_t)m * p.ldr + n);
+                    }
+    }
+#pragma unroll
+    for (int qm = 0; qm < 2; ++qm)
+#pragma unroll
+        for (int qn = 0; qn < 2; ++qn)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    float v[8];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[qm][qn][nt][2 * pr][k]),
+                                                                        __float_as_uint(acc[qm][qn][nt][2 * pr + 1][k]),
+                                                                        false, false);
+                        v[k] = __uint_as_float(r[0]);
+                        v[4 + k] = __uint_as_float(r[1]);
+                    }
+                    const float4 b0 = bias[qn][nt][0], b1 = bias[qn][nt][1];
+                    v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+                    v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+                    if constexpr (EPI == TT_EPI_GELU) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) v[k] = gelu_erf(v[k]);
+                    } else if constexpr (EPI == TT_EPI_TANH) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) v[k] = tanhf(v[k]);
+                    } else if constexpr (EPI == TT_EPI_RESIDUAL) {
+                        const uint4 r = res[qm][qn][nt][pr];
+                        v[0] += __uint_as_float(r.x << 16); v[1] += __uint_as_float(r.x & 0xFFFF0000u);
+                        v[2] += __uint_as_float(r.y << 16); v[3] += __uint_as_float(r.y & 0xFFFF0000u);
+                        v[4] += __uint_as_float(r.z << 16); v[5] += __uint_as_float(r.z & 0xFFFF0000u);
+                        v[6] += __uint_as_float(r.w << 16); v[7] += __uint_as_float(r.w & 0xFFFF0000u);
+                    }
+                    const int m = m0 + qm * 128 + mrow + (pr * 2 + (odd ? 1 : 0)) * 16;
+                    const int n = n0 + qn * 128 + nt * 16 + ncol;
+                    uint4 o;
+                    o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
+                    o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
+                    *reinterpret_cast<uint4*>(p.C + (size_t)m * p.ldc + n) = o;
+                }
+}
+
 #define TT_SLOT_END()                                         \
     do {                                                      \
         __builtin_amdgcn_sched_barrier(0);                    \
@@ -506,6 +583,13 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
         voffW[j] = (uint32_t)r * (uint32_t)p.K * 2u + (uint32_t)chunk * 16u;
     }
 
+    unsigned long long* dbg0 = reinterpret_cast<unsigned long long*>(p.vt);
+    auto cstamp = [&](int slot) {
+        if constexpr (SLOTS == 46) {
+            if (blockIdx.x == 0 && tid == 0 && dbg0) dbg0[20 + slot] = __builtin_amdgcn_s_memtime();
+        }
+    };
+    cstamp(0);
     // ---- prologue: tile 0 complete, tile 1 without its A-hi (issued in L1(0)); same order as steady state
     stage_half<0>(p, smem, 0, 0, 0, wave, voffA, m0, n0);
     stage_half<1>(p, smem, 0, 0, 0, wave, voffW, m0, n0);
@@ -524,6 +608,7 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     TT_SLOT_END();
+    cstamp(1);
     const bool late = (SLOTS == 45) ? ((wave & 1) != 0) : (wave >= 4);
     if (late) TT_SLOT_END();   // waves 4-7 run one slot behind
 
@@ -683,19 +768,29 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
             if (t + 1 < nk) tile4(t + 1, std::integral_constant<int, 1>{});
         }
     }
+    cstamp(2);
     if (!late) TT_SLOT_END();   // match the extra barrier the late group took up front
 
     // ---- epilogue ---------------------------------------------------------------------------------
+    if constexpr (vblk) {
 #pragma unroll
-    for (int qm = 0; qm < 2; ++qm)
+        for (int qm = 0; qm < 2; ++qm)
 #pragma unroll
-        for (int qn = 0; qn < 2; ++qn)
-        {
-            if constexpr (vblk)
+            for (int qn = 0; qn < 2; ++qn)
                 gemm_epilogue_vt<2, 4>(p, acc[qm][qn], m0 + qm * 128 + wm * 64, n0 + qn * 128 + wn * 32, lane);
-            else
+    } else if constexpr (EPI == TT_EPI_QKV) {
+#pragma unroll
+        for (int qm = 0; qm < 2; ++qm)
+#pragma unroll
+            for (int qn = 0; qn < 2; ++qn)
                 gemm_epilogue_wide<EPI, 2, 4>(p, acc[qm][qn], m0 + qm * 128 + wm * 64, n0 + qn * 128 + wn * 32, lane);
-        }
+    } else {
+        epilogue_all<EPI>(p, acc, m0, n0, wm, wn, lane);
+    }
+    if constexpr (SLOTS == 46) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        cstamp(3);
+    }
 }
 #undef TT_SLOT_END
 }  // namespace v3

@@ -20,6 +20,7 @@ int main() {
         printf("wave %d (deltas in cycles from La start %llu):\n", wv, h[wv * 32]);
         for (int i = 0; i < 13; ++i) printf("  %2d %-26s t=%6lld  d=%5lld\n", i, names[i], (long long)(h[wv * 32 + i] - h[wv * 32]), i ? (long long)(h[wv * 32 + i] - h[wv * 32 + i - 1]) : 0LL);
     }
+    printf("coarse (wave 0, block 0): prologue %lld  main loop %lld  epilogue+store drain %lld cycles\n", (long long)(h[21]-h[20]), (long long)(h[22]-h[21]), (long long)(h[23]-h[22]));
     printf("wave4 La start - wave0 La start = %lld\n", (long long)(h[4 * 32] - h[0]));
     return 0;
 }
