@@ -194,9 +194,15 @@ def main():
 
     # ---- roofline of the dominant kernel (GEMM, MFMA-bound) and of the scan (HBM-bound) -------
     H, F, L = emb_cfg.hidden, emb_cfg.ffn, emb_cfg.layers
-    gemm_flops_per_token = L * 2 * (3 * H * H + H * H + 2 * H * F)          # algorithmic, real tokens only
+    # algorithmic GEMM flops of what is computed (real tokens only): L-1 full layers + the last layer's QKV
+    # projection for every token, the last layer's output projection + FFN for the CLS rows only, the head
+    full_layer = 2 * (3 * H * H + H * H + 2 * H * F)
+    gemm_flops_per_token = (L - 1) * full_layer + 2 * 3 * H * H
+    cls_tail_flops = 2 * (H * H + 2 * H * F)
+    n_seq_step = Bq + Bq * K
     head_flops = 2 * H * H * (Bq * K)
-    gemm_flops_step = gemm_flops_per_token * (tokens_step["embed"] + tokens_step["rerank"]) + head_flops
+    gemm_flops_step = (gemm_flops_per_token * (tokens_step["embed"] + tokens_step["rerank"])
+                       + cls_tail_flops * n_seq_step + head_flops)
     gemm_ms, gemm_n = prof["gemm"]
     gemm_tf = gemm_flops_step * args.steps / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
     scan_ms, scan_n = prof["scan_filter"]

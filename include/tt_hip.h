@@ -136,6 +136,16 @@ int tt_encoder_forward(const tt_encoder_weights* w, const int32_t* ids, const in
                        int n_seq, int n_rows, int max_len, void* hidden_out,
                        void* workspace, size_t workspace_bytes, void* stream);
 
+/* Same forward, but the LAST layer is evaluated for the CLS row of every sequence only (the one row the
+ * pooling and the classification head read): cls_out is [round_up(n_seq, 256)][H] bf16, row b = final hidden
+ * state of token seq_start[b].  Identical arithmetic for those rows up to the attention kernel used for the
+ * single query row (fp32 probabilities instead of bf16); saves 1/24 of the encoder work at 24 layers. */
+size_t tt_encoder_cls_workspace_bytes(const tt_encoder_weights* w, int n_rows, int n_seq);
+int tt_encoder_forward_cls(const tt_encoder_weights* w, const int32_t* ids, const int32_t* pos,
+                           const int32_t* type_ids, const int32_t* seq_start, const int32_t* seq_len,
+                           int n_seq, int n_rows, int max_len, void* cls_out,
+                           void* workspace, size_t workspace_bytes, void* stream);
+
 /* sentence-transformers Pooling(cls) + Normalize: out[b] = h[rows[b]] / ||h[rows[b]]||_2.
  * out_bf16 (optional) is the same vector rounded to bf16, ready to be a scan query. */
 int tt_embed_pool(const void* hidden_bf16, int ld, const int32_t* rows, int n_seq, int hidden,

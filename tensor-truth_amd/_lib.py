@@ -44,6 +44,9 @@ SIGNATURES = {
     "tt_encoder_workspace_bytes": (c_size_t, [c_void_p, c_int]),
     "tt_encoder_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                    c_void_p, c_void_p, c_size_t, c_void_p]),
+    "tt_encoder_cls_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),
+    "tt_encoder_forward_cls": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                       c_void_p, c_void_p, c_size_t, c_void_p]),
     "tt_embed_pool": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "tt_rerank_head": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "tt_gemm_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

@@ -206,6 +206,81 @@ __global__ __launch_bounds__(kAttThreads) void attention_kernel(AttnParams p) {
     }
 }
 
+
+// ---- CLS-only attention (last layer): one wave per (sequence, head), the single query row t0 -------------
+// Scores with the key on the lane (fp32 dot products, K rows read as 16-B pieces), softmax across the wave,
+// then the value sum with the FEATURE on the lane (V8 layout: one 16-B load brings 8 keys of a feature).
+// Only the CLS token of the last layer is ever read by the pooling / classification head, so the other
+// rows' attention (and their output projection / FFN) is skipped: 1/24 of the encoder's flops.
+template <int DH>
+__global__ __launch_bounds__(64) void attention_cls_kernel(AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) float probs[];   // [max_len rounded up to 8]
+    const int seq = blockIdx.x, head = blockIdx.y, lane = threadIdx.x;
+    const int len = p.seq_len[seq], t0 = p.seq_start[seq];
+    // query row -> registers (every lane holds the whole q: uniform address)
+    float q[DH];
+    {
+        const uint16_t* qp = p.qk + (size_t)t0 * p.ld_qk + p.q_col0 + head * DH;
+#pragma unroll
+        for (int c = 0; c < DH / 8; ++c) {
+            const uint4 u = *reinterpret_cast<const uint4*>(qp + c * 8);
+            q[c * 8 + 0] = __uint_as_float(u.x << 16); q[c * 8 + 1] = __uint_as_float(u.x & 0xFFFF0000u);
+            q[c * 8 + 2] = __uint_as_float(u.y << 16); q[c * 8 + 3] = __uint_as_float(u.y & 0xFFFF0000u);
+            q[c * 8 + 4] = __uint_as_float(u.z << 16); q[c * 8 + 5] = __uint_as_float(u.z & 0xFFFF0000u);
+            q[c * 8 + 6] = __uint_as_float(u.w << 16); q[c * 8 + 7] = __uint_as_float(u.w & 0xFFFF0000u);
+        }
+    }
+    const float sc = p.scale * 1.4426950408889634f;
+    float mx = -__builtin_inff();
+    for (int j = lane; j < len; j += 64) {
+        const uint16_t* kp = p.qk + (size_t)(t0 + j) * p.ld_qk + p.k_col0 + head * DH;
+        float acc = 0.f;
+#pragma unroll
+        for (int c = 0; c < DH / 8; ++c) {
+            const uint4 u = *reinterpret_cast<const uint4*>(kp + c * 8);
+            acc = fmaf(q[c * 8 + 0], __uint_as_float(u.x << 16), acc);
+            acc = fmaf(q[c * 8 + 1], __uint_as_float(u.x & 0xFFFF0000u), acc);
+            acc = fmaf(q[c * 8 + 2], __uint_as_float(u.y << 16), acc);
+            acc = fmaf(q[c * 8 + 3], __uint_as_float(u.y & 0xFFFF0000u), acc);
+            acc = fmaf(q[c * 8 + 4], __uint_as_float(u.z << 16), acc);
+            acc = fmaf(q[c * 8 + 5], __uint_as_float(u.z & 0xFFFF0000u), acc);
+            acc = fmaf(q[c * 8 + 6], __uint_as_float(u.w << 16), acc);
+            acc = fmaf(q[c * 8 + 7], __uint_as_float(u.w & 0xFFFF0000u), acc);
+        }
+        acc *= sc;
+        probs[j] = acc;
+        mx = fmaxf(mx, acc);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    float sum = 0.f;
+    const int len8 = (len + 7) & ~7;
+    for (int j = lane; j < len8; j += 64) {
+        float e = 0.f;
+        if (j < len) e = __builtin_amdgcn_exp2f(probs[j] - mx);
+        probs[j] = e;      // keys beyond len (same 8-group) get probability 0
+        sum += e;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    __syncthreads();
+    // value sum: lane = feature (DH=64) or (feature, key-group parity) (DH=32)
+    constexpr int PARTS = 64 / DH;
+    const int d = lane % DH, part = lane / DH;
+    float o = 0.f;
+    for (int g8 = part; g8 * 8 < len; g8 += PARTS) {
+        const uint4 u = *reinterpret_cast<const uint4*>(p.vt + (size_t)(t0 / 8 + g8) * p.ldvt + (size_t)(head * DH + d) * 8);
+        const float4 pa = *reinterpret_cast<const float4*>(probs + g8 * 8);
+        const float4 pb = *reinterpret_cast<const float4*>(probs + g8 * 8 + 4);
+        o = fmaf(pa.x, __uint_as_float(u.x << 16), o); o = fmaf(pa.y, __uint_as_float(u.x & 0xFFFF0000u), o);
+        o = fmaf(pa.z, __uint_as_float(u.y << 16), o); o = fmaf(pa.w, __uint_as_float(u.y & 0xFFFF0000u), o);
+        o = fmaf(pb.x, __uint_as_float(u.z << 16), o); o = fmaf(pb.y, __uint_as_float(u.z & 0xFFFF0000u), o);
+        o = fmaf(pb.z, __uint_as_float(u.w << 16), o); o = fmaf(pb.w, __uint_as_float(u.w & 0xFFFF0000u), o);
+    }
+    if constexpr (PARTS == 2) o += __shfl_xor(o, 32, 64);
+    if (part == 0) p.out[(size_t)seq * p.ld_out + head * DH + d] = f32_to_bf16_bits(o / sum);
+}
+
 }  // namespace
 
 int tt_attention_launch(const AttnParams& p, hipStream_t st) {
@@ -220,6 +295,32 @@ int tt_attention_launch(const AttnParams& p, hipStream_t st) {
         hipLaunchKernelGGL(attention_kernel<64>, grid, dim3(kAttThreads), 0, st, p);
     } else if (p.head_dim == 32) {
         hipLaunchKernelGGL(attention_kernel<32>, grid, dim3(kAttThreads), 0, st, p);
+    } else {
+        tt_set_error("attention: head_dim %d not in {32, 64}", p.head_dim);
+        return TT_E_UNSUPPORTED;
+    }
+    TT_CHECK_LAUNCH();
+    return TT_OK;
+}
+
+// out: [n_seq][ld_out] (row = sequence index, NOT token row)
+int tt_attention_cls_launch(const AttnParams& p, hipStream_t st) {
+    if (p.n_seq <= 0) return TT_OK;
+    const size_t lds = (size_t)((p.max_len + 7) / 8 * 8) * sizeof(float);
+    if (lds > 160 * 1024) {
+        tt_set_error("attention_cls: max_len %d exceeds the LDS score buffer", p.max_len);
+        return TT_E_UNSUPPORTED;
+    }
+    TtProfScope prof(TT_K_ATTENTION, st);
+    const dim3 grid(p.n_seq, p.heads);
+    if (p.head_dim == 64) {
+        static thread_local bool a64 = false;
+        if (!a64) { TT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_cls_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); a64 = true; }
+        hipLaunchKernelGGL(attention_cls_kernel<64>, grid, dim3(64), lds, st, p);
+    } else if (p.head_dim == 32) {
+        static thread_local bool a32 = false;
+        if (!a32) { TT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_cls_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); a32 = true; }
+        hipLaunchKernelGGL(attention_cls_kernel<32>, grid, dim3(64), lds, st, p);
     } else {
         tt_set_error("attention: head_dim %d not in {32, 64}", p.head_dim);
         return TT_E_UNSUPPORTED;

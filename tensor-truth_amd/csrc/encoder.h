@@ -29,6 +29,8 @@ struct AttnParams {
     float scale;              // 1/sqrt(head_dim)
 };
 int tt_attention_launch(const AttnParams& p, hipStream_t st);
+// CLS-only variant: one query row (seq_start[b]) per sequence; out row index = sequence index
+int tt_attention_cls_launch(const AttnParams& p, hipStream_t st);
 
 struct EmbedParams {
     const int32_t* ids;       // [T]

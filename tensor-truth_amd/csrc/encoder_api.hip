@@ -16,9 +16,12 @@ namespace {
 
 struct EncWs {
     size_t off_xa, off_xb, off_y, off_qk, off_vt, off_ctx, off_ffn, total;
+    // CLS-only tail of the last layer (rows = sequences, padded to 256)
+    size_t off_cctx, off_cx, off_cy, off_cx1, off_cffn, off_rows;
+    int n_cls_pad;
 };
 
-EncWs enc_plan(const tt_encoder_weights* w, int n_rows) {
+EncWs enc_plan(const tt_encoder_weights* w, int n_rows, int n_seq = 0) {
     EncWs e{};
     const size_t H = (size_t)w->hidden, F = (size_t)w->ffn, T = (size_t)n_rows;
     size_t off = 0;
@@ -30,6 +33,15 @@ EncWs enc_plan(const tt_encoder_weights* w, int n_rows) {
     e.off_vt = take(H * T * 2);
     e.off_ctx = take(T * H * 2);
     e.off_ffn = take(T * F * 2);
+    e.n_cls_pad = (n_seq + 255) / 256 * 256;
+    if (n_seq > 0) {
+        const size_t B = (size_t)e.n_cls_pad;
+        e.off_cctx = take(B * H * 2);
+        e.off_cx = take(B * H * 2);
+        e.off_cy = take(B * H * 2);
+        e.off_cx1 = take(B * H * 2);
+        e.off_cffn = take(B * F * 2);
+    }
     e.total = off;
     return e;
 }
@@ -55,15 +67,16 @@ size_t tt_encoder_workspace_bytes(const tt_encoder_weights* w, int n_rows) {
     return enc_plan(w, n_rows).total;
 }
 
-int tt_encoder_forward(const tt_encoder_weights* w, const int32_t* ids, const int32_t* pos,
-                       const int32_t* type_ids, const int32_t* seq_start, const int32_t* seq_len, int n_seq,
-                       int n_rows, int max_len, void* hidden_out, void* workspace, size_t workspace_bytes,
-                       void* stream) {
+static int forward_impl(const tt_encoder_weights* w, const int32_t* ids, const int32_t* pos,
+                        const int32_t* type_ids, const int32_t* seq_start, const int32_t* seq_len, int n_seq,
+                        int n_rows, int max_len, void* hidden_out, void* cls_out, void* workspace,
+                        size_t workspace_bytes, void* stream) {
     if (int rc = check_weights(w)) return rc;
     TT_CHECK_ARG(n_rows > 0 && n_rows % 128 == 0, "n_rows=%d must be a positive multiple of 128", n_rows);
     TT_CHECK_ARG(n_seq > 0 && max_len > 0, "n_seq=%d max_len=%d", n_seq, max_len);
-    TT_CHECK_ARG(ids && pos && seq_start && seq_len && hidden_out, "null pointer");
-    const EncWs e = enc_plan(w, n_rows);
+    TT_CHECK_ARG(ids && pos && seq_start && seq_len && (hidden_out || cls_out), "null pointer");
+    const bool cls_tail = cls_out != nullptr && w->layers > 0;
+    const EncWs e = enc_plan(w, n_rows, cls_tail ? n_seq : 0);
     if (!workspace || workspace_bytes < e.total) {
         tt_set_error("tt_encoder_forward: workspace %zu < required %zu bytes", workspace_bytes, e.total);
         return TT_E_WORKSPACE;
@@ -89,7 +102,7 @@ int tt_encoder_forward(const tt_encoder_weights* w, const int32_t* ids, const in
     ep.gamma = w->emb_ln_g; ep.beta = w->emb_ln_b;
     ep.T = T; ep.H = H; ep.vocab = w->vocab; ep.max_pos = w->max_pos; ep.type_vocab = w->type_vocab;
     ep.eps = w->ln_eps;
-    uint16_t* x = w->layers == 0 ? (uint16_t*)hidden_out : xa;
+    uint16_t* x = (w->layers == 0 && hidden_out) ? (uint16_t*)hidden_out : xa;
     ep.out = x;
     {
         TtProfScope prof(TT_K_ROWOPS, st);
@@ -102,13 +115,51 @@ int tt_encoder_forward(const tt_encoder_weights* w, const int32_t* ids, const in
         TT_CHECK_ARG(lw.qkv_w && lw.qkv_b && lw.o_w && lw.o_b && lw.ln1_g && lw.ln1_b && lw.ffn1_w && lw.ffn1_b &&
                          lw.ffn2_w && lw.ffn2_b && lw.ln2_g && lw.ln2_b,
                      "layer %d has a null weight pointer", l);
-        uint16_t* x_out = (l == w->layers - 1) ? (uint16_t*)hidden_out : (x == xa ? xb : xa);
         // QKV projection
         GemmParams g{};
         g.A = x; g.lda = H; g.W = (const uint16_t*)lw.qkv_w; g.bias = lw.qkv_b;
         g.C = qk; g.ldc = 2 * H; g.vt = vt; g.ldvt = 8 * H; g.vt_col0 = 2 * H;
         g.M = T; g.N = 3 * H; g.K = H;
         if (int rc = tt_gemm_launch(g, TT_EPI_QKV, st)) return rc;
+        if (cls_tail && l == w->layers - 1) {
+            // ---- last layer, CLS rows only: attention of the one query row per sequence, then the
+            //      output projection / LayerNorm / FFN on n_seq (padded to 256) rows instead of n_rows
+            const int Bp = e.n_cls_pad;
+            uint16_t* cctx = (uint16_t*)(ws + e.off_cctx);
+            uint16_t* cx = (uint16_t*)(ws + e.off_cx);
+            uint16_t* cy = (uint16_t*)(ws + e.off_cy);
+            uint16_t* cx1 = (uint16_t*)(ws + e.off_cx1);
+            uint16_t* cffn = (uint16_t*)(ws + e.off_cffn);
+            TT_CHECK_HIP(hipMemsetAsync(cctx, 0, (size_t)Bp * H * 2, st));
+            AttnParams ac{};
+            ac.qk = qk; ac.ld_qk = 2 * H; ac.q_col0 = 0; ac.k_col0 = H; ac.vt = vt; ac.ldvt = 8 * H;
+            ac.out = cctx; ac.ld_out = H; ac.seq_start = seq_start; ac.seq_len = seq_len;
+            ac.n_seq = n_seq; ac.heads = w->heads; ac.head_dim = dh; ac.max_len = max_len;
+            ac.scale = 1.0f / sqrtf((float)dh);
+            if (int rc = tt_attention_cls_launch(ac, st)) return rc;
+            {
+                TtProfScope prof(TT_K_ROWOPS, st);
+                if (int rc = tt_gather_rows_launch(x, H, seq_start, n_seq, Bp, H, cx, st)) return rc;
+            }
+            GemmParams go{};
+            go.A = cctx; go.lda = H; go.W = (const uint16_t*)lw.o_w; go.bias = lw.o_b;
+            go.residual = cx; go.ldr = H; go.C = cy; go.ldc = H; go.M = Bp; go.N = H; go.K = H;
+            if (int rc = tt_gemm_launch(go, TT_EPI_RESIDUAL, st)) return rc;
+            {
+                TtProfScope prof(TT_K_ROWOPS, st);
+                if (int rc = tt_layernorm_launch(cy, cx1, lw.ln1_g, lw.ln1_b, Bp, H, w->ln_eps, st)) return rc;
+            }
+            GemmParams g1{};
+            g1.A = cx1; g1.lda = H; g1.W = (const uint16_t*)lw.ffn1_w; g1.bias = lw.ffn1_b;
+            g1.C = cffn; g1.ldc = F; g1.M = Bp; g1.N = F; g1.K = H;
+            if (int rc = tt_gemm_launch(g1, TT_EPI_GELU, st)) return rc;
+            GemmParams g2{};
+            g2.A = cffn; g2.lda = F; g2.W = (const uint16_t*)lw.ffn2_w; g2.bias = lw.ffn2_b;
+            g2.residual = cx1; g2.ldr = H; g2.C = cy; g2.ldc = H; g2.M = Bp; g2.N = H; g2.K = F;
+            if (int rc = tt_gemm_launch(g2, TT_EPI_RESIDUAL, st)) return rc;
+            TtProfScope prof(TT_K_ROWOPS, st);
+            return tt_layernorm_launch(cy, (uint16_t*)cls_out, lw.ln2_g, lw.ln2_b, Bp, H, w->ln_eps, st);
+        }
         // attention
         AttnParams a{};
         a.qk = qk; a.ld_qk = 2 * H; a.q_col0 = 0; a.k_col0 = H; a.vt = vt; a.ldvt = 8 * H;
@@ -138,7 +189,6 @@ int tt_encoder_forward(const tt_encoder_weights* w, const int32_t* ids, const in
         // x1 is free again after the FFN-down GEMM has consumed it as residual; the LN output
         // goes to the other hidden buffer (or straight to hidden_out on the last layer)
         uint16_t* dst = (l == w->layers - 1) ? (uint16_t*)hidden_out : x;
-        (void)x_out;
         {
             TtProfScope prof(TT_K_ROWOPS, st);
             if (int rc = tt_layernorm_launch(y, dst, lw.ln2_g, lw.ln2_b, T, H, w->ln_eps, st)) return rc;
@@ -146,6 +196,30 @@ int tt_encoder_forward(const tt_encoder_weights* w, const int32_t* ids, const in
         x = dst;
     }
     return TT_OK;
+}
+
+int tt_encoder_forward(const tt_encoder_weights* w, const int32_t* ids, const int32_t* pos,
+                       const int32_t* type_ids, const int32_t* seq_start, const int32_t* seq_len, int n_seq,
+                       int n_rows, int max_len, void* hidden_out, void* workspace, size_t workspace_bytes,
+                       void* stream) {
+    TT_CHECK_ARG(hidden_out != nullptr, "null hidden_out");
+    return forward_impl(w, ids, pos, type_ids, seq_start, seq_len, n_seq, n_rows, max_len, hidden_out, nullptr, workspace,
+                        workspace_bytes, stream);
+}
+
+size_t tt_encoder_cls_workspace_bytes(const tt_encoder_weights* w, int n_rows, int n_seq) {
+    if (!w || n_rows <= 0 || n_seq <= 0) return 0;
+    return enc_plan(w, n_rows, n_seq).total;
+}
+
+int tt_encoder_forward_cls(const tt_encoder_weights* w, const int32_t* ids, const int32_t* pos,
+                           const int32_t* type_ids, const int32_t* seq_start, const int32_t* seq_len, int n_seq,
+                           int n_rows, int max_len, void* cls_out, void* workspace, size_t workspace_bytes,
+                           void* stream) {
+    TT_CHECK_ARG(cls_out != nullptr, "null cls_out");
+    TT_CHECK_ARG(w && w->layers > 0, "tt_encoder_forward_cls needs at least one layer");
+    return forward_impl(w, ids, pos, type_ids, seq_start, seq_len, n_seq, n_rows, max_len, nullptr, cls_out, workspace,
+                        workspace_bytes, stream);
 }
 
 int tt_embed_pool(const void* hidden_bf16, int ld, const int32_t* rows, int n_seq, int hidden, float* out_f32,

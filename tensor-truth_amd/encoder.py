@@ -351,9 +351,33 @@ class Encoder:
         _lib.check(rc, "tt_encoder_forward")
         return hidden, starts
 
+    def cls_hidden_packed(self, batch: PackedBatch) -> Tuple[torch.Tensor, torch.Tensor]:
+        """-> (final hidden state of every sequence's CLS token [round_up(B,256), H] bf16, row ids [B] int32).
+        The last layer is evaluated for the CLS rows only (``tt_encoder_forward_cls``)."""
+        lib, dev, H = self.lib, self.device, self.cfg.hidden
+        if self.cfg.layers == 0:
+            hidden, starts = self.forward_packed(batch)
+            return hidden, starts
+        B = len(batch.seq_len)
+        ids, pos = self._to_dev(batch.ids), self._to_dev(batch.pos)
+        types = self._to_dev(batch.types) if batch.types is not None else None
+        starts, lens = self._to_dev(batch.seq_start), self._to_dev(batch.seq_len)
+        b_pad = (B + 255) // 256 * 256
+        cls = torch.empty((b_pad, H), dtype=torch.bfloat16, device=dev)
+        need = lib.tt_encoder_cls_workspace_bytes(ctypes.byref(self.w.struct), batch.n_rows, B)
+        ws, base = _scratch.get("enc", dev, need)
+        with torch.cuda.device(dev):
+            rc = lib.tt_encoder_forward_cls(ctypes.byref(self.w.struct), ids.data_ptr(), pos.data_ptr(),
+                                            types.data_ptr() if types is not None else None, starts.data_ptr(),
+                                            lens.data_ptr(), B, batch.n_rows, batch.max_len, cls.data_ptr(), base, need,
+                                            torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(rc, "tt_encoder_forward_cls")
+        rows = torch.arange(B, dtype=torch.int32, device=dev)
+        return cls, rows
+
     def embed_packed(self, batch: PackedBatch) -> Tuple[torch.Tensor, torch.Tensor]:
         """-> (embeddings fp32 [B, H] L2-normalised, same rounded to bf16)."""
-        hidden, cls_rows = self.forward_packed(batch)
+        hidden, cls_rows = self.cls_hidden_packed(batch)
         B, H = len(batch.seq_len), self.cfg.hidden
         out = torch.empty((B, H), dtype=torch.float32, device=self.device)
         out16 = torch.empty((B, H), dtype=torch.bfloat16, device=self.device)
@@ -367,7 +391,7 @@ class Encoder:
         """-> sigmoid scores fp32 [B] (and logits)."""
         if not self.cfg.num_labels:
             raise RuntimeError("these weights carry no classification head")
-        hidden, cls_rows = self.forward_packed(batch)
+        hidden, cls_rows = self.cls_hidden_packed(batch)
         B, H = len(batch.seq_len), self.cfg.hidden
         scores = torch.empty(B, dtype=torch.float32, device=self.device)
         logits = torch.empty(B, dtype=torch.float32, device=self.device) if want_logits else None

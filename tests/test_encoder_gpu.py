@@ -237,3 +237,32 @@ def test_encoder_longer_sequences_and_truncation(dev, built_lib):
     want = oe.embed(ids, mask, Wb, cfg_o, emulate_bf16=True)
     cos = (emb.cpu() * want).sum(1)
     assert (cos >= 0.9995).all(), cos
+
+
+@pytest.mark.parametrize("shape", ["xlmr", "bert"])
+def test_cls_only_last_layer_matches_full_forward(dev, built_lib, shape):
+    """tt_encoder_forward_cls == the CLS rows of tt_encoder_forward (the single-query attention keeps its
+    probabilities in fp32 instead of bf16: agreement to a couple of bf16 ulps)."""
+    from tensor_truth_amd.encoder import Encoder, EncoderConfig, EncoderWeights, pack_tokens
+
+    if shape == "xlmr":
+        cfg = EncoderConfig(arch="xlmr", vocab_size=2000, hidden=256, layers=3, heads=4, ffn=512, max_pos=600,
+                            type_vocab=1, pad_id=1, ln_eps=1e-5)
+    else:
+        cfg = EncoderConfig(arch="bert", vocab_size=2000, hidden=384, layers=2, heads=12, ffn=1536, max_pos=600,
+                            type_vocab=2, pad_id=0, ln_eps=1e-12)
+    from tensor_truth_amd.encoder import synthetic_state
+
+    enc = Encoder(EncoderWeights(cfg, synthetic_state(cfg, seed=7), dev))
+    g = torch.Generator().manual_seed(2)
+    lens = [300, 1, 64, 65, 129, 7, 513, 40]
+    seqs = [torch.randint(4, 2000, (n,), generator=g).tolist() for n in lens]
+    batch = pack_tokens(seqs, cfg)
+    full, starts = enc.forward_packed(batch)
+    cls, rows = enc.cls_hidden_packed(batch)
+    torch.cuda.synchronize()
+    want = full[starts.long()].float().cpu()
+    got = cls[: len(seqs)].float().cpu()
+    err = (got - want).abs()
+    assert (err <= 2 ** -6 * want.abs() + 2e-2).all(), err.max().item()
+    assert err.mean().item() < 3e-3
