@@ -157,6 +157,11 @@ int tt_embed_pool(const void* hidden_bf16, int ld, const int32_t* rows, int n_se
 int tt_rerank_head(const tt_encoder_weights* w, const void* hidden_bf16, const int32_t* rows, int n_seq,
                    float* scores, float* logits, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Semantic splitter distances (reference: SemanticSplitterNodeParser built at
+ * src/tensortruth/indexing/builder.py:393-407): out_dist[i] = 1 - cos(e[i], e[i+1]) for the
+ * n consecutive sentence-group embeddings e (fp32 [n][hidden], e.g. tt_embed_pool's output). */
+int tt_adjacent_cosine(const float* emb_f32, int n, int hidden, float* out_dist, void* stream);
+
 /* Building blocks, exported for the parity tests (same kernels the forward uses).
  * tt_attention_varlen: Q and K are row-major [rows][ld_qk] at column offsets q_col0 / k_col0;
  * V is passed in the token-blocked transposed layout the QKV GEMM epilogue writes,

@@ -49,6 +49,7 @@ SIGNATURES = {
                                        c_void_p, c_void_p, c_size_t, c_void_p]),
     "tt_embed_pool": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "tt_rerank_head": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "tt_adjacent_cosine": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "tt_gemm_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "tt_layernorm_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     "tt_attention_varlen": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p,

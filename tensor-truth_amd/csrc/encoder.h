@@ -62,3 +62,6 @@ int tt_gather_rows_launch(const uint16_t* src, int ld, const int32_t* rows, int 
 // score[b] = sigmoid(dot(t[b][:], w) + bias)   (t bf16 [n][ld], w bf16 [H]); logits optional
 int tt_head_out_sigmoid_launch(const uint16_t* t, int ld, const uint16_t* w, const float* bias, int n, int H,
                                float* scores, float* logits, hipStream_t st);
+
+// dist[i] = 1 - cos(e[i], e[i+1]), e fp32 [n][H]
+int tt_adjacent_cosine_launch(const float* e, int n, int H, float* dist, hipStream_t st);

@@ -261,6 +261,14 @@ int tt_rerank_head(const tt_encoder_weights* w, const void* hidden_bf16, const i
     return tt_head_out_sigmoid_launch(t, H, (const uint16_t*)w->cls_out_w, w->cls_out_b, n_seq, H, scores, logits, st);
 }
 
+int tt_adjacent_cosine(const float* emb_f32, int n, int hidden, float* out_dist, void* stream) {
+    TT_CHECK_ARG(n >= 0, "n=%d", n);
+    if (n <= 1) return TT_OK;
+    TT_CHECK_ARG(emb_f32 && out_dist, "null pointer");
+    TtProfScope prof(TT_K_ROWOPS, (hipStream_t)stream);
+    return tt_adjacent_cosine_launch(emb_f32, n, hidden, out_dist, (hipStream_t)stream);
+}
+
 int tt_gemm_bf16(const void* a, const void* w, const float* bias, const void* residual, void* c, int m, int n,
                  int k, int epilogue, void* stream) {
     TT_CHECK_ARG(epilogue >= TT_EPI_BIAS && epilogue <= TT_EPI_TANH, "epilogue %d", epilogue);

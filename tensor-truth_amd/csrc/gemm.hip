@@ -7,13 +7,13 @@
 // reference's bi-encoder / cross-encoder forward (transformers XLMRobertaLayer / BertLayer:
 // QKV, attention output, FFN up, FFN down).
 //
-// Structure (v1): 128x128x64 block tile, 4 waves (2x2), 64x64 per wave as 4x4 tiles of
-// v_mfma_f32_16x16x32_bf16; operands staged by global_load_lds_dwordx4 into a 2-deep LDS
-// ring ([row][64] bf16 = 128-B rows, 16-B slots XOR-swizzled on the SOURCE address so the
-// lane-linear LDS image is read conflict-free by ds_read_b128), one barrier per K-step.
-// The MFMA is issued "swapped" (a = W fragment, b = A fragment) so each lane ends up with
-// 4 consecutive N-columns of one row: the epilogue stores 8 bytes per lane.
-// Block order: XCD-contiguous, 8x8 super-tiles, so an XCD's L2 sees each A/W panel 8 times.
+// Two kernels: gemm_kernel_v3 (256x256x64 tile, 8 waves, ping-pong LDS/MFMA slots, see "v3" below) for shapes
+// divisible by 256 -- every GEMM of the 1024-wide models -- and gemm_kernel (v1: 128x128x64 tile, 4 waves x
+// 64x64, 2 blocks per CU, one barrier per K-step) for the rest (bge-small's 384 / 1152 / 1536 columns).
+// Both stage operands with global_load_lds_dwordx4 into [row][64] bf16 tiles whose 16-B slots are
+// XOR-swizzled on the SOURCE address, issue the MFMA "swapped" (a = W fragment, b = A fragment) so a lane
+// ends up with consecutive N-columns of one row, and order blocks XCD-contiguously in super-tiles.
+// A 256x128 3-stage counted-vmcnt variant of v1 (the former v2) was measured no faster and was dropped.
 //
 // Roofline: MFMA-bound; 2*M*N*K flops per launch.
 #include "common.h"
@@ -284,116 +284,6 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_kernel(GemmParams p) {
 
     gemm_epilogue<EPI>(p, acc, m0 + wm * 64, n0 + wn * 64, lane);
 }
-
-// ---------------------------------------------------------------------------------------------
-// v2: 256x128x64 block tile, 8 waves (4 along M x 2 along N, 64x64 each), THREE-deep LDS ring.
-// The global->LDS copies of K-step kt+2 are issued while kt is computed and are waited for with
-// a COUNTED s_waitcnt vmcnt(6) (one stage = 6 glds per wave stays in flight) in front of a raw
-// s_barrier -- __syncthreads() would drain the LDS-DMA queue (vmcnt(0)) every K-step, which is
-// what caps v1 (36 % MFMA busy, 36 % of wave time in s_waitcnt/barrier by SQ counters).
-namespace v2 {
-constexpr int BM2 = 256, BN2 = 128;
-constexpr int kThreads2 = 512;
-constexpr int kATile = BM2 * BK * 2;            // 32 KiB
-constexpr int kWTile = BN2 * BK * 2;            // 16 KiB
-constexpr int kStage = kATile + kWTile;         // 48 KiB
-constexpr int kStages = 3;
-constexpr int kLds2 = kStages * kStage;         // 144 KiB
-
-__device__ __forceinline__ void stage_tile2(const GemmParams& p, char* stage, int wave, int lane, int m0, int n0, int k0) {
-    const int lrow = lane >> 3;
-    const int slot = lane & 7;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int row = 32 * wave + 8 * j + lrow;
-        const int chunk = slot ^ ((row >> 1) & 7);
-        const uint16_t* src = p.A + (size_t)(m0 + row) * p.lda + k0 + chunk * 8;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(stage + (32 * wave + 8 * j) * 128),
-                                         16, 0, 0);
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int row = 16 * wave + 8 * j + lrow;
-        const int chunk = slot ^ ((row >> 1) & 7);
-        const uint16_t* src = p.W + (size_t)(n0 + row) * p.K + k0 + chunk * 8;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(stage + kATile + (16 * wave + 8 * j) * 128),
-                                         16, 0, 0);
-    }
-}
-
-template <int EPI>
-__global__ __launch_bounds__(kThreads2, 2) void gemm_kernel_v2(GemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-
-    const int mt_n = p.M / BM2, nt_n = p.N / BN2;
-    int L = blockIdx.x;
-    {
-        const int nwg = gridDim.x;
-        if ((nwg & 7) == 0) L = (L & 7) * (nwg >> 3) + (L >> 3);
-    }
-    const int SN = nt_n < 8 ? nt_n : 8;
-    const int SM = 4;
-    const int per_super = SM * SN;
-    const int supers_n = (nt_n + SN - 1) / SN;
-    const int s = L / per_super, w = L % per_super;
-    const int tm = (s / supers_n) * SM + w / SN;
-    const int tn = (s % supers_n) * SN + w % SN;
-    if (tm >= mt_n || tn >= nt_n) return;
-    const int m0 = tm * BM2, n0 = tn * BN2;
-
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int nk = p.K / BK;
-    stage_tile2(p, smem, wave, lane, m0, n0, 0);
-    if (nk > 1) stage_tile2(p, smem + kStage, wave, lane, m0, n0, BK);
-
-    const int frow = lane & 15;
-    const int fchk = lane >> 4;
-
-    for (int kt = 0; kt < nk; ++kt) {
-        // stage kt has landed once at most the 6 copies of stage kt+1 are still in flight
-        if (kt + 1 < nk) {
-            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        // every wave is past its reads of stage kt-1: its slot can take stage kt+2
-        if (kt + 2 < nk) stage_tile2(p, smem + ((kt + 2) % kStages) * kStage, wave, lane, m0, n0, (kt + 2) * BK);
-        const char* tA = smem + (kt % kStages) * kStage;
-        const char* tW = tA + kATile;
-#pragma unroll
-        for (int ss = 0; ss < 2; ++ss) {
-            bf16x8 wf[4], xf[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int rw = wn * 64 + i * 16 + frow;
-                wf[i] = *reinterpret_cast<const bf16x8*>(tW + rw * 128 + (((4 * ss + fchk) ^ ((rw >> 1) & 7)) << 4));
-                const int ra = wm * 64 + i * 16 + frow;
-                xf[i] = *reinterpret_cast<const bf16x8*>(tA + ra * 128 + (((4 * ss + fchk) ^ ((ra >> 1) & 7)) << 4));
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
-        }
-    }
-
-    gemm_epilogue<EPI>(p, acc, m0 + wm * 64, n0 + wn * 64, lane);
-}
-}  // namespace v2
 
 // ---------------------------------------------------------------------------------------------
 // v3: 256x256x64 block tile, 8 waves of 128x64, "ping-pong" schedule.
@@ -834,26 +724,6 @@ int launch(const GemmParams& p, hipStream_t st) {
     if constexpr (EPI == TT_EPI_VT) {
         tt_set_error("gemm: internal V^T epilogue needs the 256x256 kernel");
         return TT_E_UNSUPPORTED;
-    }
-    if (variant == 2 && p.M % v2::BM2 == 0) {
-        const int mt_n = p.M / v2::BM2, nt_n = p.N / v2::BN2;
-        const int SN = nt_n < 8 ? nt_n : 8, SM = 4;
-        const int supers = ((mt_n + SM - 1) / SM) * ((nt_n + SN - 1) / SN);
-        int blocks = supers * SM * SN;
-        blocks = (blocks + 7) / 8 * 8;
-        auto kern = v2::gemm_kernel_v2<EPI>;
-        static thread_local bool attr2 = false;
-        if (!attr2) {
-            TT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, v2::kLds2));
-            attr2 = true;
-        }
-        {
-            TtProfScope prof(TT_K_GEMM, st);
-            hipLaunchKernelGGL(kern, dim3(blocks), dim3(v2::kThreads2), v2::kLds2, st, p);
-        }
-        TT_CHECK_LAUNCH();
-        return TT_OK;
     }
     const int mt_n = p.M / BM, nt_n = p.N / BN;
     const int SN = nt_n < 8 ? nt_n : 8, SM = 8;

@@ -186,6 +186,25 @@ __global__ __launch_bounds__(kRowThreads) void head_out_kernel(const uint16_t* t
     }
 }
 
+// dist[i] = 1 - cos(e[i], e[i+1]) for consecutive rows of an fp32 [n][H] matrix (semantic splitter)
+__global__ __launch_bounds__(kRowThreads) void adjacent_cosine_kernel(const float* e, int n, int H, float* dist) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * (kRowThreads / 64) + (threadIdx.x >> 6);
+    if (i >= n - 1) return;
+    const float* a = e + (size_t)i * H;
+    const float* b = a + H;
+    float ab = 0.f, aa = 0.f, bb = 0.f;
+    for (int c = lane * 4; c < H; c += 256) {
+        const float4 x = *reinterpret_cast<const float4*>(a + c);
+        const float4 y = *reinterpret_cast<const float4*>(b + c);
+        ab += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+        aa += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
+        bb += y.x * y.x + y.y * y.y + y.z * y.z + y.w * y.w;
+    }
+    ab = wave_sum(ab); aa = wave_sum(aa); bb = wave_sum(bb);
+    if (lane == 0) dist[i] = 1.0f - ab / fmaxf(sqrtf(aa) * sqrtf(bb), 1e-30f);
+}
+
 int check_h(int H) {
     if (H <= 0 || H % 8 || H > 64 * 8 * kMaxChunks) {
         tt_set_error("row op: hidden size %d unsupported (multiple of 8, <= %d)", H, 64 * 8 * kMaxChunks);
@@ -238,6 +257,14 @@ int tt_head_out_sigmoid_launch(const uint16_t* t, int ld, const uint16_t* w, con
     if (n <= 0) return TT_OK;
     if (int rc = check_h(H)) return rc;
     hipLaunchKernelGGL(head_out_kernel, row_grid(n), dim3(kRowThreads), 0, st, t, ld, w, bias, n, H, scores, logits);
+    TT_CHECK_LAUNCH();
+    return TT_OK;
+}
+
+int tt_adjacent_cosine_launch(const float* e, int n, int H, float* dist, hipStream_t st) {
+    if (n <= 1) return TT_OK;
+    if (H <= 0 || H % 4) { tt_set_error("adjacent cosine: hidden %d must be a multiple of 4", H); return TT_E_UNSUPPORTED; }
+    hipLaunchKernelGGL(adjacent_cosine_kernel, row_grid(n - 1), dim3(kRowThreads), 0, st, e, n, H, dist);
     TT_CHECK_LAUNCH();
     return TT_OK;
 }

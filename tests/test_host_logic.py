@@ -263,3 +263,26 @@ def test_hash_tokenizer_pairs():
     bt = HashTokenizer("bert", 30522)
     ids, types = bt.encode_pair("a b", "c d e")
     assert ids[0] == 101 and ids[-1] == 102 and types == [0, 0, 0, 0, 1, 1, 1, 1]
+
+
+def test_pack_token_matrix_equals_pack_tokens():
+    from tensor_truth_amd.encoder import BGE_M3, BGE_SMALL_EN_V15, pack_token_matrix, pack_tokens
+
+    rng = np.random.default_rng(0)
+    for cfg, length in ((BGE_M3, 292), (BGE_SMALL_EN_V15, 17)):
+        a = rng.integers(4, 1000, size=(11, length), dtype=np.int32)
+        x, y = pack_token_matrix(a, cfg), pack_tokens([r for r in a], cfg)
+        for f in ("ids", "pos", "seq_start", "seq_len"):
+            assert (getattr(x, f) == getattr(y, f)).all(), f
+        assert (x.n_rows, x.max_len, x.n_tokens) == (y.n_rows, y.max_len, y.n_tokens)
+
+
+def test_semantic_splitter_host_logic():
+    from tensor_truth_amd.semantic import breakpoints_from_distances, split_sentences
+
+    assert split_sentences("One. Two two! Three?\nFour.") == ["One.", " Two two!", " Three?\n", "Four."]
+    assert split_sentences("   ") == []
+    # np.percentile(linear): 95th percentile of [.1,.2,.9,.15,.8,.1] = 0.875 -> only 0.9 exceeds it
+    assert breakpoints_from_distances([0.1, 0.2, 0.9, 0.15, 0.8, 0.1], 95) == [2]
+    assert breakpoints_from_distances([0.1, 0.2, 0.9, 0.15, 0.8, 0.1], 60) == [2, 4]
+    assert breakpoints_from_distances([], 95) == []

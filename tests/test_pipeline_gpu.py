@@ -161,3 +161,50 @@ def test_devices_other_than_hip_are_refused(built_lib):
 
     with pytest.raises(RuntimeError, match="HIP devices only"):
         HipHuggingFaceEmbedding("BAAI/bge-m3", device="cpu", model_kwargs={"synthetic_seed": 1})
+
+
+def test_semantic_splitter_distances_and_cuts(dev, built_lib):
+    from tensor_truth_amd.semantic import SemanticSplitter, adjacent_distances
+
+    g = torch.Generator().manual_seed(4)
+    e = torch.randn(37, 1024, generator=g)
+    want = 1 - torch.nn.functional.cosine_similarity(e[:-1], e[1:], dim=1)
+    got = adjacent_distances(e.to(dev)).cpu()
+    assert torch.allclose(got, want, atol=1e-5)
+    assert adjacent_distances(e[:1].to(dev)).numel() == 0
+
+    class TopicEmbedder:  # two topics: embeddings cluster by the word "kernel" vs "sauce"
+        text_instruction = ""
+
+        def _embed_texts(self, texts, prefix):
+            out = torch.zeros(len(texts), 128)
+            for i, t in enumerate(texts):
+                out[i, 0] = t.count("kernel") + 0.01 * i
+                out[i, 1] = t.count("sauce")
+            return torch.nn.functional.normalize(out + 1e-3, dim=1).to(dev)
+
+    text = "The kernel streams rows. The kernel uses LDS. The kernel is fast. The sauce needs basil. The sauce simmers."
+    chunks = SemanticSplitter(TopicEmbedder(), buffer_size=0, breakpoint_percentile_threshold=70).split_text(text)
+    assert len(chunks) == 2 and "kernel is fast" in chunks[0] and chunks[1].startswith("The sauce")
+
+
+def test_profiling_hooks(dev, built_lib):
+    import ctypes
+
+    from tensor_truth_amd import _lib, scan as tscan
+
+    lib = _lib.load_library()
+    c = osc.synth_corpus(70_000, 128, seed=1).to(dev)
+    q = c[:4].contiguous()
+    lib.tt_prof_enable(1)
+    for _ in range(3):
+        tscan.scan_topk(c, q, 5)
+    ms, n = ctypes.c_double(0), ctypes.c_int(0)
+    lib.tt_prof_read(1, ctypes.byref(ms), ctypes.byref(n))
+    assert n.value == 3 and 0 < ms.value < 100
+    lib.tt_prof_read(3, ctypes.byref(ms), ctypes.byref(n))
+    assert n.value == 6
+    lib.tt_prof_enable(0)
+    tscan.scan_topk(c, q, 5)
+    lib.tt_prof_read(1, ctypes.byref(ms), ctypes.byref(n))
+    assert n.value == 0
