@@ -1,0 +1,103 @@
+"""GPU parity at the BASELINE.json configurations (full model shapes, full depth).
+
+C1: 1k-chunk toy corpus, bge-small-en-v1.5 shape (BERT 12L x 384), brute-force cosine top-10, no rerank.
+C2/C3 (encoder half): bge-m3 / bge-reranker-v2-m3 shapes (XLM-R 24L x 1024) -- embeddings and rerank scores
+of full-depth models against the fp32 CPU oracle, i.e. bf16 error accumulated over all 24 layers.
+(The 1M x 1024 scan half of C2 is in test_scan_gpu.py::test_full_size_config_c2_against_oracle.)
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import encoder as oe
+from oracle import scan as osc
+
+pytestmark = pytest.mark.gpu
+
+
+def _pad(seqs, pad):
+    L = max(len(s) for s in seqs)
+    ids = torch.full((len(seqs), L), pad, dtype=torch.int64)
+    mask = torch.zeros(len(seqs), L, dtype=torch.int64)
+    for b, s in enumerate(seqs):
+        ids[b, : len(s)] = torch.tensor(s)
+        mask[b, : len(s)] = 1
+    return ids, mask
+
+
+def test_config_c1_bge_small_toy_corpus_end_to_end(dev, built_lib):
+    from tensor_truth_amd.encoder import BGE_SMALL_EN_V15, Encoder, EncoderWeights
+    from tensor_truth_amd import scan as tscan
+
+    cfg = BGE_SMALL_EN_V15
+    ocfg = oe.EncoderConfig(**cfg.__dict__)
+    W = oe.synth_weights(ocfg, seed=3)
+    Wb = {k: v.to(torch.bfloat16) for k, v in W.items()}
+    g = torch.Generator().manual_seed(777)
+    # 1k chunks (ragged 16..128 tokens) + 16 queries; every other query repeats a chunk verbatim (planted hit)
+    lens = torch.randint(16, 129, (1000,), generator=g).tolist()
+    chunks = [[101] + torch.randint(1000, cfg.vocab_size, (n - 2,), generator=g).tolist() + [102] for n in lens]
+    queries = []
+    for i in range(16):
+        if i % 2 == 0:
+            queries.append(list(chunks[37 * i + 5]))
+        else:
+            n = int(torch.randint(8, 25, (1,), generator=g))
+            queries.append([101] + torch.randint(1000, cfg.vocab_size, (n - 2,), generator=g).tolist() + [102])
+    enc = Encoder(EncoderWeights(cfg, W, dev))
+    c_emb, c16 = enc.embed(chunks)
+    q_emb, q16 = enc.embed(queries)
+    s, i = tscan.scan_topk(c16, q16, 10)
+    torch.cuda.synchronize()
+    # oracle: same token ids through the fp32-math oracle with the bf16 rounding points emulated
+    ids, mask = _pad(chunks, cfg.pad_id)
+    want_c = oe.embed(ids, mask, Wb, ocfg, emulate_bf16=True)
+    ids, mask = _pad(queries, cfg.pad_id)
+    want_q = oe.embed(ids, mask, Wb, ocfg, emulate_bf16=True)
+    assert ((c_emb.cpu() * want_c).sum(1) >= 0.999).all()
+    assert ((q_emb.cpu() * want_q).sum(1) >= 0.999).all()
+    # scan parity on the embeddings the GPU produced (bit-exact indices on tie-free queries)
+    w_s, w_i, gap = osc.scan_topk(c16.cpu(), q16.cpu(), 10)
+    tf = gap > 1e-6
+    assert tf.sum() >= 6     # random-init embeddings crowd together: several queries have near-ties
+    assert torch.equal(i.cpu().to(torch.int64)[tf], w_i[tf])
+    assert torch.allclose(s.cpu(), w_s, rtol=1e-3, atol=1e-6)
+    # end-to-end vs the all-oracle pipeline (oracle embeddings -> oracle scan).  With random-init weights the
+    # embeddings of unrelated random token strings crowd together (cosines within ~1e-2), so bf16-level noise may
+    # reorder those near-ties; what must hold: planted hits rank first in both pipelines, and wherever the
+    # oracle's own ranking is clear-cut (gap > 2e-3) the two rankings are identical.
+    o_s, o_i, o_gap = osc.scan_topk(want_c.to(torch.bfloat16), want_q.to(torch.bfloat16), 10)
+    got_i = i.cpu().to(torch.int64)
+    for qi in range(0, 16, 2):
+        assert int(got_i[qi, 0]) == 37 * qi + 5 == int(o_i[qi, 0])
+        assert s[qi, 0].item() > 0.99
+    wide = o_gap > 2e-3
+    assert torch.equal(got_i[wide], o_i[wide])
+
+
+def test_full_depth_bge_m3_embeddings_and_reranker_scores(dev, built_lib):
+    from tensor_truth_amd.encoder import BGE_RERANKER_V2_M3, Encoder, EncoderWeights
+
+    cfg = BGE_RERANKER_V2_M3                     # same encoder as bge-m3 + the classification head
+    ocfg = oe.EncoderConfig(**cfg.__dict__)
+    W = oe.synth_weights(ocfg, seed=11)          # 568 M parameters, HF-style init
+    g = torch.Generator().manual_seed(5)
+    lens = [96, 33, 64, 17, 80, 50]
+    seqs = [[0] + torch.randint(4, cfg.vocab_size, (n - 2,), generator=g).tolist() + [2] for n in lens]
+    enc = Encoder(EncoderWeights(cfg, W, dev))
+    emb, _ = enc.embed(seqs)
+    scores, logits = enc.rerank(seqs, want_logits=True)
+    torch.cuda.synchronize()
+    ids, mask = _pad(seqs, cfg.pad_id)
+    torch.set_num_threads(max(1, min(32, torch.get_num_threads())))
+    with torch.no_grad():
+        hid = oe.encoder_forward(ids, mask, W, ocfg)                    # plain fp32, fp32 weights
+        want_e = oe.cls_pool_normalize(hid)
+        t = torch.tanh(hid[:, 0] @ W["classifier.dense.weight"].T + W["classifier.dense.bias"])
+        want_l = (t @ W["classifier.out_proj.weight"].T + W["classifier.out_proj.bias"])[:, 0]
+    cos = (emb.cpu() * want_e).sum(1)
+    assert (cos >= 0.999).all(), cos                                     # SURVEY.md 8d embedding gate, 24 layers deep
+    assert (emb.cpu() - want_e).abs().max().item() <= 4e-3
+    err = (scores.cpu() - torch.sigmoid(want_l)).abs().max().item()
+    assert err <= 2e-2, f"rerank score error after 24 bf16 layers: {err}"
+    assert np.isfinite(logits.cpu().numpy()).all()
