@@ -29,21 +29,29 @@ constexpr int kTileBytes = BM * BK * 2;          // 16 KiB per operand tile
 constexpr int kStageBytes = 2 * kTileBytes;      // A + W
 constexpr int kGemmLds = 2 * kStageBytes;        // 64 KiB
 
-// GELU(x) = 0.5 x (1 + erf(x / sqrt 2)), exact-erf form (HF "gelu").  erf by Abramowitz-Stegun 7.1.26
-// (|abs err| <= 1.5e-7, far below the bf16 output resolution) -- the libm erff costs ~3x the
-// instructions and made the FFN-up epilogue a quarter of that GEMM's time.
+// GELU(x) = 0.5 x (1 + erf(x / sqrt 2)), exact-erf form (HF "gelu"), written as
+//   gelu(x) = max(x, 0) - |x| Phi(-|x|),   Phi(-u) = 2^Q(u),
+// Q = degree-7 minimax fit of log2 Phi(-u) on [0, 9] (leading coefficient negative, so the term underflows to 0
+// beyond the fitted range).  Relative error of the correction term <= 7.5e-5 everywhere (abs error of the result
+// <= 1e-5; the bf16 output resolves 2e-3 relative), and it costs 7 FMAs + one v_exp_f32 per value: the previous
+// Abramowitz-Stegun erf (rcp + exp + 14 plain ops) made the FFN-up epilogue 10 % of that GEMM; libm erff 25 %.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
+    const f32x2 u = f32x2{fabsf(x.x), fabsf(x.y)};
+    f32x2 q = u * -9.697845371e-07f + 4.016999810e-05f;
+    q = q * u + -7.211678312e-04f;
+    q = q * u + 7.490924560e-03f;
+    q = q * u + -5.142170191e-02f;
+    q = q * u + -4.614778757e-01f;
+    q = q * u + -1.149914980e+00f;
+    q = q * u + -1.000091195e+00f;
+    const f32x2 e = f32x2{__builtin_amdgcn_exp2f(q.x), __builtin_amdgcn_exp2f(q.y)};
+    const f32x2 r = f32x2{fmaxf(x.x, 0.f), fmaxf(x.y, 0.f)};
+    return r - u * e;
+}
 __device__ __forceinline__ float gelu_erf(float x) {
-    const float z = fabsf(x) * 0.70710678118654752f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-    float poly = fmaf(1.061405429f, t, -1.453152027f);
-    poly = fmaf(poly, t, 1.421413741f);
-    poly = fmaf(poly, t, -0.284496736f);
-    poly = fmaf(poly, t, 0.254829592f);
-    poly *= t;
-    const float e = __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f);
-    const float erf_abs = fmaf(-poly, e, 1.0f);               // erf(|x|/sqrt2)
-    const float erf_v = copysignf(erf_abs, x);
-    return 0.5f * x * (1.0f + erf_v);
+    const f32x2 y = gelu_erf2(f32x2{x, x});
+    return y.x;
 }
 
 // ---- epilogue of one wave's 64x64 tile: lane holds C[m][n..n+3], m = tile row (l&15), n = 4*(l>>4)
@@ -308,7 +316,8 @@ namespace v3 {
 constexpr int BM3 = 256, BN3 = 256;
 constexpr int kThreads3 = 512;
 constexpr int kHalf = 128 * BK * 2;   // 16 KiB half-tile
-constexpr int kLds3 = 8 * kHalf;      // 128 KiB
+constexpr int kBiasOff = 8 * kHalf;   // 1 KiB: the tile's 256 bias values, staged by wave 0 in the prologue
+constexpr int kLds3 = 8 * kHalf + 1024;   // 129 KiB
 // slot offsets: [operand A=0/W=1][half][buf]
 __device__ __forceinline__ constexpr int slot_off(int operand, int half, int buf) { return ((operand * 2 + half) * 2 + buf) * kHalf; }
 
@@ -337,48 +346,98 @@ __device__ __forceinline__ void stage_half(const GemmParams& p, char* smem, int 
 }
 
 // Whole-wave epilogue of the 256x256 kernel (acc[qm][qn][nt][mt], wide 16-B layout after permlane16_swap).
-// All bias vectors (and, for the residual epilogue, all 16 residual vectors) are loaded UP FRONT: with the
-// loads inside the per-tile loop every iteration paid a full global-load latency and the epilogue took
-// 11 k cycles per 256x256 tile (20 % of a K=1024 GEMM) by in-kernel stamps.
+// No ordinary global load is left in it: the tile's bias strip is staged to LDS in the prologue and the residual
+// tile rides the operand pipeline as two pseudo K-tiles (see stage_res), so the only vector-memory waits are the
+// counted ones written here.  History: with the bias / residual loads inside the per-tile loop every iteration
+// paid a global-load latency (11 k cycles per tile); hoisted "up front" hipcc still split the 16 residual loads
+// into four waited batches (6 us per tile, +19 % on the attention-output GEMM).
+//
+// Residual image in LDS (wave-private, so no barrier is needed before reading it): part P = qm*2 + pr holds the
+// wave's rows (pr*2 + odd)*16 + [0,16) of quadrant row qm as two 2-KiB pieces [16 rows][8 chunks of 16 B]
+// (chunk c = qn*4 + nt*2 + (g>>1), XOR-swizzled with (row>>1)&7 like the operand tiles), the odd = 0 piece in
+// half-tile slot kResSlot[P], the odd = 1 piece four slots further, both at byte 2048*wave.
+__device__ __forceinline__ constexpr int res_slot(int part) { return part == 0 ? 0 : part == 1 ? 2 : part == 2 ? 1 : 3; }
+
+// LDS reads the compiler must not see as LDS reads: hipcc puts s_waitcnt vmcnt(0) in front of any ds_read that may
+// alias an LDS-DMA still in flight, which would serialise the residual parts.  The caller waits (lds_wait) before
+// the first use.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+template <int OFF>
+__device__ __forceinline__ u32x4 lds_read128_async(uint32_t addr) {
+    u32x4 r;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+    return r;
+}
+__device__ __forceinline__ void lds_wait(u32x4& a, u32x4& b, u32x4& c, u32x4& d) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
+
 template <int EPI>
-__device__ __forceinline__ void epilogue_all(const GemmParams& p, f32x4 (&acc)[2][2][2][4], int m0, int n0, int wm, int wn,
-                                             int lane) {
+__device__ __forceinline__ void epilogue_all(const GemmParams& p, f32x4 (&acc)[2][2][2][4], const char* smem, int m0, int n0,
+                                             int wm, int wn, int wave, int lane) {
     const int g = lane >> 4;
     const bool odd = (g & 1) != 0;
     const int ncol = wn * 32 + (g & ~1) * 4;           // + qn*128 + nt*16: first of this lane's 8 columns
     const int mrow = wm * 64 + (lane & 15);            // + qm*128 + (pair*2 + odd)*16
+    const int l15 = lane & 15;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)smem;
+    const uint32_t rbase = lds0 + (odd ? 4 * kHalf : 0) + 2048 * wave + l15 * 128;
+    const uint32_t rx = ((g >> 1) ^ ((l15 >> 1) & 7)) << 4;
+    const uint32_t raddr[2][2] = {{rbase + (rx ^ 0u), rbase + (rx ^ 32u)}, {rbase + (rx ^ 64u), rbase + (rx ^ 96u)}};  // [qn][nt]
+
     float4 bias[2][2][2];
-#pragma unroll
-    for (int qn = 0; qn < 2; ++qn)
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            const float* bp = p.bias + n0 + qn * 128 + nt * 16 + ncol;
-            bias[qn][nt][0] = *reinterpret_cast<const float4*>(bp);
-            bias[qn][nt][1] = *reinterpret_cast<const float4*>(bp + 4);
-        }
-    uint4 res[2][2][2][2];
     if constexpr (EPI == TT_EPI_RESIDUAL) {
+        const uint32_t baddr = lds0 + kBiasOff + ncol * 4;
+        u32x4 b[8];
+        b[0] = lds_read128_async<0>(baddr);        b[1] = lds_read128_async<16>(baddr);
+        b[2] = lds_read128_async<64>(baddr);       b[3] = lds_read128_async<80>(baddr);
+        b[4] = lds_read128_async<512>(baddr);      b[5] = lds_read128_async<528>(baddr);
+        b[6] = lds_read128_async<576>(baddr);      b[7] = lds_read128_async<592>(baddr);
+        lds_wait(b[0], b[1], b[2], b[3]);
+        lds_wait(b[4], b[5], b[6], b[7]);
 #pragma unroll
-        for (int qm = 0; qm < 2; ++qm)
+        for (int i = 0; i < 8; ++i)
+            bias[i >> 2][(i >> 1) & 1][i & 1] = float4{__uint_as_float(b[i].x), __uint_as_float(b[i].y), __uint_as_float(b[i].z),
+                                                       __uint_as_float(b[i].w)};
+    } else {
+        const char* bias_lds = smem + kBiasOff + ncol * 4;
 #pragma unroll
-            for (int qn = 0; qn < 2; ++qn)
+        for (int qn = 0; qn < 2; ++qn)
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                    for (int pr = 0; pr < 2; ++pr) {
-                        const int m = m0 + qm * 128 + mrow + (pr * 2 + (odd ? 1 : 0)) * 16;
-                        const int n = n0 + qn * 128 + nt * 16 + ncol;
-                        res[qm][qn][nt][pr] = *reinterpret_cast<const uint4*>(p.residual + (size_t)m * p.ldr + n);
-                    }
+            for (int nt = 0; nt < 2; ++nt) {
+                bias[qn][nt][0] = *reinterpret_cast<const float4*>(bias_lds + (qn * 128 + nt * 16) * 4);
+                bias[qn][nt][1] = *reinterpret_cast<const float4*>(bias_lds + (qn * 128 + nt * 16 + 4) * 4);
+            }
     }
 #pragma unroll
     for (int qm = 0; qm < 2; ++qm)
 #pragma unroll
-        for (int qn = 0; qn < 2; ++qn)
+        for (int pr = 0; pr < 2; ++pr) {
+            u32x4 res[2][2];
+            if constexpr (EPI == TT_EPI_RESIDUAL) {
+                // all but the 12 youngest vector-memory operations of this wave are done: the residual parts
+                // after this one (4 copies each) plus the 4 stores of every finished (qm, pr) block
+                asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                constexpr int kOff[4] = {0, 2 * kHalf, 1 * kHalf, 3 * kHalf};   // res_slot(part) * kHalf
+                if (qm == 0 && pr == 0) {
+                    res[0][0] = lds_read128_async<kOff[0]>(raddr[0][0]); res[0][1] = lds_read128_async<kOff[0]>(raddr[0][1]);
+                    res[1][0] = lds_read128_async<kOff[0]>(raddr[1][0]); res[1][1] = lds_read128_async<kOff[0]>(raddr[1][1]);
+                } else if (qm == 0 && pr == 1) {
+                    res[0][0] = lds_read128_async<kOff[1]>(raddr[0][0]); res[0][1] = lds_read128_async<kOff[1]>(raddr[0][1]);
+                    res[1][0] = lds_read128_async<kOff[1]>(raddr[1][0]); res[1][1] = lds_read128_async<kOff[1]>(raddr[1][1]);
+                } else if (qm == 1 && pr == 0) {
+                    res[0][0] = lds_read128_async<kOff[2]>(raddr[0][0]); res[0][1] = lds_read128_async<kOff[2]>(raddr[0][1]);
+                    res[1][0] = lds_read128_async<kOff[2]>(raddr[1][0]); res[1][1] = lds_read128_async<kOff[2]>(raddr[1][1]);
+                } else {
+                    res[0][0] = lds_read128_async<kOff[3]>(raddr[0][0]); res[0][1] = lds_read128_async<kOff[3]>(raddr[0][1]);
+                    res[1][0] = lds_read128_async<kOff[3]>(raddr[1][0]); res[1][1] = lds_read128_async<kOff[3]>(raddr[1][1]);
+                }
+                lds_wait(res[0][0], res[0][1], res[1][0], res[1][1]);
+            }
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
+            for (int qn = 0; qn < 2; ++qn)
 #pragma unroll
-                for (int pr = 0; pr < 2; ++pr) {
+                for (int nt = 0; nt < 2; ++nt) {
                     float v[8];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
@@ -393,12 +452,15 @@ __device__ __forceinline__ void epilogue_all(const GemmParams& p, f32x4 (&acc)[2
                     v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
                     if constexpr (EPI == TT_EPI_GELU) {
 #pragma unroll
-                        for (int k = 0; k < 8; ++k) v[k] = gelu_erf(v[k]);
+                        for (int k = 0; k < 8; k += 2) {
+                            const f32x2 y = gelu_erf2(f32x2{v[k], v[k + 1]});
+                            v[k] = y.x; v[k + 1] = y.y;
+                        }
                     } else if constexpr (EPI == TT_EPI_TANH) {
 #pragma unroll
                         for (int k = 0; k < 8; ++k) v[k] = tanhf(v[k]);
                     } else if constexpr (EPI == TT_EPI_RESIDUAL) {
-                        const uint4 r = res[qm][qn][nt][pr];
+                        const u32x4 r = res[qn][nt];
                         v[0] += __uint_as_float(r.x << 16); v[1] += __uint_as_float(r.x & 0xFFFF0000u);
                         v[2] += __uint_as_float(r.y << 16); v[3] += __uint_as_float(r.y & 0xFFFF0000u);
                         v[4] += __uint_as_float(r.z << 16); v[5] += __uint_as_float(r.z & 0xFFFF0000u);
@@ -411,6 +473,8 @@ __device__ __forceinline__ void epilogue_all(const GemmParams& p, f32x4 (&acc)[2
                     o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
                     *reinterpret_cast<uint4*>(p.C + (size_t)m * p.ldc + n) = o;
                 }
+            if constexpr (EPI == TT_EPI_RESIDUAL) __builtin_amdgcn_sched_barrier(0);   // keep the 4 stores in their block
+        }
 }
 
 #define TT_SLOT_END()                                         \
@@ -479,7 +543,42 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
             if (blockIdx.x == 0 && tid == 0 && dbg0) dbg0[20 + slot] = __builtin_amdgcn_s_memtime();
         }
     };
+    // residual tile -> LDS, four parts of (2 pieces x 2 copies) per wave; layout: see epilogue_all
+    constexpr bool kResLds = (EPI == TT_EPI_RESIDUAL);
+    uint32_t voffR[2] = {0u, 0u};
+    if constexpr (kResLds) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int r16 = 8 * j + (lane >> 3);
+            const int c = (lane & 7) ^ ((r16 >> 1) & 7);
+            voffR[j] = (uint32_t)r16 * (uint32_t)p.ldr * 2u + (uint32_t)(((c >> 2) * 128 + (c & 3) * 8) * 2);
+        }
+    }
+    auto stage_res = [&](int part) {
+        if constexpr (kResLds) {
+#pragma unroll
+            for (int od = 0; od < 2; ++od) {
+                const char* base = reinterpret_cast<const char*>(
+                    p.residual + (size_t)(m0 + (part >> 1) * 128 + wm * 64 + ((part & 1) * 2 + od) * 16) * p.ldr + n0 + wn * 32);
+                const unsigned long long b64 = reinterpret_cast<unsigned long long>(base);
+                const unsigned int blo = __builtin_amdgcn_readfirstlane((unsigned int)b64);
+                const unsigned int bhi = __builtin_amdgcn_readfirstlane((unsigned int)(b64 >> 32));
+                base = reinterpret_cast<const char*>(((unsigned long long)bhi << 32) | blo);
+                char* dst = smem + (res_slot(part) + 4 * od) * kHalf + 2048 * wave;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + voffR[j]),
+                                                     (__attribute__((address_space(3))) void*)(dst + 1024 * j), 16, 0, 0);
+            }
+        }
+    };
+
     cstamp(0);
+    // bias strip of this tile (256 floats = one 1-KiB copy), oldest operation of wave 0's queue
+    if (wave == 0) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.bias + n0 + lane * 4),
+                                         (__attribute__((address_space(3))) void*)(smem + kBiasOff), 16, 0, 0);
+    }
     // ---- prologue: tile 0 complete, tile 1 without its A-hi (issued in L1(0)); same order as steady state
     stage_half<0>(p, smem, 0, 0, 0, wave, voffA, m0, n0);
     stage_half<1>(p, smem, 0, 0, 0, wave, voffW, m0, n0);
@@ -488,11 +587,8 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
     if (nk > 1) {
         stage_half<0>(p, smem, 0, 1, 1, wave, voffA, m0, n0);
         stage_half<1>(p, smem, 0, 1, 1, wave, voffW, m0, n0);
-        if constexpr (SLOTS == 8) stage_half<1>(p, smem, 1, 1, 1, wave, voffW, m0, n0);
     }
-    if (SLOTS == 8 && nk > 2) {
-        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-    } else if (SLOTS != 8 && nk > 1) {
+    if (nk > 1) {
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // A-hi(0), A-lo(1), W-lo(1) may be in flight
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -543,44 +639,6 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
         }
         if constexpr (SLOTS != 44) __builtin_amdgcn_s_setprio(0);
     };
-    auto l_end = [&](bool steady) {
-        if (steady) {
-            asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        }
-        TT_SLOT_END();
-    };
-
-    auto tile = [&](int t, auto bufc) {
-        constexpr int B = decltype(bufc)::value;
-        const bool steady = t + 2 < nk;
-        // L1: A-hi(t+1) -> (A,hi,B^1); fragments A-lo, W-lo of tile t
-        if (t + 1 < nk) stage_half<0>(p, smem, 1, B ^ 1, t + 1, wave, voffA, m0, n0);
-        read_a(smem + slot_off(0, 0, B));
-        read_w(wf0, smem + slot_off(1, 0, B));
-        l_end(steady);
-        mma(acc[0][0], wf0);                       // C1
-        TT_SLOT_END();
-        // L2: A-lo(t+2) -> (A,lo,B); fragments W-hi
-        if (t + 2 < nk) stage_half<0>(p, smem, 0, B, t + 2, wave, voffA, m0, n0);
-        read_w(wf1, smem + slot_off(1, 1, B));
-        l_end(steady);
-        mma(acc[0][1], wf1);                       // C2
-        TT_SLOT_END();
-        // L3: W-lo(t+2) -> (W,lo,B); fragments A-hi
-        if (t + 2 < nk) stage_half<1>(p, smem, 0, B, t + 2, wave, voffW, m0, n0);
-        read_a(smem + slot_off(0, 1, B));
-        l_end(steady);
-        mma(acc[1][1], wf1);                       // C3
-        TT_SLOT_END();
-        // L4: W-hi(t+2) -> (W,hi,B)
-        if (t + 2 < nk) stage_half<1>(p, smem, 1, B, t + 2, wave, voffW, m0, n0);
-        l_end(steady);
-        mma(acc[1][0], wf0);                       // C4
-        TT_SLOT_END();
-    };
-
     // 4-slot variant: La (A-lo, W-lo, W-hi fragments) | Ca (quadrants 00, 01) | Lb (A-hi) | Cb (11, 10):
     // half as many barriers per MFMA.
     unsigned long long* dbg = reinterpret_cast<unsigned long long*>(p.vt);
@@ -613,6 +671,8 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
         if (more1) {
             stage_half<1>(p, smem, 1, B ^ 1, t + 1, wave, voffW, m0, n0);
             stage_half<0>(p, smem, 1, B ^ 1, t + 1, wave, voffA, m0, n0);
+        } else if (kResLds && !kNoGlds) {
+            stage_res(1);                          // last tile (B = 1): hi slots of buffer 0
         }
         stamp(t);                                  // 1: copies issued
         if (!kNoReads) {
@@ -623,7 +683,7 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
         stamp(t);                                  // 2: reads issued
         if (SLOTS == 46) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         stamp(t);                                  // 3: reads returned
-        wait_n(kNoGlds ? 0 : (t + 1 < nk ? 8 : 0));
+        wait_n(kNoGlds ? 0 : ((t + 1 < nk || kResLds) ? 8 : 0));
         stamp(t);                                  // 4: past barrier (Ca start)
         mma(acc[0][0], wf0);                       // Ca
         mma(acc[0][1], wf1);
@@ -634,13 +694,15 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
         if (more2) {
             stage_half<0>(p, smem, 0, B, t + 2, wave, voffA, m0, n0);
             stage_half<1>(p, smem, 0, B, t + 2, wave, voffW, m0, n0);
+        } else if (kResLds && !kNoGlds) {
+            stage_res(B == 0 ? 0 : 2);             // tile nk-2 (B = 0): lo slots of buffer 0; tile nk-1: of buffer 1
         }
         stamp(t);                                  // 7
         if (!kNoReads) read_a(smem + slot_off(0, 1, B));
         stamp(t);                                  // 8
         if (SLOTS == 46) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         stamp(t);                                  // 9
-        wait_n(kNoGlds ? 0 : (t + 2 < nk ? 6 : 0));
+        wait_n(kNoGlds ? 0 : ((t + 2 < nk || kResLds) ? 6 : 0));
         stamp(t);                                  // 10: Cb start
         mma(acc[1][1], wf1);                       // Cb
         mma(acc[1][0], wf0);
@@ -650,16 +712,12 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
     };
 
     for (int t = 0; t < nk; t += 2) {
-        if constexpr (SLOTS == 8) {
-            tile(t, std::integral_constant<int, 0>{});
-            if (t + 1 < nk) tile(t + 1, std::integral_constant<int, 1>{});
-        } else {
-            tile4(t, std::integral_constant<int, 0>{});
-            if (t + 1 < nk) tile4(t + 1, std::integral_constant<int, 1>{});
-        }
+        tile4(t, std::integral_constant<int, 0>{});
+        if (t + 1 < nk) tile4(t + 1, std::integral_constant<int, 1>{});
     }
     cstamp(2);
     if (!late) TT_SLOT_END();   // match the extra barrier the late group took up front
+    stage_res(3);               // every operand read is done: hi slots of buffer 1
 
     // ---- epilogue ---------------------------------------------------------------------------------
     if constexpr (vblk) {
@@ -675,7 +733,7 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
             for (int qn = 0; qn < 2; ++qn)
                 gemm_epilogue_wide<EPI, 2, 4>(p, acc[qm][qn], m0 + qm * 128 + wm * 64, n0 + qn * 128 + wn * 32, lane);
     } else {
-        epilogue_all<EPI>(p, acc, m0, n0, wm, wn, lane);
+        epilogue_all<EPI>(p, acc, smem, m0, n0, wm, wn, wave, lane);
     }
     if constexpr (SLOTS == 46) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -688,14 +746,15 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
 template <int EPI>
 int launch(const GemmParams& p, hipStream_t st) {
     static const int variant = [] { const char* e = getenv("TT_GEMM_VARIANT"); return e && e[0] ? atoi(e) : 4; }();
-    if ((variant == 3 || variant == 4) && p.M % v3::BM3 == 0 && p.N % v3::BN3 == 0 && p.ldc % 8 == 0 &&
-        (EPI != TT_EPI_RESIDUAL || p.ldr % 8 == 0)) {
+    // (the residual epilogue stages the residual tile as two pseudo K-tiles: needs an even number of K-tiles)
+    if (variant == 4 && p.M % v3::BM3 == 0 && p.N % v3::BN3 == 0 && p.ldc % 8 == 0 &&
+        (EPI != TT_EPI_RESIDUAL || (p.ldr % 8 == 0 && (p.K / BK) % 2 == 0))) {
         const int mt_n = p.M / v3::BM3, nt_n = p.N / v3::BN3;
         const int SN = nt_n < 4 ? nt_n : 4, SM = 8;
         const int supers = ((mt_n + SM - 1) / SM) * ((nt_n + SN - 1) / SN);
         int blocks = supers * SM * SN;
         blocks = (blocks + 7) / 8 * 8;
-        auto kern = variant == 4 ? v3::gemm_kernel_v3<EPI, 4> : v3::gemm_kernel_v3<EPI, 8>;
+        auto kern = v3::gemm_kernel_v3<EPI, 4>;
         if constexpr (EPI == TT_EPI_BIAS) {   // timing-only ablations of the 4-slot loop (wrong results)
             static const int abl = [] { const char* e = getenv("TT_GEMM_ABLATE"); return e && e[0] ? atoi(e) : 0; }();
             if (abl == 1) kern = v3::gemm_kernel_v3<EPI, 41>;
@@ -709,8 +768,6 @@ int launch(const GemmParams& p, hipStream_t st) {
         static thread_local bool attr3 = false;
         if (!attr3) {
             TT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(v3::gemm_kernel_v3<EPI, 4>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, v3::kLds3));
-            TT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(v3::gemm_kernel_v3<EPI, 8>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, v3::kLds3));
             attr3 = true;
         }

@@ -29,7 +29,8 @@ int main(int argc, char** argv) {
     int iters = argc > 2 ? atoi(argv[2]) : 20;
     struct Shape { int n, k, epi; const char* name; } shapes[] = {
         {3072, 1024, 0, "qkv(bias)"}, {1024, 1024, 2, "o-proj(+res)"}, {4096, 1024, 1, "ffn-up(gelu)"},
-        {1024, 4096, 2, "ffn-down(+res)"}, {1152, 384, 0, "small qkv"}, {1536, 384, 1, "small ffn-up"}};
+        {1024, 4096, 2, "ffn-down(+res)"}, {1024, 1024, 0, "o-proj shape, bias only"}, {4096, 1024, 0, "ffn-up shape, bias only"},
+        {1024, 4096, 0, "ffn-down shape, bias only"}, {1152, 384, 0, "small qkv"}, {1536, 384, 1, "small ffn-up"}};
     uint16_t *a, *w, *c, *r;
     float* bias;
     size_t maxA = (size_t)M * 4096, maxW = (size_t)4096 * 4096, maxC = (size_t)M * 4096;
