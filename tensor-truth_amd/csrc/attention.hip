@@ -6,50 +6,115 @@
 // layers (additive -inf key-padding mask == attending only to the sequence's own tokens
 // in the packed varlen layout).
 //
-// One workgroup = 4 waves = 128 query rows of one (sequence, head); keys stream through LDS
-// in tiles of 64.  Both products run "swapped" on v_mfma_f32_32x32x16_bf16 so that the
-// QUERY sits on the lane for the whole kernel:
-//   S^T[key][q] = K . Q^T      A = K fragment (ds_read_b128, XOR-swizzled), B = Q fragment (registers)
-//   O^T[d][q]  += V^T . P^T    A = V^T fragment (2 x ds_read_b64 from a padded [d][key] image),
-//                              B = the S^T accumulator itself, converted to bf16 in place
-// so the softmax row statistics are lane-local (one cross-half exchange per tile), P never
-// goes through LDS, and V is consumed from the token-blocked transposed copy the QKV GEMM
-// epilogue wrote (V8: [token/8][feature][8]: a 64-key x dh tile is 8 contiguous 1-KiB runs).
+// One workgroup = 4 waves (one per SIMD: with 5 the fifth lands on SIMD 0 again and caps the CU at two
+// workgroups) = 128 query rows of one (sequence, head); keys stream through LDS in tiles of 64, staged by
+// LDS-DMA (global_load_lds_dwordx4) into two buffers: the copies of tile t+1 are in flight while tile t is
+// computed and there is ONE barrier per tile.  Both products run "swapped" on v_mfma_f32_32x32x16_bf16 so
+// that the QUERY sits on the lane for the whole kernel:
+//   S^T[key][q] = K . Q^T      A = K fragment (ds_read_b128, XOR-swizzled rows), B = Q fragment (registers)
+//   O^T[d][q]  += V^T . P^T    A = V^T fragment (one ds_read_b128), B = the S^T accumulator itself,
+//                              converted to bf16 in place
+// so the softmax row statistics are lane-local (one cross-half exchange per tile) and P never goes through
+// LDS.  The K rows are fed to the first product in a permuted order (row bits 2 and 3 swapped) so that the
+// eight accumulator registers a lane converts into one P fragment are eight CONSECUTIVE keys: exactly one
+// 16-byte piece of the token-blocked V copy the QKV GEMM epilogue wrote (V8: [token/8][feature][8]), which
+// therefore goes global -> LDS -> MFMA operand without any transposition or padding.
 #include "common.h"
 #include "encoder.h"
 
 namespace {
 
-constexpr int kAttThreads = 256;
-constexpr int kQTile = 128;   // query rows per workgroup (32 per wave)
 constexpr int kKTile = 64;    // keys per LDS tile
-constexpr int kVtStride = kKTile * 2 + 8;  // bytes per V^T row in LDS (padded: conflict-free ds_read_b64)
+constexpr int kWaves = 4;     // 128 query rows per workgroup, one wave per SIMD
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+// LDS reads hidden from the compiler's LDS-DMA tracking (it would put s_waitcnt vmcnt(0) in front of every
+// ds_read while the next tile's copies are in flight); lds_wait4 is the matching lgkmcnt(0).
+template <int OFF>
+__device__ __forceinline__ u32x4 lds_read128_async(uint32_t addr) {
+    u32x4 r;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+    return r;
+}
+// wait until at most N LDS reads of this wave are still in flight (they return in order)
+template <int N>
+__device__ __forceinline__ void lds_wait4n(u32x4& a, u32x4& b, u32x4& c, u32x4& d) {
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
+}
+template <int N>
+__device__ __forceinline__ void lds_wait2n(u32x4& a, u32x4& b) {
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
+}
 
 template <int DH>
-__global__ __launch_bounds__(kAttThreads) void attention_kernel(AttnParams p) {
+__global__ __launch_bounds__(64 * kWaves, 4) void attention_kernel(AttnParams p) {
     constexpr int RB = DH * 2;              // bytes per K row
     constexpr int CH = RB / 16;             // 16-B chunks per K row
     constexpr int RPB = 256 / RB;           // K rows per 256-B bank row
     constexpr int KS = DH / 16;             // k-steps of Q.K
     constexpr int DT = DH / 32;             // 32-row d tiles of O^T
-    __shared__ __attribute__((aligned(16))) char k_lds[kKTile * RB];
-    __shared__ __attribute__((aligned(16))) char vt_lds[DH * kVtStride];
+    constexpr int NPK = kKTile * RB / 1024; // 1-KiB copy pieces of a K tile
+    constexpr int NPV = 8 * DH * 16 / 1024; // ... of a V tile (8 token groups x DH features x 16 B)
+    constexpr int KPW = NPK / kWaves, VPW = NPV / kWaves;   // pieces per wave: 2 + 2 (dh 64), 1 + 1 (dh 32)
+    constexpr int BUF = (NPK + NPV) * 1024;
+    __shared__ __attribute__((aligned(1024))) char lds[2 * BUF];
 
     const int seq = blockIdx.z, head = blockIdx.y, qt = blockIdx.x;
     const int len = p.seq_len[seq];
-    if (qt * kQTile >= len) return;
+    if (qt * 32 * kWaves >= len) return;
     const int t0 = p.seq_start[seq];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ql = lane & 31, hh = lane >> 5;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
 
     // ---- Q fragments (B operand), straight from global ---------------------------------
-    const int q_row = qt * kQTile + wave * 32 + ql;        // row inside the sequence
+    const int q_row = (qt * kWaves + wave) * 32 + ql;      // row inside the sequence
     const int q_row_c = q_row < len ? q_row : len - 1;     // clamp: result discarded
     const uint16_t* qp = p.qk + (size_t)(t0 + q_row_c) * p.ld_qk + p.q_col0 + head * DH + hh * 8;
     bf16x8 qf[KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + s * 16);
+
+    const int n_kt = (len + kKTile - 1) / kKTile;
+    const int n_g8 = (len + 7) >> 3;
+    // ---- staging: wave w copies K pieces w*KPW.. and V pieces w*VPW.. of each tile.  Per-lane row / token-group
+    // indices are loop constants; rows / groups beyond the sequence are clamped to its last one (finite values;
+    // their probabilities are 0) -- only the last tile can need that.
+    const uint16_t* kbase = p.qk + (size_t)t0 * p.ld_qk + p.k_col0 + head * DH;
+    const uint16_t* vbase = p.vt + (size_t)(t0 >> 3) * p.ldvt + (size_t)head * DH * 8;
+    int krow_l[KPW], kcol_l[KPW], vg_l[VPW], vcol_l[VPW];
+#pragma unroll
+    for (int i = 0; i < KPW; ++i) {
+        const int e = (wave * KPW + i) * 64 + lane;
+        const int r = e / CH, pos = e % CH;
+        krow_l[i] = r;
+        kcol_l[i] = (pos ^ ((r / RPB) & (CH - 1))) << 3;
+    }
+#pragma unroll
+    for (int i = 0; i < VPW; ++i) {
+        const int e = (wave * VPW + i) * 64 + lane;
+        vg_l[i] = e / DH;
+        vcol_l[i] = (e % DH) * 8;
+    }
+    auto issue_tile = [&](int kt) {
+        char* buf = lds + (kt & 1) * BUF;
+        const bool clamp = (kt + 1) * kKTile > len;   // wave-uniform
+#pragma unroll
+        for (int i = 0; i < KPW; ++i) {
+            int row = kt * kKTile + krow_l[i];
+            if (clamp) row = row < len ? row : len - 1;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kbase + (size_t)row * p.ld_qk + kcol_l[i]),
+                                             (__attribute__((address_space(3))) void*)(buf + (wave * KPW + i) * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < VPW; ++i) {
+            int g8 = kt * 8 + vg_l[i];
+            if (clamp) g8 = g8 < n_g8 ? g8 : n_g8 - 1;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vbase + (size_t)g8 * p.ldvt + vcol_l[i]),
+                                             (__attribute__((address_space(3))) void*)(buf + (NPK + wave * VPW + i) * 1024), 16, 0, 0);
+        }
+    };
 
     f32x16 acc_o[DT];
 #pragma unroll
@@ -59,106 +124,97 @@ __global__ __launch_bounds__(kAttThreads) void attention_kernel(AttnParams p) {
     float m_run = -__builtin_inff();
     float l_run = 0.f;
     const float sc = p.scale * 1.4426950408889634f;  // fold log2(e): softmax via exp2
+    const bool wave_active = (qt * kWaves + wave) * 32 < len;   // wave-uniform; idle waves only help staging
 
-    const int n_kt = (len + kKTile - 1) / kKTile;
-    // waves whose 32 query rows all lie beyond the sequence only help staging the tiles
-    const bool wave_active = qt * kQTile + wave * 32 < len;   // wave-uniform
+    // per-lane LDS offsets: K row perm(ql) (bits 2 and 3 of the row swapped), chunk (2s + hh) ^ swizzle(row)
+    const int krow = (ql & 0x13) | ((ql & 4) << 1) | ((ql & 8) >> 1);
+    uint32_t koff[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) koff[s] = lds0 + krow * RB + (((2 * s + hh) ^ ((krow / RPB) & (CH - 1))) << 4);
+    const uint32_t voff = lds0 + NPK * 1024 + (hh * DH + ql) * 16;    // + (4j + 2 s2) * DH*16 + 32*dt*16
 
-    // ---- staging: each thread moves KPT 16-B pieces of the K tile and VPT of the V^T tile;
-    // the NEXT tile's pieces are loaded into registers before the current tile is computed and
-    // written to LDS after it (global latency hidden behind the MFMA / softmax work).
-    constexpr int KPT = kKTile * CH / kAttThreads;          // 2 (dh 64) or 1 (dh 32)
-    constexpr int VPT = DH * (kKTile / 8) / kAttThreads;    // 2 (dh 64) or 1 (dh 32)
-    uint4 kreg[KPT], vreg[VPT];
-    auto load_tile = [&](int kt) {
-        const int k0 = kt * kKTile;
-#pragma unroll
-        for (int i = 0; i < KPT; ++i) {
-            const int piece = tid + i * kAttThreads;
-            const int r = piece / CH, c = piece % CH;
-            kreg[i] = make_uint4(0, 0, 0, 0);
-            if (k0 + r < len)
-                kreg[i] = *reinterpret_cast<const uint4*>(p.qk + (size_t)(t0 + k0 + r) * p.ld_qk + p.k_col0 + head * DH + c * 8);
-        }
-#pragma unroll
-        for (int i = 0; i < VPT; ++i) {
-            const int piece = tid + i * kAttThreads;
-            const int d = piece % DH, c = piece / DH;       // consecutive threads -> consecutive features (16 B apart)
-            vreg[i] = make_uint4(0, 0, 0, 0);
-            if (k0 + c * 8 < len)
-                vreg[i] = *reinterpret_cast<const uint4*>(p.vt + (size_t)((t0 + k0) / 8 + c) * p.ldvt + (size_t)(head * DH + d) * 8);
-        }
-    };
-    auto store_tile = [&]() {
-#pragma unroll
-        for (int i = 0; i < KPT; ++i) {
-            const int piece = tid + i * kAttThreads;
-            const int r = piece / CH, c = piece % CH;
-            *reinterpret_cast<uint4*>(k_lds + r * RB + ((c ^ ((r / RPB) & (CH - 1))) << 4)) = kreg[i];
-        }
-#pragma unroll
-        for (int i = 0; i < VPT; ++i) {
-            const int piece = tid + i * kAttThreads;
-            const int d = piece % DH, c = piece / DH;
-            uint2* dst = reinterpret_cast<uint2*>(vt_lds + d * kVtStride + c * 16);
-            dst[0] = make_uint2(vreg[i].x, vreg[i].y);
-            dst[1] = make_uint2(vreg[i].z, vreg[i].w);
-        }
-    };
-
-    load_tile(0);
+    issue_tile(0);
     for (int kt = 0; kt < n_kt; ++kt) {
         const int k0 = kt * kKTile;
-        if (kt > 0) __syncthreads();          // everyone is done reading the previous tile
-        store_tile();
-        if (kt + 1 < n_kt) load_tile(kt + 1);  // in flight while this tile is computed
-        __syncthreads();
-
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile kt have landed
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();                       // ... everyone's; and tile kt-1 is no longer read
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 1 < n_kt) issue_tile(kt + 1);
         if (!wave_active) continue;
+        const uint32_t bufo = (kt & 1) * BUF;
+
         // ---- S^T = K . Q^T for two 32-key tiles -------------------------------------------------
         f32x16 acc_s[2];
+        {
+            u32x4 kf[2][4];
+            uint32_t ka[KS];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+            for (int s = 0; s < KS; ++s) ka[s] = koff[s] + bufo;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc_s[j][r] = 0.f;
-            const int key = 32 * j + ql;
+            for (int s = 0; s < KS; ++s) kf[0][s] = lds_read128_async<0>(ka[s]);
 #pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                const int chunk = 2 * s + hh;
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(k_lds + key * RB + ((chunk ^ ((key / RPB) & (CH - 1))) << 4));
-                acc_s[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], acc_s[j], 0, 0, 0);
+            for (int s = 0; s < KS; ++s) kf[1][s] = lds_read128_async<32 * RB>(ka[s]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (j == 0) {
+                    if constexpr (KS == 4) lds_wait4n<KS>(kf[0][0], kf[0][1], kf[0][2], kf[0][3]);
+                    else lds_wait2n<KS>(kf[0][0], kf[0][1]);
+                } else {
+                    if constexpr (KS == 4) lds_wait4n<0>(kf[1][0], kf[1][1], kf[1][2], kf[1][3]);
+                    else lds_wait2n<0>(kf[1][0], kf[1][1]);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc_s[j][r] = 0.f;
+#pragma unroll
+                for (int s = 0; s < KS; ++s)
+                    acc_s[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[j][s]), qf[s], acc_s[j], 0, 0, 0);
             }
         }
+        // V fragments of the first 32 keys: in flight during the softmax
+        u32x4 vf[2][2];   // [s2][dt]
+        const uint32_t vaddr = voff + bufo;
+        vf[0][0] = lds_read128_async<0>(vaddr);
+        if constexpr (DT == 2) vf[0][1] = lds_read128_async<512>(vaddr);
+        vf[1][0] = lds_read128_async<2 * DH * 16>(vaddr);
+        if constexpr (DT == 2) vf[1][1] = lds_read128_async<2 * DH * 16 + 512>(vaddr);
+
         // ---- mask the tail, running max, exponentials --------------------------------------------
         // The softmax scale (and log2 e) is folded into one FMA per score: p = 2^(s*sc - m), with m
         // tracked in the scaled domain; v_exp_f32 is used raw (arguments are <= 0, a result that
         // underflows is 0 either way), the libm exp2f wraps it in 5 more instructions per value.
-        const bool tail = k0 + kKTile > len;  // wave-uniform
+        // Register r of tile j is key k0 + 32 j + 16 (r>>3) + 8 hh + (r & 7)  (permuted K rows).
+        if (k0 + kKTile > len) {   // wave-uniform
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = k0 + 32 * j + 16 * (r >> 3) + 8 * hh + (r & 7);
+                    if (key >= len) acc_s[j][r] = -__builtin_inff();
+                }
+        }
         float mx = -__builtin_inff();
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                if (tail) {
-                    const int key = k0 + 32 * j + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                    if (key >= len) acc_s[j][r] = -__builtin_inff();
-                }
-                mx = fmaxf(mx, acc_s[j][r]);
-            }
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, acc_s[j][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run, mx * sc);       // finite: every tile holds >= 1 valid key
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // first tile: 2^-inf = 0
         m_run = m_new;
-        float psum = 0.f;
+        f32x2 psum2 = f32x2{0.f, 0.f};
+        const f32x2 sc2 = f32x2{sc, sc}, mn2 = f32x2{m_new, m_new};
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float e = __builtin_amdgcn_exp2f(fmaf(acc_s[j][r], sc, -m_new));
-                acc_s[j][r] = e;
-                psum += e;
+            for (int r = 0; r < 16; r += 2) {
+                const f32x2 t = f32x2{acc_s[j][r], acc_s[j][r + 1]} * sc2 - mn2;
+                const f32x2 e = f32x2{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+                acc_s[j][r] = e.x;
+                acc_s[j][r + 1] = e.y;
+                psum2 += e;
             }
-        l_run = l_run * alpha + psum;
+        l_run = l_run * alpha + (psum2.x + psum2.y);
         if (!__all(alpha == 1.0f)) {          // the running max rarely moves after the first tiles
 #pragma unroll
             for (int d = 0; d < DT; ++d)
@@ -168,7 +224,20 @@ __global__ __launch_bounds__(kAttThreads) void attention_kernel(AttnParams p) {
 
         // ---- O^T += V^T . P^T ----------------------------------------------------------------------
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 2; ++j) {
+            if constexpr (DT == 2) lds_wait4n<0>(vf[0][0], vf[0][1], vf[1][0], vf[1][1]);
+            else lds_wait2n<0>(vf[0][0], vf[1][0]);
+            bf16x8 va[2][2];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int d = 0; d < DT; ++d) va[s2][d] = __builtin_bit_cast(bf16x8, vf[s2][d]);
+            if (j == 0) {   // next 32 keys' fragments, in flight during these MFMAs
+                vf[0][0] = lds_read128_async<4 * DH * 16>(vaddr);
+                if constexpr (DT == 2) vf[0][1] = lds_read128_async<4 * DH * 16 + 512>(vaddr);
+                vf[1][0] = lds_read128_async<6 * DH * 16>(vaddr);
+                if constexpr (DT == 2) vf[1][1] = lds_read128_async<6 * DH * 16 + 512>(vaddr);
+            }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 uint4 pb;
@@ -177,16 +246,11 @@ __global__ __launch_bounds__(kAttThreads) void attention_kernel(AttnParams p) {
                 pb.z = pack_bf16x2(acc_s[j][8 * s2 + 4], acc_s[j][8 * s2 + 5]);
                 pb.w = pack_bf16x2(acc_s[j][8 * s2 + 6], acc_s[j][8 * s2 + 7]);
                 const bf16x8 pf = __builtin_bit_cast(bf16x8, pb);
-                const int kb = 32 * j + 16 * s2 + 4 * hh;   // keys kb..kb+3 and kb+8..kb+11
 #pragma unroll
-                for (int d = 0; d < DT; ++d) {
-                    const char* vrow = vt_lds + (32 * d + ql) * kVtStride + kb * 2;
-                    const uint2 lo = *reinterpret_cast<const uint2*>(vrow);
-                    const uint2 hi = *reinterpret_cast<const uint2*>(vrow + 16);
-                    const uint4 vv = make_uint4(lo.x, lo.y, hi.x, hi.y);
-                    acc_o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf, acc_o[d], 0, 0, 0);
-                }
+                for (int d = 0; d < DT; ++d)
+                    acc_o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[s2][d], pf, acc_o[d], 0, 0, 0);
             }
+        }
     }
 
     // ---- normalise and store: lane = query row, registers = 4 consecutive d ------------------
@@ -289,12 +353,12 @@ int tt_attention_launch(const AttnParams& p, hipStream_t st) {
         tt_set_error("attention: leading dimensions / column offsets must keep 16-byte alignment");
         return TT_E_INVALID;
     }
-    const dim3 grid((p.max_len + kQTile - 1) / kQTile, p.heads, p.n_seq);
+    const dim3 grid((p.max_len + 32 * kWaves - 1) / (32 * kWaves), p.heads, p.n_seq);
     TtProfScope prof(TT_K_ATTENTION, st);
     if (p.head_dim == 64) {
-        hipLaunchKernelGGL(attention_kernel<64>, grid, dim3(kAttThreads), 0, st, p);
+        hipLaunchKernelGGL(attention_kernel<64>, grid, dim3(64 * kWaves), 0, st, p);
     } else if (p.head_dim == 32) {
-        hipLaunchKernelGGL(attention_kernel<32>, grid, dim3(kAttThreads), 0, st, p);
+        hipLaunchKernelGGL(attention_kernel<32>, grid, dim3(64 * kWaves), 0, st, p);
     } else {
         tt_set_error("attention: head_dim %d not in {32, 64}", p.head_dim);
         return TT_E_UNSUPPORTED;

@@ -7,6 +7,7 @@
 
 #include "../../include/tt_hip.h"
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -57,8 +58,12 @@ __device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) {
     return __builtin_bit_cast(uint16_t, b);
 }
 
+// two f32 -> packed bf16 pair, one v_cvt_pk_bf16_f32 (RNE; written as two scalar casts hipcc emits two
+// conversions plus shift / or per pair: 4x the instructions in every epilogue)
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-    return (uint32_t)f32_to_bf16_bits(lo) | ((uint32_t)f32_to_bf16_bits(hi) << 16);
+    const bf16x2_t v = __builtin_convertvector(f32x2{lo, hi}, bf16x2_t);
+    return __builtin_bit_cast(uint32_t, v);
 }
 
 // ---- per-kernel device timing (tt_prof_enable / tt_prof_read) -----------------------------

@@ -35,7 +35,6 @@ constexpr int kGemmLds = 2 * kStageBytes;        // 64 KiB
 // beyond the fitted range).  Relative error of the correction term <= 7.5e-5 everywhere (abs error of the result
 // <= 1e-5; the bf16 output resolves 2e-3 relative), and it costs 7 FMAs + one v_exp_f32 per value: the previous
 // Abramowitz-Stegun erf (rcp + exp + 14 plain ops) made the FFN-up epilogue 10 % of that GEMM; libm erff 25 %.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
     const f32x2 u = f32x2{fabsf(x.x), fabsf(x.y)};
     f32x2 q = u * -9.697845371e-07f + 4.016999810e-05f;
