@@ -276,6 +276,10 @@ int tt_gemm_bf16(const void* a, const void* w, const float* bias, const void* re
     g.A = (const uint16_t*)a; g.lda = k; g.W = (const uint16_t*)w; g.bias = bias;
     g.residual = (const uint16_t*)residual; g.ldr = n; g.C = (uint16_t*)c; g.ldc = n;
     g.M = m; g.N = n; g.K = k;
+    // timing experiment only (wrong results): every output row lands on row 0 / every A row-block reads block 0
+    static const int dbg = [] { const char* e = getenv("TT_GEMM_DEBUG_TRAFFIC"); return e && e[0] ? atoi(e) : 0; }();
+    if (dbg & 1) g.ldc = 0;
+    if (dbg & 2) g.lda = 0;
     return tt_gemm_launch(g, epilogue, (hipStream_t)stream);
 }
 

@@ -316,9 +316,23 @@ constexpr int BM3 = 256, BN3 = 256;
 constexpr int kThreads3 = 512;
 constexpr int kHalf = 128 * BK * 2;   // 16 KiB half-tile
 constexpr int kBiasOff = 8 * kHalf;   // 1 KiB: the tile's 256 bias values, staged by wave 0 in the prologue
-constexpr int kLds3 = 8 * kHalf + 1024;   // 129 KiB
+constexpr int kLds3 = 8 * kHalf + 2048;   // 130 KiB (two bias strips: the persistent kernel stages the next tile's early)
 // slot offsets: [operand A=0/W=1][half][buf]
 __device__ __forceinline__ constexpr int slot_off(int operand, int half, int buf) { return ((operand * 2 + half) * 2 + buf) * kHalf; }
+
+// Row r (0..127) of W half-tile h holds output column n0 + w_row_of(r) + 32 h: the halves interleave in runs of 32
+// so that the 64 columns a wave owns (32 of either half) are CONTIGUOUS in the output, n0 + 64 wn + [0, 64): one
+// full 128-byte line per output row, which the epilogue stores whole.
+__device__ __forceinline__ constexpr int w_row_of(int r) { return (r >> 5) * 64 + (r & 31); }
+
+// One 1-KiB LDS-DMA copy: lane l's 16 bytes from (uniform base + per-lane 32-bit offset) to LDS byte address
+// lds_addr + 16 l.  Written as asm for the SGPR-base addressing form: through the builtin hipcc adds base and
+// offset into a 64-bit VGPR pair per copy (one VALU op, two temporaries and 64-bit copies of every per-lane
+// offset: 10+ VGPRs in a kernel that has none to spare).  M0 is not used by anything else in these kernels.
+__device__ __forceinline__ void glds16(const void* base, uint32_t voff, uint32_t lds_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                 :: "v"(voff), "s"(base), "s"(lds_addr) : "memory", "m0");
+}
 
 // One half-tile = 2 global->LDS copies per wave.  The source is addressed as a wave-uniform base
 // (SGPR pair: operand + first row of the half + K offset) plus a per-lane 32-bit byte offset that is
@@ -329,19 +343,16 @@ __device__ __forceinline__ void stage_half(const GemmParams& p, char* smem, int 
     char* dst = smem + slot_off(OPERAND, half, buf);
     const char* base;
     if constexpr (OPERAND == 0) base = reinterpret_cast<const char*>(p.A + (size_t)(m0 + half * 128) * p.lda + tile * BK);
-    else base = reinterpret_cast<const char*>(p.W + (size_t)(n0 + half * 128) * p.K + tile * BK);
+    else base = reinterpret_cast<const char*>(p.W + (size_t)(n0 + half * 32) * p.K + tile * BK);   // see w_row_of()
     // keep the base in SGPRs (otherwise hipcc folds it into per-lane 64-bit VGPR addresses and
     // pays two 64-bit vector adds per copy)
     const unsigned long long b64 = reinterpret_cast<unsigned long long>(base);
     const unsigned int blo = __builtin_amdgcn_readfirstlane((unsigned int)b64);
     const unsigned int bhi = __builtin_amdgcn_readfirstlane((unsigned int)(b64 >> 32));
     base = reinterpret_cast<const char*>(((unsigned long long)bhi << 32) | blo);
+    const uint32_t lds_dst = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)dst + (16 * wave) * 128;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + voff[j]),
-                                         (__attribute__((address_space(3))) void*)(dst + (16 * wave + 8 * j) * 128),
-                                         16, 0, 0);
-    }
+    for (int j = 0; j < 2; ++j) glds16(base, voff[j], lds_dst + 8 * j * 128);
 }
 
 // Whole-wave epilogue of the 256x256 kernel (acc[qm][qn][nt][mt], wide 16-B layout after permlane16_swap).
@@ -371,42 +382,51 @@ __device__ __forceinline__ void lds_wait(u32x4& a, u32x4& b, u32x4& c, u32x4& d)
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
 }
 
-template <int EPI>
-__device__ __forceinline__ void epilogue_all(const GemmParams& p, f32x4 (&acc)[2][2][2][4], const char* smem, int m0, int n0,
-                                             int wm, int wn, int wave, int lane) {
+struct NoNext { __device__ __forceinline__ void operator()(int) const {} };
+
+// has_next / issue_next (persistent kernel): after the wave has read residual part P out of its private pieces it
+// refills exactly those pieces with the NEXT tile's operand rows (issue_next(P): 4 copies), so the counted waits
+// grow by 4 per finished block.
+__device__ __forceinline__ void lds_write128_async(uint32_t addr, uint4 v) {
+    const u32x4 d = u32x4{v.x, v.y, v.z, v.w};
+    asm volatile("ds_write_b128 %0, %1" :: "v"(addr), "v"(d) : "memory");
+}
+
+// STAGE: transpose every (qm, pr) block through the wave's private LDS pieces (the layout of the residual parts,
+// which the staged output overwrites in place) so that a store instruction writes whole 128-byte lines.
+// Needs the operand slots to be free: the one-tile-per-block kernel.
+template <int EPI, bool STAGE, class Next>
+__device__ __forceinline__ void epilogue_all(const GemmParams& p, f32x4 (&acc)[2][2][2][4], const char* smem, int bias_off, int m0,
+                                             int n0, int wm, int wn, int wave, int lane, bool has_next, Next issue_next) {
     const int g = lane >> 4;
     const bool odd = (g & 1) != 0;
-    const int ncol = wn * 32 + (g & ~1) * 4;           // + qn*128 + nt*16: first of this lane's 8 columns
+    const int ncol = wn * 64 + (g & ~1) * 4;           // + qn*32 + nt*16: first of this lane's 8 columns
     const int mrow = wm * 64 + (lane & 15);            // + qm*128 + (pair*2 + odd)*16
     const int l15 = lane & 15;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)smem;
     const uint32_t rbase = lds0 + (odd ? 4 * kHalf : 0) + 2048 * wave + l15 * 128;
     const uint32_t rx = ((g >> 1) ^ ((l15 >> 1) & 7)) << 4;
     const uint32_t raddr[2][2] = {{rbase + (rx ^ 0u), rbase + (rx ^ 32u)}, {rbase + (rx ^ 64u), rbase + (rx ^ 96u)}};  // [qn][nt]
+    constexpr uint32_t kOffB[4] = {0, 2 * kHalf, 1 * kHalf, 3 * kHalf};   // res_slot(part) * kHalf
+    // row-major read-back: rows (lane>>3) and 8 + (lane>>3) of a 16-row piece, chunk lane & 7
+    const uint32_t srow0 = lane >> 3, srow1 = 8 + (lane >> 3);
+    const uint32_t saddr[2] = {lds0 + 2048 * wave + srow0 * 128 + (((lane & 7) ^ ((srow0 >> 1) & 7)) << 4),
+                               lds0 + 2048 * wave + srow1 * 128 + (((lane & 7) ^ ((srow1 >> 1) & 7)) << 4)};
 
     float4 bias[2][2][2];
-    if constexpr (EPI == TT_EPI_RESIDUAL) {
-        const uint32_t baddr = lds0 + kBiasOff + ncol * 4;
+    {
+        const uint32_t baddr = lds0 + bias_off + ncol * 4;
         u32x4 b[8];
         b[0] = lds_read128_async<0>(baddr);        b[1] = lds_read128_async<16>(baddr);
         b[2] = lds_read128_async<64>(baddr);       b[3] = lds_read128_async<80>(baddr);
-        b[4] = lds_read128_async<512>(baddr);      b[5] = lds_read128_async<528>(baddr);
-        b[6] = lds_read128_async<576>(baddr);      b[7] = lds_read128_async<592>(baddr);
+        b[4] = lds_read128_async<128>(baddr);      b[5] = lds_read128_async<144>(baddr);
+        b[6] = lds_read128_async<192>(baddr);      b[7] = lds_read128_async<208>(baddr);
         lds_wait(b[0], b[1], b[2], b[3]);
         lds_wait(b[4], b[5], b[6], b[7]);
 #pragma unroll
         for (int i = 0; i < 8; ++i)
             bias[i >> 2][(i >> 1) & 1][i & 1] = float4{__uint_as_float(b[i].x), __uint_as_float(b[i].y), __uint_as_float(b[i].z),
                                                        __uint_as_float(b[i].w)};
-    } else {
-        const char* bias_lds = smem + kBiasOff + ncol * 4;
-#pragma unroll
-        for (int qn = 0; qn < 2; ++qn)
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                bias[qn][nt][0] = *reinterpret_cast<const float4*>(bias_lds + (qn * 128 + nt * 16) * 4);
-                bias[qn][nt][1] = *reinterpret_cast<const float4*>(bias_lds + (qn * 128 + nt * 16 + 4) * 4);
-            }
     }
 #pragma unroll
     for (int qm = 0; qm < 2; ++qm)
@@ -414,9 +434,14 @@ __device__ __forceinline__ void epilogue_all(const GemmParams& p, f32x4 (&acc)[2
         for (int pr = 0; pr < 2; ++pr) {
             u32x4 res[2][2];
             if constexpr (EPI == TT_EPI_RESIDUAL) {
-                // all but the 12 youngest vector-memory operations of this wave are done: the residual parts
-                // after this one (4 copies each) plus the 4 stores of every finished (qm, pr) block
-                asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                // all but the N youngest vector-memory operations of this wave are done: the residual parts
+                // after this one (4 copies each) plus the 4 stores (and, in the persistent kernel, the 4
+                // next-tile copies) of every finished (qm, pr) block: N = 12, or 12 + 4 * block
+                const int blk = qm * 2 + pr;
+                if (!has_next || blk == 0) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                else if (blk == 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                else if (blk == 2) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
                 constexpr int kOff[4] = {0, 2 * kHalf, 1 * kHalf, 3 * kHalf};   // res_slot(part) * kHalf
                 if (qm == 0 && pr == 0) {
                     res[0][0] = lds_read128_async<kOff[0]>(raddr[0][0]); res[0][1] = lds_read128_async<kOff[0]>(raddr[0][1]);
@@ -432,6 +457,7 @@ __device__ __forceinline__ void epilogue_all(const GemmParams& p, f32x4 (&acc)[2
                     res[1][0] = lds_read128_async<kOff[3]>(raddr[1][0]); res[1][1] = lds_read128_async<kOff[3]>(raddr[1][1]);
                 }
                 lds_wait(res[0][0], res[0][1], res[1][0], res[1][1]);
+                if (has_next) issue_next(qm * 2 + pr);
             }
 #pragma unroll
             for (int qn = 0; qn < 2; ++qn)
@@ -466,12 +492,31 @@ __device__ __forceinline__ void epilogue_all(const GemmParams& p, f32x4 (&acc)[2
                         v[6] += __uint_as_float(r.w << 16); v[7] += __uint_as_float(r.w & 0xFFFF0000u);
                     }
                     const int m = m0 + qm * 128 + mrow + (pr * 2 + (odd ? 1 : 0)) * 16;
-                    const int n = n0 + qn * 128 + nt * 16 + ncol;
+                    const int n = n0 + qn * 32 + nt * 16 + ncol;
                     uint4 o;
                     o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
                     o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
-                    *reinterpret_cast<uint4*>(p.C + (size_t)m * p.ldc + n) = o;
+                    if constexpr (STAGE) {
+                        lds_write128_async(raddr[qn][nt] + kOffB[qm * 2 + pr], o);
+                    } else {
+                        *reinterpret_cast<uint4*>(p.C + (size_t)m * p.ldc + n) = o;
+                    }
                 }
+            if constexpr (STAGE) {
+                // the block's 32 rows x 128 B now sit row-major in this wave's two private pieces: read them back a
+                // row per 8 lanes and store whole 128-byte lines instead of 32-byte runs
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                u32x4 t[4];
+                t[0] = lds_read128_async<0>(saddr[0] + kOffB[qm * 2 + pr]);
+                t[1] = lds_read128_async<0>(saddr[1] + kOffB[qm * 2 + pr]);
+                t[2] = lds_read128_async<0>(saddr[0] + kOffB[qm * 2 + pr] + 4 * kHalf);
+                t[3] = lds_read128_async<0>(saddr[1] + kOffB[qm * 2 + pr] + 4 * kHalf);
+                lds_wait(t[0], t[1], t[2], t[3]);
+                uint16_t* cp = p.C + (size_t)(m0 + qm * 128 + wm * 64 + pr * 32 + (lane >> 3)) * p.ldc + n0 + wn * 64 + (lane & 7) * 8;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    *reinterpret_cast<uint4*>(cp + (size_t)(8 * i) * p.ldc) = uint4{t[i].x, t[i].y, t[i].z, t[i].w};
+            }
             if constexpr (EPI == TT_EPI_RESIDUAL) __builtin_amdgcn_sched_barrier(0);   // keep the 4 stores in their block
         }
 }
@@ -533,7 +578,7 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
         const int r = 16 * wave + 8 * j + (lane >> 3);
         const int chunk = (lane & 7) ^ ((r >> 1) & 7);
         voffA[j] = (uint32_t)r * (uint32_t)p.lda * 2u + (uint32_t)chunk * 16u;
-        voffW[j] = (uint32_t)r * (uint32_t)p.K * 2u + (uint32_t)chunk * 16u;
+        voffW[j] = (uint32_t)w_row_of(r) * (uint32_t)p.K * 2u + (uint32_t)chunk * 16u;
     }
 
     unsigned long long* dbg0 = reinterpret_cast<unsigned long long*>(p.vt);
@@ -550,7 +595,7 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
         for (int j = 0; j < 2; ++j) {
             const int r16 = 8 * j + (lane >> 3);
             const int c = (lane & 7) ^ ((r16 >> 1) & 7);
-            voffR[j] = (uint32_t)r16 * (uint32_t)p.ldr * 2u + (uint32_t)(((c >> 2) * 128 + (c & 3) * 8) * 2);
+            voffR[j] = (uint32_t)r16 * (uint32_t)p.ldr * 2u + (uint32_t)(c * 16);
         }
     }
     auto stage_res = [&](int part) {
@@ -558,16 +603,15 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
 #pragma unroll
             for (int od = 0; od < 2; ++od) {
                 const char* base = reinterpret_cast<const char*>(
-                    p.residual + (size_t)(m0 + (part >> 1) * 128 + wm * 64 + ((part & 1) * 2 + od) * 16) * p.ldr + n0 + wn * 32);
+                    p.residual + (size_t)(m0 + (part >> 1) * 128 + wm * 64 + ((part & 1) * 2 + od) * 16) * p.ldr + n0 + wn * 64);
                 const unsigned long long b64 = reinterpret_cast<unsigned long long>(base);
                 const unsigned int blo = __builtin_amdgcn_readfirstlane((unsigned int)b64);
                 const unsigned int bhi = __builtin_amdgcn_readfirstlane((unsigned int)(b64 >> 32));
                 base = reinterpret_cast<const char*>(((unsigned long long)bhi << 32) | blo);
                 char* dst = smem + (res_slot(part) + 4 * od) * kHalf + 2048 * wave;
+                const uint32_t lds_dst = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)dst;
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + voffR[j]),
-                                                     (__attribute__((address_space(3))) void*)(dst + 1024 * j), 16, 0, 0);
+                for (int j = 0; j < 2; ++j) glds16(base, voffR[j], lds_dst + 1024 * j);
             }
         }
     };
@@ -575,8 +619,7 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
     cstamp(0);
     // bias strip of this tile (256 floats = one 1-KiB copy), oldest operation of wave 0's queue
     if (wave == 0) {
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.bias + n0 + lane * 4),
-                                         (__attribute__((address_space(3))) void*)(smem + kBiasOff), 16, 0, 0);
+        glds16(p.bias + n0, lane * 16, (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem + kBiasOff);
     }
     // ---- prologue: tile 0 complete, tile 1 without its A-hi (issued in L1(0)); same order as steady state
     stage_half<0>(p, smem, 0, 0, 0, wave, voffA, m0, n0);
@@ -724,35 +767,239 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
         for (int qm = 0; qm < 2; ++qm)
 #pragma unroll
             for (int qn = 0; qn < 2; ++qn)
-                gemm_epilogue_vt<2, 4>(p, acc[qm][qn], m0 + qm * 128 + wm * 64, n0 + qn * 128 + wn * 32, lane);
+                gemm_epilogue_vt<2, 4>(p, acc[qm][qn], m0 + qm * 128 + wm * 64, n0 + wn * 64 + qn * 32, lane);
     } else if constexpr (EPI == TT_EPI_QKV) {
 #pragma unroll
         for (int qm = 0; qm < 2; ++qm)
 #pragma unroll
             for (int qn = 0; qn < 2; ++qn)
-                gemm_epilogue_wide<EPI, 2, 4>(p, acc[qm][qn], m0 + qm * 128 + wm * 64, n0 + qn * 128 + wn * 32, lane);
+                gemm_epilogue_wide<EPI, 2, 4>(p, acc[qm][qn], m0 + qm * 128 + wm * 64, n0 + wn * 64 + qn * 32, lane);
     } else {
-        epilogue_all<EPI>(p, acc, smem, m0, n0, wm, wn, wave, lane);
+        epilogue_all<EPI, true>(p, acc, smem, kBiasOff, m0, n0, wm, wn, wave, lane, false, NoNext{});
     }
     if constexpr (SLOTS == 46) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         cstamp(3);
     }
 }
+
+// ---- persistent, continuous variant (bias / GELU / tanh epilogues) -----------------------------------------
+// One workgroup per CU walks the tile list (virtual block id v = blockIdx.x + i * gridDim.x, same XCD-aware
+// super-tile order as the one-tile-per-block kernel) and the K stream never drains: the copy schedule simply
+// runs on into the NEXT output tile (K-tile index u >= nk means K-tile u - nk of the next tile), so a tile's
+// main loop starts on landed data, and the two wave groups stay one slot apart THROUGH the epilogue -- while
+// waves 0-3 convert and store their accumulators, waves 4-7 still run the last MFMA slot, and vice versa.
+// A K=1024 tile of the one-tile-per-block kernel spends ~20 % of its time outside the main loop (dispatch,
+// first-load latency, pipeline ramp, epilogue).
+// Vector-memory bookkeeping: stores count in vmcnt and return in order with the copies.  The first copies of the
+// next tile (La(0)) are issued BEFORE the 16 epilogue stores, so the first two waits of a non-first tile allow
+// 8 + 16 and 6 + 16 operations; by the third the stores are four slots old.
+// The residual epilogue needs all eight slots for the residual tile and stays on the one-tile-per-block kernel.
+template <int EPI>
+__global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_p(GemmParams p, int nwg) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+
+    const int mt_n = p.M / BM3, nt_n = p.N / BN3;
+    const int SN = nt_n < 4 ? nt_n : 4;
+    const int SM = 8;
+    const int per_super = SM * SN;
+    const int supers_n = (nt_n + SN - 1) / SN;
+    const int nk = p.K / BK;
+    auto decode = [&](int v, int& m0, int& n0) {
+        const int L = (v & 7) * (nwg >> 3) + (v >> 3);
+        const int sidx = L / per_super, widx = L % per_super;
+        const int tm = (sidx / supers_n) * SM + widx / SN;
+        const int tn = (sidx % supers_n) * SN + widx % SN;
+        m0 = __builtin_amdgcn_readfirstlane(tm * BM3);
+        n0 = __builtin_amdgcn_readfirstlane(tn * BN3);
+        return tm < mt_n && tn < nt_n;
+    };
+    auto next_valid = [&](int v, int& m0, int& n0) {
+        for (v += gridDim.x; v < nwg; v += gridDim.x)
+            if (decode(v, m0, n0)) return v;
+        return nwg;
+    };
+
+    const int frow = lane & 15, fchk = lane >> 4, sw = (frow >> 1) & 7;
+    const int off0 = frow * 128 + ((fchk ^ sw) << 4);
+    const int off1 = frow * 128 + (((4 + fchk) ^ sw) << 4);
+    const int a_row0 = wm * 64 * 128;
+    const int w_row0 = wn * 32 * 128;
+    uint32_t voffA[2], voffW[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = 16 * wave + 8 * j + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((r >> 1) & 7);
+        voffA[j] = (uint32_t)r * (uint32_t)p.lda * 2u + (uint32_t)chunk * 16u;
+        voffW[j] = (uint32_t)w_row_of(r) * (uint32_t)p.K * 2u + (uint32_t)chunk * 16u;
+    }
+
+    int m0 = 0, n0 = 0, m1 = 0, n1 = 0;
+    int v = blockIdx.x;
+    if (!decode(v, m0, n0)) v = next_valid(v, m0, n0);
+    if (v >= nwg) return;
+    int vn = next_valid(v, m1, n1);
+    bool has_next = vn < nwg;
+
+    auto stage_bias = [&](int nn0, int par) {
+        if (wave == 0)
+            glds16(p.bias + nn0, lane * 16, (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem + kBiasOff + par * 1024);
+    };
+    // hi / lo halves of K-tile u of the current tile, or of K-tile u - nk of the next one (nk is even: same buffer)
+    auto issue_hi = [&](int u) {
+        if (u < nk) {
+            stage_half<1>(p, smem, 1, u & 1, u, wave, voffW, m0, n0);
+            stage_half<0>(p, smem, 1, u & 1, u, wave, voffA, m0, n0);
+        } else if (has_next) {
+            stage_half<1>(p, smem, 1, u & 1, u - nk, wave, voffW, m1, n1);
+            stage_half<0>(p, smem, 1, u & 1, u - nk, wave, voffA, m1, n1);
+        }
+    };
+    auto issue_lo = [&](int u) {
+        if (u < nk) {
+            stage_half<0>(p, smem, 0, u & 1, u, wave, voffA, m0, n0);
+            stage_half<1>(p, smem, 0, u & 1, u, wave, voffW, m0, n0);
+        } else if (has_next) {
+            stage_half<0>(p, smem, 0, u & 1, u - nk, wave, voffA, m1, n1);
+            stage_half<1>(p, smem, 0, u & 1, u - nk, wave, voffW, m1, n1);
+        }
+    };
+
+    const bool late = wave >= 4;
+    int bpar = 0;
+    bool first = true;
+    // ---- prologue of the first tile: K-tile 0 complete, K-tile 1 without its hi halves (La(0) brings them)
+    stage_bias(n0, bpar);
+    issue_lo(0);
+    issue_hi(0);
+    issue_lo(1);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // A-hi(0), A-lo(1), W-lo(1) may be in flight
+    TT_SLOT_END();
+    if (late) TT_SLOT_END();   // waves 4-7 run one slot behind, for the whole kernel
+
+    while (true) {
+        f32x4 acc[2][2][2][4];  // [qm][qn][n-tile][m-tile]
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) acc[a][b][c][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+        bf16x8 xf[4][2], wf0[2][2], wf1[2][2];
+        auto read_a = [&](const char* base) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                xf[mt][0] = *reinterpret_cast<const bf16x8*>(base + a_row0 + mt * 2048 + off0);
+                xf[mt][1] = *reinterpret_cast<const bf16x8*>(base + a_row0 + mt * 2048 + off1);
+            }
+        };
+        auto read_w = [&](bf16x8(&wf)[2][2], const char* base) {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                wf[nt][0] = *reinterpret_cast<const bf16x8*>(base + w_row0 + nt * 2048 + off0);
+                wf[nt][1] = *reinterpret_cast<const bf16x8*>(base + w_row0 + nt * 2048 + off1);
+            }
+        };
+        auto mma = [&](f32x4(&c)[2][4], const bf16x8(&wf)[2][2]) {
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ss = 0; ss < 2; ++ss)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt)
+                        c[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt][ss], xf[mt][ss], c[nt][mt], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+        };
+        auto wait_n = [&](int n) {
+            if (n == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+            else if (n == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+            else if (n == 22) asm volatile("s_waitcnt vmcnt(22) lgkmcnt(0)" ::: "memory");
+            else if (n == 24) asm volatile("s_waitcnt vmcnt(24) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            TT_SLOT_END();
+        };
+        auto tile4 = [&](int t, auto bufc) {
+            constexpr int B = decltype(bufc)::value;
+            const bool after_epi = t == 0 && !first;   // this wave's 16 epilogue stores are the youngest-but-copies
+            // La: hi halves of K-tile t+1 (already issued, ahead of the stores, when after_epi)
+            if (!after_epi) issue_hi(t + 1);
+            read_a(smem + slot_off(0, 0, B));
+            read_w(wf0, smem + slot_off(1, 0, B));
+            read_w(wf1, smem + slot_off(1, 1, B));
+            if (after_epi) wait_n(24);
+            else wait_n((t + 1 < nk || has_next) ? 8 : 0);
+            mma(acc[0][0], wf0);                       // Ca
+            mma(acc[0][1], wf1);
+            TT_SLOT_END();
+            // Lb: lo halves of K-tile t+2; the other group's epilogue of the previous tile is over: the bias
+            // strip it read can be refilled for the next tile
+            if (t == 0 && has_next) stage_bias(n1, bpar ^ 1);
+            issue_lo(t + 2);
+            read_a(smem + slot_off(0, 1, B));
+            if (after_epi) wait_n(22);
+            else wait_n((t + 2 < nk || has_next) ? 6 : 0);
+            mma(acc[1][1], wf1);                       // Cb
+            mma(acc[1][0], wf0);
+            TT_SLOT_END();
+        };
+        for (int t = 0; t < nk; t += 2) {
+            tile4(t, std::integral_constant<int, 0>{});
+            tile4(t + 1, std::integral_constant<int, 1>{});
+        }
+        if (has_next) issue_hi(nk + 1);   // La(0) of the next tile, ahead of this tile's stores
+
+        // the epilogue's per-lane addresses are recomputed per tile from an opaque copy of the lane id: hoisted out
+        // of the tile loop they would stay live through the main loop
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));
+        epilogue_all<EPI, false>(p, acc, smem, kBiasOff + bpar * 1024, m0, n0, wm, wn, wave, lane_e, false, NoNext{});
+        if (!has_next) break;
+        v = vn; m0 = m1; n0 = n1; bpar ^= 1; first = false;
+        vn = next_valid(v, m1, n1);
+        has_next = vn < nwg;
+    }
+    if (!late) TT_SLOT_END();   // match the extra barrier the late group took up front
+}
 #undef TT_SLOT_END
 }  // namespace v3
 
 template <int EPI>
 int launch(const GemmParams& p, hipStream_t st) {
-    static const int variant = [] { const char* e = getenv("TT_GEMM_VARIANT"); return e && e[0] ? atoi(e) : 4; }();
+    static const int variant = [] { const char* e = getenv("TT_GEMM_VARIANT"); return e && e[0] ? atoi(e) : 5; }();
     // (the residual epilogue stages the residual tile as two pseudo K-tiles: needs an even number of K-tiles)
-    if (variant == 4 && p.M % v3::BM3 == 0 && p.N % v3::BN3 == 0 && p.ldc % 8 == 0 &&
+    if (variant >= 4 && p.M % v3::BM3 == 0 && p.N % v3::BN3 == 0 && p.ldc % 8 == 0 &&
         (EPI != TT_EPI_RESIDUAL || (p.ldr % 8 == 0 && (p.K / BK) % 2 == 0))) {
         const int mt_n = p.M / v3::BM3, nt_n = p.N / v3::BN3;
         const int SN = nt_n < 4 ? nt_n : 4, SM = 8;
         const int supers = ((mt_n + SM - 1) / SM) * ((nt_n + SN - 1) / SN);
         int blocks = supers * SM * SN;
         blocks = (blocks + 7) / 8 * 8;
+        // measured (M = 236800): the persistent kernel wins where the epilogue is VALU-heavy (GELU: 1.74 vs 1.78 ms), the
+        // one-tile kernel with LDS-transposed full-line stores where it is store-bound (bias: 1.39 vs 1.40 ms)
+        if constexpr (EPI == TT_EPI_GELU) {
+            const int cus = tt_cu_count_cached() / 8 * 8;
+            if (variant == 5 && (p.K / BK) % 2 == 0 && p.K / BK >= 2 && blocks > cus && cus >= 8) {
+                static thread_local bool attrp = false;
+                if (!attrp) {
+                    TT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(v3::gemm_kernel_p<EPI>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, v3::kLds3));
+                    attrp = true;
+                }
+                {
+                    TtProfScope prof(TT_K_GEMM, st);
+                    hipLaunchKernelGGL(v3::gemm_kernel_p<EPI>, dim3(cus), dim3(v3::kThreads3), v3::kLds3, st, p, blocks);
+                }
+                TT_CHECK_LAUNCH();
+                return TT_OK;
+            }
+        }
         auto kern = v3::gemm_kernel_v3<EPI, 4>;
         if constexpr (EPI == TT_EPI_BIAS) {   // timing-only ablations of the 4-slot loop (wrong results)
             static const int abl = [] { const char* e = getenv("TT_GEMM_ABLATE"); return e && e[0] ? atoi(e) : 0; }();
@@ -822,7 +1069,7 @@ int tt_gemm_launch(const GemmParams& p, int epilogue, hipStream_t st) {
         case TT_EPI_TANH: return launch<TT_EPI_TANH>(p, st);
         case TT_EPI_QKV: {
             if (!p.vt) { tt_set_error("gemm: qkv epilogue without vt"); return TT_E_INVALID; }
-            static const int variant = [] { const char* e = getenv("TT_GEMM_VARIANT"); return e && e[0] ? atoi(e) : 4; }();
+            static const int variant = [] { const char* e = getenv("TT_GEMM_VARIANT"); return e && e[0] ? atoi(e) : 5; }();
             const int nv = p.N - p.vt_col0;
             if ((variant == 3 || variant == 4) && p.M % v3::BM3 == 0 && p.vt_col0 % v3::BN3 == 0 && nv % v3::BN3 == 0 &&
                 nv > 0 && p.ldc % 8 == 0 && p.ldvt % 8 == 0) {

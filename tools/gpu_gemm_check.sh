@@ -2,5 +2,7 @@
 # GEMM shapes (epilogue-isolating) + encoder parity tests
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
-timeout 120 ./tools/gemm_bench 236800 10 2>&1 | tee gpurun_out/gemm_shapes.log
+{
+for v in ${VARIANTS:-4 5 4 5}; do echo "== TT_GEMM_VARIANT=$v"; TT_GEMM_VARIANT=$v timeout 120 ./tools/gemm_bench 236800 10 | head -8; done
+} 2>&1 | tee gpurun_out/gemm_shapes.log
 timeout 900 python -m pytest tests/test_encoder_gpu.py -m gpu -x -q 2>&1 | tail -15
