@@ -110,6 +110,14 @@ typedef struct tt_layer_weights {
     const float* ffn2_b;
     const float* ln2_g;  /* output.LayerNorm */
     const float* ln2_b;
+    /* Optional fp8 (OCP e4m3) copies of the two projections whose input is a LayerNorm output, with one
+     * fp32 scale per output row: w ~= w8 * wscale[out].  When every layer has them (and hidden, ffn and
+     * n_rows are multiples of 256) the forward runs those GEMMs on the fp8 matrix cores, quantising the
+     * LayerNorm outputs per token; NULL = bf16 (BASELINE.json config 5, "fp8 MFMA reranker"). */
+    const void* qkv_w8;      /* [3H][H] bytes */
+    const float* qkv_wscale; /* [3H] */
+    const void* ffn1_w8;     /* [F][H] bytes */
+    const float* ffn1_wscale;/* [F] */
 } tt_layer_weights;
 
 typedef struct tt_encoder_weights {
@@ -174,8 +182,18 @@ int tt_attention_varlen(const void* qk, int ld_qk, int q_col0, int k_col0, const
                         int ld_out, const int32_t* seq_start, const int32_t* seq_len, int n_seq, int heads,
                         int head_dim, int max_len, void* stream);
 
+/* fp8 building blocks (same kernels the fp8 forward uses).
+ * tt_quantize_rows_fp8: q[r][c] = e4m3(x[r][c] * 448 / absmax_r), scale[r] = absmax_r / 448 (1 for a zero row).
+ * tt_layernorm_bf16_fp8: tt_layernorm_bf16 that also emits that quantisation of its bf16 output.
+ * tt_gemm_fp8: c = epi((a8 . w8^T) * a_scale[m] * w_scale[n] + bias), m, n, k multiples of 256, epilogue 0 / 1. */
+int tt_quantize_rows_fp8(const void* in_bf16, int rows, int cols, void* out_fp8, float* out_scale, void* stream);
+int tt_layernorm_bf16_fp8(const void* in, void* out, const float* gamma, const float* beta, int rows, int hidden,
+                          float eps, void* out_fp8, float* out_scale, void* stream);
+int tt_gemm_fp8(const void* a8, const float* a_scale, const void* w8, const float* w_scale, const float* bias, void* c,
+                int m, int n, int k, int epilogue /*0 bias, 1 gelu*/, void* stream);
+
 /* Per-kernel device timing (HIP events on the launch stream), for bench.py's roofline leg.
- * tt_prof_enable(1) starts recording one event pair per launch of the tracked kernels on the
+ * tt_prof_enable(1) (or a mask of 1 << id, to time only some kernels) starts recording one event pair per launch of the tracked kernels on the
  * calling thread; tt_prof_read() synchronises those events and returns total milliseconds
  * and launch count for kernel id `which` since the last enable, then keeps recording.
  * ids: 1 scan filter pass, 2 scan sample pass, 3 top-k select, 4 gemm, 5 attention, 6 row ops */

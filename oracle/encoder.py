@@ -92,6 +92,25 @@ def gelu_erf(x: torch.Tensor) -> torch.Tensor:
     return 0.5 * x * (1.0 + torch.erf(x * (1.0 / math.sqrt(2.0))))
 
 
+def quantize_rows_e4m3(t: torch.Tensor):
+    """Per-row OCP e4m3 quantisation as the HIP fp8 path does it (BASELINE.json config 5, "fp8 MFMA reranker"):
+    q = e4m3(t * 448 / absmax_row) (round to nearest even), scale = absmax_row / 448 (1 for an all-zero row).
+    Returns (q as fp32 values, scale [..., 1])."""
+    t = t.to(torch.float32)
+    amax = t.abs().amax(dim=-1, keepdim=True)
+    inv = torch.where(amax > 0, 448.0 / amax, torch.zeros_like(amax))
+    q = (t * inv).to(torch.float8_e4m3fn).to(torch.float32)
+    scale = torch.where(amax > 0, amax * (1.0 / 448.0), torch.ones_like(amax))
+    return q, scale
+
+
+def linear_fp8(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """x @ w.T + b with x quantised per token and w per output channel to e4m3, fp32 accumulation."""
+    xq, sx = quantize_rows_e4m3(x)
+    wq, sw = quantize_rows_e4m3(w)
+    return (xq @ wq.T) * sx * sw.transpose(-1, -2) + b
+
+
 def encoder_forward(
     ids: torch.Tensor,
     mask: torch.Tensor,
@@ -100,13 +119,17 @@ def encoder_forward(
     emulate_bf16: bool = False,
     type_ids: Optional[torch.Tensor] = None,
     layers: Optional[int] = None,
+    emulate_fp8: bool = False,
 ) -> torch.Tensor:
     """ids, mask: [B, L] int.  Returns last hidden state [B, L, H] fp32.
 
     Weight names follow the HF checkpoints (no ``roberta.``/``bert.`` prefix).
+    ``emulate_fp8``: the projections fed by a LayerNorm output (Q/K/V, FFN up) run on e4m3 operands
+    (``linear_fp8``), everything else as with ``emulate_bf16`` -- the HIP fp8 mode.
     """
     r = lambda t: _rnd(t, emulate_bf16)  # noqa: E731
     f = lambda name: W[name].to(torch.float32)  # noqa: E731
+    lin = (lambda x, w, b: linear_fp8(x, w, b)) if emulate_fp8 else (lambda x, w, b: x @ w.T + b)  # noqa: E731
     ids = ids.to(torch.int64)
     B, L = ids.shape
     H, nh, dh = cfg.hidden, cfg.heads, cfg.head_dim
@@ -126,9 +149,9 @@ def encoder_forward(
     n_layers = cfg.layers if layers is None else layers
     for i in range(n_layers):
         p = f"encoder.layer.{i}."
-        q = r(x @ f(p + "attention.self.query.weight").T + f(p + "attention.self.query.bias"))
-        k = r(x @ f(p + "attention.self.key.weight").T + f(p + "attention.self.key.bias"))
-        v = r(x @ f(p + "attention.self.value.weight").T + f(p + "attention.self.value.bias"))
+        q = r(lin(x, f(p + "attention.self.query.weight"), f(p + "attention.self.query.bias")))
+        k = r(lin(x, f(p + "attention.self.key.weight"), f(p + "attention.self.key.bias")))
+        v = r(lin(x, f(p + "attention.self.value.weight"), f(p + "attention.self.value.bias")))
         q = q.view(B, L, nh, dh).transpose(1, 2)
         k = k.view(B, L, nh, dh).transpose(1, 2)
         v = v.view(B, L, nh, dh).transpose(1, 2)
@@ -143,7 +166,7 @@ def encoder_forward(
         a = ctx @ f(p + "attention.output.dense.weight").T + f(p + "attention.output.dense.bias")
         x = r(layer_norm(r(a + x), f(p + "attention.output.LayerNorm.weight"),
                          f(p + "attention.output.LayerNorm.bias"), cfg.ln_eps))
-        h = r(gelu_erf(x @ f(p + "intermediate.dense.weight").T + f(p + "intermediate.dense.bias")))
+        h = r(gelu_erf(lin(x, f(p + "intermediate.dense.weight"), f(p + "intermediate.dense.bias"))))
         o = h @ f(p + "output.dense.weight").T + f(p + "output.dense.bias")
         x = r(layer_norm(r(o + x), f(p + "output.LayerNorm.weight"),
                          f(p + "output.LayerNorm.bias"), cfg.ln_eps))
@@ -156,21 +179,21 @@ def cls_pool_normalize(hidden: torch.Tensor) -> torch.Tensor:
     return c / c.norm(dim=-1, keepdim=True).clamp_min(1e-12)
 
 
-def embed(ids, mask, W, cfg, emulate_bf16=False, type_ids=None) -> torch.Tensor:
+def embed(ids, mask, W, cfg, emulate_bf16=False, type_ids=None, emulate_fp8=False) -> torch.Tensor:
     """Token ids -> L2-normalised CLS embeddings [B, H] fp32 (reference a2/a4)."""
-    return cls_pool_normalize(encoder_forward(ids, mask, W, cfg, emulate_bf16, type_ids))
+    return cls_pool_normalize(encoder_forward(ids, mask, W, cfg, emulate_bf16, type_ids, emulate_fp8=emulate_fp8))
 
 
-def rerank_logits(ids, mask, W, cfg, emulate_bf16=False) -> torch.Tensor:
+def rerank_logits(ids, mask, W, cfg, emulate_bf16=False, emulate_fp8=False) -> torch.Tensor:
     """XLMRobertaClassificationHead: out_proj(tanh(dense(h[:,0]))) -> [B] logits."""
-    h = encoder_forward(ids, mask, W, cfg, emulate_bf16)[:, 0, :]
+    h = encoder_forward(ids, mask, W, cfg, emulate_bf16, emulate_fp8=emulate_fp8)[:, 0, :]
     t = torch.tanh(h @ W["classifier.dense.weight"].float().T + W["classifier.dense.bias"].float())
     return (t @ W["classifier.out_proj.weight"].float().T + W["classifier.out_proj.bias"].float())[:, 0]
 
 
-def rerank_scores(ids, mask, W, cfg, emulate_bf16=False) -> torch.Tensor:
+def rerank_scores(ids, mask, W, cfg, emulate_bf16=False, emulate_fp8=False) -> torch.Tensor:
     """CrossEncoder.predict default activation for num_labels==1: sigmoid."""
-    return torch.sigmoid(rerank_logits(ids, mask, W, cfg, emulate_bf16))
+    return torch.sigmoid(rerank_logits(ids, mask, W, cfg, emulate_bf16, emulate_fp8))
 
 
 def synth_weights(cfg: EncoderConfig, seed: int = 0, dtype=torch.float32) -> Dict[str, torch.Tensor]:

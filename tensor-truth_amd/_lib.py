@@ -54,6 +54,11 @@ SIGNATURES = {
     "tt_layernorm_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     "tt_attention_varlen": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p,
                                     c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "tt_quantize_rows_fp8": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "tt_layernorm_bf16_fp8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p,
+                                      c_void_p]),
+    "tt_gemm_fp8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                            c_void_p]),
     "tt_prof_enable": (c_int, [c_int]),
     "tt_prof_read": (c_int, [c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int)]),
 }

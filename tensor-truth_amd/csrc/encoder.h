@@ -14,6 +14,11 @@ struct GemmParams {
     uint16_t* vt;             // TT_EPI_QKV: columns >= vt_col0 go to the V8 buffer:
                               //   vt[(m / 8) * ldvt + (n - vt_col0) * 8 + m % 8],  ldvt = 8 * (N - vt_col0)
     int M, N, K, lda, ldc, ldr, ldvt, vt_col0;
+    // fp8 (OCP e4m3) operands: A, W point to bytes, lda / K count elements = bytes; the result is
+    // acc * a_scale[m] * w_scale[n] (+ bias ...).  256x256 kernels only (bias, GELU and V^T epilogues).
+    const float* a_scale;     // [M] per-row dequantisation scale of A
+    const float* w_scale;     // [N] per-output-channel scale of W
+    int fp8;
 };
 int tt_gemm_launch(const GemmParams& p, int epilogue, hipStream_t st);
 
@@ -44,12 +49,15 @@ struct EmbedParams {
     uint16_t* out;            // [T][H] bf16
     int T, H, vocab, max_pos, type_vocab;
     float eps;
+    uint8_t* q8;              // optional: [T][H] e4m3 copy of out, per-row scale q8_scale[T] (fp8 GEMM operand)
+    float* q8_scale;
 };
 int tt_embed_ln_launch(const EmbedParams& p, hipStream_t st);
 
 // out = LayerNorm(in) * gamma + beta, rows of H bf16
 int tt_layernorm_launch(const uint16_t* in, uint16_t* out, const float* gamma, const float* beta, int rows, int H,
-                        float eps, hipStream_t st);
+                        float eps, hipStream_t st, uint8_t* q8 = nullptr, float* q8_scale = nullptr);
+int tt_quantize_rows_launch(const uint16_t* in, int ld, int rows, int cols, uint8_t* q8, float* scale, hipStream_t st);
 
 // out_f32[b] = x[row[b]] / max(||x[row[b]]||, 1e-12); optional bf16 copy
 int tt_cls_pool_l2norm_launch(const uint16_t* hidden, int ld, const int32_t* rows, int n, int H, float* out_f32,

@@ -19,7 +19,20 @@ struct EncWs {
     // CLS-only tail of the last layer (rows = sequences, padded to 256)
     size_t off_cctx, off_cx, off_cy, off_cx1, off_cffn, off_rows;
     int n_cls_pad;
+    // fp8 forward: e4m3 copy of the current LayerNorm output + its per-row scales
+    size_t off_q8, off_q8s;
+    bool fp8;
 };
+
+// every layer carries fp8 projections and the shapes fit the fp8 GEMM tiles
+bool fp8_ready(const tt_encoder_weights* w, int n_rows) {
+    if (w->layers <= 0 || w->hidden % 256 || w->ffn % 256 || n_rows % 256) return false;
+    for (int l = 0; l < w->layers; ++l) {
+        const tt_layer_weights& lw = w->layer[l];
+        if (!lw.qkv_w8 || !lw.qkv_wscale || !lw.ffn1_w8 || !lw.ffn1_wscale) return false;
+    }
+    return true;
+}
 
 EncWs enc_plan(const tt_encoder_weights* w, int n_rows, int n_seq = 0) {
     EncWs e{};
@@ -41,6 +54,11 @@ EncWs enc_plan(const tt_encoder_weights* w, int n_rows, int n_seq = 0) {
         e.off_cy = take(B * H * 2);
         e.off_cx1 = take(B * H * 2);
         e.off_cffn = take(B * F * 2);
+    }
+    e.fp8 = fp8_ready(w, n_rows);
+    if (e.fp8) {
+        e.off_q8 = take(T * H);
+        e.off_q8s = take(T * 4);
     }
     e.total = off;
     return e;
@@ -104,6 +122,9 @@ static int forward_impl(const tt_encoder_weights* w, const int32_t* ids, const i
     ep.eps = w->ln_eps;
     uint16_t* x = (w->layers == 0 && hidden_out) ? (uint16_t*)hidden_out : xa;
     ep.out = x;
+    uint8_t* q8 = e.fp8 ? (uint8_t*)(ws + e.off_q8) : nullptr;
+    float* q8s = e.fp8 ? (float*)(ws + e.off_q8s) : nullptr;
+    ep.q8 = q8; ep.q8_scale = q8s;
     {
         TtProfScope prof(TT_K_ROWOPS, st);
         if (int rc = tt_embed_ln_launch(ep, st)) return rc;
@@ -120,6 +141,9 @@ static int forward_impl(const tt_encoder_weights* w, const int32_t* ids, const i
         g.A = x; g.lda = H; g.W = (const uint16_t*)lw.qkv_w; g.bias = lw.qkv_b;
         g.C = qk; g.ldc = 2 * H; g.vt = vt; g.ldvt = 8 * H; g.vt_col0 = 2 * H;
         g.M = T; g.N = 3 * H; g.K = H;
+        if (e.fp8) {   // x's e4m3 copy and row scales come from the LayerNorm that produced x
+            g.A = (const uint16_t*)q8; g.W = (const uint16_t*)lw.qkv_w8; g.a_scale = q8s; g.w_scale = lw.qkv_wscale; g.fp8 = 1;
+        }
         if (int rc = tt_gemm_launch(g, TT_EPI_QKV, st)) return rc;
         if (cls_tail && l == w->layers - 1) {
             // ---- last layer, CLS rows only: attention of the one query row per sequence, then the
@@ -175,12 +199,15 @@ static int forward_impl(const tt_encoder_weights* w, const int32_t* ids, const i
         uint16_t* x1 = (x == xa) ? xb : xa;
         {
             TtProfScope prof(TT_K_ROWOPS, st);
-            if (int rc = tt_layernorm_launch(y, x1, lw.ln1_g, lw.ln1_b, T, H, w->ln_eps, st)) return rc;
+            if (int rc = tt_layernorm_launch(y, x1, lw.ln1_g, lw.ln1_b, T, H, w->ln_eps, st, q8, q8s)) return rc;
         }
         // FFN
         GemmParams g1{};
         g1.A = x1; g1.lda = H; g1.W = (const uint16_t*)lw.ffn1_w; g1.bias = lw.ffn1_b;
         g1.C = ffn; g1.ldc = F; g1.M = T; g1.N = F; g1.K = H;
+        if (e.fp8) {
+            g1.A = (const uint16_t*)q8; g1.W = (const uint16_t*)lw.ffn1_w8; g1.a_scale = q8s; g1.w_scale = lw.ffn1_wscale; g1.fp8 = 1;
+        }
         if (int rc = tt_gemm_launch(g1, TT_EPI_GELU, st)) return rc;
         GemmParams g2{};
         g2.A = ffn; g2.lda = F; g2.W = (const uint16_t*)lw.ffn2_w; g2.bias = lw.ffn2_b;
@@ -191,7 +218,7 @@ static int forward_impl(const tt_encoder_weights* w, const int32_t* ids, const i
         uint16_t* dst = (l == w->layers - 1) ? (uint16_t*)hidden_out : x;
         {
             TtProfScope prof(TT_K_ROWOPS, st);
-            if (int rc = tt_layernorm_launch(y, dst, lw.ln2_g, lw.ln2_b, T, H, w->ln_eps, st)) return rc;
+            if (int rc = tt_layernorm_launch(y, dst, lw.ln2_g, lw.ln2_b, T, H, w->ln_eps, st, q8, q8s)) return rc;
         }
         x = dst;
     }
@@ -280,6 +307,28 @@ int tt_gemm_bf16(const void* a, const void* w, const float* bias, const void* re
     static const int dbg = [] { const char* e = getenv("TT_GEMM_DEBUG_TRAFFIC"); return e && e[0] ? atoi(e) : 0; }();
     if (dbg & 1) g.ldc = 0;
     if (dbg & 2) g.lda = 0;
+    return tt_gemm_launch(g, epilogue, (hipStream_t)stream);
+}
+
+int tt_quantize_rows_fp8(const void* in_bf16, int rows, int cols, void* out_fp8, float* out_scale, void* stream) {
+    TT_CHECK_ARG(in_bf16 && out_fp8 && out_scale, "null pointer");
+    return tt_quantize_rows_launch((const uint16_t*)in_bf16, cols, rows, cols, (uint8_t*)out_fp8, out_scale, (hipStream_t)stream);
+}
+
+int tt_layernorm_bf16_fp8(const void* in, void* out, const float* gamma, const float* beta, int rows, int hidden,
+                          float eps, void* out_fp8, float* out_scale, void* stream) {
+    TT_CHECK_ARG(in && out && gamma && beta && out_fp8 && out_scale, "null pointer");
+    return tt_layernorm_launch((const uint16_t*)in, (uint16_t*)out, gamma, beta, rows, hidden, eps, (hipStream_t)stream,
+                               (uint8_t*)out_fp8, out_scale);
+}
+
+int tt_gemm_fp8(const void* a8, const float* a_scale, const void* w8, const float* w_scale, const float* bias, void* c,
+                int m, int n, int k, int epilogue, void* stream) {
+    TT_CHECK_ARG(epilogue == TT_EPI_BIAS || epilogue == TT_EPI_GELU, "epilogue %d", epilogue);
+    TT_CHECK_ARG(a8 && a_scale && w8 && w_scale && bias && c, "null pointer");
+    GemmParams g{};
+    g.A = (const uint16_t*)a8; g.lda = k; g.W = (const uint16_t*)w8; g.bias = bias; g.C = (uint16_t*)c; g.ldc = n;
+    g.M = m; g.N = n; g.K = k; g.a_scale = a_scale; g.w_scale = w_scale; g.fp8 = 1;
     return tt_gemm_launch(g, epilogue, (hipStream_t)stream);
 }
 

@@ -171,7 +171,7 @@ __device__ __forceinline__ void gemm_epilogue_wide(const GemmParams& p, f32x4 (&
 // ---- V^T epilogue (un-swapped accumulators: lane = feature column l&15, registers = 4 consecutive tokens)
 // permlane16_swap between the registers of n-tile 2i and 2i+1 gives every lane 8 consecutive tokens of one
 // feature: one 16-B store into the V8 buffer ([token/8][feature][8 tokens]) instead of eight 2-byte stores.
-template <int NT, int MT>
+template <int NT, int MT, bool FP8 = false>
 __device__ __forceinline__ void gemm_epilogue_vt(const GemmParams& p, f32x4 (&acc)[NT][MT], int mw, int nw, int lane) {
     static_assert(NT % 2 == 0, "n-tiles are processed in pairs");
     const int g = lane >> 4;
@@ -180,18 +180,28 @@ __device__ __forceinline__ void gemm_epilogue_vt(const GemmParams& p, f32x4 (&ac
     for (int i = 0; i < NT; i += 2) {
         const int n = nw + (odd ? i + 1 : i) * 16 + (lane & 15);
         const float b = p.bias[n];
+        float sw = 1.f;
+        if constexpr (FP8) sw = p.w_scale[n];
         uint16_t* col = p.vt + (size_t)(n - p.vt_col0) * 8;   // V8 layout: + (m / 8) * ldvt
 #pragma unroll
         for (int j = 0; j < MT; ++j) {
             float v[8];
+            const int m = mw + j * 16 + (g & ~1) * 4;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[i][j][k]),
                                                                 __float_as_uint(acc[i + 1][j][k]), false, false);
-                v[k] = __uint_as_float(r[0]) + b;
-                v[4 + k] = __uint_as_float(r[1]) + b;
+                v[k] = __uint_as_float(r[0]);
+                v[4 + k] = __uint_as_float(r[1]);
             }
-            const int m = mw + j * 16 + (g & ~1) * 4;
+            if constexpr (FP8) {
+                const float4 a0 = *reinterpret_cast<const float4*>(p.a_scale + m);
+                const float4 a1 = *reinterpret_cast<const float4*>(p.a_scale + m + 4);
+                v[0] *= a0.x * sw; v[1] *= a0.y * sw; v[2] *= a0.z * sw; v[3] *= a0.w * sw;
+                v[4] *= a1.x * sw; v[5] *= a1.y * sw; v[6] *= a1.z * sw; v[7] *= a1.w * sw;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] += b;
             uint4 o;
             o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
             o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
@@ -316,7 +326,8 @@ constexpr int BM3 = 256, BN3 = 256;
 constexpr int kThreads3 = 512;
 constexpr int kHalf = 128 * BK * 2;   // 16 KiB half-tile
 constexpr int kBiasOff = 8 * kHalf;   // 1 KiB: the tile's 256 bias values, staged by wave 0 in the prologue
-constexpr int kLds3 = 8 * kHalf + 2048;   // 130 KiB (two bias strips: the persistent kernel stages the next tile's early)
+constexpr int kScaleOff = kBiasOff + 2048;   // fp8: {row scales, column scales} x 2 buffers, 1 KiB each
+constexpr int kLds3 = 8 * kHalf + 2048 + 4096;   // 134 KiB
 // slot offsets: [operand A=0/W=1][half][buf]
 __device__ __forceinline__ constexpr int slot_off(int operand, int half, int buf) { return ((operand * 2 + half) * 2 + buf) * kHalf; }
 
@@ -337,13 +348,14 @@ __device__ __forceinline__ void glds16(const void* base, uint32_t voff, uint32_t
 // One half-tile = 2 global->LDS copies per wave.  The source is addressed as a wave-uniform base
 // (SGPR pair: operand + first row of the half + K offset) plus a per-lane 32-bit byte offset that is
 // constant for the whole kernel (voff[j]), so a copy costs no vector address arithmetic.
-template <int OPERAND>
+template <int OPERAND, int ES = 2>
 __device__ __forceinline__ void stage_half(const GemmParams& p, char* smem, int half, int buf, int tile, int wave,
                                            const uint32_t (&voff)[2], int m0, int n0) {
     char* dst = smem + slot_off(OPERAND, half, buf);
+    // ES = bytes per element (2 bf16, 1 fp8); a K-tile is 128 bytes of every row either way
     const char* base;
-    if constexpr (OPERAND == 0) base = reinterpret_cast<const char*>(p.A + (size_t)(m0 + half * 128) * p.lda + tile * BK);
-    else base = reinterpret_cast<const char*>(p.W + (size_t)(n0 + half * 32) * p.K + tile * BK);   // see w_row_of()
+    if constexpr (OPERAND == 0) base = reinterpret_cast<const char*>(p.A) + ((size_t)(m0 + half * 128) * p.lda) * ES + tile * 128;
+    else base = reinterpret_cast<const char*>(p.W) + ((size_t)(n0 + half * 32) * p.K) * ES + tile * 128;   // see w_row_of()
     // keep the base in SGPRs (otherwise hipcc folds it into per-lane 64-bit VGPR addresses and
     // pays two 64-bit vector adds per copy)
     const unsigned long long b64 = reinterpret_cast<unsigned long long>(base);
@@ -395,9 +407,18 @@ __device__ __forceinline__ void lds_write128_async(uint32_t addr, uint4 v) {
 // STAGE: transpose every (qm, pr) block through the wave's private LDS pieces (the layout of the residual parts,
 // which the staged output overwrites in place) so that a store instruction writes whole 128-byte lines.
 // Needs the operand slots to be free: the one-tile-per-block kernel.
-template <int EPI, bool STAGE, class Next>
-__device__ __forceinline__ void epilogue_all(const GemmParams& p, f32x4 (&acc)[2][2][2][4], const char* smem, int bias_off, int m0,
-                                             int n0, int wm, int wn, int wave, int lane, bool has_next, Next issue_next) {
+__device__ __forceinline__ float lds_read32_sync(uint32_t addr) {
+    float r;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(r) : "v"(addr));
+    return r;
+}
+
+// FP8: acc holds sums of e4m3 products; the tile's row scales (a_scale[m0..]) and column scales (w_scale[n0..]) sit in
+// two more 1-KiB LDS strips behind the bias strip pair: sa at scale_off, sw at scale_off + 1024.
+template <int EPI, bool STAGE, bool FP8, class Next>
+__device__ __forceinline__ void epilogue_all(const GemmParams& p, f32x4 (&acc)[2][2][2][4], const char* smem, int bias_off,
+                                             int scale_off, int m0, int n0, int wm, int wn, int wave, int lane, bool has_next,
+                                             Next issue_next) {
     const int g = lane >> 4;
     const bool odd = (g & 1) != 0;
     const int ncol = wn * 64 + (g & ~1) * 4;           // + qn*32 + nt*16: first of this lane's 8 columns
@@ -427,6 +448,27 @@ __device__ __forceinline__ void epilogue_all(const GemmParams& p, f32x4 (&acc)[2
         for (int i = 0; i < 8; ++i)
             bias[i >> 2][(i >> 1) & 1][i & 1] = float4{__uint_as_float(b[i].x), __uint_as_float(b[i].y), __uint_as_float(b[i].z),
                                                        __uint_as_float(b[i].w)};
+    }
+    float4 wsc[2][2][2];
+    float asc[2][2];   // [qm][pr]: this lane's output row of the block
+    if constexpr (FP8) {
+        const uint32_t saddr_w = lds0 + scale_off + 1024 + ncol * 4;
+        u32x4 b[8];
+        b[0] = lds_read128_async<0>(saddr_w);        b[1] = lds_read128_async<16>(saddr_w);
+        b[2] = lds_read128_async<64>(saddr_w);       b[3] = lds_read128_async<80>(saddr_w);
+        b[4] = lds_read128_async<128>(saddr_w);      b[5] = lds_read128_async<144>(saddr_w);
+        b[6] = lds_read128_async<192>(saddr_w);      b[7] = lds_read128_async<208>(saddr_w);
+        lds_wait(b[0], b[1], b[2], b[3]);
+        lds_wait(b[4], b[5], b[6], b[7]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            wsc[i >> 2][(i >> 1) & 1][i & 1] = float4{__uint_as_float(b[i].x), __uint_as_float(b[i].y), __uint_as_float(b[i].z),
+                                                      __uint_as_float(b[i].w)};
+#pragma unroll
+        for (int qm = 0; qm < 2; ++qm)
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr)
+                asc[qm][pr] = lds_read32_sync(lds0 + scale_off + (qm * 128 + mrow + (pr * 2 + (odd ? 1 : 0)) * 16) * 4);
     }
 #pragma unroll
     for (int qm = 0; qm < 2; ++qm)
@@ -473,8 +515,17 @@ __device__ __forceinline__ void epilogue_all(const GemmParams& p, f32x4 (&acc)[2
                         v[4 + k] = __uint_as_float(r[1]);
                     }
                     const float4 b0 = bias[qn][nt][0], b1 = bias[qn][nt][1];
-                    v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
-                    v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+                    if constexpr (FP8) {
+                        const float sa = asc[qm][pr];
+                        const float4 s0 = wsc[qn][nt][0], s1 = wsc[qn][nt][1];
+                        v[0] = fmaf(v[0] * sa, s0.x, b0.x); v[1] = fmaf(v[1] * sa, s0.y, b0.y);
+                        v[2] = fmaf(v[2] * sa, s0.z, b0.z); v[3] = fmaf(v[3] * sa, s0.w, b0.w);
+                        v[4] = fmaf(v[4] * sa, s1.x, b1.x); v[5] = fmaf(v[5] * sa, s1.y, b1.y);
+                        v[6] = fmaf(v[6] * sa, s1.z, b1.z); v[7] = fmaf(v[7] * sa, s1.w, b1.w);
+                    } else {
+                        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+                        v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+                    }
                     if constexpr (EPI == TT_EPI_GELU) {
 #pragma unroll
                         for (int k = 0; k < 8; k += 2) {
@@ -528,8 +579,21 @@ __device__ __forceinline__ void epilogue_all(const GemmParams& p, f32x4 (&acc)[2
         __builtin_amdgcn_sched_barrier(0);                    \
     } while (0)
 
-template <int EPI, int SLOTS>
+typedef int v8i __attribute__((ext_vector_type(8)));
+struct Frag2 { bf16x8 lo, hi; };
+// one K = 128 step of e4m3 products (v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales: twice the cycles of
+// the bf16 16x16x32 form at four times the K).  Lane (row, g) supplies bytes [16 g, 16 g + 16) and
+// [64 + 16 g, 64 + 16 g + 16) of its row's 128-byte K-tile for BOTH operands -- the two fragments the bf16 path
+// reads -- which is a permutation of k the instruction applies to both operands alike.
+__device__ __forceinline__ f32x4 mfma_fp8(const bf16x8& a0, const bf16x8& a1, const bf16x8& b0, const bf16x8& b1, f32x4 c) {
+    const v8i a = __builtin_bit_cast(v8i, Frag2{a0, a1});
+    const v8i b = __builtin_bit_cast(v8i, Frag2{b0, b1});
+    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+}
+
+template <int EPI, int SLOTS, bool FP8 = false>
 __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
+    constexpr int ES = FP8 ? 1 : 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -551,7 +615,7 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
     const int tn = (sidx % supers_n) * SN + widx % SN;
     if (tm >= mt_n || tn >= nt_n) return;
     const int m0 = tm * BM3, n0 = tn * BN3;
-    const int nk = p.K / BK;
+    const int nk = p.K * ES / 128;
 
     f32x4 acc[2][2][2][4];  // [qm][qn][n-tile][m-tile]
 #pragma unroll
@@ -577,8 +641,8 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
     for (int j = 0; j < 2; ++j) {
         const int r = 16 * wave + 8 * j + (lane >> 3);
         const int chunk = (lane & 7) ^ ((r >> 1) & 7);
-        voffA[j] = (uint32_t)r * (uint32_t)p.lda * 2u + (uint32_t)chunk * 16u;
-        voffW[j] = (uint32_t)w_row_of(r) * (uint32_t)p.K * 2u + (uint32_t)chunk * 16u;
+        voffA[j] = (uint32_t)r * (uint32_t)p.lda * (uint32_t)ES + (uint32_t)chunk * 16u;
+        voffW[j] = (uint32_t)w_row_of(r) * (uint32_t)p.K * (uint32_t)ES + (uint32_t)chunk * 16u;
     }
 
     unsigned long long* dbg0 = reinterpret_cast<unsigned long long*>(p.vt);
@@ -621,14 +685,18 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
     if (wave == 0) {
         glds16(p.bias + n0, lane * 16, (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem + kBiasOff);
     }
+    if constexpr (FP8 && EPI != TT_EPI_VT) {   // (the V^T epilogue reads its scales from global memory)
+        if (wave == 1) glds16(p.a_scale + m0, lane * 16, (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem + kScaleOff);
+        if (wave == 2) glds16(p.w_scale + n0, lane * 16, (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem + kScaleOff + 1024);
+    }
     // ---- prologue: tile 0 complete, tile 1 without its A-hi (issued in L1(0)); same order as steady state
-    stage_half<0>(p, smem, 0, 0, 0, wave, voffA, m0, n0);
-    stage_half<1>(p, smem, 0, 0, 0, wave, voffW, m0, n0);
-    stage_half<1>(p, smem, 1, 0, 0, wave, voffW, m0, n0);
-    stage_half<0>(p, smem, 1, 0, 0, wave, voffA, m0, n0);
+    stage_half<0, ES>(p, smem, 0, 0, 0, wave, voffA, m0, n0);
+    stage_half<1, ES>(p, smem, 0, 0, 0, wave, voffW, m0, n0);
+    stage_half<1, ES>(p, smem, 1, 0, 0, wave, voffW, m0, n0);
+    stage_half<0, ES>(p, smem, 1, 0, 0, wave, voffA, m0, n0);
     if (nk > 1) {
-        stage_half<0>(p, smem, 0, 1, 1, wave, voffA, m0, n0);
-        stage_half<1>(p, smem, 0, 1, 1, wave, voffW, m0, n0);
+        stage_half<0, ES>(p, smem, 0, 1, 1, wave, voffA, m0, n0);
+        stage_half<1, ES>(p, smem, 0, 1, 1, wave, voffW, m0, n0);
     }
     if (nk > 1) {
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // A-hi(0), A-lo(1), W-lo(1) may be in flight
@@ -662,7 +730,15 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
     auto mma = [&](f32x4(&c)[2][4], const bf16x8(&wf)[2][2]) {
         if constexpr (SLOTS == 43) return;
         if constexpr (SLOTS != 44) __builtin_amdgcn_s_setprio(1);
-        if constexpr (vblk) {
+        if constexpr (FP8) {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    if constexpr (vblk) c[nt][mt] = mfma_fp8(xf[mt][0], xf[mt][1], wf[nt][0], wf[nt][1], c[nt][mt]);
+                    else c[nt][mt] = mfma_fp8(wf[nt][0], wf[nt][1], xf[mt][0], xf[mt][1], c[nt][mt]);
+                }
+        } else if constexpr (vblk) {
 #pragma unroll
             for (int ss = 0; ss < 2; ++ss)
 #pragma unroll
@@ -711,8 +787,8 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
         // La
         stamp(t);                                  // 0: La start
         if (more1) {
-            stage_half<1>(p, smem, 1, B ^ 1, t + 1, wave, voffW, m0, n0);
-            stage_half<0>(p, smem, 1, B ^ 1, t + 1, wave, voffA, m0, n0);
+            stage_half<1, ES>(p, smem, 1, B ^ 1, t + 1, wave, voffW, m0, n0);
+            stage_half<0, ES>(p, smem, 1, B ^ 1, t + 1, wave, voffA, m0, n0);
         } else if (kResLds && !kNoGlds) {
             stage_res(1);                          // last tile (B = 1): hi slots of buffer 0
         }
@@ -734,8 +810,8 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
         // Lb
         stamp(t);                                  // 6: Lb start
         if (more2) {
-            stage_half<0>(p, smem, 0, B, t + 2, wave, voffA, m0, n0);
-            stage_half<1>(p, smem, 0, B, t + 2, wave, voffW, m0, n0);
+            stage_half<0, ES>(p, smem, 0, B, t + 2, wave, voffA, m0, n0);
+            stage_half<1, ES>(p, smem, 0, B, t + 2, wave, voffW, m0, n0);
         } else if (kResLds && !kNoGlds) {
             stage_res(B == 0 ? 0 : 2);             // tile nk-2 (B = 0): lo slots of buffer 0; tile nk-1: of buffer 1
         }
@@ -767,7 +843,7 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
         for (int qm = 0; qm < 2; ++qm)
 #pragma unroll
             for (int qn = 0; qn < 2; ++qn)
-                gemm_epilogue_vt<2, 4>(p, acc[qm][qn], m0 + qm * 128 + wm * 64, n0 + wn * 64 + qn * 32, lane);
+                gemm_epilogue_vt<2, 4, FP8>(p, acc[qm][qn], m0 + qm * 128 + wm * 64, n0 + wn * 64 + qn * 32, lane);
     } else if constexpr (EPI == TT_EPI_QKV) {
 #pragma unroll
         for (int qm = 0; qm < 2; ++qm)
@@ -775,7 +851,7 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
             for (int qn = 0; qn < 2; ++qn)
                 gemm_epilogue_wide<EPI, 2, 4>(p, acc[qm][qn], m0 + qm * 128 + wm * 64, n0 + wn * 64 + qn * 32, lane);
     } else {
-        epilogue_all<EPI, true>(p, acc, smem, kBiasOff, m0, n0, wm, wn, wave, lane, false, NoNext{});
+        epilogue_all<EPI, true, FP8>(p, acc, smem, kBiasOff, kScaleOff, m0, n0, wm, wn, wave, lane, false, NoNext{});
     }
     if constexpr (SLOTS == 46) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -795,8 +871,9 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
 // next tile (La(0)) are issued BEFORE the 16 epilogue stores, so the first two waits of a non-first tile allow
 // 8 + 16 and 6 + 16 operations; by the third the stores are four slots old.
 // The residual epilogue needs all eight slots for the residual tile and stays on the one-tile-per-block kernel.
-template <int EPI>
+template <int EPI, bool FP8 = false>
 __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_p(GemmParams p, int nwg) {
+    constexpr int ES = FP8 ? 1 : 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -808,7 +885,7 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_p(GemmParams p, int 
     const int SM = 8;
     const int per_super = SM * SN;
     const int supers_n = (nt_n + SN - 1) / SN;
-    const int nk = p.K / BK;
+    const int nk = p.K * ES / 128;
     auto decode = [&](int v, int& m0, int& n0) {
         const int L = (v & 7) * (nwg >> 3) + (v >> 3);
         const int sidx = L / per_super, widx = L % per_super;
@@ -834,8 +911,8 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_p(GemmParams p, int 
     for (int j = 0; j < 2; ++j) {
         const int r = 16 * wave + 8 * j + (lane >> 3);
         const int chunk = (lane & 7) ^ ((r >> 1) & 7);
-        voffA[j] = (uint32_t)r * (uint32_t)p.lda * 2u + (uint32_t)chunk * 16u;
-        voffW[j] = (uint32_t)w_row_of(r) * (uint32_t)p.K * 2u + (uint32_t)chunk * 16u;
+        voffA[j] = (uint32_t)r * (uint32_t)p.lda * (uint32_t)ES + (uint32_t)chunk * 16u;
+        voffW[j] = (uint32_t)w_row_of(r) * (uint32_t)p.K * (uint32_t)ES + (uint32_t)chunk * 16u;
     }
 
     int m0 = 0, n0 = 0, m1 = 0, n1 = 0;
@@ -845,27 +922,32 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_p(GemmParams p, int 
     int vn = next_valid(v, m1, n1);
     bool has_next = vn < nwg;
 
-    auto stage_bias = [&](int nn0, int par) {
-        if (wave == 0)
-            glds16(p.bias + nn0, lane * 16, (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem + kBiasOff + par * 1024);
+    // bias strip of a tile (wave 0) and, fp8, its row / column scale strips (waves 1, 2): one copy per wave
+    auto stage_strips = [&](int mm0, int nn0, int par) {
+        const uint32_t l0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+        if (wave == 0) glds16(p.bias + nn0, lane * 16, l0 + kBiasOff + par * 1024);
+        if constexpr (FP8) {
+            if (wave == 1) glds16(p.a_scale + mm0, lane * 16, l0 + kScaleOff + par * 2048);
+            if (wave == 2) glds16(p.w_scale + nn0, lane * 16, l0 + kScaleOff + par * 2048 + 1024);
+        }
     };
     // hi / lo halves of K-tile u of the current tile, or of K-tile u - nk of the next one (nk is even: same buffer)
     auto issue_hi = [&](int u) {
         if (u < nk) {
-            stage_half<1>(p, smem, 1, u & 1, u, wave, voffW, m0, n0);
-            stage_half<0>(p, smem, 1, u & 1, u, wave, voffA, m0, n0);
+            stage_half<1, ES>(p, smem, 1, u & 1, u, wave, voffW, m0, n0);
+            stage_half<0, ES>(p, smem, 1, u & 1, u, wave, voffA, m0, n0);
         } else if (has_next) {
-            stage_half<1>(p, smem, 1, u & 1, u - nk, wave, voffW, m1, n1);
-            stage_half<0>(p, smem, 1, u & 1, u - nk, wave, voffA, m1, n1);
+            stage_half<1, ES>(p, smem, 1, u & 1, u - nk, wave, voffW, m1, n1);
+            stage_half<0, ES>(p, smem, 1, u & 1, u - nk, wave, voffA, m1, n1);
         }
     };
     auto issue_lo = [&](int u) {
         if (u < nk) {
-            stage_half<0>(p, smem, 0, u & 1, u, wave, voffA, m0, n0);
-            stage_half<1>(p, smem, 0, u & 1, u, wave, voffW, m0, n0);
+            stage_half<0, ES>(p, smem, 0, u & 1, u, wave, voffA, m0, n0);
+            stage_half<1, ES>(p, smem, 0, u & 1, u, wave, voffW, m0, n0);
         } else if (has_next) {
-            stage_half<0>(p, smem, 0, u & 1, u - nk, wave, voffA, m1, n1);
-            stage_half<1>(p, smem, 0, u & 1, u - nk, wave, voffW, m1, n1);
+            stage_half<0, ES>(p, smem, 0, u & 1, u - nk, wave, voffA, m1, n1);
+            stage_half<1, ES>(p, smem, 0, u & 1, u - nk, wave, voffW, m1, n1);
         }
     };
 
@@ -873,7 +955,7 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_p(GemmParams p, int 
     int bpar = 0;
     bool first = true;
     // ---- prologue of the first tile: K-tile 0 complete, K-tile 1 without its hi halves (La(0) brings them)
-    stage_bias(n0, bpar);
+    stage_strips(m0, n0, bpar);
     issue_lo(0);
     issue_hi(0);
     issue_lo(1);
@@ -908,13 +990,20 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_p(GemmParams p, int 
         };
         auto mma = [&](f32x4(&c)[2][4], const bf16x8(&wf)[2][2]) {
             __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int ss = 0; ss < 2; ++ss)
+            if constexpr (FP8) {
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                    for (int mt = 0; mt < 4; ++mt)
-                        c[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt][ss], xf[mt][ss], c[nt][mt], 0, 0, 0);
+                    for (int mt = 0; mt < 4; ++mt) c[nt][mt] = mfma_fp8(wf[nt][0], wf[nt][1], xf[mt][0], xf[mt][1], c[nt][mt]);
+            } else {
+#pragma unroll
+                for (int ss = 0; ss < 2; ++ss)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                        for (int mt = 0; mt < 4; ++mt)
+                            c[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt][ss], xf[mt][ss], c[nt][mt], 0, 0, 0);
+            }
             __builtin_amdgcn_s_setprio(0);
         };
         auto wait_n = [&](int n) {
@@ -940,7 +1029,7 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_p(GemmParams p, int 
             TT_SLOT_END();
             // Lb: lo halves of K-tile t+2; the other group's epilogue of the previous tile is over: the bias
             // strip it read can be refilled for the next tile
-            if (t == 0 && has_next) stage_bias(n1, bpar ^ 1);
+            if (t == 0 && has_next) stage_strips(m1, n1, bpar ^ 1);
             issue_lo(t + 2);
             read_a(smem + slot_off(0, 1, B));
             if (after_epi) wait_n(22);
@@ -959,7 +1048,8 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_p(GemmParams p, int 
         // of the tile loop they would stay live through the main loop
         int lane_e = lane;
         asm volatile("" : "+v"(lane_e));
-        epilogue_all<EPI, false>(p, acc, smem, kBiasOff + bpar * 1024, m0, n0, wm, wn, wave, lane_e, false, NoNext{});
+        epilogue_all<EPI, false, FP8>(p, acc, smem, kBiasOff + bpar * 1024, kScaleOff + bpar * 2048, m0, n0, wm, wn, wave, lane_e,
+                                      false, NoNext{});
         if (!has_next) break;
         v = vn; m0 = m1; n0 = n1; bpar ^= 1; first = false;
         vn = next_valid(v, m1, n1);
@@ -970,8 +1060,42 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_p(GemmParams p, int 
 #undef TT_SLOT_END
 }  // namespace v3
 
+// fp8 operands: the 256x256 kernels only (bias / GELU / V^T epilogues), K-tiles of 128 elements
+template <int EPI>
+int launch_fp8(const GemmParams& p, hipStream_t st) {
+    if constexpr (EPI == TT_EPI_BIAS || EPI == TT_EPI_GELU || EPI == TT_EPI_VT) {
+        const int nk = p.K / 128;
+        if (p.M % v3::BM3 || p.N % v3::BN3 || p.K % 128 || nk < 2 || (nk & 1) || p.ldc % 8 || p.lda % 16 || !p.a_scale || !p.w_scale) {
+            tt_set_error("gemm fp8: M=%d N=%d K=%d must be multiples of 256/256/256 with row / column scales", p.M, p.N, p.K);
+            return TT_E_UNSUPPORTED;
+        }
+        const int mt_n = p.M / v3::BM3, nt_n = p.N / v3::BN3;
+        const int SN = nt_n < 4 ? nt_n : 4, SM = 8;
+        const int supers = ((mt_n + SM - 1) / SM) * ((nt_n + SN - 1) / SN);
+        int blocks = supers * SM * SN;
+        blocks = (blocks + 7) / 8 * 8;
+        // (the persistent kernel's fp8 GELU form spills; every fp8 GEMM runs one tile per workgroup)
+        static thread_local bool attr3 = false;
+        if (!attr3) {
+            TT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(v3::gemm_kernel_v3<EPI, 4, true>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, v3::kLds3));
+            attr3 = true;
+        }
+        {
+            TtProfScope prof(TT_K_GEMM, st);
+            hipLaunchKernelGGL((v3::gemm_kernel_v3<EPI, 4, true>), dim3(blocks), dim3(v3::kThreads3), v3::kLds3, st, p);
+        }
+        TT_CHECK_LAUNCH();
+        return TT_OK;
+    } else {
+        tt_set_error("gemm fp8: epilogue %d has no fp8 form", EPI);
+        return TT_E_UNSUPPORTED;
+    }
+}
+
 template <int EPI>
 int launch(const GemmParams& p, hipStream_t st) {
+    if (p.fp8) return launch_fp8<EPI>(p, st);
     static const int variant = [] { const char* e = getenv("TT_GEMM_VARIANT"); return e && e[0] ? atoi(e) : 5; }();
     // (the residual epilogue stages the residual tile as two pseudo K-tiles: needs an even number of K-tiles)
     if (variant >= 4 && p.M % v3::BM3 == 0 && p.N % v3::BN3 == 0 && p.ldc % 8 == 0 &&
@@ -1052,6 +1176,23 @@ int launch(const GemmParams& p, hipStream_t st) {
 
 int tt_gemm_launch(const GemmParams& p, int epilogue, hipStream_t st) {
     if (p.M <= 0 || p.N <= 0) return TT_OK;
+    if (p.fp8 && epilogue == TT_EPI_QKV) {
+        // fp8 QKV projection: Q,K columns as a bias GEMM, V columns as un-swapped tiles stored transposed
+        if (!p.vt || p.vt_col0 % v3::BN3 || (p.N - p.vt_col0) % v3::BN3 || p.ldvt % 8) {
+            tt_set_error("gemm fp8: bad qkv split");
+            return TT_E_INVALID;
+        }
+        GemmParams a = p;
+        a.N = p.vt_col0;
+        if (int rc = launch<TT_EPI_BIAS>(a, st)) return rc;
+        GemmParams b = p;
+        b.W = reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(p.W) + (size_t)p.vt_col0 * p.K);
+        b.bias = p.bias + p.vt_col0;
+        b.w_scale = p.w_scale + p.vt_col0;
+        b.N = p.N - p.vt_col0;
+        b.vt_col0 = 0;
+        return launch<TT_EPI_VT>(b, st);
+    }
     if (p.M % BM || p.N % BN || p.K % BK || p.K <= 0) {
         tt_set_error("gemm: M=%d N=%d K=%d must be multiples of %d/%d/%d", p.M, p.N, p.K, BM, BN, BK);
         return TT_E_UNSUPPORTED;

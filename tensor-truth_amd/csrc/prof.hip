@@ -7,6 +7,7 @@ namespace {
 struct Rec { int id; hipEvent_t e0, e1; };
 struct ProfState {
     bool on = false;
+    unsigned mask = ~0u;     // bit id set: kernel id is timed
     std::vector<Rec> recs;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
 };
@@ -18,6 +19,7 @@ bool tt_prof_on() { return g_prof.on && g_prof.recs.size() < kMaxRecs; }
 
 void tt_prof_begin(int id, hipStream_t st) {
     Rec r{id, nullptr, nullptr};
+    if (!((g_prof.mask >> id) & 1u)) { g_prof.recs.push_back(r); return; }   // placeholder: tt_prof_end pairs with it
     if (!g_prof.pool.empty()) {
         r.e0 = g_prof.pool.back().first;
         r.e1 = g_prof.pool.back().second;
@@ -30,13 +32,15 @@ void tt_prof_begin(int id, hipStream_t st) {
 }
 
 void tt_prof_end(hipStream_t st) {
-    if (!g_prof.recs.empty()) (void)hipEventRecord(g_prof.recs.back().e1, st);
+    if (!g_prof.recs.empty() && g_prof.recs.back().e1) (void)hipEventRecord(g_prof.recs.back().e1, st);
+    if (!g_prof.recs.empty() && !g_prof.recs.back().e0) g_prof.recs.pop_back();
 }
 
 extern "C" int tt_prof_enable(int on) {
     for (auto& r : g_prof.recs) g_prof.pool.emplace_back(r.e0, r.e1);
     g_prof.recs.clear();
     g_prof.on = on != 0;
+    g_prof.mask = (on == 0 || on == 1) ? ~0u : (unsigned)on;   // on > 1: bit mask of kernel ids (1 << id)
     return TT_OK;
 }
 

@@ -34,9 +34,28 @@ __device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
     return u;
 }
 
-// normalise x[kMaxChunks][8] (this lane's share of a row of H values) and store bf16
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+// 8 floats (already multiplied by the row's 448 / absmax) -> 8 OCP e4m3 bytes, round to nearest even
+__device__ __forceinline__ uint2 pack_fp8x8(const float (&f)[8]) {
+    int lo = 0, hi = 0;
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], lo, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], hi, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
+    return make_uint2((unsigned)lo, (unsigned)hi);
+}
+
+// normalise x[kMaxChunks][8] (this lane's share of a row of H values) and store bf16; optionally also the
+// per-row fp8 quantisation of the bf16-rounded result (q8_row, *q8_scale = absmax / 448): the A operand of the
+// fp8 GEMMs, produced while the row is in registers
 __device__ __forceinline__ void ln_finish(float (&x)[kMaxChunks][8], int nchunk_total, int lane, int H, float eps,
-                                          const float* gamma, const float* beta, uint16_t* out_row) {
+                                          const float* gamma, const float* beta, uint16_t* out_row,
+                                          uint8_t* q8_row = nullptr, float* q8_scale = nullptr) {
     float s = 0.f;
 #pragma unroll
     for (int c = 0; c < kMaxChunks; ++c)
@@ -67,13 +86,37 @@ __device__ __forceinline__ void ln_finish(float (&x)[kMaxChunks][8], int nchunk_
             float y[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) y[i] = (x[c][i] - mean) * rstd * g[i] + b[i];
-            *reinterpret_cast<uint4*>(out_row + ch * 8) = pack8(y);
+            const uint4 packed = pack8(y);
+            *reinterpret_cast<uint4*>(out_row + ch * 8) = packed;
+            if (q8_row) unpack8(packed, x[c]);   // keep the bf16-rounded values for the quantisation pass
+        }
+    }
+    if (q8_row) {
+        float amax = 0.f;
+#pragma unroll
+        for (int c = 0; c < kMaxChunks; ++c)
+            if (lane + 64 * c < nchunk_total)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) amax = fmaxf(amax, fabsf(x[c][i]));
+        amax = wave_max(amax);
+        const float inv = amax > 0.f ? __fdiv_rn(448.0f, amax) : 0.f   /* correctly rounded: the oracle divides in IEEE fp32 */;
+        if (lane == 0) *q8_scale = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
+#pragma unroll
+        for (int c = 0; c < kMaxChunks; ++c) {
+            const int ch = lane + 64 * c;
+            if (ch < nchunk_total) {
+                float q[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) q[i] = x[c][i] * inv;
+                *reinterpret_cast<uint2*>(q8_row + ch * 8) = pack_fp8x8(q);
+            }
         }
     }
 }
 
 __global__ __launch_bounds__(kRowThreads) void layernorm_kernel(const uint16_t* in, uint16_t* out, const float* gamma,
-                                                               const float* beta, int rows, int H, float eps) {
+                                                               const float* beta, int rows, int H, float eps, uint8_t* q8,
+                                                               float* q8_scale) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * (kRowThreads / 64) + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -87,7 +130,8 @@ __global__ __launch_bounds__(kRowThreads) void layernorm_kernel(const uint16_t* 
             unpack8(u, x[c]);
         }
     }
-    ln_finish(x, nch, lane, H, eps, gamma, beta, out + (size_t)row * H);
+    ln_finish(x, nch, lane, H, eps, gamma, beta, out + (size_t)row * H, q8 ? q8 + (size_t)row * H : nullptr,
+              q8 ? q8_scale + row : nullptr);
 }
 
 __global__ __launch_bounds__(kRowThreads) void embed_ln_kernel(EmbedParams p) {
@@ -113,7 +157,8 @@ __global__ __launch_bounds__(kRowThreads) void embed_ln_kernel(EmbedParams p) {
             for (int i = 0; i < 8; ++i) x[c][i] = a[i] + b[i] + t[i];
         }
     }
-    ln_finish(x, nch, lane, p.H, p.eps, p.gamma, p.beta, p.out + (size_t)row * p.H);
+    ln_finish(x, nch, lane, p.H, p.eps, p.gamma, p.beta, p.out + (size_t)row * p.H, p.q8 ? p.q8 + (size_t)row * p.H : nullptr,
+              p.q8 ? p.q8_scale + row : nullptr);
 }
 
 __global__ __launch_bounds__(kRowThreads) void cls_pool_kernel(const uint16_t* hidden, int ld, const int32_t* rows, int n,
@@ -218,10 +263,50 @@ inline dim3 row_grid(int rows) { return dim3((rows + kRowThreads / 64 - 1) / (kR
 }  // namespace
 
 int tt_layernorm_launch(const uint16_t* in, uint16_t* out, const float* gamma, const float* beta, int rows, int H,
-                        float eps, hipStream_t st) {
+                        float eps, hipStream_t st, uint8_t* q8, float* q8_scale) {
     if (rows <= 0) return TT_OK;
     if (int rc = check_h(H)) return rc;
-    hipLaunchKernelGGL(layernorm_kernel, row_grid(rows), dim3(kRowThreads), 0, st, in, out, gamma, beta, rows, H, eps);
+    hipLaunchKernelGGL(layernorm_kernel, row_grid(rows), dim3(kRowThreads), 0, st, in, out, gamma, beta, rows, H, eps, q8,
+                       q8_scale);
+    TT_CHECK_LAUNCH();
+    return TT_OK;
+}
+
+// per-row fp8 quantisation of a bf16 matrix (cols a multiple of 8): q = e4m3(x * 448 / absmax_row), scale = absmax / 448
+namespace {
+__global__ __launch_bounds__(kRowThreads) void quantize_rows_kernel(const uint16_t* in, int ld, int rows, int cols, uint8_t* q8,
+                                                                   float* scale) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (kRowThreads / 64) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const uint16_t* src = in + (size_t)row * ld;
+    float amax = 0.f;
+    for (int ch = lane; ch * 8 < cols; ch += 64) {
+        float f[8];
+        unpack8(*reinterpret_cast<const uint4*>(src + ch * 8), f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) amax = fmaxf(amax, fabsf(f[i]));
+    }
+    amax = wave_max(amax);
+    const float inv = amax > 0.f ? __fdiv_rn(448.0f, amax) : 0.f   /* correctly rounded: the oracle divides in IEEE fp32 */;
+    if (lane == 0) scale[row] = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
+    for (int ch = lane; ch * 8 < cols; ch += 64) {
+        float f[8];
+        unpack8(*reinterpret_cast<const uint4*>(src + ch * 8), f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[i] *= inv;
+        *reinterpret_cast<uint2*>(q8 + (size_t)row * cols + ch * 8) = pack_fp8x8(f);
+    }
+}
+}  // namespace
+
+int tt_quantize_rows_launch(const uint16_t* in, int ld, int rows, int cols, uint8_t* q8, float* scale, hipStream_t st) {
+    if (rows <= 0) return TT_OK;
+    if (cols <= 0 || cols % 8 || ld % 8) {
+        tt_set_error("quantize_rows: cols=%d ld=%d must be multiples of 8", cols, ld);
+        return TT_E_INVALID;
+    }
+    hipLaunchKernelGGL(quantize_rows_kernel, row_grid(rows), dim3(kRowThreads), 0, st, in, ld, rows, cols, q8, scale);
     TT_CHECK_LAUNCH();
     return TT_OK;
 }

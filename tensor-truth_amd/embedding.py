@@ -48,6 +48,7 @@ class HipHuggingFaceEmbedding:
         cfg, state, mdir = _weights.resolve(model_name, model_kwargs, dev, want_head=False)
         self.config = cfg
         self._model = EncoderWeights(cfg, state, dev)       # .parameters() for memory accounting
+        self._model.set_gemm_dtype((model_kwargs or {}).get("gemm_dtype", "bf16"))
         self._encoder = Encoder(self._model)
         self._tokenizer = (model_kwargs or {}).get("tokenizer") or load_tokenizer(mdir, cfg.arch, cfg.vocab_size)
         self.max_length = min(max_length or cfg.max_seq_len, cfg.max_seq_len)

@@ -59,7 +59,8 @@ KNOWN_CONFIGS = {
 
 class _LayerW(Structure):
     _fields_ = [(n, c_void_p) for n in ("qkv_w", "qkv_b", "o_w", "o_b", "ln1_g", "ln1_b", "ffn1_w", "ffn1_b",
-                                        "ffn2_w", "ffn2_b", "ln2_g", "ln2_b")]
+                                        "ffn2_w", "ffn2_b", "ln2_g", "ln2_b",
+                                        "qkv_w8", "qkv_wscale", "ffn1_w8", "ffn1_wscale")]
 
 
 class _EncW(Structure):
@@ -119,6 +120,10 @@ class EncoderWeights:
         if self.word.shape != (cfg.vocab_size, H) or self.pos.shape != (cfg.max_pos, H):
             raise ValueError(f"embedding tables {tuple(self.word.shape)} / {tuple(self.pos.shape)} do not match {cfg}")
         self._layers = (_LayerW * max(cfg.layers, 1))()
+        self._qkv_w: List[torch.Tensor] = []
+        self._ffn1_w: List[torch.Tensor] = []
+        self._fp8: List[torch.Tensor] = []
+        self.gemm_dtype = "bf16"
         for i in range(cfg.layers):
             p = f"encoder.layer.{i}."
             qkv_w = torch.cat([sd[p + f"attention.self.{n}.weight"] for n in ("query", "key", "value")], 0)
@@ -126,12 +131,15 @@ class EncoderWeights:
             qkv_w = qkv_w.to(device=device, dtype=torch.bfloat16).contiguous()
             qkv_b = qkv_b.to(device=device, dtype=torch.float32).contiguous()
             self._keep += [qkv_w, qkv_b]
+            self._qkv_w.append(qkv_w)
             L = self._layers[i]
             L.qkv_w, L.qkv_b = qkv_w.data_ptr(), qkv_b.data_ptr()
             L.o_w, L.o_b = mat(p + "attention.output.dense.weight").data_ptr(), vec(p + "attention.output.dense.bias").data_ptr()
             L.ln1_g = vec(p + "attention.output.LayerNorm.weight").data_ptr()
             L.ln1_b = vec(p + "attention.output.LayerNorm.bias").data_ptr()
-            L.ffn1_w, L.ffn1_b = mat(p + "intermediate.dense.weight").data_ptr(), vec(p + "intermediate.dense.bias").data_ptr()
+            ffn1_w = mat(p + "intermediate.dense.weight")
+            self._ffn1_w.append(ffn1_w)
+            L.ffn1_w, L.ffn1_b = ffn1_w.data_ptr(), vec(p + "intermediate.dense.bias").data_ptr()
             L.ffn2_w, L.ffn2_b = mat(p + "output.dense.weight").data_ptr(), vec(p + "output.dense.bias").data_ptr()
             L.ln2_g = vec(p + "output.LayerNorm.weight").data_ptr()
             L.ln2_b = vec(p + "output.LayerNorm.bias").data_ptr()
@@ -150,12 +158,47 @@ class EncoderWeights:
             w.cls_out_b = vec("classifier.out_proj.bias").data_ptr()
         self.struct = w
 
+    @staticmethod
+    def _quantize_rows(w: torch.Tensor):
+        """bf16 [out][in] -> (e4m3 bytes [out][in], fp32 scale [out]) with w ~= w8 * scale[out]."""
+        wf = w.to(torch.float32)
+        amax = wf.abs().amax(dim=1, keepdim=True)
+        inv = torch.where(amax > 0, 448.0 / amax, torch.zeros_like(amax))
+        w8 = (wf * inv).to(torch.float8_e4m3fn).view(torch.uint8).contiguous()
+        scale = torch.where(amax > 0, amax * (1.0 / 448.0), torch.ones_like(amax)).reshape(-1).contiguous()
+        return w8, scale
+
+    def set_gemm_dtype(self, dtype: str) -> None:
+        """"bf16" (default) or "fp8": the Q/K/V and FFN-up projections (the GEMMs whose input is a LayerNorm output)
+        run on OCP e4m3 operands -- weights quantised here per output channel, activations per token inside the
+        LayerNorm kernels -- with fp32 accumulation (BASELINE.json config 5, "fp8 MFMA reranker").  Needs hidden and
+        ffn to be multiples of 256; the bf16 weights stay resident for the other GEMMs and the CLS tail."""
+        if dtype not in ("bf16", "fp8"):
+            raise ValueError(f"gemm dtype {dtype!r} not in ('bf16', 'fp8')")
+        if dtype == "fp8":
+            if self.cfg.hidden % 256 or self.cfg.ffn % 256:
+                raise ValueError("fp8 GEMMs need hidden and ffn to be multiples of 256")
+            if not self._fp8:
+                for i in range(self.cfg.layers):
+                    q8, qs = self._quantize_rows(self._qkv_w[i])
+                    f8, fs = self._quantize_rows(self._ffn1_w[i])
+                    self._fp8 += [q8, qs, f8, fs]
+            for i in range(self.cfg.layers):
+                L = self._layers[i]
+                q8, qs, f8, fs = self._fp8[4 * i: 4 * i + 4]
+                L.qkv_w8, L.qkv_wscale, L.ffn1_w8, L.ffn1_wscale = q8.data_ptr(), qs.data_ptr(), f8.data_ptr(), fs.data_ptr()
+        else:
+            for i in range(self.cfg.layers):
+                L = self._layers[i]
+                L.qkv_w8 = L.qkv_wscale = L.ffn1_w8 = L.ffn1_wscale = None
+        self.gemm_dtype = dtype
+
     def parameters(self) -> Iterable[torch.Tensor]:
         """For ModelManager-style memory accounting (reference model_manager.py:477-507)."""
-        return iter(self._keep)
+        return iter(self._keep + self._fp8)
 
     def nbytes(self) -> int:
-        return sum(t.numel() * t.element_size() for t in self._keep)
+        return sum(t.numel() * t.element_size() for t in self._keep + self._fp8)
 
 
 def synthetic_state(cfg: EncoderConfig, seed: int = 0) -> Dict[str, torch.Tensor]:

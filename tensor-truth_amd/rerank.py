@@ -39,6 +39,8 @@ class HipSentenceTransformerRerank:
             raise ValueError(f"'{model}' has no classification head (not a cross-encoder)")
         self.config = cfg
         self.model = EncoderWeights(cfg, state, dev)    # `.model` is what the reference's memory accounting reads
+        # model_kwargs["gemm_dtype"] = "fp8": Q/K/V and FFN-up projections on the e4m3 matrix cores (BASELINE config 5)
+        self.model.set_gemm_dtype((model_kwargs or {}).get("gemm_dtype", "bf16"))
         self._encoder = Encoder(self.model)
         self._tokenizer = (model_kwargs or {}).get("tokenizer") or load_tokenizer(mdir, cfg.arch, cfg.vocab_size)
 

@@ -58,5 +58,30 @@ int main(int argc, char** argv) {
         double fl = 2.0 * M * s.n * s.k;
         printf("%-16s M=%d N=%d K=%d  %.3f ms  %.1f TF/s\n", s.name, M, s.n, s.k, ms, fl / (ms * 1e-3) / 1e12);
     }
+    // fp8 (e4m3) forms of the two projections the fp8 mode moves to the fp8 matrix cores
+    {
+        uint8_t *a8, *w8; float *sa, *sw;
+        CK(hipMalloc(&a8, (size_t)M * 1024)); CK(hipMalloc(&w8, (size_t)4096 * 1024));
+        CK(hipMalloc(&sa, (size_t)M * 4)); CK(hipMalloc(&sw, 4096 * 4));
+        fill_bf16<<<2048, 256>>>((uint16_t*)a8, (size_t)M * 512, 7, 1.0f);    // random bytes (most are finite e4m3 values)
+        fill_bf16<<<2048, 256>>>((uint16_t*)w8, (size_t)4096 * 512, 8, 1.0f);
+        CK(hipMemset(sa, 0, (size_t)M * 4)); CK(hipMemset(sw, 0, 4096 * 4));
+        CK(hipDeviceSynchronize());
+        struct S8 { int n, epi; const char* name; } s8[] = {{2048, 0, "fp8 qk(bias)"}, {3072, 0, "fp8 qkv-sized(bias)"}, {4096, 1, "fp8 ffn-up(gelu)"}};
+        for (auto& s : s8) {
+            for (int i = 0; i < 3; ++i) {
+                int rc = tt_gemm_fp8(a8, sa, w8, sw, bias, c, M, s.n, 1024, s.epi, st);
+                if (rc) { fprintf(stderr, "rc=%d %s\n", rc, tt_last_error()); return 1; }
+            }
+            CK(hipStreamSynchronize(st));
+            CK(hipEventRecord(e0, st));
+            for (int i = 0; i < iters; ++i) tt_gemm_fp8(a8, sa, w8, sw, bias, c, M, s.n, 1024, s.epi, st);
+            CK(hipEventRecord(e1, st));
+            CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= iters;
+            double fl = 2.0 * M * s.n * 1024;
+            printf("%-22s M=%d N=%d K=1024  %.3f ms  %.1f TF/s\n", s.name, M, s.n, ms, fl / (ms * 1e-3) / 1e12);
+        }
+    }
     return 0;
 }
