@@ -1212,7 +1212,9 @@ int tt_gemm_launch(const GemmParams& p, int epilogue, hipStream_t st) {
             if (!p.vt) { tt_set_error("gemm: qkv epilogue without vt"); return TT_E_INVALID; }
             static const int variant = [] { const char* e = getenv("TT_GEMM_VARIANT"); return e && e[0] ? atoi(e) : 5; }();
             const int nv = p.N - p.vt_col0;
-            if ((variant == 3 || variant == 4) && p.M % v3::BM3 == 0 && p.vt_col0 % v3::BN3 == 0 && nv % v3::BN3 == 0 &&
+            // (TT_GEMM_QKV_SPLIT=0: one launch with the mixed epilogue -- measured 2 % slower end to end)
+            static const int split = [] { const char* e = getenv("TT_GEMM_QKV_SPLIT"); return e && e[0] ? atoi(e) : 1; }();
+            if (variant >= 3 && split && p.M % v3::BM3 == 0 && p.vt_col0 % v3::BN3 == 0 && nv % v3::BN3 == 0 &&
                 nv > 0 && p.ldc % 8 == 0 && p.ldvt % 8 == 0) {
                 // Q,K columns: plain bias GEMM; V columns: un-swapped tiles stored transposed (two launches,
                 // same number of tile rounds as one)
