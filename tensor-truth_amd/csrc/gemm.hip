@@ -1096,6 +1096,8 @@ int launch_fp8(const GemmParams& p, hipStream_t st) {
 template <int EPI>
 int launch(const GemmParams& p, hipStream_t st) {
     if (p.fp8) return launch_fp8<EPI>(p, st);
+    static const bool trace = [] { const char* e = getenv("TT_GEMM_TRACE"); return e && e[0] == '1'; }();
+    if (trace) fprintf(stderr, "gemm launch<%d> M=%d N=%d K=%d lda=%d ldc=%d ldr=%d\n", EPI, p.M, p.N, p.K, p.lda, p.ldc, p.ldr);
     static const int variant = [] { const char* e = getenv("TT_GEMM_VARIANT"); return e && e[0] ? atoi(e) : 5; }();
     // (the residual epilogue stages the residual tile as two pseudo K-tiles: needs an even number of K-tiles)
     if (variant >= 4 && p.M % v3::BM3 == 0 && p.N % v3::BN3 == 0 && p.ldc % 8 == 0 &&

@@ -12,7 +12,9 @@ import sys
 
 
 def load(dirname, counter):
-    f = glob.glob(f"{dirname}/*/*counter_collection.csv")[0]
+    import os
+    # newest file: gpurun merges every call's outputs into the same local directory
+    f = max(glob.glob(f"{dirname}/*/*counter_collection.csv"), key=os.path.getmtime)
     rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
     return rows
