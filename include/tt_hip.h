@@ -118,6 +118,15 @@ typedef struct tt_layer_weights {
     const float* qkv_wscale; /* [3H] */
     const void* ffn1_w8;     /* [F][H] bytes */
     const float* ffn1_wscale;/* [F] */
+    /* ... and of the other two: the attention output (its input, the attention context, is quantised per
+     * token by a row pass) and the FFN output projection, whose input -- the GELU output, rows of F values
+     * spread over F/256 tiles -- is written as e4m3 by the FFN-up epilogue with ONE static scale per layer,
+     * ffn_act_scale (> 0; from a calibration forward: tt_encoder_weights.ffn_absmax_out). */
+    const void* o_w8;        /* [H][H] bytes */
+    const float* o_wscale;   /* [H] */
+    const void* ffn2_w8;     /* [H][F] bytes */
+    const float* ffn2_wscale;/* [H] */
+    float ffn_act_scale;     /* 0 = FFN output projection stays bf16 */
 } tt_layer_weights;
 
 typedef struct tt_encoder_weights {
@@ -133,6 +142,9 @@ typedef struct tt_encoder_weights {
     const float* cls_dense_b;
     const void* cls_out_w;    /* [1][H] bf16 */
     const float* cls_out_b;   /* [1] */
+    /* calibration hook: device float[layers] (zero it first); every forward that produces the bf16 FFN
+     * intermediate raises entry l to max |GELU output| of layer l.  NULL = off. */
+    float* ffn_absmax_out;
 } tt_encoder_weights;
 
 size_t tt_encoder_workspace_bytes(const tt_encoder_weights* w, int n_rows);
@@ -191,6 +203,11 @@ int tt_layernorm_bf16_fp8(const void* in, void* out, const float* gamma, const f
                           float eps, void* out_fp8, float* out_scale, void* stream);
 int tt_gemm_fp8(const void* a8, const float* a_scale, const void* w8, const float* w_scale, const float* bias, void* c,
                 int m, int n, int k, int epilogue /*0 bias, 1 gelu*/, void* stream);
+/* ... with the residual epilogue (epilogue 2: + residual[m][n], bf16) or, epilogues 0 / 1, an e4m3 result instead of
+ * the bf16 one: c_fp8[m][n] = e4m3(bf16(result) * c_fp8_inv_scale) (c_bf16 is then not written and may be NULL). */
+int tt_gemm_fp8_ex(const void* a8, const float* a_scale, const void* w8, const float* w_scale, const float* bias,
+                   const void* residual, void* c_bf16, void* c_fp8, float c_fp8_inv_scale, int m, int n, int k,
+                   int epilogue, void* stream);
 
 /* Per-kernel device timing (HIP events on the launch stream), for bench.py's roofline leg.
  * tt_prof_enable(1) (or a mask of 1 << id, to time only some kernels) starts recording one event pair per launch of the tracked kernels on the

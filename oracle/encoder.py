@@ -120,12 +120,15 @@ def encoder_forward(
     type_ids: Optional[torch.Tensor] = None,
     layers: Optional[int] = None,
     emulate_fp8: bool = False,
+    ffn_act_scales=None,
 ) -> torch.Tensor:
     """ids, mask: [B, L] int.  Returns last hidden state [B, L, H] fp32.
 
     Weight names follow the HF checkpoints (no ``roberta.``/``bert.`` prefix).
-    ``emulate_fp8``: the projections fed by a LayerNorm output (Q/K/V, FFN up) run on e4m3 operands
-    (``linear_fp8``), everything else as with ``emulate_bf16`` -- the HIP fp8 mode.
+    ``emulate_fp8``: the layer projections run on e4m3 operands (``linear_fp8``: per-token activation and
+    per-output-channel weight scales), everything else as with ``emulate_bf16`` -- the HIP fp8 mode.  The FFN
+    output projection joins in when ``ffn_act_scales`` (one static scale per layer for the GELU output, as the HIP
+    calibration produces) is given; without it that projection stays bf16, as in the HIP path.
     """
     r = lambda t: _rnd(t, emulate_bf16)  # noqa: E731
     f = lambda name: W[name].to(torch.float32)  # noqa: E731
@@ -163,11 +166,17 @@ def encoder_forward(
         denom = e.sum(dim=-1, keepdim=True)
         ctx = (r(e) @ v) / denom
         ctx = r(ctx.transpose(1, 2).reshape(B, L, H))
-        a = ctx @ f(p + "attention.output.dense.weight").T + f(p + "attention.output.dense.bias")
+        a = lin(ctx, f(p + "attention.output.dense.weight"), f(p + "attention.output.dense.bias"))
         x = r(layer_norm(r(a + x), f(p + "attention.output.LayerNorm.weight"),
                          f(p + "attention.output.LayerNorm.bias"), cfg.ln_eps))
         h = r(gelu_erf(lin(x, f(p + "intermediate.dense.weight"), f(p + "intermediate.dense.bias"))))
-        o = h @ f(p + "output.dense.weight").T + f(p + "output.dense.bias")
+        if emulate_fp8 and ffn_act_scales is not None:
+            sf = float(ffn_act_scales[i])
+            hq = (h * (1.0 / sf)).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).to(torch.float32)   # saturating, static scale
+            wq, sw = quantize_rows_e4m3(f(p + "output.dense.weight"))
+            o = (hq @ wq.T) * sf * sw.transpose(-1, -2) + f(p + "output.dense.bias")
+        else:
+            o = h @ f(p + "output.dense.weight").T + f(p + "output.dense.bias")
         x = r(layer_norm(r(o + x), f(p + "output.LayerNorm.weight"),
                          f(p + "output.LayerNorm.bias"), cfg.ln_eps))
     return x
@@ -184,16 +193,16 @@ def embed(ids, mask, W, cfg, emulate_bf16=False, type_ids=None, emulate_fp8=Fals
     return cls_pool_normalize(encoder_forward(ids, mask, W, cfg, emulate_bf16, type_ids, emulate_fp8=emulate_fp8))
 
 
-def rerank_logits(ids, mask, W, cfg, emulate_bf16=False, emulate_fp8=False) -> torch.Tensor:
+def rerank_logits(ids, mask, W, cfg, emulate_bf16=False, emulate_fp8=False, ffn_act_scales=None) -> torch.Tensor:
     """XLMRobertaClassificationHead: out_proj(tanh(dense(h[:,0]))) -> [B] logits."""
-    h = encoder_forward(ids, mask, W, cfg, emulate_bf16, emulate_fp8=emulate_fp8)[:, 0, :]
+    h = encoder_forward(ids, mask, W, cfg, emulate_bf16, emulate_fp8=emulate_fp8, ffn_act_scales=ffn_act_scales)[:, 0, :]
     t = torch.tanh(h @ W["classifier.dense.weight"].float().T + W["classifier.dense.bias"].float())
     return (t @ W["classifier.out_proj.weight"].float().T + W["classifier.out_proj.bias"].float())[:, 0]
 
 
-def rerank_scores(ids, mask, W, cfg, emulate_bf16=False, emulate_fp8=False) -> torch.Tensor:
+def rerank_scores(ids, mask, W, cfg, emulate_bf16=False, emulate_fp8=False, ffn_act_scales=None) -> torch.Tensor:
     """CrossEncoder.predict default activation for num_labels==1: sigmoid."""
-    return torch.sigmoid(rerank_logits(ids, mask, W, cfg, emulate_bf16, emulate_fp8))
+    return torch.sigmoid(rerank_logits(ids, mask, W, cfg, emulate_bf16, emulate_fp8, ffn_act_scales))
 
 
 def synth_weights(cfg: EncoderConfig, seed: int = 0, dtype=torch.float32) -> Dict[str, torch.Tensor]:

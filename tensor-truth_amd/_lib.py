@@ -59,6 +59,8 @@ SIGNATURES = {
                                       c_void_p]),
     "tt_gemm_fp8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                             c_void_p]),
+    "tt_gemm_fp8_ex": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
+                               c_int, c_int, c_int, c_int, c_void_p]),
     "tt_prof_enable": (c_int, [c_int]),
     "tt_prof_read": (c_int, [c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int)]),
 }

@@ -19,6 +19,10 @@ struct GemmParams {
     const float* a_scale;     // [M] per-row dequantisation scale of A
     const float* w_scale;     // [N] per-output-channel scale of W
     int fp8;
+    // fp8 OUTPUT (bias / GELU epilogues of the one-tile kernel): C8[m][ldc] = e4m3(bf16(result) * c8_inv_scale),
+    // one static scale for the whole tensor (the FFN intermediate, whose rows span 16 tiles); C is not written
+    uint8_t* C8;
+    float c8_inv_scale;
 };
 int tt_gemm_launch(const GemmParams& p, int epilogue, hipStream_t st);
 
@@ -57,6 +61,7 @@ int tt_embed_ln_launch(const EmbedParams& p, hipStream_t st);
 // out = LayerNorm(in) * gamma + beta, rows of H bf16
 int tt_layernorm_launch(const uint16_t* in, uint16_t* out, const float* gamma, const float* beta, int rows, int H,
                         float eps, hipStream_t st, uint8_t* q8 = nullptr, float* q8_scale = nullptr);
+int tt_absmax_launch(const uint16_t* x, size_t n, float* out, hipStream_t st);
 int tt_quantize_rows_launch(const uint16_t* in, int ld, int rows, int cols, uint8_t* q8, float* scale, hipStream_t st);
 
 // out_f32[b] = x[row[b]] / max(||x[row[b]]||, 1e-12); optional bf16 copy

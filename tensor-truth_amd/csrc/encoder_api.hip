@@ -20,7 +20,7 @@ struct EncWs {
     size_t off_cctx, off_cx, off_cy, off_cx1, off_cffn, off_rows;
     int n_cls_pad;
     // fp8 forward: e4m3 copy of the current LayerNorm output + its per-row scales
-    size_t off_q8, off_q8s;
+    size_t off_q8, off_q8s, off_q8c;
     bool fp8;
 };
 
@@ -59,6 +59,7 @@ EncWs enc_plan(const tt_encoder_weights* w, int n_rows, int n_seq = 0) {
     if (e.fp8) {
         e.off_q8 = take(T * H);
         e.off_q8s = take(T * 4);
+        e.off_q8c = take(T * 4);   // constant row scales (the FFN intermediate's static scale)
     }
     e.total = off;
     return e;
@@ -195,6 +196,13 @@ static int forward_impl(const tt_encoder_weights* w, const int32_t* ids, const i
         GemmParams go{};
         go.A = ctx; go.lda = H; go.W = (const uint16_t*)lw.o_w; go.bias = lw.o_b;
         go.residual = x; go.ldr = H; go.C = y; go.ldc = H; go.M = T; go.N = H; go.K = H;
+        if (e.fp8 && lw.o_w8 && lw.o_wscale) {   // the QKV GEMM is done with q8: reuse it for the context's e4m3 copy
+            {
+                TtProfScope prof(TT_K_ROWOPS, st);
+                if (int rc = tt_quantize_rows_launch(ctx, H, T, H, q8, q8s, st)) return rc;
+            }
+            go.A = (const uint16_t*)q8; go.W = (const uint16_t*)lw.o_w8; go.a_scale = q8s; go.w_scale = lw.o_wscale; go.fp8 = 1;
+        }
         if (int rc = tt_gemm_launch(go, TT_EPI_RESIDUAL, st)) return rc;
         uint16_t* x1 = (x == xa) ? xb : xa;
         {
@@ -205,13 +213,28 @@ static int forward_impl(const tt_encoder_weights* w, const int32_t* ids, const i
         GemmParams g1{};
         g1.A = x1; g1.lda = H; g1.W = (const uint16_t*)lw.ffn1_w; g1.bias = lw.ffn1_b;
         g1.C = ffn; g1.ldc = F; g1.M = T; g1.N = F; g1.K = H;
+        const bool f8 = e.fp8 && lw.ffn2_w8 && lw.ffn2_wscale && lw.ffn_act_scale > 0.f;
         if (e.fp8) {
             g1.A = (const uint16_t*)q8; g1.W = (const uint16_t*)lw.ffn1_w8; g1.a_scale = q8s; g1.w_scale = lw.ffn1_wscale; g1.fp8 = 1;
+            if (f8) {   // the intermediate is written as e4m3 (static scale) into the same buffer, half its size
+                g1.C8 = (uint8_t*)ffn; g1.c8_inv_scale = 1.0f / lw.ffn_act_scale;
+            }
         }
         if (int rc = tt_gemm_launch(g1, TT_EPI_GELU, st)) return rc;
+        if (w->ffn_absmax_out && !f8) {
+            TtProfScope prof(TT_K_ROWOPS, st);
+            if (int rc = tt_absmax_launch(ffn, (size_t)T * F, w->ffn_absmax_out + l, st)) return rc;
+        }
         GemmParams g2{};
         g2.A = ffn; g2.lda = F; g2.W = (const uint16_t*)lw.ffn2_w; g2.bias = lw.ffn2_b;
         g2.residual = x1; g2.ldr = H; g2.C = y; g2.ldc = H; g2.M = T; g2.N = H; g2.K = F;
+        if (f8) {
+            float* q8c = (float*)(ws + e.off_q8c);
+            const float act_scale = lw.ffn_act_scale;
+            const unsigned bits = __builtin_bit_cast(unsigned, act_scale);
+            TT_CHECK_HIP(hipMemsetD32Async(q8c, (int)bits, (size_t)T, st));
+            g2.W = (const uint16_t*)lw.ffn2_w8; g2.a_scale = q8c; g2.w_scale = lw.ffn2_wscale; g2.fp8 = 1;
+        }
         if (int rc = tt_gemm_launch(g2, TT_EPI_RESIDUAL, st)) return rc;
         // x1 is free again after the FFN-down GEMM has consumed it as residual; the LN output
         // goes to the other hidden buffer (or straight to hidden_out on the last layer)
@@ -329,6 +352,22 @@ int tt_gemm_fp8(const void* a8, const float* a_scale, const void* w8, const floa
     GemmParams g{};
     g.A = (const uint16_t*)a8; g.lda = k; g.W = (const uint16_t*)w8; g.bias = bias; g.C = (uint16_t*)c; g.ldc = n;
     g.M = m; g.N = n; g.K = k; g.a_scale = a_scale; g.w_scale = w_scale; g.fp8 = 1;
+    return tt_gemm_launch(g, epilogue, (hipStream_t)stream);
+}
+
+int tt_gemm_fp8_ex(const void* a8, const float* a_scale, const void* w8, const float* w_scale, const float* bias,
+                   const void* residual, void* c_bf16, void* c_fp8, float c_fp8_inv_scale, int m, int n, int k,
+                   int epilogue, void* stream) {
+    TT_CHECK_ARG(epilogue == TT_EPI_BIAS || epilogue == TT_EPI_GELU || epilogue == TT_EPI_RESIDUAL, "epilogue %d", epilogue);
+    TT_CHECK_ARG(a8 && a_scale && w8 && w_scale && bias && (c_bf16 || c_fp8), "null pointer");
+    TT_CHECK_ARG(epilogue != TT_EPI_RESIDUAL || (residual && c_bf16 && !c_fp8), "residual epilogue: bf16 result only");
+    GemmParams g{};
+    g.A = (const uint16_t*)a8; g.lda = k; g.W = (const uint16_t*)w8; g.bias = bias; g.ldc = n;
+    // (C only has to be non-null for the launcher's argument check when the result goes to c_fp8)
+    g.C = c_bf16 ? (uint16_t*)c_bf16 : (uint16_t*)c_fp8;
+    g.residual = (const uint16_t*)residual; g.ldr = n;
+    g.M = m; g.N = n; g.K = k; g.a_scale = a_scale; g.w_scale = w_scale; g.fp8 = 1;
+    if (c_fp8) { g.C8 = (uint8_t*)c_fp8; g.c8_inv_scale = c_fp8_inv_scale; }
     return tt_gemm_launch(g, epilogue, (hipStream_t)stream);
 }
 

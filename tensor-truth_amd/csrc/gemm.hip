@@ -563,10 +563,33 @@ __device__ __forceinline__ void epilogue_all(const GemmParams& p, f32x4 (&acc)[2
                 t[2] = lds_read128_async<0>(saddr[0] + kOffB[qm * 2 + pr] + 4 * kHalf);
                 t[3] = lds_read128_async<0>(saddr[1] + kOffB[qm * 2 + pr] + 4 * kHalf);
                 lds_wait(t[0], t[1], t[2], t[3]);
-                uint16_t* cp = p.C + (size_t)(m0 + qm * 128 + wm * 64 + pr * 32 + (lane >> 3)) * p.ldc + n0 + wn * 64 + (lane & 7) * 8;
+                const size_t crow = (size_t)(m0 + qm * 128 + wm * 64 + pr * 32 + (lane >> 3)) * p.ldc + n0 + wn * 64 + (lane & 7) * 8;
+                if (p.C8) {
+                    // e4m3 output: quantise the bf16-rounded values with the tensor's static scale, 8 bytes per lane
+                    // (64 contiguous bytes per row and instruction)
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    *reinterpret_cast<uint4*>(cp + (size_t)(8 * i) * p.ldc) = uint4{t[i].x, t[i].y, t[i].z, t[i].w};
+                    for (int i = 0; i < 4; ++i) {
+                        const float s = p.c8_inv_scale;
+                        const unsigned w[4] = {t[i].x, t[i].y, t[i].z, t[i].w};
+                        float f[8];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {   // saturate: the conversion itself returns NaN beyond the e4m3 range
+                            f[2 * k] = __builtin_amdgcn_fmed3f(__uint_as_float(w[k] << 16) * s, -448.0f, 448.0f);
+                            f[2 * k + 1] = __builtin_amdgcn_fmed3f(__uint_as_float(w[k] & 0xFFFF0000u) * s, -448.0f, 448.0f);
+                        }
+                        int lo = 0, hi = 0;
+                        lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], lo, false);
+                        lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
+                        hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], hi, false);
+                        hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
+                        *reinterpret_cast<uint2*>(p.C8 + crow + (size_t)(8 * i) * p.ldc) = make_uint2((unsigned)lo, (unsigned)hi);
+                    }
+                } else {
+                    uint16_t* cp = p.C + crow;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        *reinterpret_cast<uint4*>(cp + (size_t)(8 * i) * p.ldc) = uint4{t[i].x, t[i].y, t[i].z, t[i].w};
+                }
             }
             if constexpr (EPI == TT_EPI_RESIDUAL) __builtin_amdgcn_sched_barrier(0);   // keep the 4 stores in their block
         }
@@ -1068,8 +1091,12 @@ inline bool small_grid_v1() {
 // fp8 operands: the 256x256 kernels only (bias / GELU / V^T epilogues), K-tiles of 128 elements
 template <int EPI>
 int launch_fp8(const GemmParams& p, hipStream_t st) {
-    if constexpr (EPI == TT_EPI_BIAS || EPI == TT_EPI_GELU || EPI == TT_EPI_VT) {
+    if constexpr (EPI == TT_EPI_BIAS || EPI == TT_EPI_GELU || EPI == TT_EPI_VT || EPI == TT_EPI_RESIDUAL) {
         const int nk = p.K / 128;
+        if (EPI == TT_EPI_RESIDUAL && (!p.residual || p.ldr % 8)) {
+            tt_set_error("gemm fp8: residual epilogue without residual");
+            return TT_E_INVALID;
+        }
         if (p.M % v3::BM3 || p.N % v3::BN3 || p.K % 128 || nk < 2 || (nk & 1) || p.ldc % 8 || p.lda % 16 || !p.a_scale || !p.w_scale) {
             tt_set_error("gemm fp8: M=%d N=%d K=%d must be multiples of 256/256/256 with row / column scales", p.M, p.N, p.K);
             return TT_E_UNSUPPORTED;

@@ -300,6 +300,28 @@ __global__ __launch_bounds__(kRowThreads) void quantize_rows_kernel(const uint16
 }
 }  // namespace
 
+namespace {
+__global__ __launch_bounds__(256) void absmax_kernel(const uint16_t* x, size_t n8, float* out) {
+    float m = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+        float f[8];
+        unpack8(*reinterpret_cast<const uint4*>(x + i * 8), f);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) m = fmaxf(m, fabsf(f[k]));
+    }
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(reinterpret_cast<unsigned int*>(out), __float_as_uint(m));   // m >= 0: bit order = value order
+}
+}  // namespace
+
+// *out = max(*out, max |x|) over n bf16 values (n a multiple of 8); NaNs are ignored
+int tt_absmax_launch(const uint16_t* x, size_t n, float* out, hipStream_t st) {
+    if (n == 0) return TT_OK;
+    hipLaunchKernelGGL(absmax_kernel, dim3(2048), dim3(256), 0, st, x, n / 8, out);
+    TT_CHECK_LAUNCH();
+    return TT_OK;
+}
+
 int tt_quantize_rows_launch(const uint16_t* in, int ld, int rows, int cols, uint8_t* q8, float* scale, hipStream_t st) {
     if (rows <= 0) return TT_OK;
     if (cols <= 0 || cols % 8 || ld % 8) {

@@ -60,7 +60,8 @@ KNOWN_CONFIGS = {
 class _LayerW(Structure):
     _fields_ = [(n, c_void_p) for n in ("qkv_w", "qkv_b", "o_w", "o_b", "ln1_g", "ln1_b", "ffn1_w", "ffn1_b",
                                         "ffn2_w", "ffn2_b", "ln2_g", "ln2_b",
-                                        "qkv_w8", "qkv_wscale", "ffn1_w8", "ffn1_wscale")]
+                                        "qkv_w8", "qkv_wscale", "ffn1_w8", "ffn1_wscale",
+                                        "o_w8", "o_wscale", "ffn2_w8", "ffn2_wscale")] + [("ffn_act_scale", c_float)]
 
 
 class _EncW(Structure):
@@ -70,6 +71,7 @@ class _EncW(Structure):
         ("word_emb", c_void_p), ("pos_emb", c_void_p), ("type_emb", c_void_p), ("emb_ln_g", c_void_p),
         ("emb_ln_b", c_void_p), ("layer", POINTER(_LayerW)),
         ("cls_dense_w", c_void_p), ("cls_dense_b", c_void_p), ("cls_out_w", c_void_p), ("cls_out_b", c_void_p),
+        ("ffn_absmax_out", c_void_p),
     ]
 
 
@@ -122,7 +124,10 @@ class EncoderWeights:
         self._layers = (_LayerW * max(cfg.layers, 1))()
         self._qkv_w: List[torch.Tensor] = []
         self._ffn1_w: List[torch.Tensor] = []
+        self._o_w: List[torch.Tensor] = []
+        self._ffn2_w: List[torch.Tensor] = []
         self._fp8: List[torch.Tensor] = []
+        self.ffn_act_scales: Optional[List[float]] = None   # per layer, from calibrate_fp8()
         self.gemm_dtype = "bf16"
         for i in range(cfg.layers):
             p = f"encoder.layer.{i}."
@@ -134,13 +139,17 @@ class EncoderWeights:
             self._qkv_w.append(qkv_w)
             L = self._layers[i]
             L.qkv_w, L.qkv_b = qkv_w.data_ptr(), qkv_b.data_ptr()
-            L.o_w, L.o_b = mat(p + "attention.output.dense.weight").data_ptr(), vec(p + "attention.output.dense.bias").data_ptr()
+            o_w = mat(p + "attention.output.dense.weight")
+            self._o_w.append(o_w)
+            L.o_w, L.o_b = o_w.data_ptr(), vec(p + "attention.output.dense.bias").data_ptr()
             L.ln1_g = vec(p + "attention.output.LayerNorm.weight").data_ptr()
             L.ln1_b = vec(p + "attention.output.LayerNorm.bias").data_ptr()
             ffn1_w = mat(p + "intermediate.dense.weight")
             self._ffn1_w.append(ffn1_w)
             L.ffn1_w, L.ffn1_b = ffn1_w.data_ptr(), vec(p + "intermediate.dense.bias").data_ptr()
-            L.ffn2_w, L.ffn2_b = mat(p + "output.dense.weight").data_ptr(), vec(p + "output.dense.bias").data_ptr()
+            ffn2_w = mat(p + "output.dense.weight")
+            self._ffn2_w.append(ffn2_w)
+            L.ffn2_w, L.ffn2_b = ffn2_w.data_ptr(), vec(p + "output.dense.bias").data_ptr()
             L.ln2_g = vec(p + "output.LayerNorm.weight").data_ptr()
             L.ln2_b = vec(p + "output.LayerNorm.bias").data_ptr()
         w = _EncW()
@@ -169,28 +178,34 @@ class EncoderWeights:
         return w8, scale
 
     def set_gemm_dtype(self, dtype: str) -> None:
-        """"bf16" (default) or "fp8": the Q/K/V and FFN-up projections (the GEMMs whose input is a LayerNorm output)
-        run on OCP e4m3 operands -- weights quantised here per output channel, activations per token inside the
-        LayerNorm kernels -- with fp32 accumulation (BASELINE.json config 5, "fp8 MFMA reranker").  Needs hidden and
-        ffn to be multiples of 256; the bf16 weights stay resident for the other GEMMs and the CLS tail."""
+        """"bf16" (default) or "fp8": the encoder layers' projections run on OCP e4m3 operands with fp32 accumulation
+        (BASELINE.json config 5, "fp8 MFMA reranker").  Weights are quantised here per output channel; activations
+        per token inside the LayerNorm kernels (Q/K/V, FFN-up inputs) or by a row pass (attention context); the FFN
+        intermediate is written as e4m3 by the FFN-up epilogue with one static scale per layer, which needs
+        ``calibrate_fp8`` first -- without it the FFN output projection stays bf16.  Needs hidden and ffn to be
+        multiples of 256; the bf16 weights stay resident (CLS tail, small batches)."""
         if dtype not in ("bf16", "fp8"):
             raise ValueError(f"gemm dtype {dtype!r} not in ('bf16', 'fp8')")
+        n = self.cfg.layers
         if dtype == "fp8":
             if self.cfg.hidden % 256 or self.cfg.ffn % 256:
                 raise ValueError("fp8 GEMMs need hidden and ffn to be multiples of 256")
             if not self._fp8:
-                for i in range(self.cfg.layers):
-                    q8, qs = self._quantize_rows(self._qkv_w[i])
-                    f8, fs = self._quantize_rows(self._ffn1_w[i])
-                    self._fp8 += [q8, qs, f8, fs]
-            for i in range(self.cfg.layers):
+                for i in range(n):
+                    for w in (self._qkv_w[i], self._ffn1_w[i], self._o_w[i], self._ffn2_w[i]):
+                        self._fp8 += list(self._quantize_rows(w))
+            for i in range(n):
                 L = self._layers[i]
-                q8, qs, f8, fs = self._fp8[4 * i: 4 * i + 4]
+                q8, qs, f8, fs, o8, os_, d8, ds = self._fp8[8 * i: 8 * i + 8]
                 L.qkv_w8, L.qkv_wscale, L.ffn1_w8, L.ffn1_wscale = q8.data_ptr(), qs.data_ptr(), f8.data_ptr(), fs.data_ptr()
+                L.o_w8, L.o_wscale, L.ffn2_w8, L.ffn2_wscale = o8.data_ptr(), os_.data_ptr(), d8.data_ptr(), ds.data_ptr()
+                L.ffn_act_scale = float(self.ffn_act_scales[i]) if self.ffn_act_scales else 0.0
         else:
-            for i in range(self.cfg.layers):
+            for i in range(n):
                 L = self._layers[i]
                 L.qkv_w8 = L.qkv_wscale = L.ffn1_w8 = L.ffn1_wscale = None
+                L.o_w8 = L.o_wscale = L.ffn2_w8 = L.ffn2_wscale = None
+                L.ffn_act_scale = 0.0
         self.gemm_dtype = dtype
 
     def parameters(self) -> Iterable[torch.Tensor]:
@@ -393,6 +408,24 @@ class Encoder:
                                         hidden.data_ptr(), base, need, torch.cuda.current_stream(dev).cuda_stream)
         _lib.check(rc, "tt_encoder_forward")
         return hidden, starts
+
+    def calibrate_fp8(self, batch: PackedBatch, margin: float = 2.0) -> List[float]:
+        """One bf16 forward over ``batch`` that records max |GELU output| per layer (``ffn_absmax_out`` hook) and sets
+        the static e4m3 scales of the FFN intermediate, ``margin * max / 448`` (values beyond saturate).  Call before
+        ``weights.set_gemm_dtype("fp8")`` to move the FFN output projection to fp8 as well."""
+        w = self.w
+        prev = w.gemm_dtype
+        w.set_gemm_dtype("bf16")
+        absmax = torch.zeros(max(self.cfg.layers, 1), dtype=torch.float32, device=self.device)
+        w.struct.ffn_absmax_out = absmax.data_ptr()
+        try:
+            self.forward_packed(batch)
+            vals = absmax.cpu().tolist()
+        finally:
+            w.struct.ffn_absmax_out = None
+        w.ffn_act_scales = [max(v, 1e-6) * margin / 448.0 for v in vals[: self.cfg.layers]]
+        w.set_gemm_dtype(prev)
+        return w.ffn_act_scales
 
     def cls_hidden_packed(self, batch: PackedBatch) -> Tuple[torch.Tensor, torch.Tensor]:
         """-> (final hidden state of every sequence's CLS token [round_up(B,256), H] bf16, row ids [B] int32).

@@ -98,6 +98,43 @@ def test_gemm_fp8_exact_products(dev, built_lib, m, n, k, epi):
     assert (err <= 2.0 ** -7 * want.abs() + 1e-3).all(), (err.max().item(), want.abs().max().item())
 
 
+def test_gemm_fp8_residual_and_fp8_output(dev, built_lib):
+    from tensor_truth_amd import _lib
+
+    lib = _lib.load_library()
+    m, n, k = 512, 1024, 4096
+    g = torch.Generator().manual_seed(3)
+    a = torch.randn(m, k, generator=g).to(torch.bfloat16)
+    w = (0.05 * torch.randn(n, k, generator=g)).to(torch.bfloat16)
+    bias = torch.randn(n, generator=g)
+    res = torch.randn(m, n, generator=g).to(torch.bfloat16)
+    aq, sa = oe.quantize_rows_e4m3(a.float())
+    wq, sw = oe.quantize_rows_e4m3(w.float())
+    a8 = aq.to(torch.float8_e4m3fn).view(torch.uint8).to(dev)
+    w8 = wq.to(torch.float8_e4m3fn).view(torch.uint8).to(dev)
+    sad, swd, bd, rd = sa.reshape(-1).contiguous().to(dev), sw.reshape(-1).contiguous().to(dev), bias.to(dev), res.to(dev)
+    base = (aq.double() @ wq.double().T).float() * sa * sw.T + bias
+    # residual epilogue
+    c = torch.empty(m, n, dtype=torch.bfloat16, device=dev)
+    _lib.check(lib.tt_gemm_fp8_ex(a8.data_ptr(), sad.data_ptr(), w8.data_ptr(), swd.data_ptr(), bd.data_ptr(), rd.data_ptr(),
+                                  c.data_ptr(), None, 0.0, m, n, k, 2, _stream()), "gemm fp8 res")
+    want = base + res.float()
+    assert ((c.float().cpu() - want).abs() <= 2.0 ** -7 * want.abs() + 1e-3).all()
+    # GELU epilogue with an e4m3 result under a static scale: = e4m3(bf16(gelu) / s), saturating
+    sf = 0.02
+    c8 = torch.zeros(m, n, dtype=torch.uint8, device=dev)
+    _lib.check(lib.tt_gemm_fp8_ex(a8.data_ptr(), sad.data_ptr(), w8.data_ptr(), swd.data_ptr(), bd.data_ptr(), None, None,
+                                  c8.data_ptr(), 1.0 / sf, m, n, k, 1, _stream()), "gemm fp8 out8")
+    got = c8.cpu().view(torch.float8_e4m3fn).float()
+    want8 = (oe.gelu_erf(base).to(torch.bfloat16).float() / sf).clamp(-448, 448).to(torch.float8_e4m3fn).float()
+    assert torch.isfinite(got).all()
+    # one e4m3 step (2^-3 relative) where the bf16 rounding of the GELU value or an exact tie went the other way, plus
+    # the fp32 accumulation error of K = 4096 products (2e-4 on a pre-activation that cancels to ~0) in scaled units
+    close = (got - want8).abs() <= 0.125 * want8.abs() + 2e-4 / sf
+    assert close.all()
+    assert (got != want8).float().mean().item() < 0.02
+
+
 XENC = dict(arch="xlmr", vocab_size=2000, hidden=256, layers=2, heads=4, ffn=1024, max_pos=300, type_vocab=1,
             pad_id=1, ln_eps=1e-5, num_labels=1)
 
@@ -141,6 +178,19 @@ def test_fp8_forward_matches_its_emulation_and_stays_near_fp32(dev, built_lib):
     # (b) vs fp32: the stated fp8 bound (bf16 mode: 2e-2 on 24 layers; e4m3 has 3 mantissa bits)
     assert (s_fp8 - ref).abs().max().item() < 5e-2
     assert torch.isfinite(l_fp8).all()
+
+    # ---- all four projections: calibrate the FFN intermediate's static scales first
+    from tensor_truth_amd.encoder import pack_tokens
+
+    scales = enc.calibrate_fp8(pack_tokens(seqs, cfg, None, 512))
+    assert len(scales) == cfg.layers and all(s > 0 for s in scales)
+    weights.set_gemm_dtype("fp8")
+    s_all = enc.rerank(seqs).cpu()
+    weights.set_gemm_dtype("bf16")
+    assert not torch.equal(s_all, s_fp8)                                       # the FFN output projection changed path
+    emu_all = oe.rerank_scores(ids, mask, W, ocfg, emulate_bf16=True, emulate_fp8=True, ffn_act_scales=scales)
+    assert (s_all - emu_all).abs().max().item() < 1.5e-2
+    assert (s_all - ref).abs().max().item() < 5e-2
 
 
 def test_fp8_needs_tileable_shapes(dev, built_lib):
