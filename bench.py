@@ -232,6 +232,22 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt_embed = float(t.item())
     chunks_per_s = world * args.embed_chunks / dt_embed
+    if fp8_leg is not None:   # the ingest leg with the bi-encoder's layer projections in e4m3, same protocol
+        embedder.calibrate_fp8(chunk_batch)
+        embedder.w.set_gemm_dtype("fp8")
+        embedder.embed_packed(chunk_batch)
+        sync_all()
+        t1 = time.perf_counter()
+        for _ in range(2):
+            embedder.embed_packed(chunk_batch)
+        sync_all()
+        dt8e = (time.perf_counter() - t1) / 2
+        embedder.w.set_gemm_dtype("bf16")
+        if world > 1:
+            t = torch.tensor([dt8e], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt8e = float(t.item())
+        fp8_leg["chunks_embedded_per_s"] = world * args.embed_chunks / dt8e
 
     # ---- roofline of the dominant kernel (GEMM, MFMA-bound) and of the scan (HBM-bound) -------
     H, F, L = emb_cfg.hidden, emb_cfg.ffn, emb_cfg.layers

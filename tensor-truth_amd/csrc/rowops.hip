@@ -53,6 +53,7 @@ __device__ __forceinline__ uint2 pack_fp8x8(const float (&f)[8]) {
 // normalise x[kMaxChunks][8] (this lane's share of a row of H values) and store bf16; optionally also the
 // per-row fp8 quantisation of the bf16-rounded result (q8_row, *q8_scale = absmax / 448): the A operand of the
 // fp8 GEMMs, produced while the row is in registers
+template <bool NTS = false>
 __device__ __forceinline__ void ln_finish(float (&x)[kMaxChunks][8], int nchunk_total, int lane, int H, float eps,
                                           const float* gamma, const float* beta, uint16_t* out_row,
                                           uint8_t* q8_row = nullptr, float* q8_scale = nullptr) {
@@ -87,7 +88,12 @@ __device__ __forceinline__ void ln_finish(float (&x)[kMaxChunks][8], int nchunk_
 #pragma unroll
             for (int i = 0; i < 8; ++i) y[i] = (x[c][i] - mean) * rstd * g[i] + b[i];
             const uint4 packed = pack8(y);
-            *reinterpret_cast<uint4*>(out_row + ch * 8) = packed;
+            if constexpr (NTS) {
+                typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+                __builtin_nontemporal_store(u4v{packed.x, packed.y, packed.z, packed.w}, reinterpret_cast<u4v*>(out_row + ch * 8));
+            } else {
+                *reinterpret_cast<uint4*>(out_row + ch * 8) = packed;
+            }
             if (q8_row) unpack8(packed, x[c]);   // keep the bf16-rounded values for the quantisation pass
         }
     }
@@ -114,24 +120,44 @@ __device__ __forceinline__ void ln_finish(float (&x)[kMaxChunks][8], int nchunk_
     }
 }
 
+// NT bit 0: streaming (non-temporal) loads of the input, which is read exactly once (+7.5 %); bit 1: two rows per
+// wave, both rows' loads issued before either is reduced (measured slower); bit 2: streaming stores (+6 %).
+template <int NT>
 __global__ __launch_bounds__(kRowThreads) void layernorm_kernel(const uint16_t* in, uint16_t* out, const float* gamma,
                                                                const float* beta, int rows, int H, float eps, uint8_t* q8,
                                                                float* q8_scale) {
+    constexpr int RPW = (NT & 2) ? 2 : 1;
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * (kRowThreads / 64) + (threadIdx.x >> 6);
-    if (row >= rows) return;
+    const int row0 = (blockIdx.x * (kRowThreads / 64) + (threadIdx.x >> 6)) * RPW;
+    if (row0 >= rows) return;
     const int nch = H / 8;
-    float x[kMaxChunks][8];
+    float x[RPW][kMaxChunks][8];
 #pragma unroll
-    for (int c = 0; c < kMaxChunks; ++c) {
-        const int ch = lane + 64 * c;
-        if (ch < nch) {
-            const uint4 u = *reinterpret_cast<const uint4*>(in + (size_t)row * H + ch * 8);
-            unpack8(u, x[c]);
+    for (int r = 0; r < RPW; ++r) {
+        const int row = row0 + r < rows ? row0 + r : rows - 1;
+#pragma unroll
+        for (int c = 0; c < kMaxChunks; ++c) {
+            const int ch = lane + 64 * c;
+            if (ch < nch) {
+                uint4 u;
+                if constexpr (NT & 1) {
+                    typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+                    const u4v t = __builtin_nontemporal_load(reinterpret_cast<const u4v*>(in + (size_t)row * H + ch * 8));
+                    u = make_uint4(t.x, t.y, t.z, t.w);
+                } else {
+                    u = *reinterpret_cast<const uint4*>(in + (size_t)row * H + ch * 8);
+                }
+                unpack8(u, x[r][c]);
+            }
         }
     }
-    ln_finish(x, nch, lane, H, eps, gamma, beta, out + (size_t)row * H, q8 ? q8 + (size_t)row * H : nullptr,
-              q8 ? q8_scale + row : nullptr);
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        const int row = row0 + r;
+        if (row < rows)
+            ln_finish<(NT & 4) != 0>(x[r], nch, lane, H, eps, gamma, beta, out + (size_t)row * H,
+                                     q8 ? q8 + (size_t)row * H : nullptr, q8 ? q8_scale + row : nullptr);
+    }
 }
 
 __global__ __launch_bounds__(kRowThreads) void embed_ln_kernel(EmbedParams p) {
@@ -266,8 +292,21 @@ int tt_layernorm_launch(const uint16_t* in, uint16_t* out, const float* gamma, c
                         float eps, hipStream_t st, uint8_t* q8, float* q8_scale) {
     if (rows <= 0) return TT_OK;
     if (int rc = check_h(H)) return rc;
-    hipLaunchKernelGGL(layernorm_kernel, row_grid(rows), dim3(kRowThreads), 0, st, in, out, gamma, beta, rows, H, eps, q8,
-                       q8_scale);
+    // default 5 = streaming loads + streaming stores: 0.197 -> 0.172 ms for 236800 x 1024 (4.9 -> 5.6 TB/s) with the
+    // caches cold as they are between two GEMMs, -0.8 ms per bench step; two rows per wave (3) measured slower
+    static const int nt = [] { const char* e = getenv("TT_LN_NT"); return e && e[0] ? atoi(e) : 5; }();
+    if (nt == 3)
+        hipLaunchKernelGGL(layernorm_kernel<3>, row_grid((rows + 1) / 2), dim3(kRowThreads), 0, st, in, out, gamma, beta, rows, H,
+                           eps, q8, q8_scale);
+    else if (nt == 5)
+        hipLaunchKernelGGL(layernorm_kernel<5>, row_grid(rows), dim3(kRowThreads), 0, st, in, out, gamma, beta, rows, H, eps, q8,
+                           q8_scale);
+    else if (nt == 1)
+        hipLaunchKernelGGL(layernorm_kernel<1>, row_grid(rows), dim3(kRowThreads), 0, st, in, out, gamma, beta, rows, H, eps, q8,
+                           q8_scale);
+    else
+        hipLaunchKernelGGL(layernorm_kernel<0>, row_grid(rows), dim3(kRowThreads), 0, st, in, out, gamma, beta, rows, H, eps, q8,
+                           q8_scale);
     TT_CHECK_LAUNCH();
     return TT_OK;
 }
