@@ -23,6 +23,7 @@ struct GemmParams {
     // one static scale for the whole tensor (the FFN intermediate, whose rows span 16 tiles); C is not written
     uint8_t* C8;
     float c8_inv_scale;
+    int nt_store;             // whole-line output stores issued as streaming stores (set by the launcher)
 };
 int tt_gemm_launch(const GemmParams& p, int epilogue, hipStream_t st);
 
