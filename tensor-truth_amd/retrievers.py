@@ -38,18 +38,40 @@ class MultiIndexRetriever:
     """
 
     def __init__(self, retrievers: List, max_workers: Optional[int] = None, enable_cache: bool = True,
-                 cache_size: int = 128, balance_strategy: str = "top_k_per_index") -> None:
+                 cache_size: int = 128, balance_strategy: str = "top_k_per_index",
+                 share_query_embedding: bool = True) -> None:
         self.retrievers = retrievers
         self.max_workers = max_workers or min(len(retrievers), 8)
         self.enable_cache = enable_cache
         self.balance_strategy = balance_strategy
+        # The reference embeds the query once PER INDEX (every VectorIndexRetriever calls the embed model itself,
+        # SURVEY.md section 8 row a4).  When every retriever searches with the same embed-model object the embedding
+        # is computed once here and handed down in the QueryBundle: same vectors, n_indexes x fewer encoder passes.
+        self.share_query_embedding = share_query_embedding
         if enable_cache:
             self._retrieve_cached = lru_cache(maxsize=cache_size)(self._retrieve_impl)
         else:
             self._retrieve_cached = self._retrieve_impl
 
+    def _shared_embed_model(self):
+        models = []
+        for r in self.retrievers:
+            base = getattr(r, "_vector_retriever", r)            # AutoMergingRetriever wraps the index retriever
+            em = getattr(getattr(base, "index", None), "embed_model", None)
+            if em is None or not hasattr(em, "get_agg_embedding_from_queries"):
+                return None
+            models.append(em)
+        return models[0] if models and all(m is models[0] for m in models) else None
+
     def _retrieve_impl(self, query_text: str):
         bundle = QueryBundle(query_str=query_text)
+        if self.share_query_embedding and len(self.retrievers) > 1:
+            em = self._shared_embed_model()
+            if em is not None:
+                try:
+                    bundle.embedding = list(em.get_agg_embedding_from_queries(bundle.embedding_strs))
+                except Exception:  # noqa: BLE001 - fall back to per-index embedding, as the reference does it
+                    bundle.embedding = None
         combined = []
         with ThreadPoolExecutor(max_workers=max(1, self.max_workers)) as pool:
             futures = {pool.submit(r.retrieve, bundle): i for i, r in enumerate(self.retrievers)}

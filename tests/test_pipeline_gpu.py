@@ -156,6 +156,50 @@ def test_rerank_postprocessor_and_service(dev, built_lib):
     mm.ModelManager.reset_instance()
 
 
+def test_multi_index_embeds_the_query_once(dev, built_lib):
+    """MultiIndexRetriever over indexes that share one embed model: one encoder pass per query instead of one per
+    index (reference behaviour), same nodes and scores either way."""
+    from tensor_truth_amd.embedding import HipHuggingFaceEmbedding
+    from tensor_truth_amd.encoder import EncoderConfig
+    from tensor_truth_amd.retrievers import AutoMergingRetriever, MultiIndexRetriever
+    from tensor_truth_amd.schema import TextNode
+    from tensor_truth_amd.vector_index import HipVectorIndex
+
+    cfg = EncoderConfig(**SMALL)
+    emb = HipHuggingFaceEmbedding("test/bge-small-shaped", device="cuda",
+                                  model_kwargs={"encoder_config": cfg, "synthetic_seed": 21})
+    texts = _texts(90)
+    retrievers = []
+    for part in range(3):
+        ix = HipVectorIndex(cfg.hidden, embed_model=emb)
+        ix.add([TextNode(text=t, id_=f"i{part}_{j}") for j, t in enumerate(texts[part * 30:(part + 1) * 30])])
+        retrievers.append(AutoMergingRetriever(ix.as_retriever(similarity_top_k=5), ix.docstore))
+    calls = {"n": 0}
+    orig = emb.get_agg_embedding_from_queries
+
+    def counting(qs):
+        calls["n"] += 1
+        return orig(qs)
+
+    emb.get_agg_embedding_from_queries = counting
+    dev_calls = {"n": 0}
+    orig_dev = emb.query_embedding_device
+
+    def counting_dev(qs):
+        dev_calls["n"] += 1
+        return orig_dev(qs)
+
+    emb.query_embedding_device = counting_dev
+    shared = MultiIndexRetriever(retrievers, enable_cache=False).retrieve("matrix kernel wave")
+    assert calls["n"] == 1 and dev_calls["n"] == 0
+    separate = MultiIndexRetriever(retrievers, enable_cache=False, share_query_embedding=False).retrieve("matrix kernel wave")
+    assert dev_calls["n"] == 3
+    key = lambda n: (n.node.metadata["_source_index"], n.node.id_)  # noqa: E731
+    assert sorted(map(key, shared)) == sorted(map(key, separate))
+    by_id = {key(n): n.score for n in separate}
+    assert all(abs(n.score - by_id[key(n)]) < 1e-5 for n in shared)
+
+
 def test_devices_other_than_hip_are_refused(built_lib):
     from tensor_truth_amd.embedding import HipHuggingFaceEmbedding
 
