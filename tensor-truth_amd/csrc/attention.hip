@@ -184,14 +184,13 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attention_kernel(AttnParams p)
         // tracked in the scaled domain; v_exp_f32 is used raw (arguments are <= 0, a result that
         // underflows is 0 either way), the libm exp2f wraps it in 5 more instructions per value.
         // Register r of tile j is key k0 + 32 j + 16 (r>>3) + 8 hh + (r & 7)  (permuted K rows).
-        if (k0 + kKTile > len) {   // wave-uniform
+        if (k0 + kKTile > len) {   // wave-uniform; one compare per value against a lane constant, no index arithmetic
+            const int lim = len - k0 - 8 * hh;   // register r of tile j is masked iff 32 j + 16 (r>>3) + (r&7) >= lim
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = k0 + 32 * j + 16 * (r >> 3) + 8 * hh + (r & 7);
-                    if (key >= len) acc_s[j][r] = -__builtin_inff();
-                }
+                for (int r = 0; r < 16; ++r)
+                    if (32 * j + 16 * (r >> 3) + (r & 7) >= lim) acc_s[j][r] = -__builtin_inff();
         }
         float mx = -__builtin_inff();
 #pragma unroll
@@ -215,7 +214,7 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attention_kernel(AttnParams p)
                 psum2 += e;
             }
         l_run = l_run * alpha + (psum2.x + psum2.y);
-        if (!__all(alpha == 1.0f)) {          // the running max rarely moves after the first tiles
+        if (kt > 0 && !__all(alpha == 1.0f)) {   // (first tile: O is still zero) the running max rarely moves later
 #pragma unroll
             for (int d = 0; d < DT; ++d)
 #pragma unroll
