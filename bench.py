@@ -41,7 +41,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--corpus-rows", type=int, default=10_000_000, help="total rows, sharded over the GPUs")
     ap.add_argument("--dim", type=int, default=1024)
-    ap.add_argument("--queries-per-gpu", type=int, default=16)
+    ap.add_argument("--queries-per-gpu", type=int, default=32,
+                    help="query batch per GPU and step (measured on one MI355X: 16 -> 107, 32 -> 112, 64 -> 111, 128 -> 114 q/s: "
+                         "the per-batch embed / scan latency and the GEMMs' tail rounds amortise)")
     ap.add_argument("--top-k", type=int, default=50)
     ap.add_argument("--top-n", type=int, default=10)
     ap.add_argument("--query-len", type=int, default=32)
@@ -271,7 +273,7 @@ def main():
     # profiles/r01_pmc_traffic.json holds them for exactly this default single-GPU command
     # (tools/gpu_pmc_bench.sh + tools/pmc_to_traffic.py), otherwise null.
     traffic = {"gemm": None, "scan_filter": None}
-    default_cfg = (world == 1 and args.corpus_rows == 10_000_000 and D == 1024 and Bq == 16 and K == 50
+    default_cfg = (world == 1 and args.corpus_rows == 10_000_000 and D == 1024 and Bq == 32 and K == 50
                    and args.chunk_len == 256 and args.query_len == 32 and L == 24)
     tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
     if default_cfg and os.path.exists(tpath):

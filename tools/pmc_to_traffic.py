@@ -26,7 +26,9 @@ def main(fetch_dir, write_dir, out):
         fr = [r for r in load(fetch_dir, "FETCH_SIZE") if match in r["Kernel_Name"]]
         wr = [r for r in load(write_dir, "WRITE_SIZE") if match in r["Kernel_Name"]]
         if kind == "gemm":
-            per_step = 241  # 2 forwards x 24 layers x 5 GEMM launches + the rerank-head GEMM
+            # rerank forward: 24 layers x 5 launches (QKV as two) + the head GEMM; query-embedding forward (small grid,
+            # 128x128 kernel, fused QKV): 24 x 4
+            per_step = 121 + 96
             fr, wr = fr[per_step:2 * per_step], wr[per_step:2 * per_step]
         else:
             fr, wr = fr[1:2], wr[1:2]
