@@ -266,3 +266,30 @@ def test_cls_only_last_layer_matches_full_forward(dev, built_lib, shape):
     err = (got - want).abs()
     assert (err <= 2 ** -6 * want.abs() + 2e-2).all(), err.max().item()
     assert err.mean().item() < 3e-3
+
+
+def test_forward_is_bit_reproducible(dev, built_lib):
+    """The GEMM / attention kernels order their LDS-DMA copies with hand-counted waits: a mis-counted one would show up
+    as an occasional different bit.  Same batch, same weights -> the same bits every time (bf16 and fp8 modes);
+    tools/probes/soak.py is the long version."""
+    import numpy as np
+
+    from tensor_truth_amd.encoder import Encoder, EncoderConfig, EncoderWeights, pack_token_matrix
+
+    cfg = EncoderConfig(arch="xlmr", vocab_size=3000, hidden=1024, layers=2, heads=16, ffn=4096, max_pos=300, type_vocab=1,
+                        pad_id=1, ln_eps=1e-5, num_labels=1)
+    ocfg = oe.EncoderConfig(**cfg.__dict__)
+    W = {k: v.to(torch.bfloat16) for k, v in oe.synth_weights(ocfg, seed=9).items()}
+    enc = Encoder(EncoderWeights(cfg, W, dev))
+    rng = np.random.default_rng(0)
+    pairs = rng.integers(4, cfg.vocab_size, size=(300, 292), dtype=np.int32)
+    pairs[:, 0], pairs[:, -1] = 0, 2
+    batch = pack_token_matrix(pairs, cfg)          # 88800 rows: hundreds of tiles per GEMM, several per CU
+    for mode in ("bf16", "fp8"):
+        if mode == "fp8":
+            enc.calibrate_fp8(pack_token_matrix(pairs[:32], cfg))
+            enc.w.set_gemm_dtype("fp8")
+        ref = enc.rerank_packed(batch).clone()
+        assert torch.isfinite(ref).all()
+        for _ in range(10):
+            assert torch.equal(enc.rerank_packed(batch), ref), mode
