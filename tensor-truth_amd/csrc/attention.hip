@@ -63,6 +63,10 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attention_kernel(AttnParams p)
     const int len = p.seq_len[seq];
     if (qt * 32 * kWaves >= len) return;
     const int t0 = p.seq_start[seq];
+    // Sequences may start at any row.  Keys are walked in the ALIGNED frame of the V8 token groups: aligned key ka is
+    // global row t0a + ka, t0a = t0 rounded down to 8; the off = t0 - t0a rows in front of the sequence (the tail of its
+    // predecessor) and everything from off + len on are masked.
+    const int t0a = t0 & ~7, off = t0 - t0a, alen = off + len;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ql = lane & 31, hh = lane >> 5;
@@ -76,13 +80,13 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attention_kernel(AttnParams p)
 #pragma unroll
     for (int s = 0; s < KS; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + s * 16);
 
-    const int n_kt = (len + kKTile - 1) / kKTile;
-    const int n_g8 = (len + 7) >> 3;
+    const int n_kt = (alen + kKTile - 1) / kKTile;
+    const int n_g8 = (alen + 7) >> 3;
     // ---- staging: wave w copies K pieces w*KPW.. and V pieces w*VPW.. of each tile.  Per-lane row / token-group
     // indices are loop constants; rows / groups beyond the sequence are clamped to its last one (finite values;
     // their probabilities are 0) -- only the last tile can need that.
-    const uint16_t* kbase = p.qk + (size_t)t0 * p.ld_qk + p.k_col0 + head * DH;
-    const uint16_t* vbase = p.vt + (size_t)(t0 >> 3) * p.ldvt + (size_t)head * DH * 8;
+    const uint16_t* kbase = p.qk + (size_t)t0a * p.ld_qk + p.k_col0 + head * DH;
+    const uint16_t* vbase = p.vt + (size_t)(t0a >> 3) * p.ldvt + (size_t)head * DH * 8;
     int krow_l[KPW], kcol_l[KPW], vg_l[VPW], vcol_l[VPW];
 #pragma unroll
     for (int i = 0; i < KPW; ++i) {
@@ -99,11 +103,11 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attention_kernel(AttnParams p)
     }
     auto issue_tile = [&](int kt) {
         char* buf = lds + (kt & 1) * BUF;
-        const bool clamp = (kt + 1) * kKTile > len;   // wave-uniform
+        const bool clamp = (kt + 1) * kKTile > alen || (kt == 0 && off != 0);   // wave-uniform
 #pragma unroll
         for (int i = 0; i < KPW; ++i) {
             int row = kt * kKTile + krow_l[i];
-            if (clamp) row = row < len ? row : len - 1;
+            if (clamp) row = row < off ? off : (row < alen ? row : alen - 1);   // rows of this sequence only
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kbase + (size_t)row * p.ld_qk + kcol_l[i]),
                                              (__attribute__((address_space(3))) void*)(buf + (wave * KPW + i) * 1024), 16, 0, 0);
         }
@@ -184,8 +188,15 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attention_kernel(AttnParams p)
         // tracked in the scaled domain; v_exp_f32 is used raw (arguments are <= 0, a result that
         // underflows is 0 either way), the libm exp2f wraps it in 5 more instructions per value.
         // Register r of tile j is key k0 + 32 j + 16 (r>>3) + 8 hh + (r & 7)  (permuted K rows).
-        if (k0 + kKTile > len) {   // wave-uniform; one compare per value against a lane constant, no index arithmetic
-            const int lim = len - k0 - 8 * hh;   // register r of tile j is masked iff 32 j + 16 (r>>3) + (r&7) >= lim
+        if (kt == 0 && off != 0) {   // wave-uniform: the first off (< 8) aligned keys belong to the previous sequence
+            if (hh == 0) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+                    if (r < off) acc_s[0][r] = -__builtin_inff();
+            }
+        }
+        if (k0 + kKTile > alen) {   // wave-uniform; one compare per value against a lane constant, no index arithmetic
+            const int lim = alen - k0 - 8 * hh;   // register r of tile j is masked iff 32 j + 16 (r>>3) + (r&7) >= lim
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -280,6 +291,7 @@ __global__ __launch_bounds__(64) void attention_cls_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) float probs[];   // [max_len rounded up to 8]
     const int seq = blockIdx.x, head = blockIdx.y, lane = threadIdx.x;
     const int len = p.seq_len[seq], t0 = p.seq_start[seq];
+    const int t0a = t0 & ~7, off = t0 - t0a, alen = off + len;   // aligned key frame, as in attention_kernel
     // query row -> registers (every lane holds the whole q: uniform address)
     float q[DH];
     {
@@ -295,8 +307,8 @@ __global__ __launch_bounds__(64) void attention_cls_kernel(AttnParams p) {
     }
     const float sc = p.scale * 1.4426950408889634f;
     float mx = -__builtin_inff();
-    for (int j = lane; j < len; j += 64) {
-        const uint16_t* kp = p.qk + (size_t)(t0 + j) * p.ld_qk + p.k_col0 + head * DH;
+    for (int j = off + lane; j < alen; j += 64) {
+        const uint16_t* kp = p.qk + (size_t)(t0a + j) * p.ld_qk + p.k_col0 + head * DH;
         float acc = 0.f;
 #pragma unroll
         for (int c = 0; c < DH / 8; ++c) {
@@ -317,11 +329,11 @@ __global__ __launch_bounds__(64) void attention_cls_kernel(AttnParams p) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
     float sum = 0.f;
-    const int len8 = (len + 7) & ~7;
+    const int len8 = (alen + 7) & ~7;
     for (int j = lane; j < len8; j += 64) {
         float e = 0.f;
-        if (j < len) e = __builtin_amdgcn_exp2f(probs[j] - mx);
-        probs[j] = e;      // keys beyond len (same 8-group) get probability 0
+        if (j >= off && j < alen) e = __builtin_amdgcn_exp2f(probs[j] - mx);
+        probs[j] = e;      // aligned keys outside the sequence (same 8-groups) get probability 0
         sum += e;
     }
 #pragma unroll
@@ -331,8 +343,8 @@ __global__ __launch_bounds__(64) void attention_cls_kernel(AttnParams p) {
     constexpr int PARTS = 64 / DH;
     const int d = lane % DH, part = lane / DH;
     float o = 0.f;
-    for (int g8 = part; g8 * 8 < len; g8 += PARTS) {
-        const uint4 u = *reinterpret_cast<const uint4*>(p.vt + (size_t)(t0 / 8 + g8) * p.ldvt + (size_t)(head * DH + d) * 8);
+    for (int g8 = part; g8 * 8 < alen; g8 += PARTS) {
+        const uint4 u = *reinterpret_cast<const uint4*>(p.vt + (size_t)(t0a / 8 + g8) * p.ldvt + (size_t)(head * DH + d) * 8);
         const float4 pa = *reinterpret_cast<const float4*>(probs + g8 * 8);
         const float4 pb = *reinterpret_cast<const float4*>(probs + g8 * 8 + 4);
         o = fmaf(pa.x, __uint_as_float(u.x << 16), o); o = fmaf(pa.y, __uint_as_float(u.x & 0xFFFF0000u), o);
@@ -369,7 +381,7 @@ int tt_attention_launch(const AttnParams& p, hipStream_t st) {
 // out: [n_seq][ld_out] (row = sequence index, NOT token row)
 int tt_attention_cls_launch(const AttnParams& p, hipStream_t st) {
     if (p.n_seq <= 0) return TT_OK;
-    const size_t lds = (size_t)((p.max_len + 7) / 8 * 8) * sizeof(float);
+    const size_t lds = (size_t)((p.max_len + 14) / 8 * 8) * sizeof(float);   // aligned key frame: up to 7 leading slots
     if (lds > 160 * 1024) {
         tt_set_error("attention_cls: max_len %d exceeds the LDS score buffer", p.max_len);
         return TT_E_UNSUPPORTED;

@@ -12,6 +12,7 @@ option, ``model_manager.py:218-229``); there is no CPU path.
 from __future__ import annotations
 
 import ctypes
+import os
 import threading
 from ctypes import POINTER, Structure, c_float, c_int32, c_void_p
 from dataclasses import dataclass
@@ -289,6 +290,11 @@ def synthetic_state_device(cfg: EncoderConfig, device: torch.device, seed: int =
     return W
 
 
+# rows between sequence starts are rounded up to this (1 = back to back; 8 = every sequence owns its V8 token groups,
+# the layout before the attention kernels learned to mask shared groups): timing experiments only
+_PACK_ALIGN = max(1, int(os.environ.get("TT_PACK_ALIGN", "1")))
+
+
 @dataclass
 class PackedBatch:
     """Varlen packed token batch (host arrays): see include/tt_hip.h 'Token layout'."""
@@ -296,7 +302,7 @@ class PackedBatch:
     ids: np.ndarray        # [n_rows] int32
     pos: np.ndarray        # [n_rows] int32
     types: Optional[np.ndarray]
-    seq_start: np.ndarray  # [B] int32, multiples of 8
+    seq_start: np.ndarray  # [B] int32 (any row: the attention kernels mask the shared 8-row token groups)
     seq_len: np.ndarray    # [B] int32
     n_rows: int            # multiple of 128
     max_len: int
@@ -305,8 +311,8 @@ class PackedBatch:
 
 def pack_tokens(seqs: Sequence[Sequence[int]], cfg: EncoderConfig,
                 type_ids: Optional[Sequence[Sequence[int]]] = None, max_len: Optional[int] = None) -> PackedBatch:
-    """Pack token-id sequences (already carrying their special tokens) without padding
-    tokens: sequence starts are aligned to 8 rows, the total to 128 rows.  Sequences longer
+    """Pack token-id sequences (already carrying their special tokens) back to back, without padding
+    tokens between them; only the total is rounded up, to the 256-row GEMM tile.  Sequences longer
     than ``max_len`` (default: the model's limit) are truncated on the right, as the
     reference's tokenizer call does (``truncation=True``)."""
     limit = cfg.max_seq_len if max_len is None else min(max_len, cfg.max_seq_len)
@@ -317,7 +323,7 @@ def pack_tokens(seqs: Sequence[Sequence[int]], cfg: EncoderConfig,
     off = 0
     for i, n in enumerate(lens):
         starts[i] = off
-        off += (int(n) + 7) // 8 * 8
+        off += (int(n) + _PACK_ALIGN - 1) // _PACK_ALIGN * _PACK_ALIGN
     n_rows = max(256, (off + 255) // 256 * 256)   # multiple of 256: the 256-row GEMM tile
     ids = np.full(n_rows, cfg.pad_id, dtype=np.int32)
     pos = np.zeros(n_rows, dtype=np.int32)
@@ -345,7 +351,7 @@ def pack_token_matrix(ids2d: np.ndarray, cfg: EncoderConfig, type_ids2d: Optiona
     if length > cfg.max_seq_len:
         ids2d = ids2d[:, : cfg.max_seq_len]
         length = cfg.max_seq_len
-    stride = (length + 7) // 8 * 8
+    stride = (length + _PACK_ALIGN - 1) // _PACK_ALIGN * _PACK_ALIGN
     n_rows = max(256, (n * stride + 255) // 256 * 256)
     ids = np.full(n_rows, cfg.pad_id, dtype=np.int32)
     pos = np.zeros(n_rows, dtype=np.int32)

@@ -89,10 +89,11 @@ def test_layernorm(dev, built_lib, rows, h, eps):
     assert (err <= 2 ** -7 * ref.abs() + 2e-3).all(), err.max().item()
 
 
+@pytest.mark.parametrize("align", [8, 1])
 @pytest.mark.parametrize("heads,dh,lens", [(16, 64, [16, 9, 5, 12]), (12, 32, [16, 7, 11, 3]),
                                            (4, 64, [300, 64, 65, 129, 1]), (2, 32, [513, 128]),
                                            (2, 64, [1100])])
-def test_attention_varlen(dev, built_lib, heads, dh, lens):
+def test_attention_varlen(dev, built_lib, heads, dh, lens, align):
     from tensor_truth_amd import _lib
 
     lib = _lib.load_library()
@@ -101,7 +102,7 @@ def test_attention_varlen(dev, built_lib, heads, dh, lens):
     starts, off = [], 0
     for n in lens:
         starts.append(off)
-        off += (n + 7) // 8 * 8
+        off += (n + align - 1) // align * align      # align 1: sequences share 8-row token groups
     T = (off + 127) // 128 * 128
     q = _bf(torch.randn(T, H, generator=g))
     k = _bf(torch.randn(T, H, generator=g))
