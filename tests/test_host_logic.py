@@ -286,3 +286,44 @@ def test_semantic_splitter_host_logic():
     assert breakpoints_from_distances([0.1, 0.2, 0.9, 0.15, 0.8, 0.1], 95) == [2]
     assert breakpoints_from_distances([0.1, 0.2, 0.9, 0.15, 0.8, 0.1], 60) == [2, 4]
     assert breakpoints_from_distances([], 95) == []
+
+
+# ---- fp8 emulation in the oracle (what the HIP fp8 mode is checked against) ------------------------------------------
+def test_oracle_e4m3_quantisation_properties():
+    import torch
+
+    from oracle import encoder as oe
+
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(64, 512, generator=g) * torch.logspace(-3, 2, 64).unsqueeze(1)
+    x[5] = 0
+    q, s = oe.quantize_rows_e4m3(x)
+    assert q.abs().max().item() == 448.0 and s[5].item() == 1.0 and (q[5] == 0).all()
+    assert torch.equal(q, q.to(torch.float8_e4m3fn).float())                       # values ARE e4m3 numbers
+    back = q * s
+    amax = x.abs().amax(1, keepdim=True)
+    # 3 mantissa bits: relative error <= 2^-4 for normal values, absolute <= half a subnormal step (2^-10 in scaled units)
+    err = (back - x).abs()
+    assert (err <= x.abs() * 2.0 ** -4 + amax / 448 * 2.0 ** -10 + 1e-30).all()
+    # per-token x per-channel fp8 linear stays within a few percent of the fp32 one
+    w = torch.randn(128, 512, generator=g) * 0.05
+    b = torch.randn(128, generator=g)
+    y8, y = oe.linear_fp8(x[:8], w, b), x[:8] @ w.T + b
+    rel = (y8 - y).norm(dim=1) / y.norm(dim=1)
+    assert rel.max().item() < 0.06
+
+
+def test_oracle_fp8_forward_close_to_fp32():
+    import torch
+
+    from oracle import encoder as oe
+
+    cfg = oe.EncoderConfig(arch="xlmr", vocab_size=500, hidden=256, layers=2, heads=4, ffn=512, max_pos=80, type_vocab=1,
+                           pad_id=1, ln_eps=1e-5, num_labels=1)
+    W = oe.synth_weights(cfg, seed=4)
+    ids, mask = oe.synth_tokens(6, 40, cfg, seed=1, lengths=[40, 33, 12, 40, 25, 7])
+    ref = oe.rerank_scores(ids, mask, W, cfg)
+    f8 = oe.rerank_scores(ids, mask, W, cfg, emulate_bf16=True, emulate_fp8=True)
+    f8_all = oe.rerank_scores(ids, mask, W, cfg, emulate_bf16=True, emulate_fp8=True, ffn_act_scales=[0.05, 0.05])
+    assert (f8 - ref).abs().max().item() < 5e-2 and (f8_all - ref).abs().max().item() < 5e-2
+    assert not torch.equal(f8, f8_all)
