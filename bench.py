@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--top-n", type=int, default=10)
     ap.add_argument("--query-len", type=int, default=32)
     ap.add_argument("--chunk-len", type=int, default=256)
-    ap.add_argument("--embed-chunks", type=int, default=512, help="chunks per GPU in the ingest (chunks embedded/s) leg")
+    ap.add_argument("--embed-chunks", type=int, default=1024, help="chunks per GPU in the ingest (chunks embedded/s) leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp8-leg", action="store_true", help="skip the extra fp8-reranker timing (BASELINE config 5)")
     ap.add_argument("--layers", type=int, default=24, help="encoder depth (24 = the named models; for debugging only)")
