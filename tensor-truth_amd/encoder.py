@@ -290,9 +290,12 @@ def synthetic_state_device(cfg: EncoderConfig, device: torch.device, seed: int =
     return W
 
 
-# rows between sequence starts are rounded up to this (1 = back to back; 8 = every sequence owns its V8 token groups,
-# the layout before the attention kernels learned to mask shared groups): timing experiments only
-_PACK_ALIGN = max(1, int(os.environ.get("TT_PACK_ALIGN", "1")))
+# Rows between sequence starts are rounded up to this.  8 (default): every sequence owns its V8 token groups, so its
+# attention tiles -- and therefore its bits -- do not depend on where it sits in the batch (scores are invariant under
+# permuting / splitting a batch: tests/test_configs_gpu.py).  1: back to back, no padding rows at all (the attention
+# kernels mask the token group two sequences share): -0.8 % step time on 292-token pairs, more on short texts, at the
+# price of one-bf16-ulp differences between placements (a different tiling of the same keys).
+_PACK_ALIGN = max(1, int(os.environ.get("TT_PACK_ALIGN", "8")))
 
 
 @dataclass
@@ -302,7 +305,7 @@ class PackedBatch:
     ids: np.ndarray        # [n_rows] int32
     pos: np.ndarray        # [n_rows] int32
     types: Optional[np.ndarray]
-    seq_start: np.ndarray  # [B] int32 (any row: the attention kernels mask the shared 8-row token groups)
+    seq_start: np.ndarray  # [B] int32 (any row is legal for the kernels; multiples of _PACK_ALIGN here)
     seq_len: np.ndarray    # [B] int32
     n_rows: int            # multiple of 128
     max_len: int
@@ -311,8 +314,8 @@ class PackedBatch:
 
 def pack_tokens(seqs: Sequence[Sequence[int]], cfg: EncoderConfig,
                 type_ids: Optional[Sequence[Sequence[int]]] = None, max_len: Optional[int] = None) -> PackedBatch:
-    """Pack token-id sequences (already carrying their special tokens) back to back, without padding
-    tokens between them; only the total is rounded up, to the 256-row GEMM tile.  Sequences longer
+    """Pack token-id sequences (already carrying their special tokens) without padding tokens: sequence
+    starts are aligned to ``_PACK_ALIGN`` rows (8 by default, see above), the total to the 256-row GEMM tile.  Sequences longer
     than ``max_len`` (default: the model's limit) are truncated on the right, as the
     reference's tokenizer call does (``truncation=True``)."""
     limit = cfg.max_seq_len if max_len is None else min(max_len, cfg.max_seq_len)

@@ -101,3 +101,27 @@ def test_full_depth_bge_m3_embeddings_and_reranker_scores(dev, built_lib):
     err = (scores.cpu() - torch.sigmoid(want_l)).abs().max().item()
     assert err <= 2e-2, f"rerank score error after 24 bf16 layers: {err}"
     assert np.isfinite(logits.cpu().numpy()).all()
+
+
+def test_full_size_rerank_is_batch_invariant(dev, built_lib):
+    """BASELINE config 3 at full size (24-layer bge-reranker-v2-m3 shape, 16 queries x 50 pairs x 292 tokens): the score
+    of a pair must not depend on what else is in the batch -- every kernel computes a token row / a sequence from its
+    own data in a fixed order.  Permuting the batch permutes the scores, and half the batch alone scores the same bits.
+    (The CPU oracle needs minutes per pair at this depth; depth parity itself is test_full_depth_models_vs_fp32_oracle.)"""
+    import numpy as np
+
+    from tensor_truth_amd.encoder import BGE_RERANKER_V2_M3, Encoder, EncoderWeights, pack_token_matrix, synthetic_state_device
+
+    cfg = BGE_RERANKER_V2_M3
+    enc = Encoder(EncoderWeights(cfg, synthetic_state_device(cfg, dev, seed=2), dev))
+    rng = np.random.default_rng(11)
+    pairs = rng.integers(4, cfg.vocab_size, size=(800, 292), dtype=np.int32)
+    pairs[:, 0], pairs[:, -1] = 0, 2
+    pairs[:, 34:36] = 2                                           # </s></s> between query and passage
+    s_all = enc.rerank_packed(pack_token_matrix(pairs, cfg)).cpu()
+    assert torch.isfinite(s_all).all() and ((s_all > 0) & (s_all < 1)).all()
+    perm = rng.permutation(800)
+    s_perm = enc.rerank_packed(pack_token_matrix(pairs[perm], cfg)).cpu()
+    assert torch.equal(s_perm, s_all[torch.from_numpy(perm)])
+    s_half = enc.rerank_packed(pack_token_matrix(pairs[:400], cfg)).cpu()
+    assert torch.equal(s_half, s_all[:400])
