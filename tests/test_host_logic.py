@@ -327,3 +327,42 @@ def test_oracle_fp8_forward_close_to_fp32():
     f8_all = oe.rerank_scores(ids, mask, W, cfg, emulate_bf16=True, emulate_fp8=True, ffn_act_scales=[0.05, 0.05])
     assert (f8 - ref).abs().max().item() < 5e-2 and (f8_all - ref).abs().max().item() < 5e-2
     assert not torch.equal(f8, f8_all)
+
+
+# ---- importer for reference-built indexes ---------------------------------------------------------------------------
+def _llamaindex_docstore_blob():
+    def rel(nid, ntype="1"):
+        return {"node_id": nid, "node_type": ntype, "metadata": {}, "hash": "h", "class_name": "RelatedNodeInfo"}
+
+    def node(nid, text, rels, meta=None):
+        return {"__data__": {"id_": nid, "embedding": None, "metadata": meta or {"file_name": "a.md"},
+                             "excluded_embed_metadata_keys": ["file_name"], "excluded_llm_metadata_keys": [],
+                             "relationships": rels, "text": text, "start_char_idx": 0, "end_char_idx": len(text),
+                             "class_name": "TextNode"}, "__type__": "1"}
+
+    return {
+        "docstore/metadata": {"p": {"doc_hash": "x"}},
+        "docstore/data": {
+            "p": node("p", "parent text", {"1": rel("doc", "4"), "5": [rel("c1"), rel("c2")]}),
+            "c1": node("c1", "child one", {"1": rel("doc", "4"), "4": rel("p"), "3": rel("c2")}),
+            "c2": node("c2", "child two", {"1": rel("doc", "4"), "4": rel("p"), "2": rel("c1")}),
+        },
+        "docstore/ref_doc_info": {"doc": {"node_ids": ["p", "c1", "c2"], "metadata": {}}},
+    }
+
+
+def test_llamaindex_docstore_json_is_parsed_without_llamaindex(tmp_path):
+    import json
+
+    from tensor_truth_amd.chroma_import import load_llamaindex_docstore, read_chroma_collection
+
+    path = tmp_path / "docstore.json"
+    path.write_text(json.dumps(_llamaindex_docstore_blob()))
+    nodes = load_llamaindex_docstore(str(path))
+    assert set(nodes) == {"p", "c1", "c2"}
+    assert nodes["p"].child_ids == ["c1", "c2"] and nodes["p"].parent_id is None
+    assert nodes["c1"].parent_id == "p" and nodes["c1"].next_id == "c2" and nodes["c1"].prev_id is None
+    assert nodes["c2"].prev_id == "c1" and nodes["c2"].text == "child two"
+    assert nodes["c1"].metadata == {"file_name": "a.md"} and nodes["c1"].excluded_embed_metadata_keys == ["file_name"]
+    with pytest.raises(ImportError, match="chromadb"):          # not installed here: a clear message, no fallback
+        read_chroma_collection(str(tmp_path))

@@ -252,3 +252,61 @@ def test_profiling_hooks(dev, built_lib):
     tscan.scan_topk(c, q, 5)
     lib.tt_prof_read(1, ctypes.byref(ms), ctypes.byref(n))
     assert n.value == 0
+
+
+def test_import_reference_index_with_chroma_stub(dev, built_lib, tmp_path, monkeypatch):
+    """A reference-built index directory (Chroma collection "data" + LlamaIndex docstore.json) becomes a
+    HipVectorIndex: same leaves, hierarchy intact, auto-merging works on it.  chromadb itself is not installed here,
+    so a stub with the three calls the importer makes stands in for it."""
+    import json
+    import sys
+    import types
+
+    from tensor_truth_amd.chroma_import import import_reference_index
+    from tensor_truth_amd.retrievers import AutoMergingRetriever
+    from tensor_truth_amd.schema import QueryBundle
+
+    def rel(nid):
+        return {"node_id": nid, "node_type": "1", "metadata": {}, "hash": "h"}
+
+    def entry(nid, text, rels):
+        return {"__data__": {"id_": nid, "metadata": {"file_name": "doc.md"}, "excluded_embed_metadata_keys": [],
+                             "relationships": rels, "text": text}, "__type__": "1"}
+
+    data = {"P": entry("P", "parent", {"5": [rel("a"), rel("b"), rel("c")]})}
+    for j, nid in enumerate("abc"):
+        data[nid] = entry(nid, f"leaf {nid}", {"4": rel("P")})
+    data["z"] = entry("z", "unrelated leaf", {})
+    (tmp_path / "docstore.json").write_text(json.dumps({"docstore/data": data}))
+
+    g = torch.Generator().manual_seed(0)
+    base = torch.nn.functional.normalize(torch.randn(128, generator=g), dim=0)
+    vecs = {nid: torch.nn.functional.normalize(base + 0.05 * torch.randn(128, generator=g), dim=0) for nid in "abc"}
+    vecs["z"] = torch.nn.functional.normalize(torch.randn(128, generator=g), dim=0)
+    order = ["a", "z", "b", "c"]
+
+    class Collection:
+        def count(self):
+            return len(order)
+
+        def get(self, limit, offset, include):
+            ids = order[offset:offset + limit]
+            return {"ids": ids, "embeddings": [vecs[i].tolist() for i in ids], "documents": [f"leaf {i}" for i in ids],
+                    "metadatas": [{"file_name": "doc.md", "_node_content": "{}"} for _ in ids]}
+
+    class Client:
+        def __init__(self, path):
+            assert path == str(tmp_path)
+
+        def get_collection(self, name):
+            assert name == "data"
+            return Collection()
+
+    monkeypatch.setitem(sys.modules, "chromadb", types.SimpleNamespace(PersistentClient=Client))
+    index = import_reference_index(str(tmp_path), score_mode="cosine")
+    assert index.n == 4 and index.leaf_ids == order and set(index.docstore) == {"P", "a", "b", "c", "z"}
+    q = QueryBundle(query_str="q", embedding=base.tolist())
+    hits = index.as_retriever(similarity_top_k=3).retrieve(q)
+    assert [h.node.id_ for h in hits] == sorted("abc", key=lambda n: -float(vecs[n] @ base))
+    merged = AutoMergingRetriever(index.as_retriever(similarity_top_k=3), index.docstore).retrieve(q)
+    assert [m.node.id_ for m in merged] == ["P"]                 # all three children hit -> merged into the parent
