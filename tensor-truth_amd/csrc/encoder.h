@@ -24,6 +24,7 @@ struct GemmParams {
     uint8_t* C8;
     float c8_inv_scale;
     int nt_store;             // whole-line output stores issued as streaming stores (set by the launcher)
+    int sn;                   // super-tile width in N-tiles (32 tiles per super-tile: sm = 32 / sn); set by the launcher
 };
 int tt_gemm_launch(const GemmParams& p, int epilogue, hipStream_t st);
 

@@ -634,8 +634,8 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
         const int nwg = gridDim.x;
         if ((nwg & 7) == 0) L = (L & 7) * (nwg >> 3) + (L >> 3);
     }
-    const int SN = nt_n < 4 ? nt_n : 4;
-    const int SM = 8;
+    const int SN = p.sn > 0 ? p.sn : (nt_n < 4 ? nt_n : 4);
+    const int SM = 32 / SN > 0 ? 32 / SN : 1;
     const int per_super = SM * SN;
     const int supers_n = (nt_n + SN - 1) / SN;
     const int sidx = L / per_super, widx = L % per_super;
@@ -909,8 +909,8 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_p(GemmParams p, int 
     const int wm = wave >> 2, wn = wave & 3;
 
     const int mt_n = p.M / BM3, nt_n = p.N / BN3;
-    const int SN = nt_n < 4 ? nt_n : 4;
-    const int SM = 8;
+    const int SN = p.sn > 0 ? p.sn : (nt_n < 4 ? nt_n : 4);
+    const int SM = 32 / SN > 0 ? 32 / SN : 1;
     const int per_super = SM * SN;
     const int supers_n = (nt_n + SN - 1) / SN;
     const int nk = p.K * ES / 128;
@@ -1088,6 +1088,16 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_p(GemmParams p, int 
 #undef TT_SLOT_END
 }  // namespace v3
 
+// Super-tile shape: the 32 tiles an XCD works on at a time are SM row-blocks x SN column-blocks (SM * SN = 32); the A
+// row-blocks of a super-tile are shared through that XCD's L2 by its SN column tiles.
+inline int super_sn(int nt_n) {
+    static const int env = [] { const char* e = getenv("TT_GEMM_SN"); return e && e[0] ? atoi(e) : 0; }();
+    int sn = env > 0 ? env : 4;
+    if (sn > nt_n) sn = nt_n;
+    while (32 % sn) --sn;
+    return sn;
+}
+
 inline bool small_grid_v1() {
     static const bool on = [] { const char* e = getenv("TT_GEMM_SMALL_V1"); return !(e && e[0] == '0'); }();
     return on;
@@ -1107,7 +1117,7 @@ int launch_fp8(const GemmParams& p, hipStream_t st) {
             return TT_E_UNSUPPORTED;
         }
         const int mt_n = p.M / v3::BM3, nt_n = p.N / v3::BN3;
-        const int SN = nt_n < 4 ? nt_n : 4, SM = 8;
+        const int SN = super_sn(nt_n), SM = 32 / SN;
         const int supers = ((mt_n + SM - 1) / SM) * ((nt_n + SN - 1) / SN);
         int blocks = supers * SM * SN;
         blocks = (blocks + 7) / 8 * 8;
@@ -1120,7 +1130,9 @@ int launch_fp8(const GemmParams& p, hipStream_t st) {
         }
         {
             TtProfScope prof(TT_K_GEMM, st);
-            hipLaunchKernelGGL((v3::gemm_kernel_v3<EPI, 4, true>), dim3(blocks), dim3(v3::kThreads3), v3::kLds3, st, p);
+            GemmParams q = p;
+            q.sn = SN;
+            hipLaunchKernelGGL((v3::gemm_kernel_v3<EPI, 4, true>), dim3(blocks), dim3(v3::kThreads3), v3::kLds3, st, q);
         }
         TT_CHECK_LAUNCH();
         return TT_OK;
@@ -1143,7 +1155,7 @@ int launch(const GemmParams& p, hipStream_t st) {
     if (variant >= 4 && !small_grid && p.M % v3::BM3 == 0 && p.N % v3::BN3 == 0 && p.ldc % 8 == 0 &&
         (EPI != TT_EPI_RESIDUAL || (p.ldr % 8 == 0 && (p.K / BK) % 2 == 0))) {
         const int mt_n = p.M / v3::BM3, nt_n = p.N / v3::BN3;
-        const int SN = nt_n < 4 ? nt_n : 4, SM = 8;
+        const int SN = super_sn(nt_n), SM = 32 / SN;
         const int supers = ((mt_n + SM - 1) / SM) * ((nt_n + SN - 1) / SN);
         int blocks = supers * SM * SN;
         blocks = (blocks + 7) / 8 * 8;
@@ -1160,7 +1172,9 @@ int launch(const GemmParams& p, hipStream_t st) {
                 }
                 {
                     TtProfScope prof(TT_K_GEMM, st);
-                    hipLaunchKernelGGL(v3::gemm_kernel_p<EPI>, dim3(cus), dim3(v3::kThreads3), v3::kLds3, st, p, blocks);
+                    GemmParams q = p;
+                    q.sn = SN;
+                    hipLaunchKernelGGL(v3::gemm_kernel_p<EPI>, dim3(cus), dim3(v3::kThreads3), v3::kLds3, st, q, blocks);
                 }
                 TT_CHECK_LAUNCH();
                 return TT_OK;
@@ -1188,6 +1202,7 @@ int launch(const GemmParams& p, hipStream_t st) {
         // runs the same hint cost 18 %: no write combining in L2)
         static const int nts = [] { const char* e = getenv("TT_GEMM_NT_STORE"); return e && e[0] ? atoi(e) : 1; }();
         q.nt_store = nts;
+        q.sn = SN;
         {
             TtProfScope prof(TT_K_GEMM, st);
             hipLaunchKernelGGL(kern, dim3(blocks), dim3(v3::kThreads3), v3::kLds3, st, q);
