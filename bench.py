@@ -188,8 +188,10 @@ def main():
     stage_prof = read_prof()
     lib.tt_prof_enable(0)
 
-    # ---- the similarity scan alone (BASELINE configs 2 / 4): 256 resident query embeddings per GPU against the shard
-    scan_q = torch.nn.functional.normalize(torch.randn(256, D, device=dev, generator=torch.Generator(device=dev).manual_seed(4321)), dim=1).to(torch.bfloat16)
+    # ---- the similarity scan alone (BASELINE configs 2 / 4): 256 resident query embeddings (256 / world per GPU, gathered)
+    # against the sharded corpus
+    nq_scan = max(1, 256 // world)
+    scan_q = torch.nn.functional.normalize(torch.randn(nq_scan, D, device=dev, generator=torch.Generator(device=dev).manual_seed(4321)), dim=1).to(torch.bfloat16)
     corpus.search(gather_queries(scan_q), K)
     sync_all()
     t3 = time.perf_counter()
@@ -201,8 +203,8 @@ def main():
         t = torch.tensor([dt_scan], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt_scan = float(t.item())
-    scan_only = {"queries_per_s": world * 256 / dt_scan, "ms_per_batch": dt_scan * 1e3,
-                 "what": f"exact top-{K} of {world * 256} queries over the {args.corpus_rows} x {D} corpus (gather + scan + merge), no encoders"}
+    scan_only = {"queries_per_s": world * nq_scan / dt_scan, "ms_per_batch": dt_scan * 1e3,
+                 "what": f"exact top-{K} of {world * nq_scan} queries over the {args.corpus_rows} x {D} corpus (gather + scan + merge), no encoders"}
 
     # ---- BASELINE config 5's "fp8 MFMA reranker": the same steps with the cross-encoder's Q/K/V and FFN-up
     # projections on e4m3 operands.  Reported beside the headline (which stays bf16), never as it.
