@@ -733,7 +733,7 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
     }
     TT_SLOT_END();
     cstamp(1);
-    const bool late = (SLOTS == 45) ? ((wave & 1) != 0) : (wave >= 4);
+    const bool late = wave >= 4;   // (grouping by SIMD parity instead, both waves of a SIMD in the same slot: -36 %)
     if (late) TT_SLOT_END();   // waves 4-7 run one slot behind
 
     bf16x8 xf[4][2], wf0[2][2], wf1[2][2];
@@ -756,8 +756,7 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
     // consecutive TOKENS of one feature, which is what the transposed V^T store wants.
     constexpr bool vblk = (EPI == TT_EPI_VT);
     auto mma = [&](f32x4(&c)[2][4], const bf16x8(&wf)[2][2]) {
-        if constexpr (SLOTS == 43) return;
-        if constexpr (SLOTS != 44) __builtin_amdgcn_s_setprio(1);
+        __builtin_amdgcn_s_setprio(1);
         if constexpr (FP8) {
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
@@ -783,7 +782,7 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
                     for (int mt = 0; mt < 4; ++mt)
                         c[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt][ss], xf[mt][ss], c[nt][mt], 0, 0, 0);
         }
-        if constexpr (SLOTS != 44) __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_setprio(0);
     };
     // 4-slot variant: La (A-lo, W-lo, W-hi fragments) | Ca (quadrants 00, 01) | Lb (A-hi) | Cb (11, 10):
     // half as many barriers per MFMA.
@@ -805,31 +804,28 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         TT_SLOT_END();
     };
-    constexpr bool kNoGlds = SLOTS == 41, kNoReads = SLOTS == 42;
     // Copy schedule:  La(t): W-hi(t+1), A-hi(t+1)   Lb(t): A-lo(t+2), W-lo(t+2).
     // (Moving half of the copies into the C slots was measured neutral-to-worse: an LDS-DMA issue
     // costs ~100 cycles wherever it sits, and the C slot is then as long as the L slot.)
     auto tile4 = [&](int t, auto bufc) {
         constexpr int B = decltype(bufc)::value;
-        const bool more1 = !kNoGlds && t + 1 < nk, more2 = !kNoGlds && t + 2 < nk;
+        const bool more1 = t + 1 < nk, more2 = t + 2 < nk;
         // La
         stamp(t);                                  // 0: La start
         if (more1) {
             stage_half<1, ES>(p, smem, 1, B ^ 1, t + 1, wave, voffW, m0, n0);
             stage_half<0, ES>(p, smem, 1, B ^ 1, t + 1, wave, voffA, m0, n0);
-        } else if (kResLds && !kNoGlds) {
+        } else if (kResLds) {
             stage_res(1);                          // last tile (B = 1): hi slots of buffer 0
         }
         stamp(t);                                  // 1: copies issued
-        if (!kNoReads) {
-            read_a(smem + slot_off(0, 0, B));
-            read_w(wf0, smem + slot_off(1, 0, B));
-            read_w(wf1, smem + slot_off(1, 1, B));
-        }
+        read_a(smem + slot_off(0, 0, B));
+        read_w(wf0, smem + slot_off(1, 0, B));
+        read_w(wf1, smem + slot_off(1, 1, B));
         stamp(t);                                  // 2: reads issued
         if (SLOTS == 46) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         stamp(t);                                  // 3: reads returned
-        wait_n(kNoGlds ? 0 : ((t + 1 < nk || kResLds) ? 8 : 0));
+        wait_n((t + 1 < nk || kResLds) ? 8 : 0);
         stamp(t);                                  // 4: past barrier (Ca start)
         mma(acc[0][0], wf0);                       // Ca
         mma(acc[0][1], wf1);
@@ -840,15 +836,15 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
         if (more2) {
             stage_half<0, ES>(p, smem, 0, B, t + 2, wave, voffA, m0, n0);
             stage_half<1, ES>(p, smem, 0, B, t + 2, wave, voffW, m0, n0);
-        } else if (kResLds && !kNoGlds) {
+        } else if (kResLds) {
             stage_res(B == 0 ? 0 : 2);             // tile nk-2 (B = 0): lo slots of buffer 0; tile nk-1: of buffer 1
         }
         stamp(t);                                  // 7
-        if (!kNoReads) read_a(smem + slot_off(0, 1, B));
+        read_a(smem + slot_off(0, 1, B));
         stamp(t);                                  // 8
         if (SLOTS == 46) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         stamp(t);                                  // 9
-        wait_n(kNoGlds ? 0 : ((t + 2 < nk || kResLds) ? 6 : 0));
+        wait_n((t + 2 < nk || kResLds) ? 6 : 0);
         stamp(t);                                  // 10: Cb start
         mma(acc[1][1], wf1);                       // Cb
         mma(acc[1][0], wf0);
@@ -1181,15 +1177,10 @@ int launch(const GemmParams& p, hipStream_t st) {
             }
         }
         auto kern = v3::gemm_kernel_v3<EPI, 4>;
-        if constexpr (EPI == TT_EPI_BIAS) {   // timing-only ablations of the 4-slot loop (wrong results)
+        if constexpr (EPI == TT_EPI_BIAS) {   // diagnostic build of the 4-slot loop with s_memtime stamps (tools/gemm_stamps)
             static const int abl = [] { const char* e = getenv("TT_GEMM_ABLATE"); return e && e[0] ? atoi(e) : 0; }();
-            if (abl == 1) kern = v3::gemm_kernel_v3<EPI, 41>;
-            if (abl == 2) kern = v3::gemm_kernel_v3<EPI, 42>;
-            if (abl == 3) kern = v3::gemm_kernel_v3<EPI, 43>;
-            if (abl == 4) kern = v3::gemm_kernel_v3<EPI, 44>;
-            if (abl == 5) kern = v3::gemm_kernel_v3<EPI, 45>;
             if (abl == 6) kern = v3::gemm_kernel_v3<EPI, 46>;
-            if (abl) TT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, v3::kLds3));
+            if (abl == 6) TT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, v3::kLds3));
         }
         static thread_local bool attr3 = false;
         if (!attr3) {
