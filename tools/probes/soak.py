@@ -18,16 +18,18 @@ for mode in ("bf16", "fp8"):
         rr.calibrate_fp8(pack_token_matrix(pairs[:64], cfg)); rr.w.set_gemm_dtype("fp8")
     ref = rr.rerank_packed(batch).clone(); bad = 0
     t0 = time.time()
-    for i in range(60):
+    n_rep = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+    for i in range(n_rep):
         s = rr.rerank_packed(batch)
         if not torch.equal(s, ref): bad += 1
     torch.cuda.synchronize()
-    print(f"{mode}: 60 repeated forwards (6 layers, 800x292), non-identical results: {bad}  ({time.time()-t0:.1f}s)", flush=True)
+    print(f"{mode}: {n_rep} repeated forwards (6 layers, 800x292), non-identical results: {bad}  ({time.time()-t0:.1f}s)", flush=True)
 rr.w.set_gemm_dtype("bf16")
 # ---- 2. GEMM epilogues vs torch on fresh data
 shapes = [(3072, 1024), (1024, 1024), (4096, 1024), (1024, 4096)]
 worst = 0.0
-for rep in range(12):
+n_gemm = int(sys.argv[2]) if len(sys.argv) > 2 else 12
+for rep in range(n_gemm):
     M = int(rng.integers(8, 400)) * 256
     for n, k in shapes:
         for epi in (0, 1, 2):
@@ -44,4 +46,4 @@ for rep in range(12):
             err = ((c.float() - want).abs() / (want.abs() * 2.0 ** -7 + 2e-2)).max().item()
             worst = max(worst, err)
             assert err < 1.0, (M, n, k, epi, err)
-print(f"gemm: 12 x 4 shapes x 3 epilogues on random M, worst error / tolerance = {worst:.3f}")
+print(f"gemm: {n_gemm} x 4 shapes x 3 epilogues on random M, worst error / tolerance = {worst:.3f}")
