@@ -72,6 +72,22 @@ int tt_scan_topk_exact(const void* corpus_bf16, int64_t n_rows, int dim,
                        float* out_scores, int32_t* out_idx,
                        void* workspace, size_t workspace_bytes, void* stream);
 
+/* Segmented variant for several index modules living in ONE matrix (replaces the thread-pool fan-out
+ * over per-module retrievers, src/tensortruth/rag_engine.py:420-424, and the n_indexes separate vector
+ * searches behind it): rows [seg_offsets[s], seg_offsets[s+1]) are module s (host array of
+ * n_segments + 1 non-decreasing offsets within [0, n_rows], 1 <= n_segments <= 64).  One pass over the
+ * matrix scores every row once; every (query, segment) then gets its own exact top-k, ordered by
+ * (score desc, row asc):  out_scores / out_idx are [n_queries][n_segments][k], indices are
+ * SEGMENT-LOCAL rows, short or empty segments are padded with (-inf, -1).
+ * Workspace: n_queries * rows * 4 bytes -- meant for the handful of queries of an
+ * interactive retrieve(); large query batches over one big index go through tt_scan_topk. */
+size_t tt_scan_segmented_workspace_bytes(int64_t n_rows, int dim, int n_queries, int k);
+int tt_scan_topk_segmented(const void* corpus_bf16, int64_t n_rows, int dim,
+                           const void* queries_bf16, int n_queries, int k,
+                           const int64_t* seg_offsets, int n_segments,
+                           float* out_scores, int32_t* out_idx,
+                           void* workspace, size_t workspace_bytes, void* stream);
+
 /* Merge per-shard partial top-k lists (the step after the RCCL all-gather of
  * SURVEY.md section 8e; also MultiIndexRetriever's concatenate+sort,
  * rag_engine.py:463-507, when indexes live in one matrix).

@@ -79,6 +79,19 @@ def scan_topk(corpus_bf16, queries_bf16, k: int, chunk: int = 262144):
     return merge_topk(v, i, k, want_gap=True)
 
 
+def scan_topk_segmented(corpus_bf16, queries_bf16, k: int, seg_offsets):
+    """One exact search per index module, as the reference runs them (one retriever per module on a
+    thread pool, ``rag_engine.py:420-424``): module ``s`` = rows ``[seg_offsets[s], seg_offsets[s+1])``.
+    Returns (vals [Q,S,k], module-local idx [Q,S,k], gap [Q,S])."""
+    vs, ixs, gaps = [], [], []
+    for s in range(len(seg_offsets) - 1):
+        v, i, g = scan_topk(corpus_bf16[seg_offsets[s]:seg_offsets[s + 1]], queries_bf16, k)
+        vs.append(v)
+        ixs.append(i)
+        gaps.append(g)
+    return torch.stack(vs, 1), torch.stack(ixs, 1), torch.stack(gaps, 1)
+
+
 def merge_topk(vals: torch.Tensor, idx: torch.Tensor, k: int, want_gap: bool = False):
     """Merge candidate lists [Q,M] by (score desc, global index asc) -> top-k.
 

@@ -40,6 +40,9 @@ SIGNATURES = {
     "tt_scan_exact_workspace_bytes": (c_size_t, [c_int64, c_int, c_int, c_int]),
     "tt_scan_topk_exact": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_int, c_int32, c_void_p, c_void_p,
                                    c_void_p, c_size_t, c_void_p]),
+    "tt_scan_segmented_workspace_bytes": (c_size_t, [c_int64, c_int, c_int, c_int]),
+    "tt_scan_topk_segmented": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p,
+                                       c_void_p, c_void_p, c_size_t, c_void_p]),
     "tt_topk_merge": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "tt_encoder_workspace_bytes": (c_size_t, [c_void_p, c_int]),
     "tt_encoder_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,

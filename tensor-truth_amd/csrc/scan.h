@@ -26,6 +26,8 @@ struct ScanParams {
 
 #define TT_SCAN_PRIV_SLOTS 16
 #define TT_SCAN_WAVES_PER_BLOCK 8
+#define TT_SCAN_MAX_SEGMENTS 64   // index modules per tt_scan_topk_segmented call
+#define TT_SCAN_MAX_PIECES 256    // selection blocks per query (long modules are cut into pieces)
 
 // mode 0: A fragments loaded directly from global; mode 1: full-line loads
 // transposed through wave-private LDS.  blocks = grid.x (clamped to the work).
@@ -52,6 +54,13 @@ struct SelectParams {
     float* thr_out;           // optional [Q]: k-th best score (or -inf if fewer than k valid)
     int32_t* cnt_out;         // optional [Q]: number of valid outputs (<= k)
     int32_t* overflow_flag;   // optional
+    // optional segmentation of each query's list (tt_scan_topk_segmented): block (q, s) selects over
+    // positions [seg_off[s], seg_off[s+1]) of query q's scores (and idx, when given), writes output row
+    // q * n_seg + s; implicit indices are emitted as (position in the segment) + seg_add[s].
+    // n_seg == 0: one block per query over m_fixed / cnt entries.
+    int n_seg;
+    int32_t seg_off[TT_SCAN_MAX_PIECES + 1];
+    int32_t seg_add[TT_SCAN_MAX_PIECES];
 };
 
 int tt_select_launch(const SelectParams& p, int n_queries, hipStream_t stream);

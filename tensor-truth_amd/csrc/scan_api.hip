@@ -306,6 +306,115 @@ int tt_scan_topk(const void* corpus_bf16, int64_t n_rows, int dim, const void* q
     return tt_select_launch(s2, n_queries, st);
 }
 
+constexpr int64_t kPieceRows = 65536;   // longest row range one selection block walks (8 LDS rounds)
+
+static size_t seg_dense_bytes(int64_t rows, int n_queries) {
+    return tt_align_up((size_t)n_queries * (size_t)((rows + 31) / 32 * 32) * sizeof(float), 256);
+}
+
+size_t tt_scan_segmented_workspace_bytes(int64_t n_rows, int dim, int n_queries, int k) {
+    (void)dim;
+    if (n_rows < 0 || n_queries <= 0 || k < 1) return 0;
+    // dense scores of the valid queries + per-piece partial top-k lists (long modules only)
+    return seg_dense_bytes(n_rows, n_queries) + 2 * tt_align_up((size_t)n_queries * TT_SCAN_MAX_PIECES * k * 4, 256);
+}
+
+// One dense pass over rows [seg_offsets[0], seg_offsets[S]) (every score written once: Q * 4 bytes per
+// row next to the 2 * dim bytes read) + ONE selection launch with a block per (query, module).  Modules
+// longer than kPieceRows are cut into pieces (a block per piece) and a second launch merges the pieces.
+int tt_scan_topk_segmented(const void* corpus_bf16, int64_t n_rows, int dim, const void* queries_bf16,
+                           int n_queries, int k, const int64_t* seg_offsets, int n_segments, float* out_scores,
+                           int32_t* out_idx, void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = check_common(corpus_bf16, n_rows, dim, queries_bf16, n_queries, k, out_scores, out_idx);
+    if (rc) return rc;
+    TT_CHECK_ARG(n_segments >= 1 && n_segments <= TT_SCAN_MAX_SEGMENTS, "n_segments=%d outside [1,%d]", n_segments,
+                 TT_SCAN_MAX_SEGMENTS);
+    TT_CHECK_ARG(seg_offsets != nullptr, "null seg_offsets");
+    TT_CHECK_ARG(seg_offsets[0] >= 0 && seg_offsets[n_segments] <= n_rows, "segment offsets outside [0, n_rows]");
+    for (int s = 0; s < n_segments; ++s)
+        TT_CHECK_ARG(seg_offsets[s] <= seg_offsets[s + 1], "segment offsets must be non-decreasing (segment %d)", s);
+    if (n_queries == 0) return TT_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t lo = seg_offsets[0], rows = seg_offsets[n_segments] - lo;
+    if (rows == 0) {
+        const int64_t n = (int64_t)n_queries * n_segments * k;
+        hipLaunchKernelGGL(fill_pad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, out_scores, out_idx, n);
+        TT_CHECK_LAUNCH();
+        return TT_OK;
+    }
+    const size_t need = tt_scan_segmented_workspace_bytes(rows, dim, n_queries, k);
+    if (!workspace || workspace_bytes < need) {
+        tt_set_error("tt_scan_topk_segmented: workspace %zu < required %zu bytes", workspace_bytes, need);
+        return TT_E_WORKSPACE;
+    }
+    TT_CHECK_ARG(((uintptr_t)workspace % 16) == 0, "workspace must be 16-byte aligned");
+    const int64_t stride = (rows + 31) / 32 * 32;
+    ScanParams sp{};
+    sp.corpus = (const uint16_t*)corpus_bf16 + (size_t)lo * dim;
+    sp.queries = (const uint16_t*)queries_bf16;
+    sp.row_lo = 0;
+    sp.row_hi = rows;
+    sp.n_queries = n_queries;
+    sp.dense = (float*)workspace;
+    sp.dense_stride = stride;
+    rc = tt_scan_launch(sp, dim, scan_mode_from_env(), 1, tt_cu_count_cached(), st);
+    if (rc) return rc;
+
+    // cut the modules into pieces of at most piece_rows rows, at most TT_SCAN_MAX_PIECES in all
+    int64_t piece_rows = kPieceRows;
+    const int64_t spare = TT_SCAN_MAX_PIECES - n_segments;
+    if ((rows + piece_rows - 1) / piece_rows > spare) piece_rows = (rows + spare - 1) / spare;
+    SelectParams se{};
+    int first_piece[TT_SCAN_MAX_SEGMENTS + 1];
+    int n_pieces = 0;
+    for (int s = 0; s < n_segments; ++s) {
+        first_piece[s] = n_pieces;
+        const int64_t b = seg_offsets[s] - lo, e = seg_offsets[s + 1] - lo;
+        int64_t pos = b;
+        do {
+            const int64_t end = (e - pos > piece_rows) ? pos + piece_rows : e;
+            se.seg_off[n_pieces] = (int32_t)pos;
+            se.seg_add[n_pieces] = (int32_t)(pos - b);
+            ++n_pieces;
+            pos = end;
+        } while (pos < e);
+    }
+    first_piece[n_segments] = n_pieces;
+    se.seg_off[n_pieces] = (int32_t)rows;
+    // a piece ends where the next one starts, except the last piece of a module followed by a gap-free
+    // neighbour -- which is the same thing: modules are contiguous in [lo, lo + rows)
+    se.scores = sp.dense;
+    se.stride = stride;
+    se.cap = INT_MAX;
+    se.k = k;
+    se.out_stride = k;
+    se.n_seg = n_pieces;
+    if (n_pieces == n_segments) {
+        se.out_scores = out_scores;
+        se.out_idx = out_idx;
+        return tt_select_launch(se, n_queries, st);
+    }
+    char* tmp = (char*)workspace + seg_dense_bytes(rows, n_queries);
+    float* part_s = (float*)tmp;
+    int32_t* part_i = (int32_t*)(tmp + tt_align_up((size_t)n_queries * TT_SCAN_MAX_PIECES * k * 4, 256));
+    se.out_scores = part_s;
+    se.out_idx = part_i;
+    rc = tt_select_launch(se, n_queries, st);
+    if (rc) return rc;
+    SelectParams sm{};
+    sm.scores = part_s;
+    sm.idx = part_i;
+    sm.stride = (int64_t)n_pieces * k;
+    sm.cap = INT_MAX;
+    sm.k = k;
+    sm.out_scores = out_scores;
+    sm.out_idx = out_idx;
+    sm.out_stride = k;
+    sm.n_seg = n_segments;
+    for (int s = 0; s <= n_segments; ++s) sm.seg_off[s] = first_piece[s] * k;
+    return tt_select_launch(sm, n_queries, st);
+}
+
 int tt_topk_merge(const float* in_scores, const int32_t* in_idx, int n_queries, int n_candidates, int k_out,
                   float* out_scores, int32_t* out_idx, void* stream) {
     TT_CHECK_ARG(n_queries >= 0 && n_candidates >= 0, "negative size");

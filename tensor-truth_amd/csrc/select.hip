@@ -169,6 +169,17 @@ __global__ __launch_bounds__(kSelThreads) void select_kernel(SelectParams p) {
     const float* sc = p.scores ? p.scores + (size_t)q * p.stride : nullptr;
     const int32_t* ix = p.idx ? p.idx + (size_t)q * p.stride : nullptr;
     int m = p.m_fixed;
+    size_t out_row = q;
+    int32_t idx_add = p.idx_base;
+    if (p.n_seg > 0) {  // segmented list: blockIdx.y = segment
+        const int s = blockIdx.y;
+        const int lo = p.seg_off[s];
+        m = p.seg_off[s + 1] - lo;
+        if (sc) sc += lo;
+        if (ix) ix += lo;
+        idx_add = p.seg_add[s];
+        out_row = (size_t)q * p.n_seg + s;
+    }
     if (p.cnt) {
         const int c = p.cnt[q];
         m = c < p.cap ? c : p.cap;
@@ -313,10 +324,10 @@ __global__ __launch_bounds__(kSelThreads) void select_kernel(SelectParams p) {
         if (e != 0ull) {
             s = key_score((uint32_t)(e >> 32));
             id = (int32_t)(0xFFFFFFFFu - (uint32_t)(e & 0xFFFFFFFFull));
-            if (!ix) id += p.idx_base;
+            if (!ix) id += idx_add;
         }
-        p.out_scores[(size_t)q * p.out_stride + i] = s;
-        p.out_idx[(size_t)q * p.out_stride + i] = id;
+        p.out_scores[out_row * p.out_stride + i] = s;
+        p.out_idx[out_row * p.out_stride + i] = id;
     }
     if (p.thr_out || p.cnt_out) {
         if (tid == 0) lds_ctr[1] = 0;
@@ -327,8 +338,8 @@ __global__ __launch_bounds__(kSelThreads) void select_kernel(SelectParams p) {
         __syncthreads();
         if (tid == 0) {
             const u64 e = buf[k - 1];
-            if (p.thr_out) p.thr_out[q] = (e != 0ull) ? key_score((uint32_t)(e >> 32)) : -__builtin_inff();
-            if (p.cnt_out) p.cnt_out[q] = lds_ctr[1];
+            if (p.thr_out) p.thr_out[out_row] = (e != 0ull) ? key_score((uint32_t)(e >> 32)) : -__builtin_inff();
+            if (p.cnt_out) p.cnt_out[out_row] = lds_ctr[1];
         }
     }
 }
@@ -350,7 +361,7 @@ int tt_select_launch(const SelectParams& p, int n_queries, hipStream_t stream) {
     }
     {
         TtProfScope prof(TT_K_SELECT, stream);
-        hipLaunchKernelGGL(select_kernel, dim3(n_queries), dim3(kSelThreads), lds, stream, p);
+        hipLaunchKernelGGL(select_kernel, dim3(n_queries, p.n_seg > 0 ? p.n_seg : 1), dim3(kSelThreads), lds, stream, p);
     }
     TT_CHECK_LAUNCH();
     return TT_OK;

@@ -39,7 +39,7 @@ class MultiIndexRetriever:
 
     def __init__(self, retrievers: List, max_workers: Optional[int] = None, enable_cache: bool = True,
                  cache_size: int = 128, balance_strategy: str = "top_k_per_index",
-                 share_query_embedding: bool = True) -> None:
+                 share_query_embedding: bool = True, single_pass: bool = True) -> None:
         self.retrievers = retrievers
         self.max_workers = max_workers or min(len(retrievers), 8)
         self.enable_cache = enable_cache
@@ -48,6 +48,12 @@ class MultiIndexRetriever:
         # SURVEY.md section 8 row a4).  When every retriever searches with the same embed-model object the embedding
         # is computed once here and handed down in the QueryBundle: same vectors, n_indexes x fewer encoder passes.
         self.share_query_embedding = share_query_embedding
+        # When every retriever is a HipVectorRetriever (directly or under an AutoMergingRetriever) on one
+        # device, the module matrices are packed into one (HipIndexGroup) and searched with ONE pass
+        # (tt_scan_topk_segmented) instead of one search per worker thread; per-module results, auto-merging,
+        # tagging and balancing are unchanged.  Anything unexpected falls back to the thread pool.
+        self.single_pass = single_pass
+        self._group = None
         if enable_cache:
             self._retrieve_cached = lru_cache(maxsize=cache_size)(self._retrieve_impl)
         else:
@@ -73,22 +79,65 @@ class MultiIndexRetriever:
                 except Exception:  # noqa: BLE001 - fall back to per-index embedding, as the reference does it
                     bundle.embedding = None
         combined = []
-        with ThreadPoolExecutor(max_workers=max(1, self.max_workers)) as pool:
-            futures = {pool.submit(r.retrieve, bundle): i for i, r in enumerate(self.retrievers)}
-            for fut in as_completed(futures):
-                try:
-                    nodes = fut.result()
-                except Exception as exc:  # noqa: BLE001 - degrade like the reference (rag_engine.py:453-455)
-                    print(f"Retriever failed: {exc}")
-                    continue
+        per_index = None
+        if self.single_pass and len(self.retrievers) > 1 and bundle.embedding is not None:
+            try:
+                per_index = self._single_pass_retrieve(bundle)
+            except Exception as exc:  # noqa: BLE001 - the per-index path below degrades per retriever
+                print(f"Single-pass retrieval unavailable ({exc}); using one search per index")
+                per_index = None
+        if per_index is not None:
+            for i, nodes in enumerate(per_index):
                 for n in nodes:
                     md = _node_metadata(n)
                     if md is not None:
-                        md["_source_index"] = futures[fut]
+                        md["_source_index"] = i
                 combined.extend(nodes)
+        else:
+            with ThreadPoolExecutor(max_workers=max(1, self.max_workers)) as pool:
+                futures = {pool.submit(r.retrieve, bundle): i for i, r in enumerate(self.retrievers)}
+                for fut in as_completed(futures):
+                    try:
+                        nodes = fut.result()
+                    except Exception as exc:  # noqa: BLE001 - degrade like the reference (rag_engine.py:453-455)
+                        print(f"Retriever failed: {exc}")
+                        continue
+                    for n in nodes:
+                        md = _node_metadata(n)
+                        if md is not None:
+                            md["_source_index"] = futures[fut]
+                    combined.extend(nodes)
         if len(self.retrievers) > 1 and self.balance_strategy == "top_k_per_index":
             combined = self._balance_top_k_per_index(combined)
         return combined
+
+    def _single_pass_retrieve(self, bundle):
+        """One segmented scan for all modules -> per-retriever node lists, or None when the retrievers are not
+        all HIP index retrievers on one device."""
+        import torch
+
+        from .vector_index import HipIndexGroup, HipVectorRetriever
+
+        bases = [getattr(r, "_vector_retriever", r) for r in self.retrievers]
+        if not all(isinstance(b, HipVectorRetriever) for b in bases) or len(bases) > 64:
+            return None
+        indexes = [b.index for b in bases]
+        if len({(ix.dim, ix.device) for ix in indexes}) != 1 or len({id(ix) for ix in indexes}) != len(indexes):
+            return None
+        if self._group is None or [id(ix) for ix in self._group.indexes] != [id(ix) for ix in indexes]:
+            self._group = HipIndexGroup(indexes)
+        k = max(min(b.similarity_top_k, ix.n) for b, ix in zip(bases, indexes))
+        if k < 1:
+            return [[] for _ in bases]
+        q = torch.tensor([bundle.embedding], dtype=torch.float32)
+        scores, rows = self._group.search(q, k)
+        scores, rows = scores[0].cpu().tolist(), rows[0].cpu().tolist()
+        out = []
+        for i, (r, b) in enumerate(zip(self.retrievers, bases)):
+            kk = min(b.similarity_top_k, indexes[i].n)
+            nodes = b.nodes_from_hits(scores[i][:kk], rows[i][:kk])
+            out.append(r.merge(nodes) if r is not b and hasattr(r, "merge") else nodes)
+        return out
 
     def _balance_top_k_per_index(self, nodes: List[NodeWithScore]) -> List[NodeWithScore]:
         groups: Dict[int, list] = defaultdict(list)
@@ -187,7 +236,10 @@ class AutoMergingRetriever:
         return nodes, (c1 or c2)
 
     def retrieve(self, query) -> List[NodeWithScore]:
-        nodes = self._vector_retriever.retrieve(as_query_bundle(query))
+        return self.merge(self._vector_retriever.retrieve(as_query_bundle(query)))
+
+    def merge(self, nodes: List[NodeWithScore]) -> List[NodeWithScore]:
+        """Fill-in + parent merging to a fixpoint over already-retrieved leaves."""
         nodes, changed = self._try_merging(nodes)
         while changed:
             nodes, changed = self._try_merging(nodes)

@@ -102,6 +102,46 @@ def scan_topk(
     return out_s, out_i
 
 
+def scan_topk_segmented(corpus: torch.Tensor, queries: torch.Tensor, k: int, seg_offsets) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Several index modules in one matrix: rows ``[seg_offsets[s], seg_offsets[s+1])`` are module ``s``.
+    One pass over the matrix, then an exact top-k per (query, module) ->
+    (scores [Q,S,k] fp32, rows [Q,S,k] int32, module-local, padding (-inf, -1)).
+    Stands in for the reference's per-module thread fan-out (``rag_engine.py:420-424``)."""
+    import ctypes
+    lib = _lib.load_library()
+    _require_cuda(corpus, "corpus")
+    _require_cuda(queries, "queries")
+    if corpus.dtype != torch.bfloat16 or queries.dtype != torch.bfloat16:
+        raise TypeError("corpus and queries must be torch.bfloat16")
+    if corpus.dim() != 2 or queries.dim() != 2 or corpus.shape[1] != queries.shape[1]:
+        raise ValueError(f"shape mismatch: corpus {tuple(corpus.shape)} queries {tuple(queries.shape)}")
+    if corpus.device != queries.device:
+        raise ValueError("corpus and queries must be on the same device")
+    if not corpus.is_contiguous() or not queries.is_contiguous():
+        raise ValueError("corpus and queries must be contiguous row-major")
+    offs = [int(o) for o in seg_offsets]
+    n_seg = len(offs) - 1
+    if n_seg < 1:
+        raise ValueError("seg_offsets needs at least two entries")
+    n, d = corpus.shape
+    q = queries.shape[0]
+    dev = corpus.device
+    out_s = torch.empty((q, n_seg, k), dtype=torch.float32, device=dev)
+    out_i = torch.empty((q, n_seg, k), dtype=torch.int32, device=dev)
+    if q == 0:
+        return out_s, out_i
+    c_offs = (ctypes.c_int64 * (n_seg + 1))(*offs)
+    with torch.cuda.device(dev):
+        need = lib.tt_scan_segmented_workspace_bytes(max(offs[-1] - offs[0], 0), d, q, k)
+        ws = _ws.get(dev, need + 256)
+        base = (ws.data_ptr() + 255) // 256 * 256
+        rc = lib.tt_scan_topk_segmented(corpus.data_ptr(), n, d, queries.data_ptr(), q, k, c_offs, n_seg,
+                                        out_s.data_ptr(), out_i.data_ptr(), base,
+                                        ws.numel() - (base - ws.data_ptr()), _stream_ptr(dev))
+        _lib.check(rc, "tt_scan_topk_segmented")
+    return out_s, out_i
+
+
 def topk_merge(scores: torch.Tensor, idx: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
     """Merge candidate lists [Q, M] (fp32 scores, int32 global indices, idx<0 =
     padding) into the top-k by (score desc, idx asc)."""

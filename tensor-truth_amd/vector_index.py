@@ -42,6 +42,7 @@ class HipVectorIndex:
         self.leaf_ids: List[str] = []          # row -> node id
         self.docstore: Dict[str, TextNode] = {}  # every node (leaves + parents), for auto-merging
         self._lock = threading.RLock()
+        self._version = 0                      # bumped by every mutation (HipIndexGroup repacks on change)
 
     # ---- build / mutate ------------------------------------------------------------------------
     def _reserve(self, n_new: int) -> None:
@@ -79,6 +80,7 @@ class HipVectorIndex:
                 self.leaf_ids.append(nd.id_)
                 self.docstore[nd.id_] = nd
             self.n += len(nodes)
+            self._version += 1
         return [nd.id_ for nd in nodes]
 
     def add_to_docstore(self, nodes: Iterable[TextNode]) -> None:
@@ -98,6 +100,7 @@ class HipVectorIndex:
                 self._mat[: len(keep)] = self._mat[: self.n].index_select(0, idx)
                 self.leaf_ids = [self.leaf_ids[i] for i in keep]
                 self.n = len(keep)
+                self._version += 1
             for nid in drop:
                 self.docstore.pop(nid, None)
         return removed
@@ -192,7 +195,11 @@ class HipVectorRetriever:
                 q = torch.tensor([em.get_agg_embedding_from_queries(strs)], dtype=torch.float32)
         k = min(self.similarity_top_k, idx.n)
         scores, rows = idx.search(q, k)
-        scores, rows = scores[0].cpu().tolist(), rows[0].cpu().tolist()
+        return self.nodes_from_hits(scores[0].cpu().tolist(), rows[0].cpu().tolist())
+
+    def nodes_from_hits(self, scores: Sequence[float], rows: Sequence[int]) -> List[NodeWithScore]:
+        """(cosine, row) pairs of this retriever's index -> NodeWithScore list (padding rows < 0 skipped)."""
+        idx = self.index
         out = []
         for s, r in zip(scores, rows):
             if r < 0:
@@ -211,3 +218,52 @@ class HipVectorRetriever:
         return out
 
     _retrieve = retrieve
+
+
+class HipIndexGroup:
+    """Several module indexes packed into ONE matrix in HBM, searched with one pass
+    (``tt_scan_topk_segmented``) instead of one search per module on a thread pool
+    (reference: ``rag_engine.py:420-424``).
+
+    Packing is zero-copy afterwards: every member index's matrix becomes a view of its row range in
+    the group matrix.  A member that is mutated (``add`` / ``delete``) bumps its version and the group
+    repacks on the next search."""
+
+    def __init__(self, indexes: Sequence[HipVectorIndex]):
+        if not indexes:
+            raise ValueError("HipIndexGroup needs at least one index")
+        if len({(ix.dim, ix.device) for ix in indexes}) != 1:
+            raise ValueError("grouped indexes must share embedding width and device")
+        self.indexes = list(indexes)
+        self.dim, self.device = indexes[0].dim, indexes[0].device
+        self._lock = threading.RLock()
+        self._stamp = None
+        self._mat = None
+        self.offsets: List[int] = []
+
+    def _pack(self) -> None:
+        for ix in self.indexes:
+            ix._lock.acquire()
+        try:
+            stamp = tuple((ix._version, ix.n) for ix in self.indexes)
+            if stamp == self._stamp:
+                return
+            offs = [0]
+            for ix in self.indexes:
+                offs.append(offs[-1] + ix.n)
+            mat = torch.empty((offs[-1], self.dim), dtype=torch.bfloat16, device=self.device)
+            for ix, lo in zip(self.indexes, offs):
+                mat[lo:lo + ix.n] = ix._mat[: ix.n]
+                ix._mat = mat[lo:lo + ix.n]
+            self._mat, self.offsets, self._stamp = mat, offs, stamp
+        finally:
+            for ix in self.indexes:
+                ix._lock.release()
+
+    def search(self, query_emb: torch.Tensor, k: int):
+        """query_emb [Q, D] -> (cosine scores [Q, S, k] fp32, module-local rows [Q, S, k] int32)."""
+        q = query_emb.to(self.device, dtype=torch.float32)
+        q = (q / q.norm(dim=1, keepdim=True).clamp_min(1e-12)).to(torch.bfloat16).contiguous()
+        with self._lock:
+            self._pack()
+            return _scan.scan_topk_segmented(self._mat, q, k, self.offsets)

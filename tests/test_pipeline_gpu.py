@@ -200,6 +200,81 @@ def test_multi_index_embeds_the_query_once(dev, built_lib):
     assert all(abs(n.score - by_id[key(n)]) < 1e-5 for n in shared)
 
 
+def test_multi_index_single_pass_scan_equals_per_index_searches(dev, built_lib, monkeypatch):
+    """All modules packed into one matrix and searched with ONE segmented pass
+    returns what one search per module returns -- through auto-merging, tagging and balancing -- including an
+    empty module, unequal sizes, different top-k per module, and a module mutated after packing."""
+    from tensor_truth_amd import scan as tscan
+    from tensor_truth_amd.retrievers import AutoMergingRetriever, MultiIndexRetriever
+    from tensor_truth_amd.schema import QueryBundle, TextNode
+    from tensor_truth_amd.vector_index import HipVectorIndex
+
+    dim = 256
+    g = torch.Generator().manual_seed(17)
+
+    class FixedEmbed:  # stands in for the embedding model: deterministic vectors, no encoder needed here
+        model_name = "fixed"
+
+        def get_agg_embedding_from_queries(self, qs):
+            v = torch.randn(dim, generator=torch.Generator().manual_seed(len(qs[0])))
+            return (v / v.norm()).tolist()
+
+    emb = FixedEmbed()
+    sizes, topk = [37, 0, 400, 9], [5, 5, 12, 20]
+    retrievers, indexes = [], []
+    for part, n in enumerate(sizes):
+        ix = HipVectorIndex(dim, embed_model=emb, score_mode="chroma")
+        leaves = [TextNode(text=f"m{part} leaf {j}", id_=f"m{part}_{j}") for j in range(n)]
+        parents = []
+        for p0 in range(0, n, 4):  # parents of 4 consecutive leaves, prev/next chain: auto-merge has work to do
+            kids = leaves[p0:p0 + 4]
+            par = TextNode(text=f"m{part} parent {p0 // 4}", id_=f"m{part}_p{p0 // 4}")
+            par.child_ids = [c.id_ for c in kids]
+            for a, c in enumerate(kids):
+                c.parent_id = par.id_
+                c.prev_id = kids[a - 1].id_ if a else None
+                c.next_id = kids[a + 1].id_ if a + 1 < len(kids) else None
+            parents.append(par)
+        ix.add_to_docstore(parents)
+        if n:
+            base = torch.randn(max(1, n // 4 + 1), dim, generator=g)   # siblings share a direction: merges happen
+            vecs = base.repeat_interleave(4, 0)[:n] + 0.15 * torch.randn(n, dim, generator=g)
+            ix.add(leaves, embeddings=vecs)
+        indexes.append(ix)
+        retrievers.append(AutoMergingRetriever(ix.as_retriever(similarity_top_k=topk[part]), ix.docstore))
+
+    calls = {"seg": 0, "one": 0}
+    orig_seg, orig_one = tscan.scan_topk_segmented, tscan.scan_topk
+    monkeypatch.setattr(tscan, "scan_topk_segmented", lambda *a, **k: (calls.__setitem__("seg", calls["seg"] + 1), orig_seg(*a, **k))[1])
+    monkeypatch.setattr(tscan, "scan_topk", lambda *a, **k: (calls.__setitem__("one", calls["one"] + 1), orig_one(*a, **k))[1])
+
+    def canon(nodes):
+        return [(n.node.id_, n.node.metadata.get("_source_index"), round(n.score, 6)) for n in nodes]
+
+    for query in ("short", "a somewhat longer query string"):
+        calls.update(seg=0, one=0)
+        fast = MultiIndexRetriever(retrievers, enable_cache=False).retrieve(query)
+        assert calls == {"seg": 1, "one": 0}
+        slow = MultiIndexRetriever(retrievers, enable_cache=False, single_pass=False).retrieve(query)
+        assert calls["one"] == 3                                  # the empty module never reaches the scan
+        assert sorted(canon(fast)) == sorted(canon(slow)) and len(fast) > 0
+        assert [n.score for n in fast] == sorted((n.score for n in fast), reverse=True)
+        assert any(n.node.id_.split("_")[1].startswith("p") for n in fast), "expected at least one merged parent"
+
+    # mutate a packed module: the group repacks, the member keeps working on its own too
+    mir = MultiIndexRetriever(retrievers, enable_cache=False)
+    before = mir.retrieve("short")
+    qv = torch.tensor(emb.get_agg_embedding_from_queries(["short"]))
+    indexes[3].add([TextNode(text="planted", id_="m3_planted")], embeddings=qv[None])
+    after = mir.retrieve("short")
+    assert after[0].node.id_ == "m3_planted" and abs(after[0].score - 1.0) < 1e-2
+    alone = indexes[3].as_retriever(similarity_top_k=1).retrieve(QueryBundle(query_str="short", embedding=qv.tolist()))
+    assert alone[0].node.id_ == "m3_planted"
+    indexes[3].delete(["m3_planted"])
+    again = mir.retrieve("short")
+    assert canon(again) == canon(before)
+
+
 def test_devices_other_than_hip_are_refused(built_lib):
     from tensor_truth_amd.embedding import HipHuggingFaceEmbedding
 

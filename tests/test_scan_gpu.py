@@ -264,3 +264,47 @@ def test_full_size_config_c4_shard_layouts_vs_torch(dev, built_lib):
         parts.append(tscan.scan_topk(corpus[lo:hi], queries, k, idx_base=lo))
     ms, mi = tscan.topk_merge(torch.cat([p[0] for p in parts], 1), torch.cat([p[1] for p in parts], 1), k)
     assert torch.equal(ms, s) and torch.equal(mi[tie_free], i[tie_free])
+
+
+@pytest.mark.parametrize("offsets,k,nq", [
+    ([0, 1000, 1000, 1037, 5000, 12288], 10, 3),     # ragged modules, an empty one, one shorter than 64 rows
+    ([5, 9, 300, 4096], 50, 1),                      # rows before/after the modules are ignored; 4 rows < k
+    ([0, 70000], 20, 2),                             # one module longer than a selection piece (65536 rows)
+    ([3, 140000, 140100, 206000], 50, 2),            # long + short + long: pieces merged per module
+])
+def test_segmented_scan_matches_per_module_oracle(dev, built_lib, offsets, k, nq):
+    """Several index modules in one matrix: per-(query, module) top-k from one pass
+    equals the oracle's one-search-per-module, and is bit-identical to separate tt_scan_topk calls."""
+    from tensor_truth_amd import scan as tscan
+
+    n = max(offsets[-1] + 17, 4200)
+    corpus = osc.synth_corpus(n, 1024, seed=99)
+    queries, _ = osc.synth_queries(corpus, nq, seed=7)
+    want_s, want_i, gap = osc.scan_topk_segmented(corpus, queries, k, offsets)
+    cd, qd = corpus.to(dev), queries.to(dev)
+    s, i = tscan.scan_topk_segmented(cd, qd, k, offsets)
+    torch.cuda.synchronize()
+    n_seg = len(offsets) - 1
+    assert s.shape == (nq, n_seg, k) and i.shape == (nq, n_seg, k)
+    _check(s.reshape(nq * n_seg, k), i.reshape(nq * n_seg, k), want_s.reshape(nq * n_seg, k),
+           want_i.reshape(nq * n_seg, k), gap.reshape(-1))
+    for m in range(n_seg):
+        lo, hi = offsets[m], offsets[m + 1]
+        if hi == lo:
+            assert (i[:, m] == -1).all() and torch.isinf(s[:, m]).all()
+            continue
+        s1, i1 = tscan.scan_topk(cd[lo:hi].contiguous(), qd, k, exact_dense=True)
+        assert torch.equal(s1, s[:, m]) and torch.equal(i1, i[:, m])
+
+
+def test_segmented_scan_argument_errors(dev, built_lib):
+    from tensor_truth_amd import scan as tscan
+
+    corpus = osc.synth_corpus(256, 128, seed=1).to(dev)
+    q = corpus[:2].contiguous()
+    with pytest.raises(RuntimeError, match="non-decreasing"):
+        tscan.scan_topk_segmented(corpus, q, 5, [0, 100, 50])
+    with pytest.raises(RuntimeError, match="n_rows"):
+        tscan.scan_topk_segmented(corpus, q, 5, [0, 300])
+    with pytest.raises(RuntimeError, match="n_segments"):
+        tscan.scan_topk_segmented(corpus, q, 5, list(range(0, 67)))
