@@ -9,6 +9,7 @@ truncate to the model limit).
 """
 from __future__ import annotations
 
+from concurrent.futures import ThreadPoolExecutor
 from typing import Any, Dict, List, Optional, Sequence
 
 import torch
@@ -54,21 +55,56 @@ class HipHuggingFaceEmbedding:
         self.max_length = min(max_length or cfg.max_seq_len, cfg.max_seq_len)
         self.query_instruction = query_instruction_for(model_name) if query_instruction is None else query_instruction
         self.text_instruction = text_instruction or ""
+        # texts tokenized per pipeline step (see _embed_texts): one encoder batch -- sequences are packed without
+        # padding tokens, so nothing is lost by sorting by length inside a window only
+        self.pipeline_window = int((model_kwargs or {}).get("pipeline_window", max(embed_batch_size, 256)))
 
     # ---- token-id level (what the kernels see) ------------------------------------------------
     def embed_token_batches(self, seqs: Sequence[Sequence[int]]) -> torch.Tensor:
         """Embeds tokenised sequences -> fp32 [n, H] on the device, original order."""
         order = sorted(range(len(seqs)), key=lambda i: -len(seqs[i]))
-        out = torch.empty((len(seqs), self.config.hidden), dtype=torch.float32, device=self.device)
+        parts = []
         for lo in range(0, len(order), self.embed_batch_size):
             sel = order[lo:lo + self.embed_batch_size]
             emb, _ = self._encoder.embed_packed(pack_tokens([seqs[i] for i in sel], self.config, None, self.max_length))
-            out[torch.tensor(sel, device=self.device)] = emb
+            parts.append(emb)
+        out = torch.empty((len(seqs), self.config.hidden), dtype=torch.float32, device=self.device)
+        if parts:  # one scatter back to the caller's order (one small index upload per call, not per batch)
+            out[torch.tensor(order, dtype=torch.int64).to(self.device, non_blocking=True)] = torch.cat(parts)
         return out
 
+    def _tokenize(self, texts: Sequence[str], prefix: str):
+        tk = self._tokenizer
+        full = [prefix + t for t in texts] if prefix else list(texts)
+        if hasattr(tk, "encode_batch"):
+            return tk.encode_batch(full, self.max_length)
+        return [tk.encode(t, self.max_length) for t in full]
+
     def _embed_texts(self, texts: Sequence[str], prefix: str) -> torch.Tensor:
-        seqs = [self._tokenizer.encode(prefix + t, self.max_length) for t in texts]
-        return self.embed_token_batches(seqs)
+        """Strings -> fp32 [n, H] on the device.  Long inputs run as a pipeline over windows of
+        ``pipeline_window`` texts: a background thread tokenizes window i+1 while this thread packs window i
+        into pinned staging and enqueues its forward passes, which the GPU executes asynchronously -- host
+        tokenization overlaps the encoder instead of preceding it.  Batches are
+        formed inside a window (sorted by length, ``embed_batch_size`` each); results do not depend on the
+        batching (tests/test_configs_gpu.py)."""
+        n, win = len(texts), self.pipeline_window
+        if n <= win:
+            return self.embed_token_batches(self._tokenize(texts, prefix))
+        # a short first window puts the GPU to work early; after that two windows are always being tokenized ahead
+        bounds = [0, max(64, win // 8)]
+        while bounds[-1] < n:
+            bounds.append(min(n, bounds[-1] + win))
+        spans = list(zip(bounds[:-1], bounds[1:]))
+        out = torch.empty((n, self.config.hidden), dtype=torch.float32, device=self.device)
+        with ThreadPoolExecutor(max_workers=2) as pool:
+            futs = [pool.submit(self._tokenize, texts[a:b], prefix) for a, b in spans[:2]]
+            for i, (a, b) in enumerate(spans):
+                seqs = futs[i].result()
+                if i + 2 < len(spans):
+                    futs.append(pool.submit(self._tokenize, texts[spans[i + 2][0]:spans[i + 2][1]], prefix))
+                out[a:b] = self.embed_token_batches(seqs)
+                futs[i] = None
+        return out
 
     # ---- HuggingFaceEmbedding / BaseEmbedding surface --------------------------------------------
     def get_text_embedding(self, text: str) -> List[float]:

@@ -389,6 +389,36 @@ class _Scratch(threading.local):
 _scratch = _Scratch()
 
 
+class _Stager(threading.local):
+    """Per-thread ring of pinned host buffers for the token arrays of a batch.  One buffer holds every array
+    of one batch, goes to the device in ONE asynchronous copy on the compute stream, and is reused once the
+    event recorded behind that copy has fired -- so the host can pack and enqueue batch i+1 (and tokenize
+    batch i+2) while the GPU is still computing batch i."""
+
+    SLOTS = 4
+
+    def __init__(self):
+        self.slots = []
+        self.cursor = 0
+
+    def acquire(self, nbytes: int):
+        if len(self.slots) < self.SLOTS:
+            self.slots.append({"buf": None, "ev": None})
+            slot = self.slots[-1]
+        else:
+            slot = self.slots[self.cursor % self.SLOTS]
+        self.cursor += 1
+        if slot["ev"] is not None:
+            slot["ev"].synchronize()
+            slot["ev"] = None
+        if slot["buf"] is None or slot["buf"].numel() < nbytes:
+            slot["buf"] = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, pin_memory=True)
+        return slot
+
+
+_stager = _Stager()
+
+
 class Encoder:
     """Runs the HIP encoder for one set of weights."""
 
@@ -398,15 +428,32 @@ class Encoder:
         self.device = weights.device
         self.lib = _lib.load_library()
 
-    def _to_dev(self, arr: np.ndarray) -> torch.Tensor:
-        return torch.from_numpy(arr).to(self.device, non_blocking=True)
+    def _upload(self, batch: PackedBatch):
+        """Token arrays of a batch -> device int32 views (ids, pos, types | None, seq_start, seq_len): one pinned
+        staging buffer, one asynchronous host-to-device copy on the current stream."""
+        parts = [batch.ids, batch.pos, batch.types, batch.seq_start, batch.seq_len]
+        offs, total = [], 0
+        for a in parts:
+            offs.append(total)
+            if a is not None:
+                total += (a.size + 63) // 64 * 64          # 256-byte aligned sub-arrays
+        slot = _stager.acquire(total * 4)
+        host = slot["buf"][: total * 4].view(torch.int32)
+        hn = host.numpy()
+        for a, o in zip(parts, offs):
+            if a is not None:
+                hn[o:o + a.size] = a
+        with torch.cuda.device(self.device):
+            devbuf = torch.empty(total, dtype=torch.int32, device=self.device)
+            devbuf.copy_(host, non_blocking=True)
+            slot["ev"] = torch.cuda.Event()
+            slot["ev"].record(torch.cuda.current_stream(self.device))
+        return tuple(devbuf[o:o + a.size] if a is not None else None for a, o in zip(parts, offs))
 
     def forward_packed(self, batch: PackedBatch) -> Tuple[torch.Tensor, torch.Tensor]:
         """-> (hidden [n_rows, H] bf16, cls_rows [B] int32 device tensor)."""
         lib, dev, H = self.lib, self.device, self.cfg.hidden
-        ids, pos = self._to_dev(batch.ids), self._to_dev(batch.pos)
-        types = self._to_dev(batch.types) if batch.types is not None else None
-        starts, lens = self._to_dev(batch.seq_start), self._to_dev(batch.seq_len)
+        ids, pos, types, starts, lens = self._upload(batch)
         hidden = torch.empty((batch.n_rows, H), dtype=torch.bfloat16, device=dev)
         need = lib.tt_encoder_workspace_bytes(ctypes.byref(self.w.struct), batch.n_rows)
         ws, base = _scratch.get("enc", dev, need)
@@ -444,9 +491,7 @@ class Encoder:
             hidden, starts = self.forward_packed(batch)
             return hidden, starts
         B = len(batch.seq_len)
-        ids, pos = self._to_dev(batch.ids), self._to_dev(batch.pos)
-        types = self._to_dev(batch.types) if batch.types is not None else None
-        starts, lens = self._to_dev(batch.seq_start), self._to_dev(batch.seq_len)
+        ids, pos, types, starts, lens = self._upload(batch)
         b_pad = (B + 255) // 256 * 256
         cls = torch.empty((b_pad, H), dtype=torch.bfloat16, device=dev)
         need = lib.tt_encoder_cls_workspace_bytes(ctypes.byref(self.w.struct), batch.n_rows, B)

@@ -55,7 +55,11 @@ class HipSentenceTransformerRerank:
 
     def predict(self, pairs: Sequence[Sequence[str]]) -> List[float]:
         """CrossEncoder.predict: [(query, passage), ...] -> sigmoid scores."""
-        ids = [self._tokenizer.encode_pair(q, p, self.max_length)[0] for q, p in pairs]
+        tk = self._tokenizer
+        if hasattr(tk, "encode_pair_batch"):
+            ids = [e[0] for e in tk.encode_pair_batch(list(pairs), self.max_length)]
+        else:
+            ids = [tk.encode_pair(q, p, self.max_length)[0] for q, p in pairs]
         return self.score_token_pairs(ids).cpu().tolist()
 
     # ---- postprocessor surface ------------------------------------------------------------------------

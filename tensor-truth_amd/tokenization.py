@@ -12,6 +12,7 @@ from __future__ import annotations
 import hashlib
 import os
 import re
+import threading
 from typing import List, Optional, Sequence, Tuple
 
 _WORD = re.compile(r"\w+|[^\w\s]", re.UNICODE)
@@ -50,6 +51,12 @@ class HashTokenizer:
             body = body[: max(0, max_length - 2)]
         return [self.sp.bos] + body + [self.sp.eos]
 
+    def encode_batch(self, texts: Sequence[str], max_length: Optional[int] = None) -> List[List[int]]:
+        return [self.encode(t, max_length) for t in texts]
+
+    def encode_pair_batch(self, pairs: Sequence[Tuple[str, str]], max_length: int = 512):
+        return [self.encode_pair(a, b, max_length) for a, b in pairs]
+
     def encode_pair(self, a: str, b: str, max_length: int = 512) -> Tuple[List[int], List[int]]:
         """-> (ids, token_type_ids); truncation 'longest_first' like CrossEncoder's tokenizer call."""
         ia, ib = self._ids(a), self._ids(b)
@@ -66,25 +73,55 @@ class HashTokenizer:
 
 
 class HFTokenizer:
-    """Adapter over a local HF ``tokenizer.json`` (``tokenizers`` library)."""
+    """Adapter over a local HF ``tokenizer.json`` (``tokenizers`` library).  Two tokenizer objects: one that never
+    truncates (single texts; long ones are cut here, keeping the closing special token) and one with
+    ``longest_first`` truncation for pairs -- a Rust tokenizer cannot be reconfigured while another thread is
+    encoding with it, and the ingest pipeline tokenizes from background threads."""
 
     def __init__(self, tokenizer_json: str, arch: str):
         from tokenizers import Tokenizer  # local import: optional dependency
 
+        self._path = tokenizer_json
         self.tk = Tokenizer.from_file(tokenizer_json)
+        self.tk.no_truncation()
+        self.tk.no_padding()
+        self._pair_tk = None
+        self._pair_len = None
+        self._lock = threading.Lock()
         self.arch = arch
         self.sp = SpecialTokens(arch)
 
-    def encode(self, text: str, max_length: Optional[int] = None) -> List[int]:
-        ids = self.tk.encode(text).ids
+    @staticmethod
+    def _cut(ids: List[int], max_length: Optional[int]) -> List[int]:
         if max_length is not None and len(ids) > max_length:
-            ids = ids[: max_length - 1] + [ids[-1]]
+            return ids[: max_length - 1] + [ids[-1]]
         return ids
 
+    def encode(self, text: str, max_length: Optional[int] = None) -> List[int]:
+        return self._cut(self.tk.encode(text).ids, max_length)
+
+    def encode_batch(self, texts: Sequence[str], max_length: Optional[int] = None) -> List[List[int]]:
+        """Whole batch in one call: the Rust tokenizer fans it out over the host cores and releases the GIL, so
+        background threads can tokenize the next windows while this one is packed and enqueued (embedding.py)."""
+        return [self._cut(enc.ids, max_length) for enc in self.tk.encode_batch(list(texts))]
+
+    def _pairs(self, max_length: int):
+        from tokenizers import Tokenizer
+
+        with self._lock:
+            if self._pair_tk is None or self._pair_len != max_length:
+                tk = Tokenizer.from_file(self._path)
+                tk.no_padding()
+                tk.enable_truncation(max_length=max_length, strategy="longest_first")
+                self._pair_tk, self._pair_len = tk, max_length
+            return self._pair_tk
+
     def encode_pair(self, a: str, b: str, max_length: int = 512):
-        self.tk.enable_truncation(max_length=max_length, strategy="longest_first")
-        enc = self.tk.encode(a, b)
+        enc = self._pairs(max_length).encode(a, b)
         return enc.ids, enc.type_ids
+
+    def encode_pair_batch(self, pairs: Sequence[Tuple[str, str]], max_length: int = 512):
+        return [(enc.ids, enc.type_ids) for enc in self._pairs(max_length).encode_batch([(a, b) for a, b in pairs])]
 
 
 def load_tokenizer(model_dir: Optional[str], arch: str, vocab_size: int):

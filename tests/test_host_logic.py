@@ -265,6 +265,56 @@ def test_hash_tokenizer_pairs():
     assert ids[0] == 101 and ids[-1] == 102 and types == [0, 0, 0, 0, 1, 1, 1, 1]
 
 
+def _write_wordlevel_tokenizer(path, words):
+    from tokenizers import Tokenizer, models, pre_tokenizers, processors
+
+    vocab = {"<s>": 0, "<pad>": 1, "</s>": 2, "<unk>": 3}
+    for w in words:
+        vocab.setdefault(w, len(vocab))
+    tk = Tokenizer(models.WordLevel(vocab, unk_token="<unk>"))
+    tk.pre_tokenizer = pre_tokenizers.Whitespace()
+    tk.post_processor = processors.TemplateProcessing(single="<s> $A </s>", pair="<s> $A </s> </s> $B </s>",
+                                                      special_tokens=[("<s>", 0), ("</s>", 2)])
+    tk.save(str(path / "tokenizer.json"))
+    return vocab
+
+
+def test_hf_tokenizer_adapter_batches_pairs_and_threads(tmp_path):
+    """tokenizer.json next to the weights -> HFTokenizer: batch == one-by-one, single texts are
+    cut at max_length keeping </s>, pairs are truncated longest-first to max_length, and single / pair encoding
+    can run from several threads at once (the ingest pipeline tokenizes on background threads)."""
+    import threading
+
+    from tensor_truth_amd.tokenization import HFTokenizer, load_tokenizer
+
+    words = [f"w{i}" for i in range(50)]
+    vocab = _write_wordlevel_tokenizer(tmp_path, words)
+    tk = load_tokenizer(str(tmp_path), "xlmr", len(vocab))
+    assert isinstance(tk, HFTokenizer)
+    texts = [" ".join(words[(i * 7 + j) % 50] for j in range(3 + i % 40)) for i in range(64)]
+    one = [tk.encode(t, 16) for t in texts]
+    assert tk.encode_batch(texts, 16) == one
+    assert all(s[0] == 0 and s[-1] == 2 and len(s) <= 16 for s in one) and max(map(len, one)) == 16
+    assert tk.encode("w1 w2 nope", None) == [0, vocab["w1"], vocab["w2"], 3, 2]
+    ids, types = tk.encode_pair("w1 w2", "w3 w4 w5", 512)
+    assert ids == [0, vocab["w1"], vocab["w2"], 2, 2, vocab["w3"], vocab["w4"], vocab["w5"], 2] and len(types) == len(ids)
+    pairs = [(texts[i], texts[63 - i]) for i in range(64)]
+    pb = tk.encode_pair_batch(pairs, 24)
+    assert pb == [tk.encode_pair(a, b, 24) for a, b in pairs] and max(len(p[0]) for p in pb) == 24
+    got, errs = {}, []
+
+    def work(i):
+        try:
+            got[i] = tk.encode_batch(texts, 16) if i % 2 == 0 else tk.encode_pair_batch(pairs, 24)
+        except Exception as exc:  # noqa: BLE001
+            errs.append(exc)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(6)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    assert not errs and got[0] == got[2] == got[4] == one and got[1] == got[3] == got[5] == pb
+
+
 def test_pack_token_matrix_equals_pack_tokens():
     from tensor_truth_amd.encoder import BGE_M3, BGE_SMALL_EN_V15, pack_token_matrix, pack_tokens
 

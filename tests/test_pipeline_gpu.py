@@ -275,6 +275,33 @@ def test_multi_index_single_pass_scan_equals_per_index_searches(dev, built_lib, 
     assert canon(again) == canon(before)
 
 
+def test_text_ingest_pipeline_equals_single_shot(dev, built_lib, tmp_path):
+    """Long inputs are embedded as a pipeline (background tokenization of the next windows, pinned staging, forward
+    passes enqueued asynchronously): same embeddings, bit for bit, as tokenizing
+    everything first and embedding it in one go -- with the HF tokenizer adapter and with the hash tokenizer."""
+    from tensor_truth_amd.embedding import HipHuggingFaceEmbedding
+    from tensor_truth_amd.encoder import EncoderConfig
+    from tensor_truth_amd.tokenization import HFTokenizer
+
+    from test_host_logic import _write_wordlevel_tokenizer
+
+    words = ["tensor", "kernel", "wave", "matrix", "retrieval", "index", "corpus", "query", "rerank", "chunk",
+             "gradient", "vector", "cache", "stream", "shard", "token", "layer", "norm", "attention", "softmax"]
+    _write_wordlevel_tokenizer(tmp_path, words + [f"doc{i}" for i in range(700)])
+    cfg = EncoderConfig(**SMALL)
+    texts = _texts(700)
+    for tok in (HFTokenizer(str(tmp_path / "tokenizer.json"), "bert"), None):
+        kw = {"encoder_config": cfg, "synthetic_seed": 5, "pipeline_window": 96}
+        if tok is not None:
+            kw["tokenizer"] = tok
+        emb = HipHuggingFaceEmbedding("test/bge-small-shaped", device="cuda", embed_batch_size=64, model_kwargs=kw)
+        single = emb.embed_token_batches(emb._tokenize(texts, ""))
+        piped = emb._embed_texts(texts, "")
+        assert piped.shape == (700, cfg.hidden) and torch.equal(single, piped)
+        lists = emb.get_text_embedding_batch(texts[:130])
+        assert torch.equal(torch.tensor(lists), single[:130].cpu())
+
+
 def test_devices_other_than_hip_are_refused(built_lib):
     from tensor_truth_amd.embedding import HipHuggingFaceEmbedding
 
