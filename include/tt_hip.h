@@ -109,7 +109,8 @@ int tt_topk_merge(const float* in_scores, const int32_t* in_idx,
  * Token layout: sequences are PACKED (no padding tokens are computed): token rows
  * [seq_start[b], seq_start[b] + seq_len[b]) belong to sequence b (any start row, sequences may
  * follow each other without a gap: the attention kernels mask the 8-row token groups two
- * sequences share), and the row count n_rows (>= last start + len) is a multiple of 128;
+ * sequences share), and the row count n_rows (>= last start + len) is a multiple of 128 -- or 64 / 192:
+ * up to 256 rows (one query, a handful of short texts) the projections run as weight-streaming skinny GEMMs;
  * rows that belong to no sequence are computed but never read.
  * All weights are bf16 [out][in] (nn.Linear layout), biases / LayerNorm parameters fp32.
  * The structs below hold DEVICE pointers but live in HOST memory.

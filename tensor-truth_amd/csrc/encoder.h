@@ -27,6 +27,8 @@ struct GemmParams {
     int sn;                   // super-tile width in N-tiles (32 tiles per super-tile: sm = 32 / sn); set by the launcher
 };
 int tt_gemm_launch(const GemmParams& p, int epilogue, hipStream_t st);
+// M <= 256 (a multiple of 64) runs on the weight-streaming skinny kernel unless TT_GEMM_SKINNY=0 (A/B switch)
+bool tt_gemm_skinny_enabled();
 
 struct AttnParams {
     const uint16_t* qk;       // [T][ld_qk] bf16: Q at column q_col0 + h*dh, K at k_col0 + h*dh

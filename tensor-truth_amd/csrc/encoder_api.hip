@@ -36,7 +36,8 @@ bool fp8_ready(const tt_encoder_weights* w, int n_rows) {
 
 EncWs enc_plan(const tt_encoder_weights* w, int n_rows, int n_seq = 0) {
     EncWs e{};
-    const size_t H = (size_t)w->hidden, F = (size_t)w->ffn, T = (size_t)n_rows;
+    // buffers are sized for a multiple of 256 rows: the attention kernels read whole key tiles
+    const size_t H = (size_t)w->hidden, F = (size_t)w->ffn, T = ((size_t)n_rows + 255) / 256 * 256;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += tt_align_up(bytes, 256); return o; };
     e.off_xa = take(T * H * 2);
@@ -46,7 +47,8 @@ EncWs enc_plan(const tt_encoder_weights* w, int n_rows, int n_seq = 0) {
     e.off_vt = take(H * T * 2);
     e.off_ctx = take(T * H * 2);
     e.off_ffn = take(T * F * 2);
-    e.n_cls_pad = (n_seq + 255) / 256 * 256;
+    e.n_cls_pad = (n_seq <= 256 && tt_gemm_skinny_enabled()) ? (n_seq + 63) / 64 * 64      // <= 256 rows: skinny GEMMs
+                                                             : (n_seq + 255) / 256 * 256;
     if (n_seq > 0) {
         const size_t B = (size_t)e.n_cls_pad;
         e.off_cctx = take(B * H * 2);
@@ -91,7 +93,8 @@ static int forward_impl(const tt_encoder_weights* w, const int32_t* ids, const i
                         int n_rows, int max_len, void* hidden_out, void* cls_out, void* workspace,
                         size_t workspace_bytes, void* stream) {
     if (int rc = check_weights(w)) return rc;
-    TT_CHECK_ARG(n_rows > 0 && n_rows % 128 == 0, "n_rows=%d must be a positive multiple of 128", n_rows);
+    TT_CHECK_ARG(n_rows > 0 && (n_rows % 128 == 0 || (n_rows < 256 && n_rows % 64 == 0)),
+                 "n_rows=%d must be a positive multiple of 128 (or 64 / 192)", n_rows);
     TT_CHECK_ARG(n_seq > 0 && max_len > 0, "n_seq=%d max_len=%d", n_seq, max_len);
     TT_CHECK_ARG(ids && pos && seq_start && seq_len && (hidden_out || cls_out), "null pointer");
     const bool cls_tail = cls_out != nullptr && w->layers > 0;

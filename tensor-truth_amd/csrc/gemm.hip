@@ -1138,6 +1138,69 @@ int launch_fp8(const GemmParams& p, hipStream_t st) {
     }
 }
 
+// ---- skinny: M <= 256 rows (one query's embedding, the CLS-row tail of the last layer, the rerank head) -----------
+// With a few dozen token rows a GEMM is a stream of the weight matrix and nothing else: the tiled kernels put
+// 16 (N = 1024) to 64 workgroups on the chip and walk K in 64-element steps behind a barrier each (8 us at K = 1024,
+// 30 us at K = 4096, times 6 GEMMs x 24 layers = most of a query embedding's 3.4 ms).  Here ONE WAVE owns 16 output
+// columns x 64 rows x all of K: no LDS, no barrier, operands straight from global memory into MFMA fragments (a
+// fragment is 16 contiguous bytes of a K-contiguous row in both operands), kPf K-steps of loads in flight per wave,
+// N/16 x M/64 waves per launch.  The activations (<= 256 x K) are re-read by every wave from L2.
+// Same instruction, operand order and K order as the tiled kernels, same epilogue code: results are bit-identical
+// to theirs, so an embedding does not depend on whether the text was embedded alone or in a large batch.
+constexpr int kPf = 8;
+template <int EPI>
+__global__ __launch_bounds__(64) void gemm_skinny_kernel(GemmParams p) {
+    const int lane = threadIdx.x;
+    const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 64;
+    const int frow = lane & 15, fchk = lane >> 4;
+    const uint16_t* wp = p.W + (size_t)(n0 + frow) * p.K + fchk * 8;
+    const uint16_t* ap = p.A + (size_t)(m0 + frow) * p.lda + fchk * 8;
+    const size_t a16 = (size_t)16 * p.lda;
+    f32x4 acc[1][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[0][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 wb[kPf], ab[kPf][4];
+    const int nks = p.K / 32;
+#pragma unroll
+    for (int s = 0; s < kPf; ++s)
+        if (s < nks) {
+            wb[s] = *reinterpret_cast<const bf16x8*>(wp + s * 32);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ab[s][j] = *reinterpret_cast<const bf16x8*>(ap + j * a16 + s * 32);
+        }
+    for (int ks = 0; ks < nks; ks += kPf) {
+#pragma unroll
+        for (int s = 0; s < kPf; ++s) {
+            if (ks + s < nks) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[s], ab[s][j], acc[0][j], 0, 0, 0);
+                const int nx = ks + s + kPf;
+                if (nx < nks) {
+                    wb[s] = *reinterpret_cast<const bf16x8*>(wp + nx * 32);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) ab[s][j] = *reinterpret_cast<const bf16x8*>(ap + j * a16 + nx * 32);
+                }
+            }
+        }
+    }
+    gemm_epilogue_tile<EPI, 1, 4>(p, acc, m0, n0, lane);
+}
+
+bool skinny_shape(const GemmParams& p) {
+    return !p.fp8 && tt_gemm_skinny_enabled() && p.M > 0 && p.M <= 256 && p.M % 64 == 0 && p.N % 16 == 0 && p.K % 32 == 0 && p.K > 0;
+}
+
+template <int EPI>
+int launch_skinny(const GemmParams& p, hipStream_t st) {
+    {
+        TtProfScope prof(TT_K_GEMM, st);
+        hipLaunchKernelGGL(gemm_skinny_kernel<EPI>, dim3(p.N / 16, p.M / 64), dim3(64), 0, st, p);
+    }
+    TT_CHECK_LAUNCH();
+    return TT_OK;
+}
+
 template <int EPI>
 int launch(const GemmParams& p, hipStream_t st) {
     if (p.fp8) return launch_fp8<EPI>(p, st);
@@ -1227,6 +1290,11 @@ int launch(const GemmParams& p, hipStream_t st) {
 
 }  // namespace
 
+bool tt_gemm_skinny_enabled() {
+    static const bool on = [] { const char* e = getenv("TT_GEMM_SKINNY"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 int tt_gemm_launch(const GemmParams& p, int epilogue, hipStream_t st) {
     if (p.M <= 0 || p.N <= 0) return TT_OK;
     if (p.fp8 && epilogue == TT_EPI_QKV) {
@@ -1246,13 +1314,27 @@ int tt_gemm_launch(const GemmParams& p, int epilogue, hipStream_t st) {
         b.vt_col0 = 0;
         return launch<TT_EPI_VT>(b, st);
     }
-    if (p.M % BM || p.N % BN || p.K % BK || p.K <= 0) {
-        tt_set_error("gemm: M=%d N=%d K=%d must be multiples of %d/%d/%d", p.M, p.N, p.K, BM, BN, BK);
-        return TT_E_UNSUPPORTED;
-    }
     if ((p.lda % 8) || (p.ldc % 4) || !p.A || !p.W || !p.C || !p.bias) {
         tt_set_error("gemm: bad leading dimension / null pointer");
         return TT_E_INVALID;
+    }
+    if (skinny_shape(p)) {
+        switch (epilogue) {
+            case TT_EPI_BIAS: return launch_skinny<TT_EPI_BIAS>(p, st);
+            case TT_EPI_GELU: return launch_skinny<TT_EPI_GELU>(p, st);
+            case TT_EPI_RESIDUAL:
+                if (!p.residual || p.ldr % 4) { tt_set_error("gemm: residual epilogue without residual"); return TT_E_INVALID; }
+                return launch_skinny<TT_EPI_RESIDUAL>(p, st);
+            case TT_EPI_TANH: return launch_skinny<TT_EPI_TANH>(p, st);
+            case TT_EPI_QKV:
+                if (!p.vt || p.vt_col0 % 16) { tt_set_error("gemm: qkv epilogue without vt"); return TT_E_INVALID; }
+                return launch_skinny<TT_EPI_QKV>(p, st);
+            default: tt_set_error("gemm: unknown epilogue %d", epilogue); return TT_E_INVALID;
+        }
+    }
+    if (p.M % BM || p.N % BN || p.K % BK || p.K <= 0) {
+        tt_set_error("gemm: M=%d N=%d K=%d must be multiples of %d/%d/%d (or M a multiple of 64 up to 256)", p.M, p.N, p.K, BM, BN, BK);
+        return TT_E_UNSUPPORTED;
     }
     switch (epilogue) {
         case TT_EPI_BIAS: return launch<TT_EPI_BIAS>(p, st);

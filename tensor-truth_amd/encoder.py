@@ -312,6 +312,14 @@ class PackedBatch:
     n_tokens: int          # real tokens (sum of seq_len)
 
 
+def _round_rows(used: int) -> int:
+    """Token rows of a batch: a multiple of the 256-row GEMM tile; up to 256 rows (one query, a few short texts) a
+    multiple of 64 -- the projections then run as weight-streaming skinny GEMMs (csrc/gemm.hip)."""
+    if used <= 256 and os.environ.get("TT_GEMM_SKINNY", "1") != "0":   # (=0: A/B switch of tools/gpu_skinny.sh)
+        return max(64, (used + 63) // 64 * 64)
+    return (used + 255) // 256 * 256
+
+
 def pack_tokens(seqs: Sequence[Sequence[int]], cfg: EncoderConfig,
                 type_ids: Optional[Sequence[Sequence[int]]] = None, max_len: Optional[int] = None) -> PackedBatch:
     """Pack token-id sequences (already carrying their special tokens) without padding tokens: sequence
@@ -327,7 +335,7 @@ def pack_tokens(seqs: Sequence[Sequence[int]], cfg: EncoderConfig,
     for i, n in enumerate(lens):
         starts[i] = off
         off += (int(n) + _PACK_ALIGN - 1) // _PACK_ALIGN * _PACK_ALIGN
-    n_rows = max(256, (off + 255) // 256 * 256)   # multiple of 256: the 256-row GEMM tile
+    n_rows = _round_rows(off)
     ids = np.full(n_rows, cfg.pad_id, dtype=np.int32)
     pos = np.zeros(n_rows, dtype=np.int32)
     types = np.zeros(n_rows, dtype=np.int32) if type_ids is not None else None
@@ -355,7 +363,7 @@ def pack_token_matrix(ids2d: np.ndarray, cfg: EncoderConfig, type_ids2d: Optiona
         ids2d = ids2d[:, : cfg.max_seq_len]
         length = cfg.max_seq_len
     stride = (length + _PACK_ALIGN - 1) // _PACK_ALIGN * _PACK_ALIGN
-    n_rows = max(256, (n * stride + 255) // 256 * 256)
+    n_rows = _round_rows(n * stride)
     ids = np.full(n_rows, cfg.pad_id, dtype=np.int32)
     pos = np.zeros(n_rows, dtype=np.int32)
     pos_off = cfg.pad_id + 1 if cfg.arch == "xlmr" else 0

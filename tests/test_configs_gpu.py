@@ -142,3 +142,26 @@ def test_full_size_rerank_is_batch_invariant(dev, built_lib):
     assert torch.equal(s_perm, s_all[torch.from_numpy(perm)])
     s_half = enc.rerank_packed(pack_token_matrix(pairs[:400], cfg)).cpu()
     assert torch.equal(s_half, s_all[:400])
+    # three pairs alone: their CLS tail (64 rows) runs on the skinny GEMMs, the batch's (1024 rows) on the tiled ones
+    s_few = enc.rerank_packed(pack_token_matrix(pairs[5:8], cfg)).cpu()
+    assert torch.equal(s_few, s_all[5:8])
+
+
+def test_query_embedding_alone_equals_query_embedding_in_a_batch(dev, built_lib):
+    """One query on its own (64 token rows: every projection of the 24 layers is a skinny weight-streaming GEMM) gets
+    bit for bit the embedding it gets inside a batch of 200 queries (8000 rows: tiled kernels)."""
+    import numpy as np
+
+    from tensor_truth_amd.encoder import BGE_M3, Encoder, EncoderWeights, pack_token_matrix, synthetic_state_device
+
+    cfg = BGE_M3
+    enc = Encoder(EncoderWeights(cfg, synthetic_state_device(cfg, dev, seed=1), dev))
+    rng = np.random.default_rng(5)
+    q = rng.integers(4, cfg.vocab_size, size=(200, 34), dtype=np.int32)
+    q[:, 0], q[:, -1] = 0, 2
+    e_all, _ = enc.embed_packed(pack_token_matrix(q, cfg))
+    assert pack_token_matrix(q[:1], cfg).n_rows == 64 and pack_token_matrix(q[:6], cfg).n_rows == 256
+    for lo, hi in ((0, 1), (7, 8), (10, 16), (100, 104)):
+        e_few, _ = enc.embed_packed(pack_token_matrix(q[lo:hi], cfg))
+        assert torch.equal(e_few, e_all[lo:hi]), (lo, hi)
+    assert torch.isfinite(e_all).all() and (e_all.norm(dim=1) - 1).abs().max() < 1e-3

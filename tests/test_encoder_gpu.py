@@ -31,7 +31,9 @@ def _bf(x):
 
 
 @pytest.mark.parametrize("m,n,k", [(128, 128, 64), (256, 384, 384), (384, 1152, 384), (128, 1536, 384),
-                                   (512, 1024, 1024), (256, 4096, 1024), (256, 1024, 4096)])
+                                   (512, 1024, 1024), (256, 4096, 1024), (256, 1024, 4096),
+                                   (64, 1024, 1024), (192, 3072, 1024), (64, 1024, 4096), (64, 1152, 384),   # skinny
+                                   (384, 128, 64), (640, 1024, 4096), (1024, 384, 1536)])                    # 128x128 tiles
 @pytest.mark.parametrize("epi", [0, 1, 2, 3])
 def test_gemm_epilogues(dev, built_lib, m, n, k, epi):
     from tensor_truth_amd import _lib
@@ -58,6 +60,33 @@ def test_gemm_epilogues(dev, built_lib, m, n, k, epi):
     got = c_d.float().cpu()
     err = (got - ref).abs()
     assert (err <= 2 ** -7 * ref.abs() + 2e-3).all(), f"max err {err.max().item()}"
+
+
+@pytest.mark.parametrize("epi", [0, 1, 2, 3])
+@pytest.mark.parametrize("n,k", [(1024, 1024), (1024, 4096), (384, 1536)])
+def test_skinny_gemm_is_bit_identical_to_the_tiled_kernels(dev, built_lib, n, k, epi):
+    """Up to 256 rows the projections run as weight-streaming skinny GEMMs (one wave per 16 columns, no LDS); same MFMA,
+    same K order, same epilogue code as the tiled kernels -> the same bits for the same rows, whatever else is in the
+    batch.  64 rows alone (skinny) vs the same rows inside 512- and 2048-row GEMMs (128x128 and 256x256 tiles)."""
+    from tensor_truth_amd import _lib
+
+    lib = _lib.load_library()
+    g = torch.Generator().manual_seed(n + k + epi)
+    big = 2048
+    a = _bf(torch.randn(big, k, generator=g)).to(dev)
+    w = _bf(torch.randn(n, k, generator=g) * 0.05).to(dev)
+    bias = (torch.randn(n, generator=g) * 0.1).to(dev)
+    res = _bf(torch.randn(big, n, generator=g)).to(dev)
+    outs = []
+    for m in (64, 192, 512, big):
+        c = torch.empty(m, n, dtype=torch.bfloat16, device=dev)
+        rc = lib.tt_gemm_bf16(a.data_ptr(), w.data_ptr(), bias.data_ptr(), res.data_ptr() if epi == 2 else None,
+                              c.data_ptr(), m, n, k, epi, _stream())
+        _lib.check(rc, "tt_gemm_bf16")
+        outs.append(c)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1][:64]) and torch.equal(outs[0], outs[2][:64]) and torch.equal(outs[0], outs[3][:64])
+    assert torch.equal(outs[1], outs[3][:192])
 
 
 def test_gemm_rejects_bad_shapes(dev, built_lib):

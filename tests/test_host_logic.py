@@ -238,14 +238,14 @@ def test_pack_tokens_layout():
     from tensor_truth_amd.encoder import BGE_M3, BGE_SMALL_EN_V15, pack_tokens
 
     b = pack_tokens([[0, 5, 6, 2], [0, 9, 2], list(range(4, 24))], BGE_M3)
-    assert b.n_rows % 256 == 0 and (b.seq_start % 8 == 0).all()
+    assert b.n_rows == 64 and (b.seq_start % 8 == 0).all()      # up to 256 rows: multiples of 64 (skinny GEMMs)
     assert b.seq_len.tolist() == [4, 3, 20] and b.seq_start.tolist() == [0, 8, 16]
     assert b.pos[:4].tolist() == [2, 3, 4, 5]                 # XLM-R positions start at pad_id + 1
     assert b.ids[4] == 1 and b.n_tokens == 27 and b.max_len == 20
     s = pack_tokens([[101, 7, 102]], BGE_SMALL_EN_V15, type_ids=[[0, 0, 0]])
     assert s.pos[:3].tolist() == [0, 1, 2] and s.types is not None
     long = pack_tokens([list(range(4, 4 + 9000))], BGE_M3)
-    assert long.seq_len[0] == 8192                             # truncated to the model limit
+    assert long.seq_len[0] == 8192 and long.n_rows % 256 == 0  # truncated to the model limit; 256-row GEMM tiles
     with pytest.raises(ValueError):
         pack_tokens([[]], BGE_M3)
     with pytest.raises(ValueError):
