@@ -1,0 +1,134 @@
+"""Hierarchical chunking on the host: the node parser in front of the GPU embedder.
+
+Restates what the reference gets from llama-index at ``src/tensortruth/indexing/builder.py:383-420`` and
+``document_index.py:300``: ``HierarchicalNodeParser.from_defaults(chunk_sizes, chunk_overlap)`` = one
+sentence-aware splitter per level; every chunk of level ``i`` is split again at level ``i+1``; chunks of one parent
+are chained PREVIOUS/NEXT and linked PARENT/CHILD; the leaves (``get_leaf_nodes``) are what gets embedded, all nodes
+go to the docstore for auto-merging.  When ``llama_index`` is importable the reference's own parser can be used
+unchanged (anything with ``get_nodes_from_documents`` plugs into ``index_builder``); this module is for hosts
+without it.  Token counts: llama-index counts with its global tokenizer (tiktoken); here the counter is pluggable and
+defaults to a word/punctuation count, so chunk BOUNDARIES are not claimed to match llama-index token for token --
+the structure (levels, links, overlap semantics, metadata inheritance) is what the retrieval path depends on.
+"""
+from __future__ import annotations
+
+import re
+from typing import Callable, Iterable, List, Optional, Sequence
+
+from .schema import TextNode
+
+_TOKEN = re.compile(r"\w+|[^\w\s]", re.UNICODE)
+_SENTENCE = re.compile(r"[^.!?\n]+[.!?]*\s*|\n+")
+_PARAGRAPH = re.compile(r"\n\s*\n")
+
+
+def count_tokens(text: str) -> int:
+    return len(_TOKEN.findall(text))
+
+
+class SentenceSplitter:
+    """Greedy sentence packing: consecutive sentences are joined until ``chunk_size`` tokens would be exceeded; the
+    next chunk starts with the trailing sentences of the previous one worth at most ``chunk_overlap`` tokens; a
+    sentence longer than ``chunk_size`` is cut at word boundaries (llama-index ``SentenceSplitter`` semantics)."""
+
+    def __init__(self, chunk_size: int = 1024, chunk_overlap: int = 200, tokenizer: Optional[Callable[[str], int]] = None):
+        if chunk_overlap >= chunk_size:
+            raise ValueError(f"chunk_overlap {chunk_overlap} must be smaller than chunk_size {chunk_size}")
+        self.chunk_size, self.chunk_overlap = chunk_size, chunk_overlap
+        self._count = tokenizer or count_tokens
+
+    def _pieces(self, text: str) -> List[str]:
+        out = []
+        for para in _PARAGRAPH.split(text):
+            for m in _SENTENCE.finditer(para):
+                s = m.group(0)
+                if not s.strip():
+                    continue
+                if self._count(s) <= self.chunk_size:
+                    out.append(s)
+                    continue
+                words, cur, n = re.findall(r"\S+\s*", s), [], 0      # oversized sentence: cut at words
+                for w in words:
+                    c = self._count(w)
+                    if cur and n + c > self.chunk_size:
+                        out.append("".join(cur))
+                        cur, n = [], 0
+                    cur.append(w)
+                    n += c
+                if cur:
+                    out.append("".join(cur))
+            if out and not out[-1].endswith("\n"):
+                out[-1] = out[-1] + "\n"
+        return out
+
+    def split_text(self, text: str) -> List[str]:
+        pieces = self._pieces(text)
+        sizes = [self._count(p) for p in pieces]
+        chunks, cur, n, i = [], [], 0, 0
+        while i < len(pieces):
+            if cur and n + sizes[i] > self.chunk_size:
+                chunks.append("".join(cur).strip())
+                keep, kn = [], 0                                       # overlap: trailing pieces of the closed chunk
+                for j in range(len(cur) - 1, -1, -1):
+                    c = self._count(cur[j])
+                    if kn + c > self.chunk_overlap or kn + c + sizes[i] > self.chunk_size:
+                        break
+                    keep.insert(0, cur[j])
+                    kn += c
+                cur, n = keep, kn
+                continue
+            cur.append(pieces[i])
+            n += sizes[i]
+            i += 1
+        if cur and "".join(cur).strip():
+            chunks.append("".join(cur).strip())
+        return [c for c in chunks if c]
+
+
+class HierarchicalNodeParser:
+    def __init__(self, chunk_sizes: Sequence[int], chunk_overlap: int = 20, tokenizer: Optional[Callable[[str], int]] = None):
+        if not chunk_sizes or list(chunk_sizes) != sorted(chunk_sizes, reverse=True):
+            raise ValueError("chunk_sizes must be non-empty and decreasing, e.g. [2048, 512, 256]")
+        self.chunk_sizes = list(chunk_sizes)
+        self.splitters = [SentenceSplitter(cs, min(chunk_overlap, cs - 1), tokenizer) for cs in chunk_sizes]
+
+    @classmethod
+    def from_defaults(cls, chunk_sizes: Optional[Sequence[int]] = None, chunk_overlap: int = 20, **kw):
+        return cls(chunk_sizes or [2048, 512, 128], chunk_overlap, kw.get("tokenizer"))
+
+    def _split(self, parent_text: str, meta: dict, level: int, parent: Optional[TextNode], out: List[TextNode],
+               excluded: Sequence[str]) -> None:
+        chunks = self.splitters[level].split_text(parent_text)
+        prev: Optional[TextNode] = None
+        for c in chunks:
+            nd = TextNode(text=c, metadata=dict(meta))
+            nd.excluded_embed_metadata_keys = list(excluded)
+            if parent is not None:
+                nd.parent_id = parent.id_
+                parent.child_ids.append(nd.id_)
+            if prev is not None:
+                prev.next_id, nd.prev_id = nd.id_, prev.id_
+            out.append(nd)
+            prev = nd
+            if level + 1 < len(self.splitters):
+                self._split(c, meta, level + 1, nd, out, excluded)
+
+    def get_nodes_from_documents(self, documents: Iterable, show_progress: bool = False) -> List[TextNode]:
+        """Documents (or nodes, as the reference feeds the semantic splitter's output back in, builder.py:415-418)
+        -> every node of every level, top level first within a document."""
+        out: List[TextNode] = []
+        for doc in documents:
+            text = doc.get_content() if hasattr(doc, "get_content") else str(doc)
+            if not text.strip():
+                continue
+            meta = dict(getattr(doc, "metadata", {}) or {})
+            self._split(text, meta, 0, None, out, getattr(doc, "excluded_embed_metadata_keys", []) or [])
+        return out
+
+
+def get_leaf_nodes(nodes: Iterable[TextNode]) -> List[TextNode]:
+    return [n for n in nodes if not getattr(n, "child_ids", None)]
+
+
+def get_root_nodes(nodes: Iterable[TextNode]) -> List[TextNode]:
+    return [n for n in nodes if getattr(n, "parent_id", None) is None]

@@ -12,7 +12,9 @@ from __future__ import annotations
 import json
 import math
 import os
+import re
 import threading
+from datetime import datetime, timezone
 from typing import Dict, Iterable, List, Optional, Sequence
 
 import numpy as np
@@ -23,6 +25,15 @@ from .schema import MetadataMode, NodeWithScore, QueryBundle, TextNode, as_query
 
 INDEX_METADATA_FILENAME = "index_metadata.json"   # reference: indexing/metadata.py:17
 INDEX_VERSION = "1.0"
+
+
+def sanitize_model_id(model_name: str) -> str:
+    """"BAAI/bge-m3" -> "bge-m3": the directory level of ``indexes/{model_id}/{module}/`` (reference:
+    indexing/metadata.py:22-52: last path component, lower case, anything outside [a-z0-9-_.] -> "-", runs of
+    dashes collapsed, leading/trailing dashes dropped)."""
+    name = model_name.split("/")[-1].lower()
+    name = re.sub(r"[^a-z0-9\-_.]", "-", name)
+    return re.sub(r"-+", "-", name).strip("-")
 
 
 class HipVectorIndex:
@@ -126,7 +137,7 @@ class HipVectorIndex:
 
     # ---- persistence ---------------------------------------------------------------------------------
     def persist(self, persist_dir: str, embedding_model: Optional[str] = None, chunk_sizes=None,
-                chunking_strategy: Optional[str] = None) -> None:
+                chunking_strategy: Optional[str] = None, chunk_overlap: Optional[int] = None) -> None:
         os.makedirs(persist_dir, exist_ok=True)
         with self._lock:
             self.matrix.cpu().view(torch.int16).numpy().tofile(os.path.join(persist_dir, "corpus.bf16"))
@@ -136,13 +147,13 @@ class HipVectorIndex:
                      for nid, nd in self.docstore.items()}
             with open(os.path.join(persist_dir, "nodes.json"), "w") as f:
                 json.dump({"dim": self.dim, "leaf_ids": self.leaf_ids, "nodes": nodes}, f)
-        meta = {"embedding_model": embedding_model or getattr(self.embed_model, "model_name", None),
-                "embedding_dim": self.dim, "index_version": INDEX_VERSION, "num_vectors": self.n,
-                "store": "tensor_truth_amd/corpus.bf16"}
-        if chunk_sizes is not None:
-            meta["chunk_sizes"] = list(chunk_sizes)
-        if chunking_strategy is not None:
-            meta["chunking_strategy"] = chunking_strategy
+        # the reference's index_metadata.json (indexing/metadata.py:103-146) + what this store adds
+        model = embedding_model or getattr(self.embed_model, "model_name", None)
+        meta = {"embedding_model": model, "embedding_model_id": sanitize_model_id(model) if model else None,
+                "created_at": datetime.now(timezone.utc).isoformat(), "index_version": INDEX_VERSION,
+                "chunk_sizes": list(chunk_sizes) if chunk_sizes is not None else None, "chunk_overlap": chunk_overlap,
+                "chunking_strategy": chunking_strategy,
+                "embedding_dim": self.dim, "num_vectors": self.n, "store": "tensor_truth_amd/corpus.bf16"}
         with open(os.path.join(persist_dir, INDEX_METADATA_FILENAME), "w") as f:
             json.dump(meta, f, indent=2)
 

@@ -416,3 +416,59 @@ def test_llamaindex_docstore_json_is_parsed_without_llamaindex(tmp_path):
     assert nodes["c1"].metadata == {"file_name": "a.md"} and nodes["c1"].excluded_embed_metadata_keys == ["file_name"]
     with pytest.raises(ImportError, match="chromadb"):          # not installed here: a clear message, no fallback
         read_chroma_collection(str(tmp_path))
+
+
+# ---- hierarchical node parser / index metadata (host side of the ingest path) ----------------------------------------
+def test_hierarchical_node_parser_structure():
+    """Levels, links and overlap semantics of the parser the reference builds at indexing/builder.py:385-388."""
+    from tensor_truth_amd.node_parser import (HierarchicalNodeParser, SentenceSplitter, count_tokens, get_leaf_nodes,
+                                              get_root_nodes)
+    from tensor_truth_amd.schema import TextNode
+
+    sents = [f"Sentence number {i} talks about topic {i % 7} at some length." for i in range(120)]
+    doc = TextNode(text=" ".join(sents[:60]) + "\n\n" + " ".join(sents[60:]), metadata={"title": "T", "doc_type": "book"})
+    doc.excluded_embed_metadata_keys = ["doc_type"]
+    parser = HierarchicalNodeParser.from_defaults(chunk_sizes=[256, 64, 32], chunk_overlap=8)
+    nodes = parser.get_nodes_from_documents([doc, TextNode(text="   ")])
+    by_id = {n.id_: n for n in nodes}
+    roots, leaves = get_root_nodes(nodes), get_leaf_nodes(nodes)
+    assert len(roots) >= 4 and len(leaves) > len(roots) and len(by_id) == len(nodes)
+    depth = {}
+    for n in nodes:                                   # parents precede children; three levels exactly
+        depth[n.id_] = 0 if n.parent_id is None else depth[n.parent_id] + 1
+        assert n.metadata == {"title": "T", "doc_type": "book"} and n.excluded_embed_metadata_keys == ["doc_type"]
+    assert set(depth.values()) == {0, 1, 2}
+    limits = {0: 256, 1: 64, 2: 32}
+    for n in nodes:
+        assert 0 < count_tokens(n.text) <= limits[depth[n.id_]]
+        assert (depth[n.id_] == 2) == (not n.child_ids)
+        for cid in n.child_ids:
+            assert by_id[cid].parent_id == n.id_ and by_id[cid].text.split()[0] in n.text
+        if n.child_ids:                               # children of one parent are chained prev/next, in order
+            kids = [by_id[c] for c in n.child_ids]
+            assert kids[0].prev_id is None and kids[-1].next_id is None
+            assert all(a.next_id == b.id_ and b.prev_id == a.id_ for a, b in zip(kids, kids[1:]))
+            covered = " ".join(k.text for k in kids)  # the children cover the parent's text (with overlap)
+            assert all(w in covered for w in n.text.split()[:20])
+    # overlap: consecutive chunks share trailing sentences worth <= chunk_overlap tokens
+    sp = SentenceSplitter(chunk_size=40, chunk_overlap=12)
+    chunks = sp.split_text(" ".join(sents[:12]))
+    assert len(chunks) >= 3
+    for a, b in zip(chunks, chunks[1:]):
+        first_sentence = b.split(".")[0]
+        assert first_sentence in a and count_tokens(b) <= 40
+    assert SentenceSplitter(16, 0).split_text("word " * 100)[0].count("word") <= 16   # oversized sentence cut at words
+    with pytest.raises(ValueError):
+        HierarchicalNodeParser.from_defaults(chunk_sizes=[64, 256])
+    with pytest.raises(ValueError):
+        SentenceSplitter(10, 10)
+
+
+def test_sanitize_model_id_known_answers():
+    """The two examples of the reference's docstring (indexing/metadata.py:34-38) + edge cases of its regex."""
+    from tensor_truth_amd.vector_index import sanitize_model_id
+
+    assert sanitize_model_id("BAAI/bge-m3") == "bge-m3"
+    assert sanitize_model_id("sentence-transformers/all-MiniLM-L6-v2") == "all-minilm-l6-v2"
+    assert sanitize_model_id("org/My Model@@v1.5_x") == "my-model-v1.5_x"
+    assert sanitize_model_id("--weird//name--") == "name"

@@ -334,6 +334,100 @@ def test_semantic_splitter_distances_and_cuts(dev, built_lib):
     assert len(chunks) == 2 and "kernel is fast" in chunks[0] and chunks[1].startswith("The sauce")
 
 
+def test_semantic_splitter_batches_documents_without_changing_the_cuts(dev, built_lib):
+    """All documents' sentence groups go through ONE embedding call and ONE adjacent-cosine launch; the cuts are
+    those of one call per document (the reference's SemanticSplitterNodeParser loop, builder.py:393-407)."""
+    from tensor_truth_amd.embedding import HipHuggingFaceEmbedding
+    from tensor_truth_amd.encoder import EncoderConfig
+    from tensor_truth_amd.schema import TextNode
+    from tensor_truth_amd.semantic import SemanticSplitter
+
+    cfg = EncoderConfig(**SMALL)
+    emb = HipHuggingFaceEmbedding("test/bge-small-shaped", device="cuda", embed_batch_size=32,
+                                  model_kwargs={"encoder_config": cfg, "synthetic_seed": 8, "pipeline_window": 48})
+    base = _texts(120)
+    docs = [". ".join(base[i * 9:(i + 1) * 9 + (i % 4)]) + "." for i in range(12)] + ["one sentence only", "", "A. B."]
+    sp = SemanticSplitter(emb, buffer_size=1, breakpoint_percentile_threshold=80)
+    calls = {"n": 0}
+    orig = emb._embed_texts
+
+    def counting(texts, prefix):
+        calls["n"] += 1
+        return orig(texts, prefix)
+
+    emb._embed_texts = counting
+    together = sp.split_texts(docs)
+    assert calls["n"] == 1
+    one_by_one = [sp.split_text(d) for d in docs]
+    assert together == one_by_one
+    assert together[12] == ["one sentence only"] and together[13] == [] and sum(len(c) > 1 for c in together) >= 8
+    nodes = sp.get_nodes_from_documents([TextNode(text=d, metadata={"doc": i}) for i, d in enumerate(docs)],
+                                        max_groups_per_call=20)
+    assert [n.text for n in nodes] == [c for chunks in together for c in chunks]
+    by_doc = {}
+    for n in nodes:
+        by_doc.setdefault(n.metadata["doc"], []).append(n)
+    for chain in by_doc.values():       # prev/next links stay inside a document
+        assert chain[0].prev_id is None and chain[-1].next_id is None
+        assert all(a.next_id == b.id_ and b.prev_id == a.id_ for a, b in zip(chain, chain[1:]))
+
+
+@pytest.mark.parametrize("strategy", ["hierarchical", "semantic", "semantic_hierarchical"])
+def test_build_index_strategies_persist_and_retrieve(dev, built_lib, tmp_path, strategy):
+    """The core of the reference's build_module (indexing/builder.py:376-453) on the HIP embedder: parse with the chosen
+    ChunkingStrategy, embed the leaves, docstore + index, index_metadata.json; reload and retrieve with auto-merging."""
+    import json
+
+    from tensor_truth_amd.embedding import HipHuggingFaceEmbedding
+    from tensor_truth_amd.encoder import EncoderConfig
+    from tensor_truth_amd.index_builder import build_index
+    from tensor_truth_amd.node_parser import get_leaf_nodes
+    from tensor_truth_amd.retrievers import AutoMergingRetriever
+    from tensor_truth_amd.schema import QueryBundle, TextNode
+    from tensor_truth_amd.vector_index import HipVectorIndex
+
+    cfg = EncoderConfig(**SMALL)
+    emb = HipHuggingFaceEmbedding("test/bge-small-shaped", device="cuda", embed_batch_size=64,
+                                  model_kwargs={"encoder_config": cfg, "synthetic_seed": 12})
+    base = _texts(160)
+    docs = [TextNode(text=". ".join(base[i * 20:(i + 1) * 20]) + ".", metadata={"title": f"doc {i}"}) for i in range(8)]
+    stages = []
+    index = build_index(docs, emb, persist_dir=str(tmp_path / "m"), chunking_strategy=strategy, chunk_sizes=[128, 48, 24],
+                        chunk_overlap=6, semantic_breakpoint_threshold=75,
+                        progress_callback=lambda st, cur, tot: stages.append((st, cur, tot)))
+    leaves = get_leaf_nodes(index.docstore.values())
+    assert index.n == len(leaves) > 8 and stages[0] == ("parsing", 0, 8) and stages[-1] == ("embedding", index.n, index.n)
+    if strategy != "semantic":
+        assert len(index.docstore) > index.n           # parents are in the docstore, only leaves in the matrix
+    meta = json.load(open(tmp_path / "m" / "index_metadata.json"))
+    assert meta["embedding_model"] == "test/bge-small-shaped" and meta["embedding_model_id"] == "bge-small-shaped"
+    assert meta["chunk_sizes"] == [128, 48, 24] and meta["chunk_overlap"] == 6 and meta["chunking_strategy"] == strategy
+    assert meta["index_version"] == "1.0" and meta["num_vectors"] == index.n and "created_at" in meta
+    again = HipVectorIndex.load(str(tmp_path / "m"), embed_model=emb)
+    assert again.n == index.n and torch.equal(again.matrix, index.matrix) and set(again.docstore) == set(index.docstore)
+    # query with a leaf's own stored vector (the synthetic random-weight model maps all texts close together, so a text
+    # query is not a sharp probe): the leaf -- or the parent it was merged into -- comes back first
+    row = index.n // 2
+    probe_id = again.leaf_ids[row]
+    qb = QueryBundle(query_str="probe", embedding=again.matrix[row].float().cpu().tolist())
+    hits = AutoMergingRetriever(again.as_retriever(similarity_top_k=6), again.docstore).retrieve(qb)
+    assert hits and hits[0].score > 0.97
+    ids = [h.node.id_ for h in hits]
+    assert probe_id in ids or any(probe_id in _descendants(again.docstore, i) for i in ids)
+    assert [h.score for h in hits] == sorted((h.score for h in hits), reverse=True)
+    with pytest.raises(ValueError):
+        build_index(docs, emb, chunking_strategy="fixed")
+
+
+def _descendants(docstore, node_id):
+    out, todo = set(), [node_id]
+    while todo:
+        for c in getattr(docstore[todo.pop()], "child_ids", []) or []:
+            out.add(c)
+            todo.append(c)
+    return out
+
+
 def test_profiling_hooks(dev, built_lib):
     import ctypes
 
