@@ -4,6 +4,7 @@ restate the reference's control flow so the HIP retriever drops into the same pi
 """
 from __future__ import annotations
 
+import threading
 from collections import OrderedDict, defaultdict
 from concurrent.futures import ThreadPoolExecutor, as_completed
 from functools import lru_cache
@@ -54,6 +55,7 @@ class MultiIndexRetriever:
         # tagging and balancing are unchanged.  Anything unexpected falls back to the thread pool.
         self.single_pass = single_pass
         self._group = None
+        self._group_lock = threading.Lock()
         if enable_cache:
             self._retrieve_cached = lru_cache(maxsize=cache_size)(self._retrieve_impl)
         else:
@@ -124,13 +126,15 @@ class MultiIndexRetriever:
         indexes = [b.index for b in bases]
         if len({(ix.dim, ix.device) for ix in indexes}) != 1 or len({id(ix) for ix in indexes}) != len(indexes):
             return None
-        if self._group is None or [id(ix) for ix in self._group.indexes] != [id(ix) for ix in indexes]:
-            self._group = HipIndexGroup(indexes)
+        with self._group_lock:   # retrieve() is called from several threads (rag_engine.py:392,420)
+            if self._group is None or [id(ix) for ix in self._group.indexes] != [id(ix) for ix in indexes]:
+                self._group = HipIndexGroup(indexes)
+            group = self._group
         k = max(min(b.similarity_top_k, ix.n) for b, ix in zip(bases, indexes))
         if k < 1:
             return [[] for _ in bases]
         q = torch.tensor([bundle.embedding], dtype=torch.float32)
-        scores, rows = self._group.search(q, k)
+        scores, rows = group.search(q, k)
         scores, rows = scores[0].cpu().tolist(), rows[0].cpu().tolist()
         out = []
         for i, (r, b) in enumerate(zip(self.retrievers, bases)):

@@ -35,14 +35,21 @@ class HashTokenizer:
         self.arch = arch
         self.vocab_size = vocab_size
         self.sp = SpecialTokens(arch)
+        self._cache = {}           # word -> id (words repeat; bounded below)
 
     def _ids(self, text: str) -> List[int]:
         lo = self.sp.first_free
         span = self.vocab_size - lo
+        cache = self._cache
         out = []
         for w in _WORD.findall(text):
-            h = int.from_bytes(hashlib.blake2b(w.encode("utf-8"), digest_size=8).digest(), "little")
-            out.append(lo + h % span)
+            t = cache.get(w)
+            if t is None:
+                h = int.from_bytes(hashlib.blake2b(w.encode("utf-8"), digest_size=8).digest(), "little")
+                t = lo + h % span
+                if len(cache) < (1 << 20):
+                    cache[w] = t
+            out.append(t)
         return out
 
     def encode(self, text: str, max_length: Optional[int] = None) -> List[int]:

@@ -302,6 +302,56 @@ def test_text_ingest_pipeline_equals_single_shot(dev, built_lib, tmp_path):
         assert torch.equal(torch.tensor(lists), single[:130].cpu())
 
 
+def test_retrieve_and_rerank_from_eight_threads(dev, built_lib):
+    """The reference calls the retrievers from up to 8 worker threads and the postprocessor from executor threads
+    (rag_engine.py:392,420): scratch buffers, pinned staging and error text are per thread, the
+    library keeps no global mutable state -- concurrent calls return exactly what serial calls return."""
+    import threading
+
+    from tensor_truth_amd.embedding import HipHuggingFaceEmbedding
+    from tensor_truth_amd.encoder import EncoderConfig
+    from tensor_truth_amd.rerank import HipSentenceTransformerRerank
+    from tensor_truth_amd.retrievers import AutoMergingRetriever, MultiIndexRetriever
+    from tensor_truth_amd.schema import QueryBundle, TextNode
+    from tensor_truth_amd.vector_index import HipVectorIndex
+
+    cfg = EncoderConfig(**SMALL)
+    emb = HipHuggingFaceEmbedding("test/bge-small-shaped", device="cuda",
+                                  model_kwargs={"encoder_config": cfg, "synthetic_seed": 31})
+    rr = HipSentenceTransformerRerank(model="test/xenc", top_n=4, device="cuda",
+                                      model_kwargs={"encoder_config": EncoderConfig(**XENC), "synthetic_seed": 32})
+    texts = _texts(240)
+    retrievers = []
+    for part in range(3):
+        ix = HipVectorIndex(cfg.hidden, embed_model=emb)
+        ix.add([TextNode(text=t, id_=f"i{part}_{j}") for j, t in enumerate(texts[part * 80:(part + 1) * 80])])
+        retrievers.append(AutoMergingRetriever(ix.as_retriever(similarity_top_k=8), ix.docstore))
+    queries = [" ".join(texts[7 * i + 3].split()[:6]) for i in range(16)]
+
+    def run(mir, q):
+        nodes = mir.retrieve(q)
+        ranked = rr.postprocess_nodes(nodes, query_bundle=QueryBundle(query_str=q))
+        return [(n.node.id_, n.node.metadata["_source_index"], n.score) for n in ranked]
+
+    for single_pass in (True, False):
+        mir = MultiIndexRetriever(retrievers, enable_cache=False, single_pass=single_pass)
+        serial = [run(mir, q) for q in queries]
+        got, errs = [None] * len(queries), []
+
+        def work(t):
+            try:
+                for i in range(t, len(queries), 8):
+                    got[i] = run(mir, queries[i])
+            except Exception as exc:  # noqa: BLE001
+                errs.append(exc)
+
+        threads = [threading.Thread(target=work, args=(t,)) for t in range(8)]
+        [t.start() for t in threads]
+        [t.join() for t in threads]
+        assert not errs, errs
+        assert got == serial and all(len(r) == 4 for r in got)
+
+
 def test_devices_other_than_hip_are_refused(built_lib):
     from tensor_truth_amd.embedding import HipHuggingFaceEmbedding
 
