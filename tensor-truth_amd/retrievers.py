@@ -130,7 +130,7 @@ class MultiIndexRetriever:
             if self._group is None or [id(ix) for ix in self._group.indexes] != [id(ix) for ix in indexes]:
                 self._group = HipIndexGroup(indexes)
             group = self._group
-        k = max(min(b.similarity_top_k, ix.n) for b, ix in zip(bases, indexes))
+        k = max(min(b.similarity_top_k, ix.num_live) for b, ix in zip(bases, indexes))
         if k < 1:
             return [[] for _ in bases]
         q = torch.tensor([bundle.embedding], dtype=torch.float32)
@@ -138,7 +138,7 @@ class MultiIndexRetriever:
         scores, rows = scores[0].cpu().tolist(), rows[0].cpu().tolist()
         out = []
         for i, (r, b) in enumerate(zip(self.retrievers, bases)):
-            kk = min(b.similarity_top_k, indexes[i].n)
+            kk = min(b.similarity_top_k, indexes[i].num_live)
             nodes = b.nodes_from_hits(scores[i][:kk], rows[i][:kk])
             out.append(r.merge(nodes) if r is not b and hasattr(r, "merge") else nodes)
         return out

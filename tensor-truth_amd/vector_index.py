@@ -54,6 +54,8 @@ class HipVectorIndex:
         self.docstore: Dict[str, TextNode] = {}  # every node (leaves + parents), for auto-merging
         self._lock = threading.RLock()
         self._version = 0                      # bumped by every mutation (HipIndexGroup repacks on change)
+        self._dead = 0                         # tombstoned rows (NaN-filled, leaf id None), see delete()
+        self._row_of: Optional[Dict[str, int]] = None   # leaf id -> row, built on the first delete
 
     # ---- build / mutate ------------------------------------------------------------------------
     def _reserve(self, n_new: int) -> None:
@@ -87,9 +89,11 @@ class HipVectorIndex:
         with self._lock:
             self._reserve(len(nodes))
             self._mat[self.n:self.n + len(nodes)] = emb.to(torch.bfloat16)
-            for nd in nodes:
+            for j, nd in enumerate(nodes):
                 self.leaf_ids.append(nd.id_)
                 self.docstore[nd.id_] = nd
+                if self._row_of is not None:
+                    self._row_of[nd.id_] = self.n + j
             self.n += len(nodes)
             self._version += 1
         return [nd.id_ for nd in nodes]
@@ -101,20 +105,43 @@ class HipVectorIndex:
                 self.docstore.setdefault(nd.id_, nd)
 
     def delete(self, node_ids: Iterable[str]) -> int:
-        """Remove leaves by id (``document_index.py:568``): rows are compacted, order preserved."""
+        """Remove leaves by id (``document_index.py:568``).  The rows become TOMBSTONES: they are overwritten with
+        NaN, so their dot product with any query is NaN, which the scan's threshold compare and the selection's
+        key both reject -- a deleted row can never be returned and the scan kernels need no mask.  One small
+        scatter per call; rows are compacted (order preserved) once a quarter of the matrix is dead, and before
+        persisting."""
         drop = set(node_ids)
         with self._lock:
-            keep = [i for i, nid in enumerate(self.leaf_ids) if nid not in drop]
-            removed = self.n - len(keep)
-            if removed:
-                idx = torch.tensor(keep, dtype=torch.long, device=self.device)
-                self._mat[: len(keep)] = self._mat[: self.n].index_select(0, idx)
-                self.leaf_ids = [self.leaf_ids[i] for i in keep]
-                self.n = len(keep)
+            if self._row_of is None:
+                self._row_of = {nid: i for i, nid in enumerate(self.leaf_ids) if nid is not None}
+            rows = [self._row_of.pop(nid) for nid in drop if nid in self._row_of]
+            if rows:
+                idx = torch.tensor(rows, dtype=torch.long, device=self.device)
+                self._mat[: self.n].index_fill_(0, idx, float("nan"))
+                for r in rows:
+                    self.leaf_ids[r] = None
+                self._dead += len(rows)
                 self._version += 1
+                if self._dead > max(1024, self.n // 4):
+                    self._compact()
             for nid in drop:
                 self.docstore.pop(nid, None)
-        return removed
+        return len(rows)
+
+    def _compact(self) -> None:
+        with self._lock:
+            if not self._dead:
+                return
+            keep = [i for i, nid in enumerate(self.leaf_ids) if nid is not None]
+            idx = torch.tensor(keep, dtype=torch.long, device=self.device)
+            self._mat[: len(keep)] = self._mat[: self.n].index_select(0, idx)
+            self.leaf_ids = [self.leaf_ids[i] for i in keep]
+            self.n, self._dead, self._row_of = len(keep), 0, None
+            self._version += 1
+
+    @property
+    def num_live(self) -> int:
+        return self.n - self._dead
 
     @property
     def matrix(self) -> torch.Tensor:
@@ -140,6 +167,7 @@ class HipVectorIndex:
                 chunking_strategy: Optional[str] = None, chunk_overlap: Optional[int] = None) -> None:
         os.makedirs(persist_dir, exist_ok=True)
         with self._lock:
+            self._compact()                    # tombstones are not written
             self.matrix.cpu().view(torch.int16).numpy().tofile(os.path.join(persist_dir, "corpus.bf16"))
             nodes = {nid: {"text": nd.text, "metadata": nd.metadata, "parent_id": getattr(nd, "parent_id", None),
                            "child_ids": list(getattr(nd, "child_ids", []) or []),
@@ -191,7 +219,7 @@ class HipVectorRetriever:
     def retrieve(self, query) -> List[NodeWithScore]:
         qb = as_query_bundle(query)
         idx = self.index
-        if idx.n == 0:
+        if idx.num_live == 0:
             return []
         if getattr(qb, "embedding", None) is not None:
             q = torch.tensor([qb.embedding], dtype=torch.float32)
@@ -204,7 +232,7 @@ class HipVectorRetriever:
                 q = em.query_embedding_device(strs).mean(dim=0, keepdim=True)
             else:
                 q = torch.tensor([em.get_agg_embedding_from_queries(strs)], dtype=torch.float32)
-        k = min(self.similarity_top_k, idx.n)
+        k = min(self.similarity_top_k, idx.num_live)
         scores, rows = idx.search(q, k)
         return self.nodes_from_hits(scores[0].cpu().tolist(), rows[0].cpu().tolist())
 

@@ -87,7 +87,7 @@ def test_embedding_index_retriever_roundtrip(dev, built_lib, tmp_path):
                                  score_mode="cosine")
     assert loaded.n == 300 and torch.equal(loaded.matrix.cpu().view(torch.int16), index.matrix.cpu().view(torch.int16))
     assert [r.node.id_ for r in loaded.as_retriever(10).retrieve(query)] == [r.node.id_ for r in res]
-    assert loaded.delete(["n17"]) == 1 and loaded.n == 299
+    assert loaded.delete(["n17"]) == 1 and loaded.num_live == 299
     assert loaded.as_retriever(10).retrieve(query)[0].node.id_ != "n17"
     # chroma-style score mapping
     chroma = HipVectorIndex.load(str(tmp_path / "indexes" / "bge-small" / "library_x"), embed_model=emb)
@@ -350,6 +350,59 @@ def test_retrieve_and_rerank_from_eight_threads(dev, built_lib):
         [t.join() for t in threads]
         assert not errs, errs
         assert got == serial and all(len(r) == 4 for r in got)
+
+
+def test_deleted_rows_are_tombstones_that_never_rank(dev, built_lib, tmp_path):
+    """delete() NaN-fills the rows (document_index.py:568 remove path): the scan needs no
+    mask, results equal those of an index that never held the deleted nodes -- through the filter scan (20k rows), the
+    dense scan (small index), the segmented multi-index scan, compaction and persist/load."""
+    from tensor_truth_amd.retrievers import MultiIndexRetriever
+    from tensor_truth_amd.schema import QueryBundle, TextNode
+    from tensor_truth_amd.vector_index import HipVectorIndex
+
+    dim = 256
+    g = torch.Generator().manual_seed(23)
+    for n, n_del in ((20000, 3000), (500, 200)):
+        vecs = torch.randn(n, dim, generator=g)
+        nodes = [TextNode(text=f"t{i}", id_=f"d{i}") for i in range(n)]
+        full = HipVectorIndex(dim, score_mode="cosine")
+        full.add(nodes, embeddings=vecs)
+        qv = torch.nn.functional.normalize(vecs[:40] + 0.3 * torch.randn(40, dim, generator=g), dim=1)
+        dead = set(torch.randperm(n, generator=g)[:n_del].tolist()) | set(range(0, 40, 2))   # incl. the best matches
+        keep = [i for i in range(n) if i not in dead]
+        clean = HipVectorIndex(dim, score_mode="cosine")
+        clean.add([nodes[i] for i in keep], embeddings=vecs[keep])
+        assert full.delete([f"d{i}" for i in dead] + ["not-there"]) == len(dead)
+        assert full.num_live == len(keep) and full.n == n          # below the compaction threshold: tombstones stay
+        for q in range(40):
+            qb = QueryBundle(query_str="q", embedding=qv[q].tolist())
+            a = full.as_retriever(similarity_top_k=25).retrieve(qb)
+            b = clean.as_retriever(similarity_top_k=25).retrieve(qb)
+            assert [(x.node.id_, x.score) for x in a] == [(x.node.id_, x.score) for x in b] and len(a) == 25
+            assert not any(int(x.node.id_[1:]) in dead for x in a)
+        # a deleted id can come back as a fresh row; the segmented path sees tombstones the same way
+        full.add([nodes[0]], embeddings=vecs[:1])
+        other = HipVectorIndex(dim, score_mode="cosine")
+        other.add([TextNode(text="o", id_=f"o{i}") for i in range(64)], embeddings=torch.randn(64, dim, generator=g))
+        class E:  # noqa: E701 - embed model stub shared by both indexes
+            def get_agg_embedding_from_queries(self, qs):
+                return qv[1].tolist()
+        full.embed_model = other.embed_model = E()
+        hits = MultiIndexRetriever([full.as_retriever(similarity_top_k=10), other.as_retriever(similarity_top_k=10)],
+                                   enable_cache=False).retrieve("anything")
+        ids = [h.node.id_ for h in hits]
+        assert not any(i.startswith("d") and int(i[1:]) in dead - {0} for i in ids) and len(hits) == 20
+        full.persist(str(tmp_path / f"ix{n}"))
+        again = HipVectorIndex.load(str(tmp_path / f"ix{n}"), score_mode="cosine")
+        assert again.n == len(keep) + 1 and not torch.isnan(again.matrix.float()).any() and None not in again.leaf_ids
+        if n == 20000:   # a quarter of the rows dead (and more than 1024): compaction, same results
+            more = [i for i in keep if i % 4 == 1][:2500]
+            clean.delete([f"d{i}" for i in more])
+            assert full.delete([f"d{i}" for i in more]) == 2500 and full.n == full.num_live == len(keep) + 1 - 2500
+            qb = QueryBundle(query_str="q", embedding=qv[3].tolist())
+            a = full.as_retriever(similarity_top_k=25).retrieve(qb)
+            b = clean.as_retriever(similarity_top_k=25).retrieve(qb)
+            assert [(x.node.id_, x.score) for x in a if x.node.id_ != "d0"] == [(x.node.id_, x.score) for x in b]
 
 
 def test_devices_other_than_hip_are_refused(built_lib):
