@@ -395,10 +395,11 @@ def test_deleted_rows_are_tombstones_that_never_rank(dev, built_lib, tmp_path):
         full.persist(str(tmp_path / f"ix{n}"))
         again = HipVectorIndex.load(str(tmp_path / f"ix{n}"), score_mode="cosine")
         assert again.n == len(keep) + 1 and not torch.isnan(again.matrix.float()).any() and None not in again.leaf_ids
-        if n == 20000:   # a quarter of the rows dead (and more than 1024): compaction, same results
-            more = [i for i in keep if i % 4 == 1][:2500]
+        if n == 20000:   # persist() compacted; now more than a quarter of the rows (and more than 1024) die: compaction again
+            assert full.n == full.num_live == len(keep) + 1
+            more = [i for i in keep if i % 3 == 1][:4500]
             clean.delete([f"d{i}" for i in more])
-            assert full.delete([f"d{i}" for i in more]) == 2500 and full.n == full.num_live == len(keep) + 1 - 2500
+            assert full.delete([f"d{i}" for i in more]) == 4500 and full.n == full.num_live == len(keep) + 1 - 4500
             qb = QueryBundle(query_str="q", embedding=qv[3].tolist())
             a = full.as_retriever(similarity_top_k=25).retrieve(qb)
             b = clean.as_retriever(similarity_top_k=25).retrieve(qb)
