@@ -51,6 +51,10 @@ def parse():
     ap.add_argument("--embed-chunks", type=int, default=1024, help="chunks per GPU in the ingest (chunks embedded/s) leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp8-leg", action="store_true", help="skip the extra fp8-reranker timing (BASELINE config 5)")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="run only the warm-up and timed steps (no scan-only / fp8 / ingest legs): every kernel of the process then "
+                         "belongs to the timed workload, so a rocprofv3 --stats summary of this command can be compared with "
+                         "roofline.avg_launch_ms directly (tools/rocprof_vs_bench.py)")
     ap.add_argument("--layers", type=int, default=24, help="encoder depth (24 = the named models; for debugging only)")
     return ap.parse_args()
 
@@ -188,28 +192,30 @@ def main():
     stage_prof = read_prof()
     lib.tt_prof_enable(0)
 
-    # ---- the similarity scan alone (BASELINE configs 2 / 4): 256 resident query embeddings (256 / world per GPU, gathered)
-    # against the sharded corpus
-    nq_scan = max(1, 256 // world)
-    scan_q = torch.nn.functional.normalize(torch.randn(nq_scan, D, device=dev, generator=torch.Generator(device=dev).manual_seed(4321)), dim=1).to(torch.bfloat16)
-    corpus.search(gather_queries(scan_q), K)
-    sync_all()
-    t3 = time.perf_counter()
-    for _ in range(3):
+    scan_only = None
+    if not args.headline_only:
+        # ---- the similarity scan alone (BASELINE configs 2 / 4): 256 resident query embeddings (256 / world per GPU, gathered)
+        # against the sharded corpus
+        nq_scan = max(1, 256 // world)
+        scan_q = torch.nn.functional.normalize(torch.randn(nq_scan, D, device=dev, generator=torch.Generator(device=dev).manual_seed(4321)), dim=1).to(torch.bfloat16)
         corpus.search(gather_queries(scan_q), K)
-    sync_all()
-    dt_scan = (time.perf_counter() - t3) / 3
-    if world > 1:
-        t = torch.tensor([dt_scan], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt_scan = float(t.item())
-    scan_only = {"queries_per_s": world * nq_scan / dt_scan, "ms_per_batch": dt_scan * 1e3,
-                 "what": f"exact top-{K} of {world * nq_scan} queries over the {args.corpus_rows} x {D} corpus (gather + scan + merge), no encoders"}
+        sync_all()
+        t3 = time.perf_counter()
+        for _ in range(3):
+            corpus.search(gather_queries(scan_q), K)
+        sync_all()
+        dt_scan = (time.perf_counter() - t3) / 3
+        if world > 1:
+            t = torch.tensor([dt_scan], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt_scan = float(t.item())
+        scan_only = {"queries_per_s": world * nq_scan / dt_scan, "ms_per_batch": dt_scan * 1e3,
+                     "what": f"exact top-{K} of {world * nq_scan} queries over the {args.corpus_rows} x {D} corpus (gather + scan + merge), no encoders"}
 
     # ---- BASELINE config 5's "fp8 MFMA reranker": the same steps with the cross-encoder's Q/K/V and FFN-up
     # projections on e4m3 operands.  Reported beside the headline (which stays bf16), never as it.
     fp8_leg = None
-    if not args.no_fp8_leg:
+    if not args.no_fp8_leg and not args.headline_only:
         # static scale of the FFN intermediate per layer: one bf16 calibration forward over 64 synthetic pairs
         cal = rng.integers(4, vocab, size=(64, args.query_len + args.chunk_len + 4), dtype=np.int32)
         cal[:, 0], cal[:, -1] = 0, 2
@@ -236,38 +242,40 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # ---- second half of the BASELINE metric: batch chunk embedding (ingest), separately timed ----
-    chunk_tok = rng.integers(4, vocab, size=(args.embed_chunks, args.chunk_len), dtype=np.int32)
-    chunk_seqs = [np.concatenate(([0], c, [2])) for c in chunk_tok]
-    chunk_batch = pack_tokens(chunk_seqs, emb_cfg)
-    embedder.embed_packed(chunk_batch)
-    sync_all()
-    t1 = time.perf_counter()
-    for _ in range(2):
-        embedder.embed_packed(chunk_batch)
-    sync_all()
-    dt_embed = (time.perf_counter() - t1) / 2
-    if world > 1:
-        t = torch.tensor([dt_embed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt_embed = float(t.item())
-    chunks_per_s = world * args.embed_chunks / dt_embed
-    if fp8_leg is not None:   # the ingest leg with the bi-encoder's layer projections in e4m3, same protocol
-        embedder.calibrate_fp8(chunk_batch)
-        embedder.w.set_gemm_dtype("fp8")
+    chunks_per_s = None
+    if not args.headline_only:
+        # ---- second half of the BASELINE metric: batch chunk embedding (ingest), separately timed ----
+        chunk_tok = rng.integers(4, vocab, size=(args.embed_chunks, args.chunk_len), dtype=np.int32)
+        chunk_seqs = [np.concatenate(([0], c, [2])) for c in chunk_tok]
+        chunk_batch = pack_tokens(chunk_seqs, emb_cfg)
         embedder.embed_packed(chunk_batch)
         sync_all()
         t1 = time.perf_counter()
         for _ in range(2):
             embedder.embed_packed(chunk_batch)
         sync_all()
-        dt8e = (time.perf_counter() - t1) / 2
-        embedder.w.set_gemm_dtype("bf16")
+        dt_embed = (time.perf_counter() - t1) / 2
         if world > 1:
-            t = torch.tensor([dt8e], dtype=torch.float64, device=dev)
+            t = torch.tensor([dt_embed], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt8e = float(t.item())
-        fp8_leg["chunks_embedded_per_s"] = world * args.embed_chunks / dt8e
+            dt_embed = float(t.item())
+        chunks_per_s = world * args.embed_chunks / dt_embed
+        if fp8_leg is not None:   # the ingest leg with the bi-encoder's layer projections in e4m3, same protocol
+            embedder.calibrate_fp8(chunk_batch)
+            embedder.w.set_gemm_dtype("fp8")
+            embedder.embed_packed(chunk_batch)
+            sync_all()
+            t1 = time.perf_counter()
+            for _ in range(2):
+                embedder.embed_packed(chunk_batch)
+            sync_all()
+            dt8e = (time.perf_counter() - t1) / 2
+            embedder.w.set_gemm_dtype("bf16")
+            if world > 1:
+                t = torch.tensor([dt8e], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt8e = float(t.item())
+            fp8_leg["chunks_embedded_per_s"] = world * args.embed_chunks / dt8e
 
     # ---- roofline of the dominant kernel (GEMM, MFMA-bound) and of the scan (HBM-bound) -------
     H, F, L = emb_cfg.hidden, emb_cfg.ffn, emb_cfg.layers
