@@ -175,8 +175,8 @@ int tt_encoder_forward(const tt_encoder_weights* w, const int32_t* ids, const in
                        void* workspace, size_t workspace_bytes, void* stream);
 
 /* Same forward, but the LAST layer is evaluated for the CLS row of every sequence only (the one row the
- * pooling and the classification head read): cls_out is [round_up(n_seq, 256)][H] bf16, row b = final hidden
- * state of token seq_start[b].  Identical arithmetic for those rows up to the attention kernel used for the
+ * pooling and the classification head read): cls_out is [round_up(n_seq, 256)][H] bf16 (rows beyond round_up(n_seq, 64)
+ * are not written when n_seq <= 256), row b = final hidden state of token seq_start[b].  Identical arithmetic for those rows up to the attention kernel used for the
  * single query row (fp32 probabilities instead of bf16); saves 1/24 of the encoder work at 24 layers. */
 size_t tt_encoder_cls_workspace_bytes(const tt_encoder_weights* w, int n_rows, int n_seq);
 int tt_encoder_forward_cls(const tt_encoder_weights* w, const int32_t* ids, const int32_t* pos,
@@ -204,6 +204,8 @@ int tt_adjacent_cosine(const float* emb_f32, int n, int hidden, float* out_dist,
  * tt_attention_varlen: Q and K are row-major [rows][ld_qk] at column offsets q_col0 / k_col0;
  * V is passed in the token-blocked transposed layout the QKV GEMM epilogue writes,
  * vt[(row / 8) * ldvt + feature * 8 + row % 8] with ldvt = 8 * heads * head_dim. */
+/* tt_gemm_bf16: m, n multiples of 128 and k of 64 (tiled kernels), or m a multiple of 64 up to 256 with n % 16 == 0 and
+ * k % 32 == 0 (weight-streaming skinny kernel; same bits as the tiled kernels for the same rows). */
 int tt_gemm_bf16(const void* a, const void* w, const float* bias, const void* residual, void* c,
                  int m, int n, int k, int epilogue /*0 bias,1 gelu,2 +residual,3 tanh*/, void* stream);
 int tt_layernorm_bf16(const void* in, void* out, const float* gamma, const float* beta, int rows, int hidden,
