@@ -1,0 +1,122 @@
+"""GPU: HF checkpoint directories (config.json + model.safetensors, as the reference's models ship) load through
+``weights.resolve`` and the HIP forward agrees with the upstream implementation itself -- ``transformers``' XLM-R / BERT
+forward in fp32 on the CPU, the code the reference reaches through sentence-transformers.
+
+The checkpoints are tiny random-init models written by ``save_pretrained`` into a temp dir (no network, nothing from
+/root/reference): this pins the weight-name mapping (``roberta.`` prefix, ``classifier.dense / out_proj``), config parsing,
+XLM-R position ids, CLS pooling + L2 norm and the sigmoid head against upstream, not against our own oracle.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+transformers = pytest.importorskip("transformers")
+
+
+def _perturb_layernorms(model, seed):
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if "LayerNorm.weight" in name:
+                p.add_(0.2 * torch.randn(p.shape, generator=g))
+            elif "LayerNorm.bias" in name or name.endswith(".bias"):
+                p.add_(0.1 * torch.randn(p.shape, generator=g))
+            elif p.dim() == 2 and "embeddings" not in name:
+                p.mul_(2.5)                     # default init (std 0.02) gives nearly constant outputs: widen the spread
+
+
+def _ragged(rng, n, lo, hi, vocab, bos, eos):
+    seqs = []
+    for _ in range(n):
+        length = int(rng.integers(lo, hi))
+        seqs.append([bos] + rng.integers(5, vocab, size=length - 2).tolist() + [eos])
+    return seqs
+
+
+def _padded(seqs, pad):
+    L = max(map(len, seqs))
+    ids = torch.full((len(seqs), L), pad, dtype=torch.long)
+    mask = torch.zeros((len(seqs), L), dtype=torch.long)
+    for i, s in enumerate(seqs):
+        ids[i, : len(s)] = torch.tensor(s)
+        mask[i, : len(s)] = 1
+    return ids, mask
+
+
+def test_xlmr_cross_encoder_checkpoint_vs_transformers(dev, built_lib, tmp_path):
+    from transformers import XLMRobertaConfig, XLMRobertaForSequenceClassification
+
+    from tensor_truth_amd.rerank import HipSentenceTransformerRerank
+
+    torch.manual_seed(3)
+    cfg = XLMRobertaConfig(vocab_size=1200, hidden_size=256, num_hidden_layers=3, num_attention_heads=4, intermediate_size=512,
+                           max_position_embeddings=200, type_vocab_size=1, pad_token_id=1, bos_token_id=0, eos_token_id=2,
+                           num_labels=1, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, classifier_dropout=0.0)
+    model = XLMRobertaForSequenceClassification(cfg).eval()
+    _perturb_layernorms(model, 1)
+    rng = np.random.default_rng(0)
+    seqs = _ragged(rng, 24, 6, 150, 1200, 0, 2)
+    ids, mask = _padded(seqs, 1)
+    with torch.no_grad():
+        # a random-init head scores every pair nearly alike: standardise its logits over this batch (mean 0, std 1.5)
+        # so the comparison exercises the sigmoid's whole range
+        raw = model(input_ids=ids, attention_mask=mask).logits[:, 0]
+        k = 1.5 / raw.std()
+        model.classifier.out_proj.weight.mul_(k)
+        model.classifier.out_proj.bias.mul_(k)
+        model.classifier.out_proj.bias.sub_(model(input_ids=ids, attention_mask=mask).logits[:, 0].mean())
+        want_logit = model(input_ids=ids, attention_mask=mask).logits[:, 0]
+        want = torch.sigmoid(want_logit)
+    assert 1.2 < want_logit.std().item() < 1.8 and abs(want_logit.mean().item()) < 1e-3
+    model.save_pretrained(str(tmp_path / "xenc"), safe_serialization=True)
+    rr = HipSentenceTransformerRerank(model=str(tmp_path / "xenc"), top_n=3, device="cuda")
+    assert rr.config.arch == "xlmr" and rr.config.num_labels == 1 and rr.config.layers == 3 and rr.config.max_seq_len == 198
+    got = rr.score_token_pairs(seqs).cpu()
+    err = (got - want).abs().max().item()
+    # bf16 forward vs fp32 upstream; the head was scaled up by k (tens), which scales the hidden-state rounding noise too
+    assert err < 4e-2, (err, float(k))
+    order_w, order_g = torch.argsort(want, descending=True), torch.argsort(got, descending=True)
+    gaps = torch.sort(want, descending=True).values.diff().abs()
+    if bool((gaps[:6] > 8e-2).all()):
+        assert torch.equal(order_w[:6], order_g[:6])
+    assert torch.corrcoef(torch.stack([got, want]))[0, 1].item() > 0.995
+
+
+@pytest.mark.parametrize("arch", ["xlmr", "bert"])
+def test_bi_encoder_checkpoint_vs_transformers(dev, built_lib, tmp_path, arch):
+    from tensor_truth_amd.embedding import HipHuggingFaceEmbedding
+
+    torch.manual_seed(4)
+    if arch == "xlmr":
+        from transformers import XLMRobertaConfig, XLMRobertaModel
+
+        cfg = XLMRobertaConfig(vocab_size=1500, hidden_size=256, num_hidden_layers=2, num_attention_heads=4,
+                               intermediate_size=1024, max_position_embeddings=260, type_vocab_size=1, pad_token_id=1,
+                               hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+        model = XLMRobertaModel(cfg, add_pooling_layer=False).eval()
+        bos, eos, pad = 0, 2, 1
+    else:
+        from transformers import BertConfig, BertModel
+
+        cfg = BertConfig(vocab_size=1500, hidden_size=384, num_hidden_layers=2, num_attention_heads=12, intermediate_size=1536,
+                         max_position_embeddings=256, type_vocab_size=2, pad_token_id=0, hidden_dropout_prob=0.0,
+                         attention_probs_dropout_prob=0.0)
+        model = BertModel(cfg, add_pooling_layer=True).eval()     # the pooler's weights are in the file and must be ignored
+        bos, eos, pad = 101, 102, 0
+    _perturb_layernorms(model, 2)
+    d = tmp_path / f"bi_{arch}"
+    model.save_pretrained(str(d), safe_serialization=True)
+    emb = HipHuggingFaceEmbedding(str(d), device="cuda", embed_batch_size=16)
+    assert emb.config.arch == arch and emb.config.hidden == cfg.hidden_size and emb.config.num_labels == 0
+    rng = np.random.default_rng(1)
+    seqs = _ragged(rng, 40, 3, 200, 1500, bos, eos)
+    got = emb.embed_token_batches(seqs).cpu()
+    ids, mask = _padded(seqs, pad)
+    with torch.no_grad():
+        hidden = model(input_ids=ids, attention_mask=mask).last_hidden_state
+    want = torch.nn.functional.normalize(hidden[:, 0], p=2, dim=1)          # Pooling(cls) + Normalize
+    cos = (got * want).sum(dim=1)
+    assert cos.min().item() >= 0.999 and (got - want).abs().max().item() <= 1e-2, (cos.min().item(), (got - want).abs().max().item())
+    assert (got.norm(dim=1) - 1).abs().max() < 1e-3
