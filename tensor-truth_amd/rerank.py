@@ -38,6 +38,8 @@ class HipSentenceTransformerRerank:
         if not cfg.num_labels:
             raise ValueError(f"'{model}' has no classification head (not a cross-encoder)")
         self.config = cfg
+        # pairs are truncated by the tokenizer (longest-first, specials kept): never beyond what the model has positions for
+        self.max_length = min(max_length, cfg.max_seq_len)
         self.model = EncoderWeights(cfg, state, dev)    # `.model` is what the reference's memory accounting reads
         # model_kwargs["gemm_dtype"] = "fp8": Q/K/V and FFN-up projections on the e4m3 matrix cores (BASELINE config 5)
         self.model.set_gemm_dtype((model_kwargs or {}).get("gemm_dtype", "bf16"))

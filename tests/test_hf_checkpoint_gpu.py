@@ -83,6 +83,37 @@ def test_xlmr_cross_encoder_checkpoint_vs_transformers(dev, built_lib, tmp_path)
         assert torch.equal(order_w[:6], order_g[:6])
     assert torch.corrcoef(torch.stack([got, want]))[0, 1].item() > 0.995
 
+    # ---- from strings, as SentenceTransformerRerank.postprocess_nodes / CrossEncoder.predict run it:
+    # a tokenizer.json next to the weights is picked up; pairs are encoded <s> q </s></s> p </s>, truncated longest-first
+    from tokenizers import Tokenizer, models, pre_tokenizers, processors
+
+    from tensor_truth_amd.schema import NodeWithScore, QueryBundle, TextNode
+
+    words = [f"w{i}" for i in range(1100)]
+    vocab = {"<s>": 0, "<pad>": 1, "</s>": 2, "<unk>": 3, **{w: 4 + i for i, w in enumerate(words)}}
+    tk = Tokenizer(models.WordLevel(vocab, unk_token="<unk>"))
+    tk.pre_tokenizer = pre_tokenizers.Whitespace()
+    tk.post_processor = processors.TemplateProcessing(single="<s> $A </s>", pair="<s> $A </s> </s> $B </s>",
+                                                      special_tokens=[("<s>", 0), ("</s>", 2)])
+    tk.save(str(tmp_path / "xenc" / "tokenizer.json"))
+    rr2 = HipSentenceTransformerRerank(model=str(tmp_path / "xenc"), top_n=4, device="cuda")
+    query = " ".join(words[i] for i in rng.integers(0, 1100, size=9))
+    passages = [" ".join(words[i] for i in rng.integers(0, 1100, size=int(n))) for n in rng.integers(5, 260, size=12)]
+    nodes = [NodeWithScore(node=TextNode(text=p, id_=f"p{i}"), score=0.5) for i, p in enumerate(passages)]
+    ranked = rr2.postprocess_nodes(nodes, QueryBundle(query_str=query))            # positional bundle, as web_search.py:155
+    tk.enable_truncation(max_length=198, strategy="longest_first")                 # the model's limit (200 - 2 positions)
+    encs = [tk.encode(query, p).ids for p in passages]
+    assert max(map(len, encs)) == 198
+    ids2, mask2 = _padded(encs, 1)
+    with torch.no_grad():
+        want2 = torch.sigmoid(model(input_ids=ids2, attention_mask=mask2).logits[:, 0])
+    by_id = {f"p{i}": float(want2[i]) for i in range(12)}
+    assert len(ranked) == 4 and all(isinstance(n.score, float) for n in ranked)
+    assert [n.score for n in ranked] == sorted((n.score for n in ranked), reverse=True)
+    assert max(abs(n.score - by_id[n.node.id_]) for n in ranked) < 4e-2
+    best4 = sorted(by_id.values(), reverse=True)[:4]
+    assert all(abs(n.score - b) < 6e-2 for n, b in zip(ranked, best4))
+
 
 @pytest.mark.parametrize("arch", ["xlmr", "bert"])
 def test_bi_encoder_checkpoint_vs_transformers(dev, built_lib, tmp_path, arch):
