@@ -209,7 +209,12 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attention_kernel(AttnParams p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, acc_s[j][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx * sc);       // finite: every tile holds >= 1 valid key
+        // Lazy running maximum: m only moves when a tile's maximum exceeds it by more than 2^lazy (p.lazy = 8; it is a scaling
+        // reference, not a bound: probabilities up to 2^lazy are exact in fp32 sums and keep their relative precision
+        // as bf16 MFMA operands, and the final division by l uses the same reference).  After the first tile the
+        // reference almost never moves, alpha is 1 on every lane and the 32-register rescale of O is skipped.
+        const float mt = mx * sc;
+        const float m_new = (mt > m_run + p.lazy) ? mt : m_run;       // first tile: m_run = -inf -> mt (finite: >= 1 valid key)
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // first tile: 2^-inf = 0
         m_run = m_new;
         f32x2 psum2 = f32x2{0.f, 0.f};
@@ -365,11 +370,15 @@ int tt_attention_launch(const AttnParams& p, hipStream_t st) {
         return TT_E_INVALID;
     }
     const dim3 grid((p.max_len + 32 * kWaves - 1) / (32 * kWaves), p.heads, p.n_seq);
+    // log2 slack of the running softmax reference (TT_ATT_LAZY=0: classic running maximum, the A/B switch)
+    static const float lazy = [] { const char* e = getenv("TT_ATT_LAZY"); return e && e[0] ? (float)atof(e) : 8.0f; }();
+    AttnParams q = p;
+    q.lazy = lazy;
     TtProfScope prof(TT_K_ATTENTION, st);
     if (p.head_dim == 64) {
-        hipLaunchKernelGGL(attention_kernel<64>, grid, dim3(64 * kWaves), 0, st, p);
+        hipLaunchKernelGGL(attention_kernel<64>, grid, dim3(64 * kWaves), 0, st, q);
     } else if (p.head_dim == 32) {
-        hipLaunchKernelGGL(attention_kernel<32>, grid, dim3(64 * kWaves), 0, st, p);
+        hipLaunchKernelGGL(attention_kernel<32>, grid, dim3(64 * kWaves), 0, st, q);
     } else {
         tt_set_error("attention: head_dim %d not in {32, 64}", p.head_dim);
         return TT_E_UNSUPPORTED;
