@@ -8,7 +8,8 @@ leaf embedding both run through its pipelined batch path.
 """
 from __future__ import annotations
 
-from typing import Callable, List, Optional, Sequence
+import os
+from typing import Callable, List, Optional, Sequence, Set
 
 from .node_parser import HierarchicalNodeParser, get_leaf_nodes
 from .semantic import SemanticSplitter
@@ -64,3 +65,76 @@ def build_index(documents: Sequence, embed_model, persist_dir: Optional[str] = N
                       chunk_sizes=sizes, chunking_strategy=chunking_strategy,
                       chunk_overlap=DEFAULT_CHUNK_OVERLAP if chunk_overlap is None else chunk_overlap)
     return index
+
+
+class HipDocumentIndex:
+    """Incremental per-document index: the add / remove / inspect half of the reference's ``DocumentIndexBuilder``
+    (``src/tensortruth/document_index.py:427-581``) on a ``HipVectorIndex`` -- PDF conversion, metadata extraction and
+    settings hashing stay with the caller.  ``add_documents`` parses hierarchically, puts every node in the docstore and
+    the leaves (embedded on the GPU) in the matrix, and records which nodes belong to which ``doc_id``;
+    ``remove_document`` tombstones that document's leaves and drops its nodes; both persist when ``index_dir`` is set."""
+
+    def __init__(self, embed_model, index_dir: Optional[str] = None, chunk_overlap: int = 20, node_parser_factory=None):
+        self.embed_model = embed_model
+        self.index_dir = index_dir
+        self.chunk_overlap = chunk_overlap
+        self._parser_factory = node_parser_factory or (
+            lambda chunk_sizes: HierarchicalNodeParser.from_defaults(chunk_sizes=chunk_sizes, chunk_overlap=chunk_overlap))
+        if index_dir is not None and os.path.exists(os.path.join(index_dir, "nodes.json")):
+            self.index = HipVectorIndex.load(index_dir, embed_model=embed_model)
+        else:
+            dim = embed_model.config.hidden if hasattr(embed_model, "config") else len(embed_model.get_text_embedding("x"))
+            self.index = HipVectorIndex(dim, embed_model=embed_model)
+        self._chunk_sizes: Optional[List[int]] = None
+
+    def index_exists(self) -> bool:          # document_index.py:135-139
+        return self.index.num_live > 0
+
+    def get_index_size(self) -> int:         # :427-441 (vectors in the collection)
+        return self.index.num_live
+
+    def get_document_count(self) -> int:     # :443-450
+        return len(self.index.ref_docs)
+
+    def get_indexed_doc_ids(self) -> Set[str]:   # :452-476
+        return set(self.index.ref_docs)
+
+    def _persist(self) -> None:
+        if self.index_dir is not None:
+            self.index.persist(self.index_dir, chunk_sizes=self._chunk_sizes, chunking_strategy="hierarchical",
+                               chunk_overlap=self.chunk_overlap)
+
+    def add_documents(self, documents: Sequence, doc_ids: Sequence[str], chunk_sizes: Sequence[int],
+                      progress_callback: Optional[Callable] = None) -> None:
+        """document_index.py:478-534.  A ``doc_id`` that is already indexed is replaced."""
+        if len(documents) != len(doc_ids):
+            raise ValueError("documents and doc_ids differ in length")
+        cb = progress_callback or (lambda *a: None)
+        cb("Embedding documents", 70, 100)
+        parser = self._parser_factory(list(chunk_sizes))
+        all_nodes, leaves = [], []
+        for doc, doc_id in zip(documents, doc_ids):
+            if doc_id in self.index.ref_docs:
+                self.remove_document(doc_id, persist=False)
+            nodes = parser.get_nodes_from_documents([doc])
+            self.index.ref_docs[doc_id] = [n.id_ for n in nodes]
+            all_nodes.extend(nodes)
+            leaves.extend(get_leaf_nodes(nodes))
+        self.index.add_to_docstore(all_nodes)
+        self.index.add(leaves)
+        self._chunk_sizes = list(chunk_sizes)
+        self._persist()
+        cb("Complete", 100, 100)
+
+    def remove_document(self, doc_id: str, persist: bool = True) -> bool:
+        """document_index.py:536-581: True if the document was indexed."""
+        node_ids = self.index.ref_docs.pop(doc_id, None)
+        if node_ids is None:
+            return False
+        self.index.delete(node_ids)          # leaves become tombstones, every node leaves the docstore
+        if persist:
+            self._persist()
+        return True
+
+    def as_retriever(self, similarity_top_k: int = 10):
+        return self.index.as_retriever(similarity_top_k=similarity_top_k)

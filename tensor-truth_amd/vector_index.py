@@ -52,6 +52,7 @@ class HipVectorIndex:
         self.n = 0
         self.leaf_ids: List[str] = []          # row -> node id
         self.docstore: Dict[str, TextNode] = {}  # every node (leaves + parents), for auto-merging
+        self.ref_docs: Dict[str, List[str]] = {}  # source document id -> ids of all its nodes (docstore ref_doc_info)
         self._lock = threading.RLock()
         self._version = 0                      # bumped by every mutation (HipIndexGroup repacks on change)
         self._dead = 0                         # tombstoned rows (NaN-filled, leaf id None), see delete()
@@ -174,7 +175,7 @@ class HipVectorIndex:
                            "prev_id": getattr(nd, "prev_id", None), "next_id": getattr(nd, "next_id", None)}
                      for nid, nd in self.docstore.items()}
             with open(os.path.join(persist_dir, "nodes.json"), "w") as f:
-                json.dump({"dim": self.dim, "leaf_ids": self.leaf_ids, "nodes": nodes}, f)
+                json.dump({"dim": self.dim, "leaf_ids": self.leaf_ids, "nodes": nodes, "ref_docs": self.ref_docs}, f)
         # the reference's index_metadata.json (indexing/metadata.py:103-146) + what this store adds
         model = embedding_model or getattr(self.embed_model, "model_name", None)
         meta = {"embedding_model": model, "embedding_model_id": sanitize_model_id(model) if model else None,
@@ -196,6 +197,7 @@ class HipVectorIndex:
         idx._mat = torch.from_numpy(raw).view(torch.bfloat16).to(idx.device).contiguous()
         idx.n = raw.shape[0]
         idx.leaf_ids = list(blob["leaf_ids"])
+        idx.ref_docs = {k: list(v) for k, v in (blob.get("ref_docs") or {}).items()}
         for nid, d in blob["nodes"].items():
             nd = TextNode(text=d["text"], id_=nid, metadata=d["metadata"])
             for key in ("parent_id", "child_ids", "prev_id", "next_id"):

@@ -523,6 +523,43 @@ def test_build_index_strategies_persist_and_retrieve(dev, built_lib, tmp_path, s
         build_index(docs, emb, chunking_strategy="fixed")
 
 
+def test_document_index_add_remove_roundtrip(dev, built_lib, tmp_path):
+    """add_documents / remove_document / counters of the reference's DocumentIndexBuilder (document_index.py:427-581)."""
+    from tensor_truth_amd.embedding import HipHuggingFaceEmbedding
+    from tensor_truth_amd.encoder import EncoderConfig
+    from tensor_truth_amd.index_builder import HipDocumentIndex
+    from tensor_truth_amd.schema import QueryBundle, TextNode
+
+    cfg = EncoderConfig(**SMALL)
+    emb = HipHuggingFaceEmbedding("test/bge-small-shaped", device="cuda",
+                                  model_kwargs={"encoder_config": cfg, "synthetic_seed": 14})
+    base = _texts(90)
+    docs = [TextNode(text=". ".join(base[i * 30:(i + 1) * 30]) + ".", metadata={"title": f"d{i}"}) for i in range(3)]
+    di = HipDocumentIndex(emb, index_dir=str(tmp_path / "session"))
+    assert not di.index_exists() and di.get_document_count() == 0
+    stages = []
+    di.add_documents(docs[:2], ["pdf_a", "pdf_b"], [64, 24], progress_callback=lambda *a: stages.append(a[0]))
+    assert di.get_indexed_doc_ids() == {"pdf_a", "pdf_b"} and di.get_index_size() > 4 and stages[-1] == "Complete"
+    size_ab = di.get_index_size()
+    di.add_documents(docs[2:], ["pdf_c"], [64, 24])
+    assert di.get_document_count() == 3 and di.get_index_size() > size_ab
+    # a fresh process sees the same index
+    again = HipDocumentIndex(emb, index_dir=str(tmp_path / "session"))
+    assert again.get_indexed_doc_ids() == {"pdf_a", "pdf_b", "pdf_c"} and again.get_index_size() == di.get_index_size()
+    b_nodes = set(again.index.ref_docs["pdf_b"])
+    row = next(i for i, nid in enumerate(again.index.leaf_ids) if nid in b_nodes)
+    qb = QueryBundle(query_str="q", embedding=again.index.matrix[row].float().cpu().tolist())
+    assert again.as_retriever(3).retrieve(qb)[0].node.id_ in b_nodes
+    assert again.remove_document("pdf_b") and not again.remove_document("pdf_b") and not again.remove_document("nope")
+    assert again.get_indexed_doc_ids() == {"pdf_a", "pdf_c"} and not (b_nodes & set(again.index.docstore))
+    hits = again.as_retriever(10).retrieve(qb)
+    assert hits and not any(h.node.id_ in b_nodes for h in hits)
+    third = HipDocumentIndex(emb, index_dir=str(tmp_path / "session"))       # the removal was persisted
+    assert third.get_indexed_doc_ids() == {"pdf_a", "pdf_c"} and third.get_index_size() == again.get_index_size()
+    third.add_documents([docs[0]], ["pdf_a"], [64, 24])                      # re-adding replaces
+    assert third.get_document_count() == 2 and third.get_index_size() == again.get_index_size()
+
+
 def _descendants(docstore, node_id):
     out, todo = set(), [node_id]
     while todo:
