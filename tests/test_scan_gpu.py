@@ -79,6 +79,7 @@ def test_ragged_shapes_dense_path(dev, built_lib, n, d, q, k):
 @pytest.mark.parametrize("n,d,q,k", [
     (65537, 1024, 3, 50), (100_003, 1024, 64, 50), (131_072 + 17, 512, 70, 10), (200_000, 384, 33, 100),
     (150_001, 1024, 256, 50),     # the gathered query batch of an 8-GPU bench step: four query tiles
+    (60_000, 1024, 1024, 50),     # SURVEY.md 8d's largest scan-only batch: sixteen query tiles (above the MFMA ridge)
 ])
 def test_sampled_threshold_path(dev, built_lib, n, d, q, k):
     """Shards above 65536 rows: sample -> threshold -> filtered main pass -> select."""
