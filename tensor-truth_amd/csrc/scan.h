@@ -22,6 +22,11 @@ struct ScanParams {
     // priv_cnt[q * n_sub + sub] = fill count, n_sub = grid.x * 16 (wave, lane half)
     uint2* priv;
     int32_t* priv_cnt;
+    // out=2 only (threshold sample): group g of the launch is physical 32-row group g * group_stride, so the sample is
+    // spread evenly over the shard instead of being its first rows (corpora are ingested document by document: the
+    // first rows are one topic).  0 / 1 = contiguous.  phys_rows = rows of the shard (clamp for the last group).
+    int64_t group_stride;
+    int64_t phys_rows;
 };
 
 #define TT_SCAN_PRIV_SLOTS 16

@@ -188,7 +188,8 @@ __global__ __launch_bounds__(kThreads) void scan_kernel(ScanParams p) {
     const int64_t g_hi = g_lo + per_blk + (b < rem ? 1 : 0);
 
     const uint16_t* corpus = p.corpus;
-    const int64_t last_row = p.row_hi - 1;
+    const int64_t gstride = (OUT == 2 && p.group_stride > 1) ? p.group_stride : 1;   // strided threshold sample
+    const int64_t last_row = (OUT == 2 && p.group_stride > 1) ? p.phys_rows - 1 : p.row_hi - 1;
 
     f32x16 acc[kNG];
 #pragma unroll
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(kThreads) void scan_kernel(ScanParams p) {
         auto issue = [&](uint4(&dst)[4], int64_t g, int c) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                int64_t row = p.row_lo + g * 32 + 8 * j + lrow;
+                int64_t row = p.row_lo + g * gstride * 32 + 8 * j + lrow;
                 row = row < last_row ? row : last_row;
                 dst[j] = ldg16c<(VAR & 1) == 0>(corpus + (size_t)row * D + c * 64 + lpiece * 8);
             }
@@ -292,7 +293,7 @@ __global__ __launch_bounds__(kThreads) void scan_kernel(ScanParams p) {
         constexpr int P = C::P0;
         uint4 ring[P];
         auto issue = [&](uint4& dst, int64_t g, int ks) {
-            int64_t row = p.row_lo + g * 32 + ql;
+            int64_t row = p.row_lo + g * gstride * 32 + ql;
             row = row < last_row ? row : last_row;
             dst = ldg16c<(VAR & 1) == 0>(corpus + (size_t)row * D + ks * 16 + half * 8);
         };

@@ -1,7 +1,8 @@
 // C-ABI entry points for the similarity scan (see include/tt_hip.h).
 //
 // Pipeline of tt_scan_topk for a shard of N rows (all launches on one stream):
-//   1. sample : one max per (32-row group, query) over rows [0, n0)    (scan_kernel OUT=2)
+//   1. sample : one max per (32-row group, query) over n0 / 32 groups spread evenly over the shard
+//               (every (N / n0)-th group: ingest order clusters topics)   (scan_kernel OUT=2)
 //   2. select : thr[q] = k-th best group maximum                        (select_kernel)
 //   3. filter : all N rows, scores >= thr[q] go to atomic-free private lists
 //               (overflowing lanes: shared per-query list)               (scan_kernel OUT=0)
@@ -249,6 +250,9 @@ int tt_scan_topk(const void* corpus_bf16, int64_t n_rows, int dim, const void* q
     sp.idx_base = idx_base;
     sp.dense = dense;
     sp.dense_stride = pl.stride;
+    // the n0 / 32 sampled groups are spread evenly over the shard (every group_stride-th 32-row group)
+    sp.group_stride = (n_rows / 32) / ((pl.n0 + 31) / 32);
+    sp.phys_rows = n_rows;
     rc = tt_scan_launch(sp, dim, mode, 2, cus, st);
     if (rc) return rc;
 
@@ -274,6 +278,7 @@ int tt_scan_topk(const void* corpus_bf16, int64_t n_rows, int dim, const void* q
 
     // 3. filter pass over ALL rows: scores >= thr[q] -> private lists (+ shared overflow list)
     ScanParams mp = sp;
+    mp.group_stride = 0;
     mp.row_lo = 0;
     mp.row_hi = n_rows;
     mp.dense = nullptr;

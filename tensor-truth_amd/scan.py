@@ -54,13 +54,15 @@ def scan_topk(
     idx_base: int = 0,
     exact_dense: bool = False,
     check_overflow: bool = True,
-) -> Tuple[torch.Tensor, torch.Tensor]:
+    return_flag: bool = False,
+):
     """corpus [N,D] bf16, queries [Q,D] bf16 (same HIP device) ->
     (scores [Q,k] fp32, idx [Q,k] int32), idx = idx_base + row, padding (-inf, -1).
 
     ``exact_dense`` forces the dense-score path (N*Q*4 bytes of scratch).
     ``check_overflow`` reads the device status word (one sync) and transparently
     re-runs through the dense path if a candidate list overflowed.
+    ``return_flag`` (tests / diagnostics): no fallback, returns ``(scores, idx, overflowed)``.
     """
     lib = _lib.load_library()
     _require_cuda(corpus, "corpus")
@@ -97,6 +99,8 @@ def scan_topk(
                               out_s.data_ptr(), out_i.data_ptr(), base, ws.numel() - (base - ws.data_ptr()),
                               flag.data_ptr(), st)
         _lib.check(rc, "tt_scan_topk")
+        if return_flag:
+            return out_s, out_i, int(flag.item()) != 0
         if check_overflow and int(flag.item()) != 0:
             return scan_topk(corpus, queries, k, idx_base, exact_dense=True)
     return out_s, out_i

@@ -108,6 +108,28 @@ def test_both_corpus_load_modes(dev, built_lib, mode, monkeypatch):
     _check(s, i, *want)
 
 
+def test_topic_ordered_corpus_keeps_the_filter_path(dev, built_lib):
+    """Corpora are ingested document by document, so neighbouring rows share a topic.  The threshold sample is spread
+    evenly over the shard (every (N / n0)-th 32-row group), not its first rows: a query about a topic that only occurs
+    late in the matrix still gets a tight threshold -- exact results AND no candidate-list overflow (a sample of the
+    first rows would see none of that topic, let the whole cluster through the filter and fall back to the dense path)."""
+    from tensor_truth_amd import scan as tscan
+
+    g = torch.Generator().manual_seed(31)
+    n_topics, per_topic, d = 60, 5000, 256
+    centers = torch.nn.functional.normalize(torch.randn(n_topics, d, generator=g), dim=1)
+    rows = centers.repeat_interleave(per_topic, 0) + 0.35 * torch.randn(n_topics * per_topic, d, generator=g) / d ** 0.5 * 4
+    corpus = torch.nn.functional.normalize(rows, dim=1).to(torch.bfloat16)          # 300k rows, sorted by topic
+    topics = torch.tensor([59, 58, 40, 31, 7, 0, 22, 50])
+    queries = torch.nn.functional.normalize(centers[topics] + 0.05 * torch.randn(8, d, generator=g), dim=1).to(torch.bfloat16)
+    want_s, want_i, gap = osc.scan_topk(corpus, queries, 50)
+    assert all(int(want_i[q, 0]) // per_topic == int(topics[q]) for q in range(8))    # hits lie in the query's topic
+    s, i, overflowed = tscan.scan_topk(corpus.to(dev), queries.to(dev), 50, return_flag=True)
+    torch.cuda.synchronize()
+    assert not overflowed
+    _check(s, i, want_s, want_i, gap)
+
+
 def test_duplicate_rows_tie_break_by_index(dev, built_lib):
     from tensor_truth_amd import scan as tscan
 
@@ -124,18 +146,24 @@ def test_duplicate_rows_tie_break_by_index(dev, built_lib):
 
 
 def test_candidate_overflow_falls_back_exact(dev, built_lib):
-    """Adversarial order: every row after the sample beats the sample's k-th best."""
+    """Adversarial layout: exactly the sampled row groups (every (N/32 // 1024)-th 32-row group, scan_api.hip) hold
+    unrelated rows, every other row beats the sample's k-th best -> the candidate lists overflow, the raw call says so."""
     from tensor_truth_amd import scan as tscan
 
     d = 256
     g = torch.Generator().manual_seed(3)
     qv = torch.randn(d, generator=g)
     qv = qv / qv.norm()
-    rnd = torch.randn(70_000, d, generator=g)
-    rnd = rnd / rnd.norm(dim=1, keepdim=True)
-    close = qv + 0.3 * torch.randn(60_000, d, generator=g) / (d ** 0.5)
+    n = 130_000
+    close = qv + 0.3 * torch.randn(n, d, generator=g) / (d ** 0.5)
     close = close / close.norm(dim=1, keepdim=True)
-    corpus = torch.cat([rnd, close], 0).to(torch.bfloat16).contiguous()
+    rnd = torch.randn(n, d, generator=g)
+    rnd = rnd / rnd.norm(dim=1, keepdim=True)
+    stride = (n // 32) // 1024                       # 32768 sample rows = 1024 groups
+    grp = torch.arange(n) // 32
+    sampled = (grp % stride == 0) & (grp < 1024 * stride)
+    rows = torch.where(sampled[:, None], rnd, close)
+    corpus = rows.to(torch.bfloat16).contiguous()
     queries = qv.view(1, d).to(torch.bfloat16).contiguous()
     want = osc.scan_topk(corpus, queries, 50)
     c_dev, q_dev = corpus.to(dev), queries.to(dev)
