@@ -3,7 +3,7 @@
 Order of resolution (first hit wins):
   1. ``model_kwargs["state_dict"]``      -- tensors handed over directly (tests);
   2. a local model directory             -- ``model_kwargs["model_dir"]``, ``$TT_AMD_MODEL_DIR/<org>/<name>``
-                                            or the HF hub cache, holding ``model.safetensors``
+                                            or the HF hub cache, holding ``model.safetensors`` (or ``pytorch_model.bin``)
                                             (HF checkpoint names, SURVEY.md section 8d) + ``config.json``;
   3. ``model_kwargs["synthetic_seed"]``  -- seeded random init of the known architecture
                                             (benchmarks / parity tests; no network here).
@@ -19,6 +19,9 @@ from typing import Dict, Optional, Tuple
 import torch
 
 from .encoder import KNOWN_CONFIGS, EncoderConfig, synthetic_state, synthetic_state_device
+
+
+WEIGHT_FILES = ("model.safetensors", "pytorch_model.bin")
 
 
 def _config_from_hf(d: dict, num_labels_default: int = 0) -> EncoderConfig:
@@ -44,17 +47,28 @@ def find_model_dir(model_name: str, model_kwargs: Optional[dict]) -> Optional[st
     if root:
         cands += [os.path.join(root, model_name), os.path.join(root, model_name.split("/")[-1])]
     for c in cands:
-        if os.path.exists(os.path.join(c, "model.safetensors")):
+        if any(os.path.exists(os.path.join(c, f)) for f in WEIGHT_FILES):
             return c
     try:  # HF hub cache, offline
         from huggingface_hub import try_to_load_from_cache
 
-        p = try_to_load_from_cache(model_name, "model.safetensors")
-        if isinstance(p, str) and os.path.exists(p):
-            return os.path.dirname(p)
+        for f in WEIGHT_FILES:
+            p = try_to_load_from_cache(model_name, f)
+            if isinstance(p, str) and os.path.exists(p):
+                return os.path.dirname(p)
     except Exception:  # noqa: BLE001
         pass
     return None
+
+
+def load_state(model_dir: str) -> Dict[str, torch.Tensor]:
+    """``model.safetensors`` if present, else the older ``pytorch_model.bin`` (tensors only, ``weights_only=True``)."""
+    st = os.path.join(model_dir, "model.safetensors")
+    if os.path.exists(st):
+        from safetensors.torch import load_file
+
+        return load_file(st)
+    return torch.load(os.path.join(model_dir, "pytorch_model.bin"), map_location="cpu", weights_only=True)
 
 
 def resolve(model_name: str, model_kwargs: Optional[dict], device: torch.device,
@@ -68,11 +82,9 @@ def resolve(model_name: str, model_kwargs: Optional[dict], device: torch.device,
         return cfg, mk["state_dict"], None
     mdir = find_model_dir(model_name, mk)
     if mdir is not None:
-        from safetensors.torch import load_file
-
         with open(os.path.join(mdir, "config.json")) as f:
             cfg = _config_from_hf(json.load(f), 1 if want_head else 0)
-        return cfg, load_file(os.path.join(mdir, "model.safetensors")), mdir
+        return cfg, load_state(mdir), mdir
     if "synthetic_seed" in mk:
         if cfg is None:
             raise ValueError(f"no architecture known for '{model_name}': pass model_kwargs['encoder_config']")

@@ -138,7 +138,12 @@ def test_bi_encoder_checkpoint_vs_transformers(dev, built_lib, tmp_path, arch):
         bos, eos, pad = 101, 102, 0
     _perturb_layernorms(model, 2)
     d = tmp_path / f"bi_{arch}"
-    model.save_pretrained(str(d), safe_serialization=True)
+    if arch == "xlmr":
+        model.save_pretrained(str(d), safe_serialization=True)
+    else:                                   # the older checkpoint format: config.json + pytorch_model.bin
+        d.mkdir()
+        cfg.save_pretrained(str(d))
+        torch.save(model.state_dict(), str(d / "pytorch_model.bin"))
     emb = HipHuggingFaceEmbedding(str(d), device="cuda", embed_batch_size=16)
     assert emb.config.arch == arch and emb.config.hidden == cfg.hidden_size and emb.config.num_labels == 0
     rng = np.random.default_rng(1)
