@@ -59,7 +59,18 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attention_kernel(AttnParams p)
     constexpr int BUF = (NPK + NPV) * 1024;
     __shared__ __attribute__((aligned(1024))) char lds[2 * BUF];
 
-    const int seq = blockIdx.z, head = blockIdx.y, qt = blockIdx.x;
+    // Workgroup -> (query tile, head, sequence).  The query tiles of one (sequence, head) read the same K / V rows, and
+    // every XCD has its own L2: with a plain 3-D grid the tiles of a pair are dealt round-robin to DIFFERENT XCDs and each
+    // fetches K and V from HBM again (3 x at 292 tokens -- the kernel then runs at the HBM roofline, not at its VALU bound).
+    // Linear id L goes to XCD L % 8, so slot t = L / 8 of an XCD walks (pair, query tile) with the tile fastest: the
+    // tiles of a pair run back to back on one XCD and share its L2.
+    const int nqt = p.n_qt > 0 ? p.n_qt : -p.n_qt;
+    const int L = blockIdx.x, t = L >> 3;
+    // (n_qt < 0: TT_ATT_XCD=0, the plain order -- tile fastest over ALL workgroups -- kept as the A/B switch)
+    const int qt = p.n_qt > 0 ? t % nqt : L % nqt;
+    const int pair = p.n_qt > 0 ? (t / nqt) * 8 + (L & 7) : L / nqt;
+    if (pair >= p.heads * p.n_seq) return;
+    const int head = pair % p.heads, seq = pair / p.heads;
     const int len = p.seq_len[seq];
     if (qt * 32 * kWaves >= len) return;
     const int t0 = p.seq_start[seq];
@@ -369,11 +380,19 @@ int tt_attention_launch(const AttnParams& p, hipStream_t st) {
         tt_set_error("attention: leading dimensions / column offsets must keep 16-byte alignment");
         return TT_E_INVALID;
     }
-    const dim3 grid((p.max_len + 32 * kWaves - 1) / (32 * kWaves), p.heads, p.n_seq);
+    const int n_qt = (p.max_len + 32 * kWaves - 1) / (32 * kWaves);
+    const long long pairs8 = ((long long)p.heads * p.n_seq + 7) / 8 * 8;
+    if (pairs8 * n_qt > 0x7FFFFFFFLL) {
+        tt_set_error("attention: %lld workgroups exceed the grid limit", pairs8 * n_qt);
+        return TT_E_UNSUPPORTED;
+    }
+    const dim3 grid((unsigned)(pairs8 * n_qt));
     // log2 slack of the running softmax reference (TT_ATT_LAZY=0: classic running maximum, the A/B switch)
     static const float lazy = [] { const char* e = getenv("TT_ATT_LAZY"); return e && e[0] ? (float)atof(e) : 8.0f; }();
     AttnParams q = p;
     q.lazy = lazy;
+    static const bool xcd = [] { const char* e = getenv("TT_ATT_XCD"); return !(e && e[0] == '0'); }();
+    q.n_qt = xcd ? n_qt : -n_qt;
     TtProfScope prof(TT_K_ATTENTION, st);
     if (p.head_dim == 64) {
         hipLaunchKernelGGL(attention_kernel<64>, grid, dim3(64 * kWaves), 0, st, q);

@@ -41,6 +41,7 @@ struct AttnParams {
     int ld_qk, q_col0, k_col0, ldvt, ld_out;
     float scale;              // 1/sqrt(head_dim)
     float lazy;               // set by the launcher: log2 slack of the running softmax reference
+    int n_qt;                 // set by the launcher: query tiles per sequence (grid decode)
 };
 int tt_attention_launch(const AttnParams& p, hipStream_t st);
 // CLS-only variant: one query row (seq_start[b]) per sequence; out row index = sequence index
