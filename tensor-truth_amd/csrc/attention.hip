@@ -60,10 +60,10 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attention_kernel(AttnParams p)
     __shared__ __attribute__((aligned(1024))) char lds[2 * BUF];
 
     // Workgroup -> (query tile, head, sequence).  The query tiles of one (sequence, head) read the same K / V rows, and
-    // every XCD has its own L2: with a plain 3-D grid the tiles of a pair are dealt round-robin to DIFFERENT XCDs and each
-    // fetches K and V from HBM again (3 x at 292 tokens -- the kernel then runs at the HBM roofline, not at its VALU bound).
-    // Linear id L goes to XCD L % 8, so slot t = L / 8 of an XCD walks (pair, query tile) with the tile fastest: the
-    // tiles of a pair run back to back on one XCD and share its L2.
+    // every XCD has its own L2: in the plain order (tile fastest over all workgroups) the tiles of a pair are dealt
+    // round-robin to DIFFERENT XCDs and each fetches K and V again (3.4 GB instead of 1.4 GB per launch at 800 x 292).
+    // XCD-aware order (TT_ATT_XCD=1): linear id L goes to XCD L % 8, so slot t = L / 8 of an XCD walks (pair, query tile)
+    // with the tile fastest -- the tiles of a pair run back to back on one XCD and share its L2.
     const int nqt = p.n_qt > 0 ? p.n_qt : -p.n_qt;
     const int L = blockIdx.x, t = L >> 3;
     // (n_qt < 0: TT_ATT_XCD=0, the plain order -- tile fastest over ALL workgroups -- kept as the A/B switch)
@@ -391,7 +391,9 @@ int tt_attention_launch(const AttnParams& p, hipStream_t st) {
     static const float lazy = [] { const char* e = getenv("TT_ATT_LAZY"); return e && e[0] ? (float)atof(e) : 8.0f; }();
     AttnParams q = p;
     q.lazy = lazy;
-    static const bool xcd = [] { const char* e = getenv("TT_ATT_XCD"); return !(e && e[0] == '0'); }();
+    // default: the plain order.  Stand-alone the XCD-aware order is 2-9 % faster, inside the encoder (K / V fresh from the
+    // QKV GEMM) it measured 1.8 % slower -- see DESIGN.md section 4.4.
+    static const bool xcd = [] { const char* e = getenv("TT_ATT_XCD"); return e && e[0] == '1'; }();
     q.n_qt = xcd ? n_qt : -n_qt;
     TtProfScope prof(TT_K_ATTENTION, st);
     if (p.head_dim == 64) {
