@@ -107,7 +107,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
 // lanes of even 16-lane rows their right-hand neighbour's 4 columns of m-tile 2j and the lanes of
 // odd rows their left-hand neighbour's 4 columns of m-tile 2j+1: every lane then owns 8 consecutive
 // columns of ONE row -> one 16-B store (and 16-B residual load) per pair of tiles.
-template <int EPI, int NT, int MT>
+// CM (experiment, TT_GEMM_ABLATE=7): store feature-chunk-major, C[(n / 8) * M + m][8] -- every lane's 16-byte chunk goes out
+// directly (256-byte runs per 16-lane group), no LDS transposition; times what a chunk-major activation layout would cost.
+template <int EPI, int NT, int MT, bool CM = false>
 __device__ __forceinline__ void gemm_epilogue_wide(const GemmParams& p, f32x4 (&acc)[NT][MT], int mw, int nw, int lane) {
     static_assert(MT % 2 == 0, "m-tiles are processed in pairs");
     const int g = lane >> 4;           // 16-lane row: columns 4g..4g+3 of the tile before the swap
@@ -163,7 +165,8 @@ __device__ __forceinline__ void gemm_epilogue_wide(const GemmParams& p, f32x4 (&
             uint4 o;
             o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
             o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
-            *reinterpret_cast<uint4*>(p.C + (size_t)m * p.ldc + n) = o;
+            if constexpr (CM) *reinterpret_cast<uint4*>(p.C + ((size_t)(n >> 3) * p.M + m) * 8) = o;
+            else *reinterpret_cast<uint4*>(p.C + (size_t)m * p.ldc + n) = o;
         }
     }
 }
@@ -874,6 +877,12 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
 #pragma unroll
             for (int qn = 0; qn < 2; ++qn)
                 gemm_epilogue_wide<EPI, 2, 4>(p, acc[qm][qn], m0 + qm * 128 + wm * 64, n0 + wn * 64 + qn * 32, lane);
+    } else if constexpr (SLOTS == 47) {
+#pragma unroll
+        for (int qm = 0; qm < 2; ++qm)
+#pragma unroll
+            for (int qn = 0; qn < 2; ++qn)
+                gemm_epilogue_wide<EPI, 2, 4, true>(p, acc[qm][qn], m0 + qm * 128 + wm * 64, n0 + wn * 64 + qn * 32, lane);
     } else {
         epilogue_all<EPI, true, FP8>(p, acc, smem, kBiasOff, kScaleOff, m0, n0, wm, wn, wave, lane, false, NoNext{});
     }
@@ -1243,7 +1252,8 @@ int launch(const GemmParams& p, hipStream_t st) {
         if constexpr (EPI == TT_EPI_BIAS) {   // diagnostic build of the 4-slot loop with s_memtime stamps (tools/gemm_stamps)
             static const int abl = [] { const char* e = getenv("TT_GEMM_ABLATE"); return e && e[0] ? atoi(e) : 0; }();
             if (abl == 6) kern = v3::gemm_kernel_v3<EPI, 46>;
-            if (abl == 6) TT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, v3::kLds3));
+            if (abl == 7) kern = v3::gemm_kernel_v3<EPI, 47>;   // chunk-major store experiment (output layout differs!)
+            if (abl == 6 || abl == 7) TT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, v3::kLds3));
         }
         static thread_local bool attr3 = false;
         if (!attr3) {
