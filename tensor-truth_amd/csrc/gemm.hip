@@ -680,6 +680,14 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
     auto cstamp = [&](int slot) {
         if constexpr (SLOTS == 46) {
             if (blockIdx.x == 0 && tid == 0 && dbg0) dbg0[20 + slot] = __builtin_amdgcn_s_memtime();
+            // every workgroup: entry / exit time and where it ran (tools/gemm_stamps: dispatch gaps per CU)
+            if ((slot == 0 || slot == 3) && tid == 0 && dbg0) {
+                unsigned long long* rec = dbg0 + 256 + (size_t)blockIdx.x * 4;
+                rec[slot == 0 ? 0 : 1] = __builtin_amdgcn_s_memtime();
+                if (slot == 0)
+                    rec[2] = ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32) |   // HW_REG_XCC_ID
+                             (unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11));              // HW_REG_HW_ID
+            }
         }
     };
     // residual tile -> LDS, four parts of (2 pieces x 2 copies) per wave; layout: see epilogue_all
