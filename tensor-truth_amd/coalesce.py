@@ -1,0 +1,106 @@
+"""Cross-caller batching for the plugin surface.
+
+The reference calls ``retriever.retrieve(query)`` and ``reranker.postprocess_nodes(nodes, query_bundle)`` ONE query at a
+time, from executor threads (``src/tensortruth/rag_engine.py:418-424``, ``api/routes/chat.py:367-374``,
+``services/orchestrator_tool_wrappers.py:238-247``).  On an MI355X a single query leaves the chip nearly idle (one
+34-token embedding, one scan tile, 50 rerank pairs), so concurrent callers are merged here into one embed batch, one
+scan tile and one rerank batch -- without changing the surface and without a background thread.
+
+``Coalescer`` is leader/follower batching with NATURAL windows: the first caller to arrive while nothing is running
+becomes the leader and runs a batch of whatever is queued (at least its own item); callers that arrive while a batch
+is on the GPU queue up, and when the batch completes the leader hands leadership to the oldest waiter, which runs the
+next batch with everything that accumulated meanwhile.  A lone caller therefore pays no added latency (batch of one,
+immediately), and under load the batch size grows to the arrival rate times the batch time.  ``max_wait_s`` > 0 adds
+a fixed collection window in front of every batch for callers that prefer throughput.
+"""
+from __future__ import annotations
+
+import threading
+import time
+from typing import Any, Callable, List, Sequence
+
+
+class _Slot:
+    __slots__ = ("item", "event", "done", "result", "error")
+
+    def __init__(self, item):
+        self.item = item
+        self.event = threading.Event()
+        self.done = False
+        self.result = None
+        self.error = None
+
+
+class Coalescer:
+    """``run_batch(items) -> results`` (same length, same order) is called by ONE thread at a time."""
+
+    def __init__(self, run_batch: Callable[[List[Any]], Sequence[Any]], max_batch: int = 256, max_wait_s: float = 0.0):
+        if max_batch < 1:
+            raise ValueError("max_batch must be >= 1")
+        self._run = run_batch
+        self.max_batch = max_batch
+        self.max_wait_s = max_wait_s
+        self._lock = threading.Lock()
+        self._queue: List[_Slot] = []
+        self._running = False
+        self.batches = 0          # statistics: batches run / items served
+        self.items = 0
+
+    def submit(self, item):
+        slot = _Slot(item)
+        with self._lock:
+            self._queue.append(slot)
+            lead = not self._running
+            if lead:
+                self._running = True
+        while True:
+            if not lead:
+                slot.event.wait()
+                if slot.done:
+                    break
+                slot.event.clear()      # woken as the new leader: the slot is still queued
+            if self.max_wait_s > 0:
+                deadline = time.perf_counter() + self.max_wait_s
+                while time.perf_counter() < deadline:
+                    with self._lock:
+                        if len(self._queue) >= self.max_batch:
+                            break
+                    time.sleep(min(2e-4, self.max_wait_s))
+            with self._lock:
+                batch = self._queue[: self.max_batch]
+                del self._queue[: len(batch)]
+            try:
+                results = list(self._run([s.item for s in batch]))
+                if len(results) != len(batch):
+                    raise RuntimeError(f"coalesced batch returned {len(results)} results for {len(batch)} items")
+                for s, r in zip(batch, results):
+                    s.result = r
+            except BaseException as exc:  # noqa: BLE001 - every member of the batch sees the failure, like a lone call would
+                for s in batch:
+                    s.error = exc
+            with self._lock:
+                self.batches += 1
+                self.items += len(batch)
+                for s in batch:
+                    s.done = True
+                # hand over: the oldest waiter leads the next batch (the leader never serves others forever)
+                nxt = None
+                if slot.done or not self._queue:
+                    nxt = self._queue[0] if self._queue else None
+                    if nxt is None:
+                        self._running = False
+                    keep_leading = False
+                else:
+                    keep_leading = True   # own item not served yet (queue longer than max_batch): lead once more
+            for s in batch:
+                if s is not slot:
+                    s.event.set()
+            if keep_leading:
+                lead = True
+                continue
+            if nxt is not None:
+                nxt.event.set()
+            break
+        if slot.error is not None:
+            raise slot.error
+        return slot.result

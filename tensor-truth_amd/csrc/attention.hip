@@ -419,12 +419,10 @@ int tt_attention_cls_launch(const AttnParams& p, hipStream_t st) {
     TtProfScope prof(TT_K_ATTENTION, st);
     const dim3 grid(p.n_seq, p.heads);
     if (p.head_dim == 64) {
-        static thread_local bool a64 = false;
-        if (!a64) { TT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_cls_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); a64 = true; }
+        TT_SET_MAX_LDS(attention_cls_kernel<64>, 160 * 1024);
         hipLaunchKernelGGL(attention_cls_kernel<64>, grid, dim3(64), lds, st, p);
     } else if (p.head_dim == 32) {
-        static thread_local bool a32 = false;
-        if (!a32) { TT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_cls_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); a32 = true; }
+        TT_SET_MAX_LDS(attention_cls_kernel<32>, 160 * 1024);
         hipLaunchKernelGGL(attention_cls_kernel<32>, grid, dim3(64), lds, st, p);
     } else {
         tt_set_error("attention: head_dim %d not in {32, 64}", p.head_dim);

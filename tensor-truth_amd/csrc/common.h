@@ -45,6 +45,21 @@ void tt_set_error(const char* fmt, ...);
 
 int tt_cu_count_cached();
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies PER DEVICE: the "done" flag of a launch site is a bit mask
+// over device ordinals (thread-local: no locking), so a thread that moves from GPU 0 to GPU 1 (one process driving
+// several devices) opts the kernel in on the second device too.  Devices >= 64 always set it.
+#define TT_SET_MAX_LDS(kern, bytes)                                                                              \
+    do {                                                                                                         \
+        static thread_local unsigned long long _tt_attr_mask = 0ull;                                             \
+        int _tt_dev = 0;                                                                                         \
+        TT_CHECK_HIP(hipGetDevice(&_tt_dev));                                                                    \
+        if (_tt_dev >= 64 || !((_tt_attr_mask >> _tt_dev) & 1ull)) {                                             \
+            TT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)));         \
+            if (_tt_dev < 64) _tt_attr_mask |= 1ull << _tt_dev;                                                  \
+        }                                                                                                        \
+    } while (0)
+
 static inline size_t tt_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // ---- device helpers ---------------------------------------------------------

@@ -1135,12 +1135,7 @@ int launch_fp8(const GemmParams& p, hipStream_t st) {
         int blocks = supers * SM * SN;
         blocks = (blocks + 7) / 8 * 8;
         // (the persistent kernel's fp8 GELU form spills; every fp8 GEMM runs one tile per workgroup)
-        static thread_local bool attr3 = false;
-        if (!attr3) {
-            TT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(v3::gemm_kernel_v3<EPI, 4, true>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, v3::kLds3));
-            attr3 = true;
-        }
+        TT_SET_MAX_LDS((v3::gemm_kernel_v3<EPI, 4, true>), v3::kLds3);
         {
             TtProfScope prof(TT_K_GEMM, st);
             GemmParams q = p;
@@ -1240,12 +1235,7 @@ int launch(const GemmParams& p, hipStream_t st) {
         if constexpr (EPI == TT_EPI_GELU) {
             const int cus = tt_cu_count_cached() / 8 * 8;
             if (variant == 5 && (p.K / BK) % 2 == 0 && p.K / BK >= 2 && blocks > cus && cus >= 8) {
-                static thread_local bool attrp = false;
-                if (!attrp) {
-                    TT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(v3::gemm_kernel_p<EPI>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, v3::kLds3));
-                    attrp = true;
-                }
+                TT_SET_MAX_LDS(v3::gemm_kernel_p<EPI>, v3::kLds3);
                 {
                     TtProfScope prof(TT_K_GEMM, st);
                     GemmParams q = p;
@@ -1263,12 +1253,7 @@ int launch(const GemmParams& p, hipStream_t st) {
             if (abl == 7) kern = v3::gemm_kernel_v3<EPI, 47>;   // chunk-major store experiment (output layout differs!)
             if (abl == 6 || abl == 7) TT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, v3::kLds3));
         }
-        static thread_local bool attr3 = false;
-        if (!attr3) {
-            TT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(v3::gemm_kernel_v3<EPI, 4>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, v3::kLds3));
-            attr3 = true;
-        }
+        TT_SET_MAX_LDS((v3::gemm_kernel_v3<EPI, 4>), v3::kLds3);
         GemmParams q = p;
         // whole-line stores as streaming stores: +1...3 % on the bias-only shapes, -0.7 ms per bench step (with the old 32-byte
         // runs the same hint cost 18 %: no write combining in L2)
@@ -1292,12 +1277,7 @@ int launch(const GemmParams& p, hipStream_t st) {
     int blocks = supers * SM * SN;
     blocks = (blocks + 7) / 8 * 8;
     auto kern = gemm_kernel<EPI>;
-    static thread_local bool attr_set = false;
-    if (!attr_set) {
-        TT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds));
-        attr_set = true;
-    }
+    TT_SET_MAX_LDS(kern, kGemmLds);
     {
         TtProfScope prof(TT_K_GEMM, st);
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(kGemmThreads), kGemmLds, st, p);

@@ -345,12 +345,7 @@ static int launch_one(const ScanParams& p, int blocks, int q_tiles, hipStream_t 
     using C = Cfg<D>;
     const size_t lds = (size_t)C::kQImageBytes + (MODE == 1 ? (size_t)kWaves * kScratchPerWave : 0);
     auto kern = scan_kernel<D, MODE, OUT, VAR>;
-    static thread_local bool attr_set = false;  // per instantiation, per thread: cheap & race-free
-    if (!attr_set) {
-        TT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    TT_SET_MAX_LDS(kern, lds);   // per instantiation, per thread, per device
     {
         TtProfScope prof(OUT == 0 ? TT_K_SCAN_FILTER : TT_K_SCAN_SAMPLE, stream);
         hipLaunchKernelGGL(kern, dim3(blocks, q_tiles), dim3(kThreads), lds, stream, p);

@@ -353,12 +353,7 @@ int tt_select_launch(const SelectParams& p, int n_queries, hipStream_t stream) {
         return TT_E_INVALID;
     }
     const size_t lds = (size_t)(kChunk + kAux + kAux2) * sizeof(u64) + 16;
-    static thread_local bool attr_set = false;
-    if (!attr_set) {
-        TT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(select_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    TT_SET_MAX_LDS(select_kernel, lds);
     {
         TtProfScope prof(TT_K_SELECT, stream);
         hipLaunchKernelGGL(select_kernel, dim3(n_queries, p.n_seg > 0 ? p.n_seg : 1), dim3(kSelThreads), lds, stream, p);

@@ -9,6 +9,7 @@ truncate to the model limit).
 """
 from __future__ import annotations
 
+import logging
 from concurrent.futures import ThreadPoolExecutor
 from typing import Any, Dict, List, Optional, Sequence
 
@@ -17,6 +18,8 @@ import torch
 from . import weights as _weights
 from .encoder import Encoder, EncoderWeights, pack_tokens
 from .tokenization import load_tokenizer
+
+logger = logging.getLogger(__name__)
 
 # English BGE v1 / v1.5 models get a query instruction; bge-m3 gets none
 _BGE_EN_QUERY_INSTRUCTION = "Represent this question for searching relevant passages: "
@@ -27,6 +30,23 @@ def query_instruction_for(model_name: str) -> str:
     if "bge" in n and "-en" in n and "m3" not in n:
         return _BGE_EN_QUERY_INSTRUCTION
     return ""
+
+
+def _report_unused_kwargs(model_name: str, model_kwargs, tokenizer_kwargs) -> None:
+    """The reference passes these through to sentence-transformers (model_manager.py:214-252); say what happens to
+    them here instead of dropping them silently."""
+    mk = model_kwargs or {}
+    td = mk.get("torch_dtype")
+    if td is not None and str(td).replace("torch.", "") not in ("bfloat16", "float32", "fp32"):
+        logger.warning("%s: torch_dtype=%s is not available on the HIP path; computing in bfloat16 "
+                       "(fp32 accumulation). Supported: 'bfloat16' (default), 'float32'.", model_name, td)
+    if mk.get("attn_implementation"):
+        logger.info("%s: attn_implementation=%s ignored -- attention is always the fused varlen HIP kernel "
+                    "(no padding tokens are computed)", model_name, mk["attn_implementation"])
+    side = (tokenizer_kwargs or {}).get("padding_side")
+    if side:
+        logger.info("%s: padding_side=%s has no effect -- sequences are packed without padding and CLS pooling "
+                    "reads the first token of every sequence", model_name, side)
 
 
 class HipHuggingFaceEmbedding:
@@ -46,6 +66,7 @@ class HipHuggingFaceEmbedding:
         self.embed_batch_size = embed_batch_size
         self.normalize = normalize
         self.tokenizer_kwargs = tokenizer_kwargs
+        _report_unused_kwargs(model_name, model_kwargs, tokenizer_kwargs)
         cfg, state, mdir = _weights.resolve(model_name, model_kwargs, dev, want_head=False)
         self.config = cfg
         self._model = EncoderWeights(cfg, state, dev)       # .parameters() for memory accounting

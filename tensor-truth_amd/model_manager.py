@@ -122,6 +122,11 @@ class ModelManager:
             model_kwargs: Dict[str, Any] = {"trust_remote_code": mc.trust_remote_code}
             if mc.torch_dtype:
                 model_kwargs["torch_dtype"] = mc.torch_dtype
+            if mc.flash_attention:   # reference: attn_implementation="flash_attention_2" when flash_attn imports (:232-242)
+                logger.info("flash_attention requested for %s: the HIP encoder's attention is always a fused varlen "
+                            "kernel, nothing to enable", model_name)
+            logger.info("Creating embedding model: %s (batch_size=%d, dtype=%s)", model_name, batch,
+                        mc.torch_dtype or "bfloat16 (HIP default)")
             model_kwargs.update(self.model_kwargs_overrides.get(model_name, {}))
             tokenizer_kwargs = {"padding_side": mc.padding_side} if mc.padding_side else None
             self._embedder = HipHuggingFaceEmbedding(model_name=model_name, device=device, model_kwargs=model_kwargs,

@@ -14,6 +14,7 @@ from typing import Any, Dict, List, Optional, Sequence
 import torch
 
 from . import weights as _weights
+from .coalesce import Coalescer
 from .encoder import Encoder, EncoderWeights, pack_tokens
 from .schema import MetadataMode, NodeWithScore
 from .tokenization import load_tokenizer
@@ -22,7 +23,8 @@ from .tokenization import load_tokenizer
 class HipSentenceTransformerRerank:
     def __init__(self, model: str = "BAAI/bge-reranker-v2-m3", top_n: int = 2, device: Optional[str] = None,
                  keep_retrieval_score: bool = False, model_kwargs: Optional[Dict[str, Any]] = None,
-                 max_length: int = 512, batch_pairs: int = 1024, **_ignored):
+                 max_length: int = 512, batch_pairs: int = 1024, coalesce: bool = True, max_coalesced_calls: int = 64,
+                 coalesce_wait_s: float = 0.0, **_ignored):
         dev = torch.device("cuda" if device in (None, "cuda") else device)
         if dev.type != "cuda":
             raise RuntimeError(f"device '{device}': tensor_truth_amd runs on HIP devices only (no CPU path)")
@@ -45,6 +47,10 @@ class HipSentenceTransformerRerank:
         self.model.set_gemm_dtype((model_kwargs or {}).get("gemm_dtype", "bf16"))
         self._encoder = Encoder(self.model)
         self._tokenizer = (model_kwargs or {}).get("tokenizer") or load_tokenizer(mdir, cfg.arch, cfg.vocab_size)
+        # concurrent predict() / postprocess_nodes() calls (one per request thread in the reference,
+        # rag_service.py:343-346,617-620) share ONE tokenizer call and ONE encoder batch; scores do not depend on the
+        # batch a pair travels in (tests/test_configs_gpu.py), so callers see exactly their serial results
+        self._front = Coalescer(self._predict_many, max_coalesced_calls, coalesce_wait_s) if coalesce else None
 
     # ---- token-id level ---------------------------------------------------------------------------
     def score_token_pairs(self, pair_ids: Sequence[Sequence[int]]) -> torch.Tensor:
@@ -55,14 +61,32 @@ class HipSentenceTransformerRerank:
                                                                 None, self.max_length)))
         return torch.cat(outs) if outs else torch.empty(0, device=self.device)
 
-    def predict(self, pairs: Sequence[Sequence[str]]) -> List[float]:
-        """CrossEncoder.predict: [(query, passage), ...] -> sigmoid scores."""
+    def _predict_flat(self, pairs: Sequence[Sequence[str]]) -> List[float]:
         tk = self._tokenizer
         if hasattr(tk, "encode_pair_batch"):
             ids = [e[0] for e in tk.encode_pair_batch(list(pairs), self.max_length)]
         else:
             ids = [tk.encode_pair(q, p, self.max_length)[0] for q, p in pairs]
         return self.score_token_pairs(ids).cpu().tolist()
+
+    def _predict_many(self, calls: List[Sequence[Sequence[str]]]) -> List[List[float]]:
+        """The pair lists of several concurrent callers as one batch -> each caller's scores."""
+        flat = [p for c in calls for p in c]
+        scores = self._predict_flat(flat) if flat else []
+        out, lo = [], 0
+        for c in calls:
+            out.append(scores[lo:lo + len(c)])
+            lo += len(c)
+        return out
+
+    def predict(self, pairs: Sequence[Sequence[str]]) -> List[float]:
+        """CrossEncoder.predict: [(query, passage), ...] -> sigmoid scores."""
+        pairs = list(pairs)
+        if not pairs:
+            return []
+        if self._front is not None:
+            return self._front.submit(pairs)
+        return self._predict_flat(pairs)
 
     # ---- postprocessor surface ------------------------------------------------------------------------
     def postprocess_nodes(self, nodes: List[NodeWithScore], query_bundle=None, query_str: Optional[str] = None):

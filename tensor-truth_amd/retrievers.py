@@ -134,12 +134,12 @@ class MultiIndexRetriever:
         if k < 1:
             return [[] for _ in bases]
         q = torch.tensor([bundle.embedding], dtype=torch.float32)
-        scores, rows = group.search(q, k)
+        scores, rows, snap_ids = group.search(q, k, return_snapshot=True)
         scores, rows = scores[0].cpu().tolist(), rows[0].cpu().tolist()
         out = []
         for i, (r, b) in enumerate(zip(self.retrievers, bases)):
             kk = min(b.similarity_top_k, indexes[i].num_live)
-            nodes = b.nodes_from_hits(scores[i][:kk], rows[i][:kk])
+            nodes = b.nodes_from_hits(scores[i][:kk], rows[i][:kk], snap_ids[i])
             out.append(r.merge(nodes) if r is not b and hasattr(r, "merge") else nodes)
         return out
 

@@ -132,8 +132,37 @@ class HFTokenizer:
 
 
 def load_tokenizer(model_dir: Optional[str], arch: str, vocab_size: int):
-    if model_dir:
-        tj = os.path.join(model_dir, "tokenizer.json")
-        if os.path.exists(tj):
-            return HFTokenizer(tj, arch)
-    return HashTokenizer(arch, vocab_size)
+    """``model_dir`` None (synthetic / state_dict weights: no tokenizer exists) -> the hashing stand-in.  A real
+    checkpoint directory must bring a real tokenizer: ``tokenizer.json``, or sentencepiece / WordPiece files that
+    ``transformers`` can convert to one -- real weights fed hashed ids would produce meaningless embeddings and
+    rerank scores without any error, so anything else raises (the package's no-silent-fallback policy)."""
+    if not model_dir:
+        return HashTokenizer(arch, vocab_size)
+    tj = os.path.join(model_dir, "tokenizer.json")
+    if os.path.exists(tj):
+        return HFTokenizer(tj, arch)
+    slow_files = ("sentencepiece.bpe.model", "spiece.model", "tokenizer.model", "vocab.txt")
+    if any(os.path.exists(os.path.join(model_dir, f)) for f in slow_files):
+        try:
+            from transformers import AutoTokenizer
+
+            fast = AutoTokenizer.from_pretrained(model_dir, use_fast=True, local_files_only=True)
+            backend = getattr(fast, "backend_tokenizer", None)
+            if backend is None:
+                raise RuntimeError("transformers returned a slow tokenizer")
+            cache = os.path.join(model_dir, "tokenizer.json")
+            try:
+                backend.save(cache)
+                return HFTokenizer(cache, arch)
+            except OSError:           # read-only model dir: keep the converted tokenizer in a temp file
+                import tempfile
+
+                tmp = os.path.join(tempfile.mkdtemp(prefix="tt_tok_"), "tokenizer.json")
+                backend.save(tmp)
+                return HFTokenizer(tmp, arch)
+        except Exception as exc:  # noqa: BLE001
+            raise FileNotFoundError(
+                f"{model_dir}: no tokenizer.json, and converting its sentencepiece / vocab files failed ({exc})") from exc
+    raise FileNotFoundError(
+        f"{model_dir} holds model weights but no tokenizer (tokenizer.json, sentencepiece.bpe.model or vocab.txt): "
+        "refusing to pair real weights with the hashing stand-in tokenizer")

@@ -21,6 +21,7 @@ import numpy as np
 import torch
 
 from . import scan as _scan
+from .coalesce import Coalescer
 from .schema import MetadataMode, NodeWithScore, QueryBundle, TextNode, as_query_bundle
 
 INDEX_METADATA_FILENAME = "index_metadata.json"   # reference: indexing/metadata.py:17
@@ -130,12 +131,17 @@ class HipVectorIndex:
         return len(rows)
 
     def _compact(self) -> None:
+        """Drop the tombstones.  COPY-ON-WRITE: a new matrix and a new ``leaf_ids`` list replace the old ones, which
+        are never moved or rewritten in place -- a search that took its snapshot before the compaction (``snapshot()``)
+        keeps scanning, and mapping rows through, a consistent pair (also when the old matrix was a view of a
+        ``HipIndexGroup``'s packed matrix)."""
         with self._lock:
             if not self._dead:
                 return
             keep = [i for i, nid in enumerate(self.leaf_ids) if nid is not None]
             idx = torch.tensor(keep, dtype=torch.long, device=self.device)
-            self._mat[: len(keep)] = self._mat[: self.n].index_select(0, idx)
+            self._mat = self._mat[: self.n].index_select(0, idx) if keep else torch.empty(
+                (0, self.dim), dtype=torch.bfloat16, device=self.device)
             self.leaf_ids = [self.leaf_ids[i] for i in keep]
             self.n, self._dead, self._row_of = len(keep), 0, None
             self._version += 1
@@ -149,112 +155,245 @@ class HipVectorIndex:
         return self._mat[: self.n]
 
     # ---- query -------------------------------------------------------------------------------------
-    def search(self, query_emb: torch.Tensor, k: int):
-        """query_emb fp32/bf16 [Q, D] -> (scores [Q,k] fp32 cosine, rows [Q,k] int32)."""
-        q = query_emb.to(self.device, dtype=torch.float32)
-        q = (q / q.norm(dim=1, keepdim=True).clamp_min(1e-12)).to(torch.bfloat16).contiguous()
+    def snapshot(self):
+        """(matrix view of the live rows, leaf_ids list) taken under the lock.  Appends never touch rows below ``n``
+        (growth reallocates), deletes only overwrite rows with NaN and set their ``leaf_ids`` entry to None, and
+        compaction replaces both objects (copy-on-write), so the pair stays mutually consistent for as long as the
+        caller holds it -- the scan and the row -> node mapping run WITHOUT the index lock, and the reference's
+        eight retriever threads (rag_engine.py:392,420) search one index concurrently."""
         with self._lock:
-            mat = self._mat[: self.n]
-            return _scan.scan_topk(mat, q, k)
+            return self._mat[: self.n], self.leaf_ids
+
+    def _unit_bf16(self, query_emb: torch.Tensor) -> torch.Tensor:
+        q = query_emb.to(self.device, dtype=torch.float32)
+        return (q / q.norm(dim=1, keepdim=True).clamp_min(1e-12)).to(torch.bfloat16).contiguous()
+
+    def search(self, query_emb: torch.Tensor, k: int, snapshot=None):
+        """query_emb fp32/bf16 [Q, D] -> (scores [Q,k] fp32 cosine, rows [Q,k] int32)."""
+        mat, _ = snapshot if snapshot is not None else self.snapshot()
+        return _scan.scan_topk(mat, self._unit_bf16(query_emb), k)
 
     def node_score(self, cos: float) -> float:
         return math.exp(-(2.0 - 2.0 * cos)) if self.score_mode == "chroma" else cos
 
-    def as_retriever(self, similarity_top_k: int = 10, **_kw) -> "HipVectorRetriever":
-        return HipVectorRetriever(self, similarity_top_k)
+    def as_retriever(self, similarity_top_k: int = 10, coalesce: bool = True, max_batch: int = 64,
+                     max_wait_s: float = 0.0, **_kw) -> "HipVectorRetriever":
+        return HipVectorRetriever(self, similarity_top_k, coalesce=coalesce, max_batch=max_batch, max_wait_s=max_wait_s)
 
     # ---- persistence ---------------------------------------------------------------------------------
     def persist(self, persist_dir: str, embedding_model: Optional[str] = None, chunk_sizes=None,
                 chunking_strategy: Optional[str] = None, chunk_overlap: Optional[int] = None) -> None:
+        """Write ``corpus.bf16`` + ``nodes.json`` + ``index_metadata.json``.  Every file is written under a temporary
+        name and moved into place with ``os.replace`` (atomic within a directory), ``nodes.json`` LAST: it carries the
+        row count and a generation stamp that ``corpus.bf16``'s name is derived from, so a crash or a concurrent
+        ``load`` between the writes sees either the previous complete index or the new one, never a row-count
+        mismatch (``HipDocumentIndex`` persists after every add / remove, document_index.py:478-581)."""
         os.makedirs(persist_dir, exist_ok=True)
         with self._lock:
             self._compact()                    # tombstones are not written
-            self.matrix.cpu().view(torch.int16).numpy().tofile(os.path.join(persist_dir, "corpus.bf16"))
-            nodes = {nid: {"text": nd.text, "metadata": nd.metadata, "parent_id": getattr(nd, "parent_id", None),
-                           "child_ids": list(getattr(nd, "child_ids", []) or []),
-                           "prev_id": getattr(nd, "prev_id", None), "next_id": getattr(nd, "next_id", None)}
-                     for nid, nd in self.docstore.items()}
-            with open(os.path.join(persist_dir, "nodes.json"), "w") as f:
-                json.dump({"dim": self.dim, "leaf_ids": self.leaf_ids, "nodes": nodes, "ref_docs": self.ref_docs}, f)
+            mat_host = self.matrix.cpu().view(torch.int16).numpy()
+            leaf_ids = list(self.leaf_ids)
+            nodes = {nid: _node_to_dict(nd) for nid, nd in self.docstore.items()}
+            ref_docs = {k: list(v) for k, v in self.ref_docs.items()}
+            n_rows = self.n
+        gen = _next_generation(persist_dir)
+        corpus_name = f"corpus.{gen}.bf16"
+
+        def _atomic(name: str, write) -> None:
+            tmp = os.path.join(persist_dir, f".{name}.tmp.{os.getpid()}.{threading.get_ident()}")
+            write(tmp)
+            os.replace(tmp, os.path.join(persist_dir, name))
+
+        _atomic(corpus_name, lambda t: mat_host.tofile(t))
         # the reference's index_metadata.json (indexing/metadata.py:103-146) + what this store adds
         model = embedding_model or getattr(self.embed_model, "model_name", None)
         meta = {"embedding_model": model, "embedding_model_id": sanitize_model_id(model) if model else None,
                 "created_at": datetime.now(timezone.utc).isoformat(), "index_version": INDEX_VERSION,
                 "chunk_sizes": list(chunk_sizes) if chunk_sizes is not None else None, "chunk_overlap": chunk_overlap,
                 "chunking_strategy": chunking_strategy,
-                "embedding_dim": self.dim, "num_vectors": self.n, "store": "tensor_truth_amd/corpus.bf16"}
-        with open(os.path.join(persist_dir, INDEX_METADATA_FILENAME), "w") as f:
-            json.dump(meta, f, indent=2)
+                "embedding_dim": self.dim, "num_vectors": n_rows, "store": f"tensor_truth_amd/{corpus_name}"}
+
+        def _dump(obj):
+            def w(t):
+                with open(t, "w") as f:
+                    json.dump(obj, f)
+            return w
+
+        _atomic(INDEX_METADATA_FILENAME, _dump(meta))
+        _atomic("nodes.json", _dump({"dim": self.dim, "leaf_ids": leaf_ids, "nodes": nodes, "ref_docs": ref_docs,
+                                     "corpus_file": corpus_name, "generation": gen}))
+        for name in os.listdir(persist_dir):     # older generations: unreferenced once nodes.json has moved
+            if name.startswith("corpus.") and name.endswith(".bf16") and name != corpus_name:
+                try:
+                    os.remove(os.path.join(persist_dir, name))
+                except OSError:
+                    pass
 
     @classmethod
     def load(cls, persist_dir: str, device=None, embed_model=None, score_mode: str = "chroma") -> "HipVectorIndex":
-        with open(os.path.join(persist_dir, "nodes.json")) as f:
-            blob = json.load(f)
+        blob, raw = _read_persisted(persist_dir)
         idx = cls(blob["dim"], device, embed_model, score_mode)
-        raw = np.fromfile(os.path.join(persist_dir, "corpus.bf16"), dtype=np.int16).reshape(-1, blob["dim"])
-        if raw.shape[0] != len(blob["leaf_ids"]):
-            raise ValueError("corpus.bf16 and nodes.json disagree on the number of rows")
-        idx._mat = torch.from_numpy(raw).view(torch.bfloat16).to(idx.device).contiguous()
+        idx._mat = torch.from_numpy(np.ascontiguousarray(raw)).view(torch.bfloat16).to(idx.device).contiguous()
         idx.n = raw.shape[0]
         idx.leaf_ids = list(blob["leaf_ids"])
         idx.ref_docs = {k: list(v) for k, v in (blob.get("ref_docs") or {}).items()}
-        for nid, d in blob["nodes"].items():
-            nd = TextNode(text=d["text"], id_=nid, metadata=d["metadata"])
-            for key in ("parent_id", "child_ids", "prev_id", "next_id"):
-                try:
-                    setattr(nd, key, d.get(key) if key != "child_ids" else list(d.get(key) or []))
-                except Exception:  # noqa: BLE001 - LlamaIndex nodes keep links in .relationships
-                    pass
-            idx.docstore[nid] = nd
+        idx.docstore = {nid: _node_from_dict(nid, d) for nid, d in blob["nodes"].items()}
         return idx
+
+
+_LINK_KEYS = ("parent_id", "child_ids", "prev_id", "next_id")
+# what get_content(MetadataMode.EMBED / LLM) depends on besides text and metadata: the reference's leaves inherit
+# SimpleDirectoryReader's excluded keys (file_name, file_size, dates ...), and the reranker scores
+# ``get_content(EMBED)`` of the RETRIEVED node (rerank.py) -- a hit that lost them would be scored on different text
+# than the reference scores, and than what was embedded at index time.
+_CONTENT_KEYS = ("excluded_embed_metadata_keys", "excluded_llm_metadata_keys", "metadata_template",
+                 "metadata_separator", "text_template")
+
+
+def _node_to_dict(nd) -> dict:
+    d = {"text": nd.text, "metadata": nd.metadata}
+    for key in _LINK_KEYS:
+        v = getattr(nd, key, None)
+        d[key] = list(v or []) if key == "child_ids" else v
+    for key in _CONTENT_KEYS:
+        v = getattr(nd, key, None)
+        if v:
+            d[key] = list(v) if isinstance(v, (list, tuple)) else v
+    return d
+
+
+def _copy_node_attrs(src, dst, keys) -> None:
+    for key in keys:
+        if hasattr(src, key):
+            v = getattr(src, key)
+            try:
+                setattr(dst, key, list(v) if isinstance(v, (list, tuple)) else v)
+            except Exception:  # noqa: BLE001 - LlamaIndex nodes keep links in .relationships
+                pass
+
+
+def _node_from_dict(nid: str, d: dict):
+    nd = TextNode(text=d["text"], id_=nid, metadata=d["metadata"])
+    for key in _LINK_KEYS + _CONTENT_KEYS:
+        if key in d or key in _LINK_KEYS:
+            v = d.get(key)
+            try:
+                setattr(nd, key, list(v or []) if key in ("child_ids", "excluded_embed_metadata_keys",
+                                                          "excluded_llm_metadata_keys") else v)
+            except Exception:  # noqa: BLE001
+                pass
+    return nd
+
+
+def _next_generation(persist_dir: str) -> int:
+    try:
+        with open(os.path.join(persist_dir, "nodes.json")) as f:
+            return int(json.load(f).get("generation", 0)) + 1
+    except (OSError, ValueError):
+        return 1
+
+
+def _read_persisted(persist_dir: str, rows=None):
+    """-> (nodes.json blob, int16 [n, dim] array of the bf16 rows).  ``rows``: a slice, or a function of the row count
+    returning one -- only that row range is read (the file is memory-mapped)."""
+    with open(os.path.join(persist_dir, "nodes.json")) as f:
+        blob = json.load(f)
+    path = os.path.join(persist_dir, blob.get("corpus_file", "corpus.bf16"))
+    n, dim = len(blob["leaf_ids"]), blob["dim"]
+    if os.path.getsize(path) != n * dim * 2:
+        raise ValueError(f"{path} and nodes.json disagree on the number of rows")
+    raw = np.memmap(path, dtype=np.int16, mode="r", shape=(n, dim)) if n else np.zeros((0, dim), np.int16)
+    if callable(rows):
+        rows = rows(n)
+    return blob, (raw[rows] if rows is not None else raw)
 
 
 class HipVectorRetriever:
     """``index.as_retriever(similarity_top_k=...)`` (rag_engine.py:639): query string ->
     ``List[NodeWithScore]`` sorted by score desc, at most ``similarity_top_k`` long.  Thread-safe:
-    the reference calls it from up to 8 executor threads (rag_engine.py:420-424)."""
+    the reference calls it from up to 8 executor threads (rag_engine.py:420-424) and from
+    ``run_in_executor`` request threads (api/routes/chat.py:367-374), one query per call.
 
-    def __init__(self, index: HipVectorIndex, similarity_top_k: int = 10):
+    ``coalesce`` (default on): concurrent ``retrieve`` calls are merged by a ``coalesce.Coalescer`` into ONE
+    query-embedding batch and ONE scan (up to ``max_batch`` queries share a pass over the corpus); a lone caller
+    runs immediately as a batch of one.  Results are identical to serial calls: embeddings and scan results do not
+    depend on the batch a query travels in (tests/test_coalesce_gpu.py)."""
+
+    def __init__(self, index: HipVectorIndex, similarity_top_k: int = 10, coalesce: bool = True, max_batch: int = 64,
+                 max_wait_s: float = 0.0):
         self.index = index
         self.similarity_top_k = similarity_top_k
+        self._front = Coalescer(self._retrieve_batch, max_batch, max_wait_s) if coalesce else None
 
     def retrieve(self, query) -> List[NodeWithScore]:
         qb = as_query_bundle(query)
-        idx = self.index
-        if idx.num_live == 0:
+        if self.index.num_live == 0:
             return []
-        if getattr(qb, "embedding", None) is not None:
-            q = torch.tensor([qb.embedding], dtype=torch.float32)
-        else:
+        if self._front is not None:
+            return self._front.submit(qb)
+        return self._retrieve_batch([qb])[0]
+
+    def _query_matrix(self, bundles) -> torch.Tensor:
+        """One embedding per bundle, fp32 [B, D]: the precomputed ``QueryBundle.embedding`` or the mean over the
+        bundle's ``embedding_strs`` (VectorIndexRetriever -> get_agg_embedding_from_queries); all
+        strings of all bundles go through the encoder in one batch."""
+        idx = self.index
+        strs, owner = [], []
+        for i, qb in enumerate(bundles):
+            if getattr(qb, "embedding", None) is None:
+                ss = list(qb.embedding_strs)
+                strs += ss
+                owner += [i] * len(ss)
+        rows: List[Optional[torch.Tensor]] = [None] * len(bundles)
+        if strs:
             em = idx.embed_model
             if em is None:
                 raise ValueError("retriever needs an embed_model or a QueryBundle with an embedding")
-            strs = qb.embedding_strs
             if hasattr(em, "query_embedding_device"):
-                q = em.query_embedding_device(strs).mean(dim=0, keepdim=True)
+                E = em.query_embedding_device(strs).to(idx.device, dtype=torch.float32)
             else:
-                q = torch.tensor([em.get_agg_embedding_from_queries(strs)], dtype=torch.float32)
-        k = min(self.similarity_top_k, idx.num_live)
-        scores, rows = idx.search(q, k)
-        return self.nodes_from_hits(scores[0].cpu().tolist(), rows[0].cpu().tolist())
+                E = torch.tensor([em.get_agg_embedding_from_queries([s]) for s in strs], dtype=torch.float32,
+                                 device=idx.device)
+            if len(strs) == len(set(owner)):          # one string per bundle (the reference's case): no averaging
+                for j, i in enumerate(owner):
+                    rows[i] = E[j]
+            else:
+                for i in sorted(set(owner)):
+                    sel = [j for j, o in enumerate(owner) if o == i]
+                    rows[i] = E[sel].mean(dim=0)
+        for i, qb in enumerate(bundles):
+            if rows[i] is None:
+                rows[i] = torch.tensor(qb.embedding, dtype=torch.float32, device=idx.device)
+        return torch.stack(rows, 0)
 
-    def nodes_from_hits(self, scores: Sequence[float], rows: Sequence[int]) -> List[NodeWithScore]:
-        """(cosine, row) pairs of this retriever's index -> NodeWithScore list (padding rows < 0 skipped)."""
+    def _retrieve_batch(self, bundles) -> List[List[NodeWithScore]]:
         idx = self.index
+        snap = idx.snapshot()
+        mat, leaf_ids = snap
+        k = min(self.similarity_top_k, max(idx.num_live, 0), mat.shape[0])
+        if k < 1:
+            return [[] for _ in bundles]
+        scores, rows = idx.search(self._query_matrix(bundles), k, snapshot=snap)
+        scores, rows = scores.cpu().tolist(), rows.cpu().tolist()
+        return [self.nodes_from_hits(s, r, leaf_ids) for s, r in zip(scores, rows)]
+
+    def nodes_from_hits(self, scores: Sequence[float], rows: Sequence[int], leaf_ids=None) -> List[NodeWithScore]:
+        """(cosine, row) pairs of this retriever's index -> NodeWithScore list (padding rows < 0 skipped).
+        ``leaf_ids``: the row -> id list of the snapshot the rows were found in (default: the index's current one);
+        a row deleted since (id None / node gone from the docstore) is skipped."""
+        idx = self.index
+        ids = idx.leaf_ids if leaf_ids is None else leaf_ids
         out = []
         for s, r in zip(scores, rows):
-            if r < 0:
+            if r < 0 or r >= len(ids):
                 continue
-            src = idx.docstore[idx.leaf_ids[r]]
+            src = idx.docstore.get(ids[r]) if ids[r] is not None else None
+            if src is None:
+                continue
             # a fresh node per hit with its own metadata dict: callers mutate it
             # (_source_index tagging, rag_engine.py:432-450) and may run concurrently
             node = TextNode(text=src.text, id_=src.id_, metadata=dict(src.metadata))
-            for key in ("parent_id", "child_ids", "prev_id", "next_id"):
-                if hasattr(src, key):
-                    try:
-                        setattr(node, key, getattr(src, key))
-                    except Exception:  # noqa: BLE001
-                        pass
+            _copy_node_attrs(src, node, _LINK_KEYS + _CONTENT_KEYS)
             out.append(NodeWithScore(node=node, score=float(idx.node_score(s))))
         return out
 
@@ -280,6 +419,7 @@ class HipIndexGroup:
         self._lock = threading.RLock()
         self._stamp = None
         self._mat = None
+        self._leaf_ids: List[list] = []
         self.offsets: List[int] = []
 
     def _pack(self) -> None:
@@ -296,15 +436,22 @@ class HipIndexGroup:
             for ix, lo in zip(self.indexes, offs):
                 mat[lo:lo + ix.n] = ix._mat[: ix.n]
                 ix._mat = mat[lo:lo + ix.n]
+            # the row -> id lists that belong to THIS packed matrix (a member's compaction replaces its list and
+            # its matrix copy-on-write and bumps its version, so the pair below stays consistent until the repack)
             self._mat, self.offsets, self._stamp = mat, offs, stamp
+            self._leaf_ids = [ix.leaf_ids for ix in self.indexes]
         finally:
             for ix in self.indexes:
                 ix._lock.release()
 
-    def search(self, query_emb: torch.Tensor, k: int):
-        """query_emb [Q, D] -> (cosine scores [Q, S, k] fp32, module-local rows [Q, S, k] int32)."""
+    def search(self, query_emb: torch.Tensor, k: int, return_snapshot: bool = False):
+        """query_emb [Q, D] -> (cosine scores [Q, S, k] fp32, module-local rows [Q, S, k] int32); with
+        ``return_snapshot`` also the per-module row -> id lists of the matrix that was scanned.  The scan runs
+        outside the group lock on a snapshot (matrix, offsets, id lists) taken under it."""
         q = query_emb.to(self.device, dtype=torch.float32)
         q = (q / q.norm(dim=1, keepdim=True).clamp_min(1e-12)).to(torch.bfloat16).contiguous()
         with self._lock:
             self._pack()
-            return _scan.scan_topk_segmented(self._mat, q, k, self.offsets)
+            mat, offs, ids = self._mat, list(self.offsets), list(self._leaf_ids)
+        s, r = _scan.scan_topk_segmented(mat, q, k, offs)
+        return (s, r, ids) if return_snapshot else (s, r)

@@ -38,3 +38,7 @@ def dev():
     if not torch.cuda.is_available():
         pytest.fail("gpu-marked test selected but no HIP device is visible")
     return torch.device("cuda:0")
+
+TESTS = os.path.dirname(os.path.abspath(__file__))
+if TESTS not in sys.path:      # helper modules next to the tests (rank_checks.py)
+    sys.path.insert(0, TESTS)

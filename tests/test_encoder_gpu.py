@@ -235,11 +235,11 @@ def test_rerank_head_vs_golden(dev, built_lib, golden_dir):
     gold_s = torch.from_numpy(z["scores"])
     assert (scores - gold_s).abs().max().item() < 1.5e-2  # stated bf16 bound
     assert torch.allclose(scores, torch.sigmoid(logits), atol=1e-6)
-    # order of the pairs is preserved wherever the fp32 scores are separated by the tolerance
-    order_g = torch.argsort(gold_s, descending=True)
-    gaps = (gold_s[order_g][:-1] - gold_s[order_g][1:])
-    if (gaps > 2e-2).all():
-        assert torch.equal(torch.argsort(scores, descending=True), order_g)
+    # order of the pairs is preserved wherever the fp32 scores are separated by twice the score bound -- checked on
+    # every separable pair, unconditionally (rank_checks.py), and the golden batch must contain such pairs
+    from rank_checks import assert_order_on_separable
+    n_sep = assert_order_on_separable(gold_s.numpy(), scores.numpy(), 3e-2, "xenc_head golden")
+    assert n_sep >= 1, "golden scores hold no separable pair: regenerate the fixture with a wider head"
 
 
 def test_encoder_longer_sequences_and_truncation(dev, built_lib):

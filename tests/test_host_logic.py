@@ -472,3 +472,133 @@ def test_sanitize_model_id_known_answers():
     assert sanitize_model_id("sentence-transformers/all-MiniLM-L6-v2") == "all-minilm-l6-v2"
     assert sanitize_model_id("org/My Model@@v1.5_x") == "my-model-v1.5_x"
     assert sanitize_model_id("--weird//name--") == "name"
+
+
+# ---- round 2: advisor findings + coalescing front ---------------------------------------------------------------
+
+def test_hits_keep_what_embed_content_depends_on(tmp_path):
+    """A retrieved node must give the reranker the text that was embedded: ``get_content(EMBED)`` of a hit equals the
+    stored node's (the reference's leaves inherit SimpleDirectoryReader's excluded keys; rerank.py scores
+    ``get_content(EMBED)`` of the RETRIEVED nodes, services/rag_service.py:617-620)."""
+    from tensor_truth_amd.schema import MetadataMode, TextNode
+    from tensor_truth_amd.vector_index import HipVectorRetriever, _node_from_dict, _node_to_dict
+
+    src = TextNode(text="body", id_="a", metadata={"file_name": "x.md", "file_size": 123, "title": "T"})
+    src.excluded_embed_metadata_keys = ["file_name", "file_size"]
+    src.parent_id, src.next_id = "p", "b"
+    assert src.get_content(MetadataMode.EMBED) == "title: T\n\nbody"
+
+    class FakeIndex:                      # the attributes nodes_from_hits reads
+        docstore = {"a": src}
+        leaf_ids = ["a", None]
+        num_live = 1
+
+        @staticmethod
+        def node_score(c):
+            return c
+
+    retr = HipVectorRetriever(FakeIndex(), 5, coalesce=False)
+    hits = retr.nodes_from_hits([0.9, 0.8, 0.7], [0, 1, -1])       # row 1 is a tombstone, -1 is padding
+    assert len(hits) == 1
+    hit = hits[0].node
+    assert hit.get_content(MetadataMode.EMBED) == src.get_content(MetadataMode.EMBED) == "title: T\n\nbody"
+    assert hit.get_content(MetadataMode.ALL) == src.get_content(MetadataMode.ALL)
+    assert hit.parent_id == "p" and hit.next_id == "b" and hit.metadata is not src.metadata
+    hit.excluded_embed_metadata_keys.append("title")               # a copy, not the stored node's list
+    assert src.excluded_embed_metadata_keys == ["file_name", "file_size"]
+    # ... and survives persist / load (nodes.json)
+    back = _node_from_dict("a", _node_to_dict(src))
+    assert back.get_content(MetadataMode.EMBED) == "title: T\n\nbody" and back.parent_id == "p" and back.child_ids == []
+    # a snapshot's id list wins over the index's current one (rows found before a compaction)
+    assert retr.nodes_from_hits([0.5], [1], leaf_ids=["zzz", "a"])[0].node.id_ == "a"
+
+
+def test_persisted_layout_is_generation_stamped(tmp_path):
+    """``nodes.json`` names the matrix file it belongs to; a reader never pairs it with another generation's rows."""
+    import json
+
+    import numpy as np
+
+    from tensor_truth_amd.vector_index import _next_generation, _read_persisted
+
+    d = tmp_path / "ix"
+    d.mkdir()
+    assert _next_generation(str(d)) == 1
+    rows = np.arange(3 * 128, dtype=np.int16).reshape(3, 128)
+    rows.tofile(d / "corpus.4.bf16")
+    (d / "corpus.3.bf16").write_bytes(b"stale generation, wrong size")
+    json.dump({"dim": 128, "leaf_ids": ["a", "b", "c"], "nodes": {}, "corpus_file": "corpus.4.bf16", "generation": 4},
+              open(d / "nodes.json", "w"))
+    blob, raw = _read_persisted(str(d))
+    assert raw.shape == (3, 128) and np.array_equal(np.asarray(raw), rows) and _next_generation(str(d)) == 5
+    _, part = _read_persisted(str(d), rows=lambda n: slice(1, n))
+    assert np.array_equal(np.asarray(part), rows[1:])
+    json.dump({"dim": 128, "leaf_ids": ["a", "b"], "nodes": {}, "corpus_file": "corpus.4.bf16", "generation": 4},
+              open(d / "nodes.json", "w"))
+    with pytest.raises(ValueError):
+        _read_persisted(str(d))
+    # round-1 layout (no corpus_file key) still loads
+    rows.tofile(d / "corpus.bf16")
+    json.dump({"dim": 128, "leaf_ids": ["a", "b", "c"], "nodes": {}}, open(d / "nodes.json", "w"))
+    assert _read_persisted(str(d))[1].shape == (3, 128)
+
+
+def test_real_weights_are_never_paired_with_the_hashing_tokenizer(tmp_path):
+    from tensor_truth_amd.tokenization import HashTokenizer, load_tokenizer
+
+    assert isinstance(load_tokenizer(None, "xlmr", 1000), HashTokenizer)          # synthetic / state_dict weights
+    (tmp_path / "model.safetensors").write_bytes(b"")
+    with pytest.raises(FileNotFoundError):
+        load_tokenizer(str(tmp_path), "xlmr", 1000)                                # weights, but no tokenizer files
+    (tmp_path / "vocab.txt").write_text("\n".join(["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]", "hello", "world"]))
+    try:
+        tk = load_tokenizer(str(tmp_path), "bert", 7)                              # WordPiece vocab -> converted
+    except FileNotFoundError as exc:                                               # (no config.json for AutoTokenizer)
+        assert "converting" in str(exc)
+    else:
+        assert tk.encode("hello world")[1:3] == [5, 6]
+
+
+def test_coalescer_batches_concurrent_callers_and_preserves_results():
+    import threading
+    import time
+
+    from tensor_truth_amd.coalesce import Coalescer
+
+    sizes = []
+
+    def run(items):
+        sizes.append(len(items))
+        time.sleep(0.01)
+        return [i * i for i in items]
+
+    c = Coalescer(run, max_batch=8)
+    assert c.submit(3) == 9 and sizes == [1]                      # a lone caller runs at once, alone
+    out = {}
+
+    def worker(i):
+        out[i] = c.submit(i)
+
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(40)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=30)
+    assert out == {i: i * i for i in range(40)}
+    assert max(sizes) == 8 and sum(sizes) == 41 and len(sizes) < 41 and c.items == 41 and c.batches == len(sizes)
+
+    # a failing batch fails every member, later calls are unaffected
+    state = {"fail": True}
+
+    def flaky(items):
+        if state["fail"]:
+            raise ValueError("boom")
+        return items
+
+    f = Coalescer(flaky)
+    with pytest.raises(ValueError):
+        f.submit(1)
+    state["fail"] = False
+    assert f.submit(2) == 2
+    with pytest.raises(RuntimeError):
+        Coalescer(lambda items: []).submit(1)                   # wrong result count is an error, not a hang

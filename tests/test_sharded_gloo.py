@@ -86,3 +86,76 @@ def test_shard_bounds_cover_everything():
         assert spans[0][0] == 0 and spans[-1][1] == n
         assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
         assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+def _retriever_worker(rank, world, port, n_total, d, k, mode, ret):
+    """Drive the protocol THROUGH the plugin surface: ShardedHipVectorIndex.as_retriever().retrieve() on every rank
+    (row e2 of the scope table: the reference builds this object at rag_engine.py:626-645).  The scan and merge kernels
+    are replaced by the CPU oracle (they need a GPU); sharding, both query modes, the exchange, the global-row -> node
+    mapping and the score mapping are the product's."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tensor_truth_amd.schema import QueryBundle, TextNode
+        from tensor_truth_amd.sharded import shard_bounds
+        from tensor_truth_amd.sharded_index import ShardedHipVectorIndex
+
+        corpus = osc.synth_corpus(n_total, d, seed=7)
+        queries, _ = osc.synth_queries(corpus, 2 * world, seed=9)
+        lo, hi = shard_bounds(n_total, world, rank)
+        leaf_ids = [f"leaf{j}" for j in range(n_total)]
+        docstore = {nid: TextNode(text=f"text {j}", id_=nid, metadata={"row": j}) for j, nid in enumerate(leaf_ids)}
+
+        def scan_fn(rows, q16, kk, base):
+            v, i, _ = osc.scan_topk(rows, q16, kk)
+            return v, torch.where(i >= 0, i + base, i).to(torch.int32)
+
+        def merge_fn(vals, idx, kk):
+            v, i = osc.merge_topk(vals, idx.to(torch.int64), kk)
+            return v, i.to(torch.int32)
+
+        index = ShardedHipVectorIndex(d, corpus[lo:hi].contiguous(), lo, n_total, leaf_ids, docstore, score_mode="cosine",
+                                      logical_shards=3, queries=mode, scan_fn=scan_fn, merge_fn=merge_fn)
+        retr = index.as_retriever(similarity_top_k=k)
+        # replicated: every rank asks the same two questions; partitioned: rank r asks questions 2r, 2r+1
+        mine = [0, 1] if mode == "replicated" else [2 * rank, 2 * rank + 1]
+        out = []
+        for qi in mine:
+            hits = retr.retrieve(QueryBundle(query_str=f"q{qi}", embedding=queries[qi].float().tolist()))
+            out.append((qi, [(h.node.id_, h.score, h.node.metadata["row"]) for h in hits]))
+        ret.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["replicated", "partitioned"])
+def test_two_rank_retrieve_through_the_plugin_surface(mode):
+    world, n_total, d, k = 2, 777, 128, 12
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_retriever_worker, args=(r, world, port, n_total, d, k, mode, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = dict(ret.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    corpus = osc.synth_corpus(n_total, d, seed=7)
+    queries, _ = osc.synth_queries(corpus, 2 * world, seed=9)
+    want_s, want_i, gap = osc.scan_topk(corpus, queries, k)
+    seen = set()
+    for rank, res in outs.items():
+        for qi, hits in res:
+            seen.add((rank, qi))
+            assert len(hits) == k
+            assert [h[1] for h in hits] == sorted((h[1] for h in hits), reverse=True)
+            assert all(h[0] == f"leaf{h[2]}" for h in hits)                   # node looked up by GLOBAL row
+            if gap[qi] > 1e-6:
+                assert [h[2] for h in hits] == want_i[qi].tolist()
+            assert torch.allclose(torch.tensor([h[1] for h in hits]), want_s[qi], rtol=1e-5, atol=1e-6)
+    want_seen = {(r, q) for r in range(world) for q in ([0, 1] if mode == "replicated" else [2 * r, 2 * r + 1])}
+    assert seen == want_seen
+    if mode == "replicated":      # identical answers on every rank
+        assert outs[0] == outs[1]
