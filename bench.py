@@ -53,6 +53,11 @@ def parse():
     ap.add_argument("--chunk-len", type=int, default=256)
     ap.add_argument("--embed-chunks", type=int, default=1024, help="chunks per GPU in the ingest (chunks embedded/s) leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-surface-leg", action="store_true", help="skip the plugin-surface leg (32 request threads through retrieve() / postprocess_nodes())")
+    ap.add_argument("--no-config5-leg", action="store_true", help="skip the composed BASELINE config 5 leg (semantic-hierarchical ingest + auto-merging retrieval + fp8 reranker)")
+    ap.add_argument("--surface-threads", type=int, default=32)
+    ap.add_argument("--surface-queries", type=int, default=256, help="queries the surface leg issues in all (N=1 only)")
+    ap.add_argument("--config5-docs", type=int, default=256)
     ap.add_argument("--no-fp8-leg", action="store_true", help="skip the extra fp8-reranker timing (BASELINE config 5)")
     ap.add_argument("--headline-only", action="store_true",
                     help="run only the warm-up and timed steps (no scan-only / fp8 / ingest legs): every kernel of the process then "
@@ -60,6 +65,22 @@ def parse():
                          "roofline.avg_launch_ms directly (tools/rocprof_vs_bench.py)")
     ap.add_argument("--layers", type=int, default=24, help="encoder depth (24 = the named models; for debugging only)")
     return ap.parse_args()
+
+
+def csrc_sha256() -> str:
+    """Hash of the kernel sources (csrc/*.hip, *.h + the ABI header): ties a PMC traffic file to the tree it was measured on."""
+    import glob
+    import hashlib
+
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "tensor-truth_amd", "csrc", "*.hip")) +
+                   glob.glob(os.path.join(ROOT, "tensor-truth_amd", "csrc", "*.h")) +
+                   [os.path.join(ROOT, "include", "tt_hip.h")])
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
 
 
 def synth_corpus_shard(n_rows, dim, seed, device):
@@ -107,7 +128,8 @@ def main():
     from tensor_truth_amd import _lib, scan as tscan
     from tensor_truth_amd.encoder import (BGE_M3, BGE_RERANKER_V2_M3, Encoder, EncoderConfig, EncoderWeights,
                                           pack_token_matrix, pack_tokens, synthetic_state_device)
-    from tensor_truth_amd.sharded import ShardedCorpus, gather_queries, shard_bounds
+    from tensor_truth_amd.sharded import shard_bounds
+    from tensor_truth_amd.sharded_index import ShardedHipVectorIndex
 
     lib = _lib.load_library()
     Bq, K, topn, D = args.queries_per_gpu, args.top_k, args.top_n, args.dim
@@ -118,7 +140,12 @@ def main():
 
     # ---- resident state: corpus shard + both models -------------------------------------------
     lo, hi = shard_bounds(args.corpus_rows, world, rank)
-    corpus = ShardedCorpus(synth_corpus_shard(hi - lo, D, 1234 + rank, dev), lo, args.corpus_rows)
+    # the product's row-sharded index, query batches partitioned over the ranks: its
+    # search() = all-gather of the ranks' query embeddings -> local exact scan -> ONE all-gather of the packed
+    # partial top-k -> tt_topk_merge.  Node tables are lazy (ids derived from the row), see the surface leg.
+    shard_rows = synth_corpus_shard(hi - lo, D, 1234 + rank, dev)
+    corpus = ShardedHipVectorIndex(D, shard_rows, lo, args.corpus_rows, None, None, score_mode="cosine",
+                                   queries="partitioned")
     embedder = Encoder(EncoderWeights(emb_cfg, synthetic_state_device(emb_cfg, dev, seed=1), dev))
     reranker = Encoder(EncoderWeights(rr_cfg, synthetic_state_device(rr_cfg, dev, seed=2), dev))
     vocab = emb_cfg.vocab_size
@@ -136,10 +163,9 @@ def main():
         batch = pack_token_matrix(q_ids, emb_cfg)
         _, q16 = embedder.embed_packed(batch)
         tokens_step["embed"] = batch.n_tokens
-        # 2.-4. every shard scans the gathered query batch; partial top-k all-gathered + merged
-        all_q = gather_queries(q16)
-        s, i = corpus.search(all_q, K)
-        mine = i[rank * Bq:(rank + 1) * Bq].cpu().numpy()          # candidate rows of my queries (host)
+        # 2.-4. every shard scans the gathered query batch; partial top-k all-gathered + merged (results for MY queries)
+        s, i = corpus.search(q16, K)
+        mine = i.cpu().numpy()                                       # candidate rows of my queries (host)
         # 5. rerank: <s> q </s></s> chunk </s>, 50 pairs per query
         flat = mine.reshape(-1)
         ptok = passage_tokens(np.maximum(flat, 0), args.chunk_len, vocab)
@@ -155,7 +181,7 @@ def main():
         scores = reranker.rerank_packed(rb).view(Bq, K)
         # 6. top-n by rerank score (host-visible result, as the postprocessor returns it)
         top_s, top_j = torch.topk(scores, topn, dim=1)
-        rows = torch.gather(i[rank * Bq:(rank + 1) * Bq].long(), 1, top_j)
+        rows = torch.gather(i.long(), 1, top_j)
         return top_s.cpu(), rows.cpu()
 
     def sync_all():
@@ -201,19 +227,27 @@ def main():
         # against the sharded corpus
         nq_scan = max(1, 256 // world)
         scan_q = torch.nn.functional.normalize(torch.randn(nq_scan, D, device=dev, generator=torch.Generator(device=dev).manual_seed(4321)), dim=1).to(torch.bfloat16)
-        corpus.search(gather_queries(scan_q), K)
+        corpus.search(scan_q, K)
         sync_all()
+        lib.tt_prof_enable(1 << 1)
         t3 = time.perf_counter()
         for _ in range(3):
-            corpus.search(gather_queries(scan_q), K)
+            corpus.search(scan_q, K)
         sync_all()
+        scan_only_prof = read_prof()["scan_filter"]
+        lib.tt_prof_enable(0)
         dt_scan = (time.perf_counter() - t3) / 3
         if world > 1:
             t = torch.tensor([dt_scan], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt_scan = float(t.item())
+        so_ms, so_n = scan_only_prof
+        so_gbs = (hi - lo) * D * 2 * so_n / (so_ms * 1e-3) / 1e9 if so_ms > 0 else 0.0
         scan_only = {"queries_per_s": world * nq_scan / dt_scan, "ms_per_batch": dt_scan * 1e3,
-                     "what": f"exact top-{K} of {world * nq_scan} queries over the {args.corpus_rows} x {D} corpus (gather + scan + merge), no encoders"}
+                     "what": f"exact top-{K} of {world * nq_scan} queries over the {args.corpus_rows} x {D} corpus (gather + scan + merge), no encoders",
+                     # achieved = N_local * D * 2 / t PER BATCH, whatever the kernel re-reads
+                     "filter_pass": {"achieved_GBps_algorithmic": so_gbs, "frac_of_hbm_peak": so_gbs / HBM_PEAK_GBS,
+                                     "avg_launch_ms": so_ms / max(so_n, 1), "queries_per_launch": world * nq_scan}}
 
     # ---- BASELINE config 5's "fp8 MFMA reranker": the same steps with the cross-encoder's Q/K/V and FFN-up
     # projections on e4m3 operands.  Reported beside the headline (which stays bf16), never as it.
@@ -280,6 +314,16 @@ def main():
                 dt8e = float(t.item())
             fp8_leg["chunks_embedded_per_s"] = world * args.embed_chunks / dt8e
 
+    # ---- through the plugin surface: N request threads call retrieve() / postprocess_nodes() one query at a time, as
+    # the reference's executor threads do (rag_engine.py:418-424, api/routes/chat.py:367-374); the coalescing front
+    # merges them into shared embed / scan / rerank batches.  Strings in, NodeWithScore out; the SAME resident corpus.
+    surface = None
+    if world == 1 and not args.headline_only and not args.no_surface_leg:
+        surface = surface_leg(args, dev, shard_rows, emb_cfg, rr_cfg)
+    config5 = None
+    if world == 1 and not args.headline_only and not args.no_config5_leg:
+        config5 = config5_leg(args, dev, emb_cfg, rr_cfg)
+
     # ---- roofline of the dominant kernel (GEMM, MFMA-bound) and of the scan (HBM-bound) -------
     H, F, L = emb_cfg.hidden, emb_cfg.ffn, emb_cfg.layers
     # algorithmic GEMM flops of what is computed (real tokens only): L-1 full layers + the last layer's QKV
@@ -294,21 +338,34 @@ def main():
     gemm_ms, gemm_n = prof["gemm"]
     gemm_tf = gemm_flops_step * args.steps / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
     scan_ms, scan_n = prof["scan_filter"]
+    # ALGORITHMIC bytes per launch = N_local * D * 2 (one pass of the shard per query batch); what the
+    # kernel re-reads on top of that (one pass per 64-query tile beyond the first) is reported as reread_factor, never
+    # credited to `achieved`
     q_tiles = (Bq * world + 63) // 64
-    scan_bytes = (hi - lo) * D * 2 * q_tiles                                    # per launch: shard read once per 64 queries
+    scan_bytes = (hi - lo) * D * 2
     scan_gbs = scan_bytes * scan_n / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
 
-    # HBM traffic per launch: PMC counters cannot be read from inside this process; the committed
-    # profiles/r01_pmc_traffic.json holds them for exactly this default single-GPU command
-    # (tools/gpu_pmc_bench.sh + tools/pmc_to_traffic.py), otherwise null.
+    # HBM traffic per launch: PMC counters cannot be read from inside this process; profiles/r02_pmc_traffic.json holds
+    # them for exactly this default single-GPU command (tools/gpu_pmc_bench.sh + tools/pmc_to_traffic.py: separate
+    # --pmc passes, FETCH_SIZE doubled per the gfx950 rule).  The file records the hash of the kernel sources it was
+    # measured on; a file from other sources is REFUSED (traffic null + the reason), so the number cannot go stale.
     traffic = {"gemm": None, "scan_filter": None}
+    traffic_note = None
     default_cfg = (world == 1 and args.corpus_rows == 10_000_000 and D == 1024 and Bq == 32 and K == 50
                    and args.chunk_len == 256 and args.query_len == 32 and L == 24)
-    tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if default_cfg and os.path.exists(tpath):
+    tpath = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    if not default_cfg:
+        traffic_note = "not the default single-GPU configuration the PMC passes were collected on"
+    elif not os.path.exists(tpath):
+        traffic_note = "profiles/r02_pmc_traffic.json not collected for this tree"
+    else:
         with open(tpath) as f:
             tj = json.load(f)
-        traffic = {k: tj[k]["hbm_bytes_per_launch"] for k in traffic if k in tj}
+        if tj.get("csrc_sha256") != csrc_sha256():
+            traffic_note = (f"profiles/r02_pmc_traffic.json was measured on kernel sources {str(tj.get('csrc_sha256'))[:12]}, "
+                            f"this tree is {csrc_sha256()[:12]}: refused")
+        else:
+            traffic = {k: tj[k]["hbm_bytes_per_launch"] for k in traffic if k in tj}
 
     out = {
         "metric": "queries/sec (embed+top-k+rerank) over 10M x 1024 corpus",
@@ -335,18 +392,22 @@ def main():
             "embed_batch": f"{args.embed_chunks} chunks x {args.chunk_len + 2} tok per GPU (bge-m3 shape)",
             "fp8_reranker": fp8_leg,
             "scan_only": scan_only,
+            "plugin_surface": surface,
+            "config5_composed": config5,
         },
         "roofline": {
             "kernel": "gemm_kernel (encoder GEMMs, bf16 MFMA)",
             "bound": "mfma", "achieved": gemm_tf, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
-            "frac": gemm_tf / MFMA_BF16_PEAK_TF, "traffic": traffic.get("gemm"),
+            "frac": gemm_tf / MFMA_BF16_PEAK_TF, "traffic": traffic.get("gemm"), "traffic_note": traffic_note,
             "launches": gemm_n, "avg_launch_ms": gemm_ms / max(gemm_n, 1),
+            "algorithmic_flops_per_launch": gemm_flops_step * args.steps / max(gemm_n, 1),
         },
         "roofline_scan": {
             "kernel": "scan_kernel (filter pass over the corpus shard)",
             "bound": "hbm", "achieved": scan_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": scan_gbs / HBM_PEAK_GBS, "traffic": traffic.get("scan_filter"),
             "launches": scan_n, "avg_launch_ms": scan_ms / max(scan_n, 1),
+            "algorithmic_bytes_per_launch": scan_bytes, "queries_per_launch": Bq * world, "reread_factor": q_tiles,
         },
         "stage_ms_per_step": {k: v[0] for k, v in stage_prof.items()},
     }
@@ -358,14 +419,179 @@ def main():
         dist.destroy_process_group()
 
 
+_WORDS = None
+
+
+def _words():
+    global _WORDS
+    if _WORDS is None:
+        _WORDS = [f"w{i}" for i in range(50000)]
+    return _WORDS
+
+
+def synth_text(key: int, n_words: int) -> str:
+    """Deterministic n_words-word text (one HashTokenizer token per word) for corpus row / query `key`."""
+    w = _words()
+    idx = passage_tokens(np.array([key]), n_words, len(w) + 4)[0] - 4
+    return " ".join(w[j] for j in idx)
+
+
+class _RowIds:
+    """row -> node id for a corpus whose ids derive from the row: no 10M-string table on the host."""
+
+    def __init__(self, n):
+        self.n = n
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, r):
+        return f"r{r}"
+
+
+class _SynthDocstore:
+    """node id -> TextNode with that row's synthetic chunk text (what a docstore lookup returns, made on demand)."""
+
+    def __init__(self, chunk_words):
+        self.chunk_words = chunk_words
+
+    def get(self, nid, default=None):
+        from tensor_truth_amd.schema import TextNode
+
+        if nid is None:
+            return default
+        row = int(nid[1:])
+        return TextNode(text=synth_text(row, self.chunk_words), id_=nid, metadata={"row": row})
+
+
+def _run_threads(n_threads, work_items, fn):
+    """fn(item) from n_threads threads, items dealt round-robin; -> (seconds, results in item order)."""
+    import threading
+
+    out, errs = [None] * len(work_items), []
+
+    def worker(t):
+        try:
+            for i in range(t, len(work_items), n_threads):
+                out[i] = fn(work_items[i])
+        except Exception as exc:  # noqa: BLE001
+            errs.append(exc)
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(n_threads)]
+    t0 = time.perf_counter()
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if errs:
+        raise errs[0]
+    return dt, out
+
+
+def surface_leg(args, dev, shard_rows, emb_cfg, rr_cfg):
+    from tensor_truth_amd.embedding import HipHuggingFaceEmbedding
+    from tensor_truth_amd.rerank import HipSentenceTransformerRerank
+    from tensor_truth_amd.schema import QueryBundle
+    from tensor_truth_amd.sharded_index import ShardedHipVectorIndex
+
+    K, topn = args.top_k, args.top_n
+    emb = HipHuggingFaceEmbedding("BAAI/bge-m3", device=str(dev), embed_batch_size=128,
+                                  model_kwargs={"encoder_config": emb_cfg, "synthetic_seed": 1})
+    rr = HipSentenceTransformerRerank(model="BAAI/bge-reranker-v2-m3", top_n=topn, device=str(dev), batch_pairs=4096,
+                                      model_kwargs={"encoder_config": rr_cfg, "synthetic_seed": 2})
+    n = shard_rows.shape[0]
+    index = ShardedHipVectorIndex(shard_rows.shape[1], shard_rows, 0, n, _RowIds(n), _SynthDocstore(args.chunk_len),
+                                  embed_model=emb, score_mode="cosine")
+    retr = index.as_retriever(similarity_top_k=K, max_batch=64)
+    queries = [synth_text(10_000_000_000 + i, args.query_len) for i in range(args.surface_queries)]
+
+    def one(q):
+        nodes = retr.retrieve(q)
+        return [(x.node.id_, x.score) for x in rr.postprocess_nodes(nodes, query_bundle=QueryBundle(query_str=q))]
+
+    one(queries[0])                                    # warm-up (tokenizer cache, workspaces)
+    _run_threads(args.surface_threads, queries[: args.surface_threads], one)
+    b_r0, b_x0 = retr._front.batches, rr._front.batches
+    dt, res = _run_threads(args.surface_threads, queries, one)
+    assert all(len(r) == topn for r in res)
+    t1 = time.perf_counter()
+    for q in queries[:8]:
+        one(q)
+    torch.cuda.synchronize()
+    lat = (time.perf_counter() - t1) / 8
+    return {"queries_per_s": len(queries) / dt, "threads": args.surface_threads, "queries": len(queries),
+            "scan_batches": retr._front.batches - b_r0, "rerank_batches": rr._front.batches - b_x0,
+            "single_caller_ms_per_query": lat * 1e3,
+            "what": (f"{args.surface_threads} threads each calling retriever.retrieve(str) (top-{K} over the resident "
+                     f"{n} x {shard_rows.shape[1]} corpus) then reranker.postprocess_nodes(nodes, QueryBundle) -> top-{topn}; "
+                     f"strings in ({args.query_len}-word queries, {args.chunk_len}-word chunks, hashing tokenizer), NodeWithScore out; "
+                     "concurrent callers are coalesced into shared embed / scan / rerank batches")}
+
+
+def config5_leg(args, dev, emb_cfg, rr_cfg):
+    """BASELINE config 5 as one workload, at a size that fits the default run: semantic-hierarchical ingest of synthetic
+    multi-topic documents (sentence-group embedding -> adjacent-cosine breakpoints -> hierarchical parse -> leaf
+    embedding -> index), then queries through build_retrieval_service (auto-merging retriever + fp8 reranker)."""
+    from tensor_truth_amd import model_manager as mm
+    from tensor_truth_amd.encoder import pack_token_matrix
+    from tensor_truth_amd.index_builder import build_index
+    from tensor_truth_amd.retrieval_service import build_retrieval_service
+    from tensor_truth_amd.schema import TextNode
+
+    rng = np.random.default_rng(55)
+    w = _words()
+    docs = []
+    n_sent = 0
+    for d in range(args.config5_docs):
+        sents = []
+        for block in range(4):                       # four topics per document: vocabulary bands
+            band = int(rng.integers(0, 40)) * 1000
+            for _ in range(int(rng.integers(12, 20))):
+                k = int(rng.integers(10, 24))
+                sents.append(" ".join(w[band + int(j)] for j in rng.integers(0, 1000, size=k)) + ".")
+        n_sent += len(sents)
+        docs.append(TextNode(text=" ".join(sents), metadata={"title": f"doc {d}"}))
+    mm.ModelManager.reset_instance()
+    mgr = mm.ModelManager.get_instance()
+    mgr.model_kwargs_overrides["BAAI/bge-m3"] = {"encoder_config": emb_cfg, "synthetic_seed": 1}
+    mgr.model_kwargs_overrides["BAAI/bge-reranker-v2-m3"] = {"encoder_config": rr_cfg, "synthetic_seed": 2, "gemm_dtype": "fp8"}
+    emb = mgr.get_embedder("BAAI/bge-m3", "cuda")
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    index = build_index(docs, emb, chunking_strategy="semantic_hierarchical", chunk_sizes=[512, 128, 64], chunk_overlap=8)
+    torch.cuda.synchronize()
+    t_ingest = time.perf_counter() - t0
+    params = {"reranker_top_n": args.top_n, "similarity_top_k": args.top_k, "confidence_cutoff": 0.35}
+    svc = build_retrieval_service([index], params, device="cuda", manager=mgr)
+    rr = mgr.get_reranker("BAAI/bge-reranker-v2-m3", top_n=args.top_n, device="cuda")
+    cal = rng.integers(4, rr_cfg.vocab_size, size=(64, 128), dtype=np.int32)
+    cal[:, 0], cal[:, -1] = 0, 2
+    rr._encoder.calibrate_fp8(pack_token_matrix(cal, rr_cfg))     # static e4m3 scales of the FFN intermediate
+    rr.model.set_gemm_dtype("fp8")
+    queries = [" ".join(w[int(j)] for j in rng.integers(0, 40000, size=args.query_len)) for _ in range(128)]
+    svc.retrieve(queries[0])
+    dt, res = _run_threads(args.surface_threads, queries, lambda q: svc.retrieve(q).num_sources)
+    mm.ModelManager.reset_instance()
+    return {"docs": len(docs), "sentences": n_sent, "leaves": index.n, "nodes": len(index.docstore),
+            "ingest_s": t_ingest, "docs_per_s": len(docs) / t_ingest, "leaves_per_s": index.n / t_ingest,
+            "sentence_groups_per_s": n_sent / t_ingest,
+            "queries_per_s": len(queries) / dt, "mean_sources": float(np.mean(res)),
+            "what": ("build_index(chunking_strategy='semantic_hierarchical', chunk_sizes=[512,128,64]) on the bge-m3-shaped "
+                     "embedder, then 128 queries from 32 threads through build_retrieval_service: auto-merging retriever "
+                     f"(top-{args.top_k}) + fp8 (e4m3) bge-reranker-v2-m3-shaped postprocessor -> top-{args.top_n}")}
+
+
 def cpu_baseline(args, emb_cfg, rr_cfg, embedder, reranker, corpus, q_tok, vocab):
-    """The CPU oracle (oracle/, a port of the reference's upstream arithmetic) timed on this
-    box's host cores on a BOUNDED sample of the same workload (kept to ~10-30 s):
-      * encoders: CPU_LAYERS of the 24 identical layers at full width (1024 hidden, 16 heads,
-        4096 FFN), fp32, scaled by 24/CPU_LAYERS; 1 query embedded, CPU_PAIRS of the 50 pairs
-        reranked (scaled to 50);
-      * scan: a 1M-row slice of the shard, fp32 matmul + stable top-k, scaled to the corpus.
-    A reported baseline, not the optimisation target."""
+    """The CPU oracle (oracle/, a port of the reference's upstream arithmetic) timed on this box's host cores on a
+    BOUNDED sample of the same workload -- real sizes, nothing extrapolated in depth or width: every leg runs the full
+    24-layer, 1024-wide fp32 model on real sequence lengths and the real top-k; what is bounded is the NUMBER OF UNITS
+    (queries embedded, pairs reranked, corpus rows scanned), and the three per-unit rates are printed as measured
+    (chunks/s, rows/s, pairs/s).  `value` composes ONE query of the headline workload from those
+    rates (1 query embedding + rows_total / rows_per_s + top_k / pairs_per_s) and says so.  The token vocabulary of
+    the CPU model is cut to 4096 rows (embedding lookups are not what is timed; a 250k x 1024 fp32 table only costs
+    start-up time).  A reported baseline, not the optimisation target."""
     from oracle import encoder as oe
     from oracle import scan as osc
 
@@ -373,42 +599,54 @@ def cpu_baseline(args, emb_cfg, rr_cfg, embedder, reranker, corpus, q_tok, vocab
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    cores = max(1, min(avail, 64))
+    cores = max(1, min(avail, 128))
     torch.set_num_threads(cores)
-    CPU_LAYERS, CPU_PAIRS, CPU_VOCAB = 2, 4, 4096
+    CPU_PAIRS, CPU_CHUNKS, CPU_VOCAB, CPU_ROWS = 8, 16, 4096, 2_000_000
     K = args.top_k
-    rows = min(1_000_000, corpus.shard.shape[0])
-    small = {**emb_cfg.__dict__, "layers": CPU_LAYERS, "vocab_size": CPU_VOCAB}
-    ocfg_e = oe.EncoderConfig(**small)
-    ocfg_r = oe.EncoderConfig(**{**small, "num_labels": 1})
-    W_r = oe.synth_weights(ocfg_r, seed=1)   # encoder tensors shared by both legs; values do not affect timing
-    W_e = W_r
-    host_corpus = corpus.shard[:rows].cpu()
-    scale_layers = emb_cfg.layers / CPU_LAYERS
+    rows = min(CPU_ROWS, corpus._shards[0][0].shape[0])
+    shape = {**emb_cfg.__dict__, "vocab_size": CPU_VOCAB, "max_pos": 514}
+    ocfg_e = oe.EncoderConfig(**shape)
+    ocfg_r = oe.EncoderConfig(**{**shape, "num_labels": 1})
+    W = oe.synth_weights(ocfg_r, seed=1)         # values do not affect timing; encoder tensors shared by both legs
+    host_corpus = corpus._shards[0][0][:rows].cpu()
+    QL, CL = args.query_len, args.chunk_len
     q_ids = np.concatenate(([0], q_tok[0] % CPU_VOCAB, [2]))
     q = torch.from_numpy(q_ids).view(1, -1).long()
     with torch.no_grad():
-        oe.embed(q, torch.ones_like(q), W_e, ocfg_e)  # warm the thread pool
+        oe.encoder_forward(q, torch.ones_like(q), W, ocfg_e, layers=2)           # warm the thread pool
         t0 = time.perf_counter()
-        e = oe.embed(q, torch.ones_like(q), W_e, ocfg_e)
-        t_embed = (time.perf_counter() - t0) * scale_layers
+        e = oe.embed(q, torch.ones_like(q), W, ocfg_e)                           # 1 query x 34 tok, 24 layers
+        t_q = time.perf_counter() - t0
+        # ingest leg: one reference-size CPU batch (batch_size_cpu = 16, config_schema.py:49) of chunk_len + 2 tokens
+        ctok = passage_tokens(np.arange(CPU_CHUNKS), CL, CPU_VOCAB)
+        cids = torch.from_numpy(np.concatenate((np.zeros((CPU_CHUNKS, 1), np.int32), ctok,
+                                                np.full((CPU_CHUNKS, 1), 2, np.int32)), 1)).long()
+        t0 = time.perf_counter()
+        oe.embed(cids, torch.ones_like(cids), W, ocfg_e)
+        t_chunks = time.perf_counter() - t0
         t0 = time.perf_counter()
         _, idx, _ = osc.scan_topk(host_corpus, e.to(torch.bfloat16), K)
         t_scan = time.perf_counter() - t0
-        ptok = passage_tokens(idx[0, :CPU_PAIRS].numpy(), args.chunk_len, CPU_VOCAB)
+        ptok = passage_tokens(idx[0, :CPU_PAIRS].numpy(), CL, CPU_VOCAB)
         head = np.concatenate(([0], q_tok[0] % CPU_VOCAB, [2, 2]))
         ids = torch.from_numpy(np.stack([np.concatenate((head, p, [2])) for p in ptok])).long()
         t0 = time.perf_counter()
-        oe.rerank_scores(ids, torch.ones_like(ids), W_r, ocfg_r)
-        t_rr = (time.perf_counter() - t0) * scale_layers
-    t_query = t_embed + t_scan * (args.corpus_rows / rows) + t_rr * (K / CPU_PAIRS)
+        oe.rerank_scores(ids, torch.ones_like(ids), W, ocfg_r)                   # 8 pairs x 292 tok, 24 layers
+        t_rr = time.perf_counter() - t0
+    rows_per_s = rows / t_scan
+    pairs_per_s = CPU_PAIRS / t_rr
+    t_query = t_q + args.corpus_rows / rows_per_s + K / pairs_per_s
     return {
         "value": 1.0 / t_query, "unit": "queries/s", "cores": cores, "kind": "port",
-        "sample": (f"fp32 CPU oracle, torch threads={cores} of {avail} visible: per query = embed 1 query x "
-                   f"{q.shape[1]} tok ({t_embed:.2f}s) + scan {args.corpus_rows} rows ({t_scan:.2f}s measured on {rows} rows, "
-                   f"x{args.corpus_rows / rows:.0f}) + rerank {K} pairs x {ids.shape[1]} tok ({t_rr:.2f}s measured on "
-                   f"{CPU_PAIRS} pairs, x{K / CPU_PAIRS:.1f}); encoder legs time {CPU_LAYERS} of {emb_cfg.layers} "
-                   f"identical full-width layers and scale x{scale_layers:.0f}"),
+        "per_unit": {"query_embeddings_per_s": 1.0 / t_q, "chunks_embedded_per_s": CPU_CHUNKS / t_chunks,
+                     "scan_rows_per_s": rows_per_s, "scan_GBps": rows_per_s * args.dim * 2 / 1e9,
+                     "pairs_reranked_per_s": pairs_per_s},
+        "sample": (f"fp32 CPU oracle, torch threads={cores} of {avail} visible; every leg at full depth and width "
+                   f"({emb_cfg.layers} layers x {emb_cfg.hidden}), measured, not scaled: 1 query x {q.shape[1]} tok embedded in "
+                   f"{t_q:.2f}s; {CPU_CHUNKS} chunks x {cids.shape[1]} tok (one reference CPU batch) in {t_chunks:.2f}s; exact top-{K} of 1 "
+                   f"query over {rows} corpus rows in {t_scan:.2f}s; {CPU_PAIRS} pairs x {ids.shape[1]} tok reranked in {t_rr:.2f}s. "
+                   f"value = 1 / (t_query_embed + {args.corpus_rows} rows / rows_per_s + {K} pairs / pairs_per_s) = "
+                   f"1 / ({t_q:.2f} + {args.corpus_rows / rows_per_s:.2f} + {K / pairs_per_s:.2f}) s"),
     }
 
 

@@ -3,7 +3,9 @@
 #include "common.h"
 
 enum { TT_EPI_BIAS = 0, TT_EPI_GELU = 1, TT_EPI_RESIDUAL = 2, TT_EPI_TANH = 3, TT_EPI_QKV = 4,
-       TT_EPI_VT = 5 /* internal: whole output stored transposed into vt (the V third of a QKV projection) */ };
+       TT_EPI_VT = 5 /* internal: whole output stored transposed into vt (the V third of a QKV projection) */,
+       TT_EPI_SCAN = 6 /* internal: similarity scan -- A = corpus rows, W = 256 queries, nothing is stored: scores >= the
+                          query's threshold (bias[n]) are appended to per-query candidate lists (scan_api.hip) */ };
 
 struct GemmParams {
     const uint16_t* A;        // [M][lda] bf16
@@ -25,7 +27,18 @@ struct GemmParams {
     float c8_inv_scale;
     int nt_store;             // whole-line output stores issued as streaming stores (set by the launcher)
     int sn;                   // super-tile width in N-tiles (32 tiles per super-tile: sm = 32 / sn); set by the launcher
+    // TT_EPI_SCAN: candidate lists of the filter pass (same layout as ScanParams' shared lists)
+    int32_t* scan_cnt;        // [N] running candidate count per query (may exceed scan_cap)
+    float* scan_scores;       // [N][scan_cap]
+    int32_t* scan_idx;        // [N][scan_cap]
+    int scan_cap;
+    int32_t scan_idx_base;    // emitted index = scan_idx_base + A row
 };
+// Filter pass of the similarity scan for 65..256 queries per pass as a 256x256x64-tiled MFMA contraction (gemm.hip):
+// corpus [rows][dim] bf16 with rows a multiple of 256, queries256 [256][dim] bf16 (rows beyond the batch zero),
+// thr256 [256] fp32 (+inf for rows beyond the batch).  ONE pass over the corpus whatever the batch size.
+int tt_scan_gemm_launch(const uint16_t* corpus, int64_t rows, int dim, const uint16_t* queries256, const float* thr256,
+                        int32_t* cnt, float* cand_scores, int32_t* cand_idx, int cap, int32_t idx_base, hipStream_t st);
 int tt_gemm_launch(const GemmParams& p, int epilogue, hipStream_t st);
 // M <= 256 (a multiple of 64) runs on the weight-streaming skinny kernel unless TT_GEMM_SKINNY=0 (A/B switch)
 bool tt_gemm_skinny_enabled();

@@ -603,6 +603,46 @@ __device__ __forceinline__ void epilogue_all(const GemmParams& p, f32x4 (&acc)[2
         }
 }
 
+// TT_EPI_SCAN: nothing is stored.  In the swapped accumulator layout a lane holds ONE corpus row (m-tile row l & 15)
+// and four consecutive queries per 16x16 tile, so the per-query threshold filter is four compares against a float4
+// of the tile's threshold strip (LDS, staged like a bias strip).  Survivors are rare (about k * rows / sample rows
+// per query over the whole pass) and go to the shared per-query lists with one returning atomic each -- outside the
+// main loop, where nothing is in flight behind them.  NaN scores (tombstoned rows) fail the compare.
+__device__ __forceinline__ void scan_filter_epilogue(const GemmParams& p, f32x4 (&acc)[2][2][2][4], const char* smem, int m0,
+                                                     int wm, int wn, int lane) {
+    const int g = lane >> 4, l15 = lane & 15;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)smem;
+#pragma unroll
+    for (int qn = 0; qn < 2; ++qn)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int q0 = wn * 64 + qn * 32 + nt * 16 + g * 4;
+            u32x4 tb = lds_read128_async<0>(lds0 + kBiasOff + q0 * 4);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tb));
+            const float t[4] = {__uint_as_float(tb.x), __uint_as_float(tb.y), __uint_as_float(tb.z), __uint_as_float(tb.w)};
+#pragma unroll
+            for (int qm = 0; qm < 2; ++qm)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    const f32x4 v = acc[qm][qn][nt][mt];
+                    const bool hit = (v[0] >= t[0]) | (v[1] >= t[1]) | (v[2] >= t[2]) | (v[3] >= t[3]);
+                    if (hit) {
+                        const int32_t row = m0 + qm * 128 + wm * 64 + mt * 16 + l15;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (v[r] >= t[r]) {
+                                const int q = q0 + r;
+                                const int pos = atomicAdd(p.scan_cnt + q, 1);
+                                if (pos < p.scan_cap) {
+                                    p.scan_scores[(size_t)q * p.scan_cap + pos] = v[r];
+                                    p.scan_idx[(size_t)q * p.scan_cap + pos] = p.scan_idx_base + row;
+                                }
+                            }
+                    }
+                }
+        }
+}
+
 #define TT_SLOT_END()                                         \
     do {                                                      \
         __builtin_amdgcn_sched_barrier(0);                    \
@@ -885,6 +925,8 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
 #pragma unroll
             for (int qn = 0; qn < 2; ++qn)
                 gemm_epilogue_wide<EPI, 2, 4>(p, acc[qm][qn], m0 + qm * 128 + wm * 64, n0 + wn * 64 + qn * 32, lane);
+    } else if constexpr (EPI == TT_EPI_SCAN) {
+        scan_filter_epilogue(p, acc, smem, m0, wm, wn, lane);
     } else if constexpr (SLOTS == 47) {
 #pragma unroll
         for (int qm = 0; qm < 2; ++qm)
@@ -1366,4 +1408,37 @@ int tt_gemm_launch(const GemmParams& p, int epilogue, hipStream_t st) {
         }
         default: tt_set_error("gemm: unknown epilogue %d", epilogue); return TT_E_INVALID;
     }
+}
+
+int tt_scan_gemm_launch(const uint16_t* corpus, int64_t rows, int dim, const uint16_t* queries256, const float* thr256,
+                        int32_t* cnt, float* cand_scores, int32_t* cand_idx, int cap, int32_t idx_base, hipStream_t st) {
+    if (rows <= 0) return TT_OK;
+    if (rows % v3::BM3 || dim % 128 || dim <= 0 || rows / v3::BM3 > (1 << 24)) {
+        tt_set_error("scan gemm: rows=%lld must be a multiple of 256, dim=%d of 128", (long long)rows, dim);
+        return TT_E_UNSUPPORTED;
+    }
+    GemmParams p{};
+    p.A = corpus;
+    p.W = queries256;
+    p.bias = thr256;
+    p.M = (int)rows;
+    p.N = v3::BN3;
+    p.K = dim;
+    p.lda = dim;
+    p.ldc = 8;
+    p.scan_cnt = cnt;
+    p.scan_scores = cand_scores;
+    p.scan_idx = cand_idx;
+    p.scan_cap = cap;
+    p.scan_idx_base = idx_base;
+    p.sn = 1;
+    const int mt_n = p.M / v3::BM3;
+    int blocks = (mt_n + 31) / 32 * 32;     // super-tiles of 32 row tiles x 1 column tile
+    TT_SET_MAX_LDS((v3::gemm_kernel_v3<TT_EPI_SCAN, 4>), v3::kLds3);
+    {
+        TtProfScope prof(TT_K_SCAN_FILTER, st);
+        hipLaunchKernelGGL((v3::gemm_kernel_v3<TT_EPI_SCAN, 4>), dim3(blocks), dim3(v3::kThreads3), v3::kLds3, st, p);
+    }
+    TT_CHECK_LAUNCH();
+    return TT_OK;
 }

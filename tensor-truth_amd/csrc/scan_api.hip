@@ -19,6 +19,7 @@
 
 #include "common.h"
 #include "scan.h"
+#include "encoder.h"   // tt_scan_gemm_launch
 
 static thread_local char g_err[512] = "";
 
@@ -49,6 +50,10 @@ constexpr int kCap = 16384;              // shared overflow-list slots per query
 constexpr int64_t kSampleRows = 32768;   // default sample size (1024 group maxima per query)
 
 struct Plan {
+    bool gemm;         // more than 64 queries over a large shard: the filter pass is ONE tiled MFMA contraction per 256 queries
+    int q256;          // queries rounded up to 256 (gemm path)
+    int cap;           // shared candidate-list slots per query
+    size_t off_q256;
     bool dense_only;
     int64_t n0;        // sample rows (dense_only: all rows)
     int64_t stride;    // floats per query in the dense / group-max buffer
@@ -67,12 +72,34 @@ int filter_blocks(int64_t rows, int cus) {
     return (int)b;
 }
 
-Plan make_plan(int64_t n_rows, int n_queries, int k, int cus) {
+bool scan_gemm_enabled() {
+    static const bool on = [] { const char* e = getenv("TT_SCAN_GEMM"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
+Plan make_plan(int64_t n_rows, int dim, int n_queries, int k, int cus) {
     Plan pl{};
     pl.qpad = (n_queries + 63) / 64 * 64;
+    pl.cap = kCap;
     // the sample needs >= 4k groups for a useful threshold
     int64_t n0 = kSampleRows;
     if (n0 < (int64_t)128 * k) n0 = (int64_t)128 * k;
+    // More than one 64-query tile: the streaming kernel would re-read the shard once per tile.  From 65 queries on (and a
+    // shard worth tiling) the filter pass runs as a 256-query-wide MFMA contraction instead: one pass over the rows per 256
+    // queries.  It has no lane-private lists, so every survivor goes to the shared list: a larger sample (tighter threshold;
+    // expected survivors ~ k * rows / sample rows per query) and a list sized for 4x that expectation.
+    pl.gemm = scan_gemm_enabled() && n_queries > 64 && dim % 128 == 0 && n_rows >= 262144 && n_rows >= (int64_t)2048 * k;
+    if (pl.gemm) {
+        n0 = 65536;
+        if (n0 < (int64_t)512 * k) n0 = (int64_t)512 * k;
+        if (n0 > n_rows / 2) n0 = n_rows / 2 / 32 * 32;
+        pl.q256 = (n_queries + 255) / 256 * 256;
+        pl.qpad = pl.q256;
+        int64_t cap = 4 * (int64_t)k * n_rows / n0 + 4096;
+        if (cap < kCap) cap = kCap;
+        if (cap > (1 << 20)) cap = 1 << 20;
+        pl.cap = (int)((cap + 63) / 64 * 64);
+    }
     if (n_rows < (int64_t)128 * k || n_rows <= 8192) {
         pl.dense_only = true;
         pl.n0 = n_rows;
@@ -84,11 +111,17 @@ Plan make_plan(int64_t n_rows, int n_queries, int k, int cus) {
     }
     size_t off = 0;
     pl.off_dense = off; off += tt_align_up((size_t)pl.qpad * pl.stride * sizeof(float), 256);
-    pl.off_cs = off;    off += tt_align_up((size_t)pl.qpad * kCap * sizeof(float), 256);
-    pl.off_ci = off;    off += tt_align_up((size_t)pl.qpad * kCap * sizeof(int32_t), 256);
+    pl.off_cs = off;    off += tt_align_up((size_t)pl.qpad * pl.cap * sizeof(float), 256);
+    pl.off_ci = off;    off += tt_align_up((size_t)pl.qpad * pl.cap * sizeof(int32_t), 256);
     pl.off_cnt = off;   off += tt_align_up((size_t)pl.qpad * sizeof(int32_t), 256);
     pl.off_thr = off;   off += tt_align_up((size_t)pl.qpad * sizeof(float), 256);
-    if (!pl.dense_only) {
+    if (pl.gemm) {
+        pl.off_q256 = off; off += tt_align_up((size_t)pl.q256 * dim * sizeof(uint16_t), 256);
+        pl.main_blocks = 1;                        // the < 256 tail rows go through the streaming kernel, one block
+        pl.n_sub = TT_SCAN_WAVES_PER_BLOCK * 2;
+        pl.off_priv = off; off += tt_align_up((size_t)pl.qpad * pl.n_sub * TT_SCAN_PRIV_SLOTS * sizeof(uint2), 256);
+        pl.off_pcnt = off; off += tt_align_up((size_t)pl.qpad * pl.n_sub * sizeof(int32_t), 256);
+    } else if (!pl.dense_only) {
         pl.main_blocks = filter_blocks(n_rows, cus);
         pl.n_sub = pl.main_blocks * TT_SCAN_WAVES_PER_BLOCK * 2;
         pl.off_priv = off; off += tt_align_up((size_t)pl.qpad * pl.n_sub * TT_SCAN_PRIV_SLOTS * sizeof(uint2), 256);
@@ -109,6 +142,11 @@ int check_common(const void* corpus, int64_t n_rows, int dim, const void* querie
     TT_CHECK_ARG(queries && ((uintptr_t)queries % 16) == 0, "queries must be non-null and 16-byte aligned");
     if (n_rows > 0) TT_CHECK_ARG(corpus && ((uintptr_t)corpus % 16) == 0, "corpus must be non-null and 16-byte aligned");
     return TT_OK;
+}
+
+__global__ void fill_f32_kernel(float* s, float v, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) s[i] = v;
 }
 
 __global__ void fill_pad_kernel(float* s, int32_t* ix, int64_t n) {
@@ -137,12 +175,11 @@ const char* tt_last_error(void) { return g_err; }
 int tt_device_cu_count(void) { return tt_cu_count_cached(); }
 
 size_t tt_scan_workspace_bytes(int64_t n_rows, int dim, int n_queries, int k) {
-    (void)dim;
     if (n_rows < 0 || n_queries <= 0 || k < 1) return 0;
     // sized for the largest grid the filter pass can use on any gfx950 part (256 CUs)
     int cus = tt_cu_count_cached();
     if (cus <= 0) cus = 256;
-    return make_plan(n_rows, n_queries, k, cus).total;
+    return make_plan(n_rows, dim, n_queries, k, cus).total;
 }
 
 size_t tt_scan_exact_workspace_bytes(int64_t n_rows, int dim, int n_queries, int k) {
@@ -221,7 +258,7 @@ int tt_scan_topk(const void* corpus_bf16, int64_t n_rows, int dim, const void* q
     }
     int cus_plan = tt_cu_count_cached();
     if (cus_plan <= 0) cus_plan = 256;
-    const Plan pl = make_plan(n_rows, n_queries, k, cus_plan);
+    const Plan pl = make_plan(n_rows, dim, n_queries, k, cus_plan);
     if (!workspace || workspace_bytes < pl.total) {
         tt_set_error("tt_scan_topk: workspace %zu < required %zu bytes", workspace_bytes, pl.total);
         return TT_E_WORKSPACE;
@@ -269,12 +306,61 @@ int tt_scan_topk(const void* corpus_bf16, int64_t n_rows, int dim, const void* q
     s1.k = k;
     s1.out_scores = cs;
     s1.out_idx = ci;
-    s1.out_stride = kCap;
+    s1.out_stride = pl.cap;
     s1.thr_out = thr;
     s1.cnt_out = nullptr;
+    if (pl.gemm) {   // thresholds of the padding queries: +inf (nothing passes)
+        hipLaunchKernelGGL(fill_f32_kernel, dim3((pl.q256 + 255) / 256), dim3(256), 0, st, thr, __builtin_inff(), pl.q256);
+        TT_CHECK_LAUNCH();
+    }
     rc = tt_select_launch(s1, n_queries, st);
     if (rc) return rc;
     TT_CHECK_HIP(hipMemsetAsync(cnt, 0, (size_t)pl.qpad * sizeof(int32_t), st));
+
+    if (pl.gemm) {
+        // 3'. filter pass as a tiled contraction: rows [0, rows256) x 256 queries per launch, ONE pass over the corpus per
+        //     256 queries; the < 256 tail rows through the streaming kernel (private lists of one block)
+        uint16_t* q256 = (uint16_t*)(ws + pl.off_q256);
+        TT_CHECK_HIP(hipMemsetAsync(q256, 0, (size_t)pl.q256 * dim * sizeof(uint16_t), st));
+        TT_CHECK_HIP(hipMemcpyAsync(q256, queries_bf16, (size_t)n_queries * dim * sizeof(uint16_t), hipMemcpyDeviceToDevice, st));
+        const int64_t rows256 = n_rows / 256 * 256;
+        for (int b = 0; b < pl.q256 / 256; ++b) {
+            rc = tt_scan_gemm_launch((const uint16_t*)corpus_bf16, rows256, dim, q256 + (size_t)b * 256 * dim, thr + b * 256,
+                                     cnt + b * 256, cs + (size_t)b * 256 * pl.cap, ci + (size_t)b * 256 * pl.cap, pl.cap, idx_base, st);
+            if (rc) return rc;
+        }
+        SelectParams s2{};
+        if (rows256 < n_rows) {
+            ScanParams tp = sp;
+            tp.group_stride = 0;
+            tp.row_lo = rows256;
+            tp.row_hi = n_rows;
+            tp.dense = nullptr;
+            tp.thr = thr;
+            tp.cnt = cnt;
+            tp.cand_scores = cs;
+            tp.cand_idx = ci;
+            tp.cap = pl.cap;
+            tp.priv = (uint2*)(ws + pl.off_priv);
+            tp.priv_cnt = (int32_t*)(ws + pl.off_pcnt);
+            rc = tt_scan_launch(tp, dim, mode, 0, 1, st);
+            if (rc) return rc;
+            s2.priv = tp.priv;
+            s2.priv_cnt = tp.priv_cnt;
+            s2.n_sub = pl.n_sub;
+        }
+        s2.scores = cs;
+        s2.idx = ci;
+        s2.stride = pl.cap;
+        s2.cnt = cnt;
+        s2.cap = pl.cap;
+        s2.k = k;
+        s2.out_scores = out_scores;
+        s2.out_idx = out_idx;
+        s2.out_stride = k;
+        s2.overflow_flag = status_flag;
+        return tt_select_launch(s2, n_queries, st);
+    }
 
     // 3. filter pass over ALL rows: scores >= thr[q] -> private lists (+ shared overflow list)
     ScanParams mp = sp;
@@ -286,7 +372,7 @@ int tt_scan_topk(const void* corpus_bf16, int64_t n_rows, int dim, const void* q
     mp.cnt = cnt;
     mp.cand_scores = cs;
     mp.cand_idx = ci;
-    mp.cap = kCap;
+    mp.cap = pl.cap;
     mp.priv = (uint2*)(ws + pl.off_priv);
     mp.priv_cnt = (int32_t*)(ws + pl.off_pcnt);
     rc = tt_scan_launch(mp, dim, mode, 0, pl.main_blocks, st);
@@ -296,10 +382,10 @@ int tt_scan_topk(const void* corpus_bf16, int64_t n_rows, int dim, const void* q
     SelectParams s2{};
     s2.scores = cs;
     s2.idx = ci;
-    s2.stride = kCap;
+    s2.stride = pl.cap;
     s2.cnt = cnt;
     s2.m_fixed = 0;
-    s2.cap = kCap;
+    s2.cap = pl.cap;
     s2.k = k;
     s2.out_scores = out_scores;
     s2.out_idx = out_idx;

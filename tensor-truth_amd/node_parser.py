@@ -97,12 +97,17 @@ class HierarchicalNodeParser:
         return cls(chunk_sizes or [2048, 512, 128], chunk_overlap, kw.get("tokenizer"))
 
     def _split(self, parent_text: str, meta: dict, level: int, parent: Optional[TextNode], out: List[TextNode],
-               excluded: Sequence[str]) -> None:
+               excluded: Sequence[str], excluded_llm: Sequence[str] = ()) -> None:
         chunks = self.splitters[level].split_text(parent_text)
         prev: Optional[TextNode] = None
         for c in chunks:
             nd = TextNode(text=c, metadata=dict(meta))
             nd.excluded_embed_metadata_keys = list(excluded)
+            if excluded_llm:
+                try:
+                    nd.excluded_llm_metadata_keys = list(excluded_llm)
+                except Exception:  # noqa: BLE001
+                    pass
             if parent is not None:
                 nd.parent_id = parent.id_
                 parent.child_ids.append(nd.id_)
@@ -111,7 +116,7 @@ class HierarchicalNodeParser:
             out.append(nd)
             prev = nd
             if level + 1 < len(self.splitters):
-                self._split(c, meta, level + 1, nd, out, excluded)
+                self._split(c, meta, level + 1, nd, out, excluded, excluded_llm)
 
     def get_nodes_from_documents(self, documents: Iterable, show_progress: bool = False) -> List[TextNode]:
         """Documents (or nodes, as the reference feeds the semantic splitter's output back in, builder.py:415-418)
@@ -122,7 +127,8 @@ class HierarchicalNodeParser:
             if not text.strip():
                 continue
             meta = dict(getattr(doc, "metadata", {}) or {})
-            self._split(text, meta, 0, None, out, getattr(doc, "excluded_embed_metadata_keys", []) or [])
+            self._split(text, meta, 0, None, out, getattr(doc, "excluded_embed_metadata_keys", []) or [],
+                        getattr(doc, "excluded_llm_metadata_keys", []) or [])
         return out
 
 

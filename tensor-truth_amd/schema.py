@@ -31,6 +31,7 @@ except Exception:  # noqa: BLE001
         id_: str = field(default_factory=lambda: str(uuid.uuid4()))
         metadata: Dict[str, Any] = field(default_factory=dict)
         excluded_embed_metadata_keys: List[str] = field(default_factory=list)
+        excluded_llm_metadata_keys: List[str] = field(default_factory=list)
         embedding: Optional[List[float]] = None
         # hierarchy / sequence links (LlamaIndex NodeRelationship PARENT/CHILD/PREVIOUS/NEXT)
         parent_id: Optional[str] = None
@@ -48,6 +49,8 @@ except Exception:  # noqa: BLE001
             keys = [k for k in self.metadata if not k.startswith("_")]
             if metadata_mode == MetadataMode.EMBED:
                 keys = [k for k in keys if k not in self.excluded_embed_metadata_keys]
+            elif metadata_mode == MetadataMode.LLM:
+                keys = [k for k in keys if k not in self.excluded_llm_metadata_keys]
             meta = "\n".join(f"{k}: {self.metadata[k]}" for k in keys)
             return f"{meta}\n\n{self.text}" if meta else self.text
 

@@ -120,6 +120,15 @@ class SemanticSplitter:
                 prev: Optional[TextNode] = None
                 for chunk in chunks:
                     nd = TextNode(text=chunk, metadata=dict(meta))
+                    # llama-index node parsers hand the source document's excluded-metadata keys down to every node
+                    # (what MetadataMode.EMBED / LLM content is built from)
+                    for key in ("excluded_embed_metadata_keys", "excluded_llm_metadata_keys"):
+                        val = getattr(doc, key, None)
+                        if val:
+                            try:
+                                setattr(nd, key, list(val))
+                            except Exception:  # noqa: BLE001
+                                pass
                     if prev is not None:
                         try:
                             prev.next_id, nd.prev_id = nd.id_, prev.id_

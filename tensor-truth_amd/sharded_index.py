@@ -49,13 +49,15 @@ class ShardedHipVectorIndex:
             raise ValueError("queries must be 'replicated' or 'partitioned'")
         if local_rows.dtype != torch.bfloat16 or local_rows.dim() != 2 or local_rows.shape[1] != dim:
             raise ValueError("local_rows must be a [n_local, dim] bfloat16 matrix")
-        if len(leaf_ids) != n_total:
+        if leaf_ids is not None and len(leaf_ids) != n_total:
             raise ValueError(f"leaf_ids has {len(leaf_ids)} entries for {n_total} global rows")
         if scan_fn is None and not local_rows.is_cuda:
             raise RuntimeError("ShardedHipVectorIndex needs its shard on a HIP device; tensor_truth_amd has no CPU path")
         self.dim, self.device = dim, local_rows.device
         self.row_lo, self.n_total = int(row_lo), int(n_total)
-        self.leaf_ids = list(leaf_ids)
+        # any sequence works (a list; a lazy row -> id mapping for corpora whose ids are derived from the row);
+        # None = search-only index (``search`` works, ``as_retriever`` has no nodes to return)
+        self.leaf_ids = leaf_ids if leaf_ids is None or not isinstance(leaf_ids, (list, tuple)) else list(leaf_ids)
         self.docstore = docstore
         self.embed_model = embed_model
         self.score_mode = score_mode
@@ -103,7 +105,7 @@ class ShardedHipVectorIndex:
             dev = torch.device("cuda", torch.cuda.current_device())
         import numpy as np
 
-        rows = torch.from_numpy(np.ascontiguousarray(raw)).view(torch.bfloat16).to(dev).contiguous()
+        rows = torch.from_numpy(np.array(raw, copy=True)).view(torch.bfloat16).to(dev).contiguous()
         docstore = {nid: _node_from_dict(nid, d) for nid, d in blob["nodes"].items()}
         return cls(blob["dim"], rows, lo, n, blob["leaf_ids"], docstore, embed_model=embed_model, score_mode=score_mode,
                    group=group, **kw)
@@ -144,6 +146,8 @@ class ShardedHipVectorIndex:
                      max_wait_s: float = 0.0, **_kw) -> "ShardedHipVectorRetriever":
         # concurrent callers are merged into one collective round only in single-process use: across ranks the batches
         # formed by independent coalescers need not line up, so the front is off whenever a process group is live
+        if self.leaf_ids is None or self.docstore is None:
+            raise ValueError("this ShardedHipVectorIndex was built without node tables (search-only)")
         world, _ = _world(self.group)
         return ShardedHipVectorRetriever(self, similarity_top_k, coalesce=coalesce and world == 1, max_batch=max_batch,
                                          max_wait_s=max_wait_s)

@@ -233,7 +233,7 @@ class HipVectorIndex:
     def load(cls, persist_dir: str, device=None, embed_model=None, score_mode: str = "chroma") -> "HipVectorIndex":
         blob, raw = _read_persisted(persist_dir)
         idx = cls(blob["dim"], device, embed_model, score_mode)
-        idx._mat = torch.from_numpy(np.ascontiguousarray(raw)).view(torch.bfloat16).to(idx.device).contiguous()
+        idx._mat = torch.from_numpy(np.array(raw, copy=True)).view(torch.bfloat16).to(idx.device).contiguous()
         idx.n = raw.shape[0]
         idx.leaf_ids = list(blob["leaf_ids"])
         idx.ref_docs = {k: list(v) for k, v in (blob.get("ref_docs") or {}).items()}

@@ -1,0 +1,181 @@
+"""GPU: BASELINE.json config 5 as ONE composed workload -- semantic-hierarchical ingest (streaming batch embed) ->
+auto-merging retrieval -> fp8 MFMA reranker -- through the same entry points the reference uses
+(``indexing/builder.py:376-453`` build_module, ``rag_engine.py:529-738`` load_engine_for_modules,
+``services/rag_service.py:594-661`` retrieve), against the same pipeline evaluated with the CPU oracle stage by stage:
+
+  A. semantic splitter: adjacent-cosine distances and the cuts they imply   (builder.py:391-418)
+  B. leaf embeddings in the index matrix
+  C. top-k retrieval + auto-merge (the host merge logic is shared; its INPUT, the hit list, is what can differ)
+  D. fp8 cross-encoder scores -> final top-n ids: rank agreement with the fp32 oracle.
+
+Small model shapes (2 layers) keep the oracle in seconds; every kernel and every host path is the one the full-size
+run takes (the full-size timing of this workload is ``bench.py``'s ``config5`` leg)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import encoder as oe
+from oracle import scan as osc
+from rank_checks import assert_order_on_separable, kendall_tau, topn_overlap
+
+pytestmark = pytest.mark.gpu
+
+SMALL = dict(arch="bert", vocab_size=3000, hidden=384, layers=2, heads=12, ffn=1536, max_pos=128, type_vocab=2,
+             pad_id=0, ln_eps=1e-12)
+XENC = dict(arch="xlmr", vocab_size=3000, hidden=256, layers=2, heads=4, ffn=512, max_pos=130, type_vocab=1,
+            pad_id=1, ln_eps=1e-5, num_labels=1)
+TOPICS = [
+    ["kernel", "wave", "lds", "mfma", "tile", "barrier", "register", "occupancy", "prefetch", "swizzle"],
+    ["basil", "sauce", "simmer", "garlic", "oven", "dough", "yeast", "salt", "pepper", "broth"],
+    ["orbit", "comet", "nebula", "quasar", "planet", "lunar", "solar", "rocket", "gravity", "vacuum"],
+    ["ledger", "audit", "invoice", "credit", "debit", "equity", "bond", "yield", "margin", "hedge"],
+]
+FP8_BOUND_2L = 5e-2      # stated bound of the fp8 mode on a 2-layer model's sigmoid scores
+
+
+def _pad(seqs, pad):
+    L = max(len(s) for s in seqs)
+    ids = torch.full((len(seqs), L), pad, dtype=torch.int64)
+    mask = torch.zeros(len(seqs), L, dtype=torch.int64)
+    for b, s in enumerate(seqs):
+        ids[b, : len(s)] = torch.tensor(s)
+        mask[b, : len(s)] = 1
+    return ids, mask
+
+
+def _docs(n_docs=24, seed=9):
+    """Documents that change topic a few times: the semantic splitter has real breakpoints to find."""
+    from tensor_truth_amd.schema import TextNode
+
+    g = torch.Generator().manual_seed(seed)
+    docs = []
+    for d in range(n_docs):
+        sents = []
+        for block in range(3):
+            words = TOPICS[(d + block) % len(TOPICS)]
+            for _ in range(int(torch.randint(4, 8, (1,), generator=g))):
+                k = int(torch.randint(6, 14, (1,), generator=g))
+                sents.append(" ".join(words[j] for j in torch.randint(0, len(words), (k,), generator=g).tolist()) + ".")
+        node = TextNode(text=" ".join(sents), metadata={"title": f"doc {d}", "file_name": f"d{d}.md"})
+        node.excluded_embed_metadata_keys = ["file_name"]
+        docs.append(node)
+    return docs
+
+
+def test_config5_semantic_hierarchical_ingest_automerge_fp8_rerank(dev, built_lib, tmp_path):
+    from tensor_truth_amd import model_manager as mm
+    from tensor_truth_amd.encoder import EncoderConfig
+    from tensor_truth_amd.index_builder import build_index
+    from tensor_truth_amd.node_parser import get_leaf_nodes
+    from tensor_truth_amd.retrieval_service import build_retrieval_service
+    from tensor_truth_amd.retrievers import AutoMergingRetriever
+    from tensor_truth_amd.schema import MetadataMode, NodeWithScore
+    from tensor_truth_amd.semantic import SemanticSplitter, adjacent_distances, breakpoints_from_distances, split_sentences
+
+    cfg, xcfg = EncoderConfig(**SMALL), EncoderConfig(**XENC)
+    ocfg, oxcfg = oe.EncoderConfig(**SMALL), oe.EncoderConfig(**XENC)
+    mm.ModelManager.reset_instance()
+    mgr = mm.ModelManager.get_instance()
+    mgr.model_kwargs_overrides["test/bge-small-shaped"] = {"encoder_config": cfg, "synthetic_seed": 51, "pipeline_window": 64}
+    mgr.model_kwargs_overrides["test/xenc-fp8"] = {"encoder_config": xcfg, "synthetic_seed": 52, "gemm_dtype": "fp8"}
+    emb = mgr.get_embedder("test/bge-small-shaped", "cuda")
+    W_e = {k: v.to(torch.bfloat16) for k, v in oe.synth_weights(ocfg, seed=51).items()}
+    W_x = oe.synth_weights(oxcfg, seed=52)
+
+    def oracle_embed(texts):
+        seqs = [emb._tokenizer.encode(t, emb.max_length) for t in texts]
+        out = []
+        for lo in range(0, len(seqs), 256):
+            ids, mask = _pad(seqs[lo:lo + 256], cfg.pad_id)
+            out.append(oe.embed(ids, mask, W_e, ocfg, emulate_bf16=True))
+        return torch.cat(out)
+
+    docs = _docs()
+    # ---- ingest: the reference's build_module with ChunkingStrategy.SEMANTIC_HIERARCHICAL ---------------------------
+    index = build_index(docs, emb, persist_dir=str(tmp_path / "m"), chunking_strategy="semantic_hierarchical",
+                        chunk_sizes=[96, 40, 20], chunk_overlap=4, semantic_buffer_size=1, semantic_breakpoint_threshold=80)
+    leaves = get_leaf_nodes(index.docstore.values())
+    assert index.n == len(leaves) > 100 and len(index.docstore) > index.n
+
+    # ---- A. semantic splitter vs oracle ------------------------------------------------------------------------------
+    sp = SemanticSplitter(emb, buffer_size=1, breakpoint_percentile_threshold=80)
+    checked_docs = same_cuts = 0
+    worst = 0.0
+    for doc in docs[:8]:
+        sents = split_sentences(doc.get_content())
+        groups = sp._groups(sents)
+        got_d = adjacent_distances(emb._embed_texts(groups, "")).cpu()
+        e = oracle_embed(groups)
+        want_d = 1 - torch.nn.functional.cosine_similarity(e[:-1], e[1:], dim=1)
+        worst = max(worst, (got_d - want_d).abs().max().item())
+        thr = float(np.percentile(want_d.numpy().astype(np.float64), 80))
+        decisive = bool(((want_d - thr).abs() > 4e-3).all())        # no distance within tolerance of the threshold
+        checked_docs += 1
+        if breakpoints_from_distances(got_d.tolist(), 80) == breakpoints_from_distances(want_d.tolist(), 80):
+            same_cuts += 1
+        elif decisive:
+            raise AssertionError("semantic cuts differ although every oracle distance is clear of the threshold")
+    assert worst < 2e-3, f"adjacent-cosine distance error {worst}"
+    assert same_cuts >= checked_docs - 2, (same_cuts, checked_docs)
+
+    # ---- B. leaf embeddings in the matrix vs oracle (text = metadata-prefixed EMBED content, builder.py:437-442) -----
+    ids_in_rows = [index.docstore[nid] for nid in index.leaf_ids]
+    want_E = oracle_embed([nd.get_content(metadata_mode=MetadataMode.EMBED) for nd in ids_in_rows])
+    got_E = index.matrix.float().cpu()
+    cos = (got_E * want_E).sum(1)
+    assert cos.min().item() >= 0.999, cos.min().item()
+    assert "file_name" not in ids_in_rows[0].get_content(metadata_mode=MetadataMode.EMBED)
+
+    # ---- the reference's engine: AutoMerging(index.as_retriever(k)) -> MultiIndex -> [fp8 reranker, cutoff] ----------
+    params = {"reranker_model": "test/xenc-fp8", "reranker_top_n": 5, "similarity_top_k": 16,
+              "confidence_cutoff": 0.35, "confidence_cutoff_hard": 0.0}
+    svc = build_retrieval_service([index], params, device="cuda", manager=mgr)
+    rr = mgr.get_reranker("test/xenc-fp8", top_n=5, device="cuda")
+    assert rr.model.gemm_dtype == "fp8"
+    # self-queries (a leaf's own text: decisive top-1) and topic queries
+    probe_rows = [7, len(leaves) // 3, len(leaves) // 2, len(leaves) - 5]
+    # (a self-query is the text that was EMBEDDED for the leaf -- metadata lines included -- so its top-1 is decisive)
+    queries = [ids_in_rows[r].get_content(metadata_mode=MetadataMode.EMBED) for r in probe_rows] + [" ".join(t[:6]) for t in TOPICS]
+    W_q = oracle_embed(queries)            # (bge-small-shaped test model: no query instruction for this name)
+    assert emb.query_instruction == ""
+    o_s, o_i, o_gap = osc.scan_topk(want_E.to(torch.bfloat16), W_q.to(torch.bfloat16), 16)
+    base = index.as_retriever(similarity_top_k=16)
+    amr = AutoMergingRetriever(base, index.docstore)
+    overlaps, taus, top5 = [], [], []
+    n_sep = 0
+    for qi, q in enumerate(queries):
+        # ---- C. retrieval + auto-merge
+        hits = base.retrieve(q)
+        got_ids = [h.node.id_ for h in hits]
+        want_ids = [index.leaf_ids[int(j)] for j in o_i[qi]]
+        overlaps.append(len(set(got_ids) & set(want_ids)) / 16.0)
+        if qi < len(probe_rows):
+            assert got_ids[0] == want_ids[0] == index.leaf_ids[probe_rows[qi]]
+        if o_gap[qi] > 2e-3:                                   # the oracle's ranking is clear-cut: identical lists
+            assert got_ids == want_ids
+        merged = amr.retrieve(q)
+        # the merge is host logic over (ids, scores): feeding it the product's own hit list must reproduce `merged`
+        again = AutoMergingRetriever(base, index.docstore).merge(
+            [NodeWithScore(node=h.node, score=h.score) for h in hits])
+        assert [m.node.id_ for m in again] == [m.node.id_ for m in merged] and len(merged) <= 16
+        # ---- D. fp8 rerank of the merged candidates vs fp32 oracle scores on the same token ids
+        res = svc.retrieve(q)
+        assert res.num_sources == len(res.source_nodes) <= 5 and res.confidence_level in ("normal", "low")
+        texts = [m.node.get_content(metadata_mode=MetadataMode.EMBED) for m in merged]
+        pair_ids = [rr._tokenizer.encode_pair(q, t, rr.max_length)[0] for t in texts]
+        ids, mask = _pad(pair_ids, xcfg.pad_id)
+        want = oe.rerank_scores(ids, mask, W_x, oxcfg)                       # plain fp32
+        got = torch.tensor(rr.predict([(q, t) for t in texts]))
+        err = (got - want).abs().max().item()
+        assert err <= FP8_BOUND_2L, f"query {qi}: fp8 score error {err}"
+        n_sep += assert_order_on_separable(want.numpy(), got.numpy(), 2 * FP8_BOUND_2L, f"config-5 query {qi}")
+        taus.append(kendall_tau(want.numpy(), got.numpy()))
+        top5.append(topn_overlap(want.numpy(), got.numpy(), min(5, len(texts))))
+        # the service returns the top-n of exactly these scores
+        by_score = sorted(range(len(texts)), key=lambda i: -got[i].item())[:5]
+        assert [n.node.id_ for n in res.source_nodes] == [merged[i].node.id_ for i in by_score]
+    print(f"config 5 composed: {index.n} leaves / {len(index.docstore)} nodes; splitter distance err {worst:.1e}, cuts equal on "
+          f"{same_cuts}/{checked_docs} docs; leaf cos min {cos.min().item():.5f}; retrieval overlap@16 mean {np.mean(overlaps):.2f}; "
+          f"fp8 rerank vs fp32: Kendall tau mean {np.mean(taus):.2f}, top-5 overlap mean {np.mean(top5):.2f}, {n_sep} separable pairs ordered")
+    assert np.mean(overlaps) >= 0.8 and np.mean(top5) >= 0.6
+    mm.ModelManager.reset_instance()

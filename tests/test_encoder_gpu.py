@@ -323,3 +323,41 @@ def test_forward_is_bit_reproducible(dev, built_lib):
         assert torch.isfinite(ref).all()
         for _ in range(10):
             assert torch.equal(enc.rerank_packed(batch), ref), mode
+
+
+def test_8192_token_sequence_through_the_encoder(dev, built_lib):
+    """bge-m3's limit ("L <= 8192 (embed, rare)"; max_position_embeddings 8194): one sequence at
+    the model limit, one truncated to it, and short neighbours, through tt_encoder_forward -- 128 key tiles per query
+    tile, position ids up to 8193 -- against the oracle on the same ids."""
+    from tensor_truth_amd.encoder import Encoder, EncoderConfig, EncoderWeights
+
+    shape = dict(arch="xlmr", vocab_size=4000, hidden=256, layers=2, heads=4, ffn=512, max_pos=8194, type_vocab=1,
+                 pad_id=1, ln_eps=1e-5)
+    cfg_o, cfg = oe.EncoderConfig(**shape), EncoderConfig(**shape)
+    assert cfg.max_seq_len == 8192
+    W = oe.synth_weights(cfg_o, seed=23)
+    Wb = {k: v.to(torch.bfloat16) for k, v in W.items()}
+    g = torch.Generator().manual_seed(2)
+    lens = [8192, 9000, 33, 4099]                        # the second one is truncated to 8192
+    seqs = [[0] + torch.randint(4, 4000, (n - 2,), generator=g).tolist() + [2] for n in lens]
+    enc = Encoder(EncoderWeights(cfg, W, dev))
+    emb, _ = enc.embed(seqs)
+    from tensor_truth_amd.encoder import pack_tokens
+    hidden, _ = enc.forward_packed(pack_tokens(seqs, cfg))
+    torch.cuda.synchronize()
+    emb, hidden = emb.cpu(), hidden.float().cpu()
+    assert torch.isfinite(emb).all()
+    starts = pack_tokens(seqs, cfg).seq_start
+    for b, s in enumerate(seqs):
+        s = s[:8192]
+        ids = torch.tensor([s])
+        with torch.no_grad():
+            want_h = oe.encoder_forward(ids, torch.ones_like(ids), Wb, cfg_o, emulate_bf16=True)[0]
+        want_e = torch.nn.functional.normalize(want_h[0], dim=0)
+        assert float((emb[b] * want_e).sum()) >= 0.9995, (b, float((emb[b] * want_e).sum()))
+        got_h = hidden[int(starts[b]): int(starts[b]) + len(s)]
+        err = (got_h - want_h).abs()
+        bad = (err > 2 ** -5 * want_h.abs() + 3e-2).float().mean().item()
+        assert bad < 1e-3 and err.max().item() < 0.25, (b, bad, err.max().item())
+        # the LAST token attends over the whole sequence too: check it separately (tail key tile + position table end)
+        assert err[-1].max().item() < 0.1

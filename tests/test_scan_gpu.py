@@ -80,6 +80,12 @@ def test_ragged_shapes_dense_path(dev, built_lib, n, d, q, k):
     (65537, 1024, 3, 50), (100_003, 1024, 64, 50), (131_072 + 17, 512, 70, 10), (200_000, 384, 33, 100),
     (150_001, 1024, 256, 50),     # the gathered query batch of an 8-GPU bench step: four query tiles
     (60_000, 1024, 1024, 50),     # SURVEY.md 8d's largest scan-only batch: sixteen query tiles (above the MFMA ridge)
+    # 65+ queries over >= 262144 rows: the filter pass is the 256-query-wide tiled MFMA contraction (ONE pass over the
+    # shard per 256 queries, csrc/gemm.hip TT_EPI_SCAN) + the streaming kernel for the < 256 tail rows
+    (300_007, 1024, 256, 50),     # 8-GPU bench step shape; 231 tail rows
+    (262_144, 512, 65, 10),       # smallest shard / batch on that path, no tail
+    (280_000, 128, 300, 20),      # two 256-query blocks (the second one mostly padding), narrow rows
+    (270_001, 384, 100, 128),     # bge-small width, k above a sort group
 ])
 def test_sampled_threshold_path(dev, built_lib, n, d, q, k):
     """Shards above 65536 rows: sample -> threshold -> filtered main pass -> select."""
@@ -94,6 +100,35 @@ def test_sampled_threshold_path(dev, built_lib, n, d, q, k):
     # forced dense path gives the same answer
     s2, i2 = _run(tscan, dev, corpus, queries, k, exact_dense=True)
     _check(s2, i2, *want)
+
+
+@pytest.mark.parametrize("mode", ["0", "1"])
+def test_tiled_filter_pass_skips_tombstones_and_reports_overflow(dev, built_lib):
+    """The 65+-query path with deleted rows (NaN tombstones, vector_index.delete) and with a clustered corpus that
+    overflows the shared candidate list: NaN rows never rank, and an overflow raises the status flag (the wrapper then
+    re-runs the dense exact path) instead of returning a truncated answer."""
+    from tensor_truth_amd import scan as tscan
+
+    corpus = osc.synth_corpus(262_144 + 300, 256, seed=77)
+    queries, planted = osc.synth_queries(corpus, 96, seed=78)
+    dead = planted[planted >= 0][:20]
+    want_corpus = corpus.clone()
+    want_corpus[dead] = 0                                   # a zero row scores 0: never in a top-10 of planted / random hits
+    want = osc.scan_topk(want_corpus, queries, 10)
+    c = corpus.to(dev)
+    c[dead.to(dev)] = float("nan")
+    s, i, overflowed = tscan.scan_topk(c, queries.to(dev), 10, return_flag=True)
+    torch.cuda.synchronize()
+    assert not overflowed and not torch.isin(i.cpu().long(), dead).any() and torch.isfinite(s).all()
+    _check(s, i, *want)
+    # every row identical to the query: nothing separates the sample from the rest -> every row passes the filter
+    one = torch.nn.functional.normalize(torch.randn(1, 256, generator=torch.Generator().manual_seed(1)), dim=1).to(torch.bfloat16)
+    flat = one.repeat(300_000, 1).to(dev)
+    qs = one.repeat(70, 1).to(dev)
+    s2, i2, overflowed = tscan.scan_topk(flat, qs, 10, return_flag=True)
+    assert overflowed
+    s3, i3 = tscan.scan_topk(flat, qs, 10)                  # default wrapper: dense fallback, exact (ties -> lowest rows)
+    assert torch.equal(i3.cpu(), torch.arange(10, dtype=torch.int32).repeat(70, 1))
 
 
 @pytest.mark.parametrize("mode", ["0", "1"])
