@@ -194,7 +194,7 @@ def main():
         step(make_queries())
     queries = [make_queries() for _ in range(args.steps)]
     sync_all()
-    KIDS = (("scan_filter", 1), ("scan_sample", 2), ("select", 3), ("gemm", 4), ("attention", 5), ("rowops", 6))
+    KIDS = (("scan_filter", 1), ("scan_sample", 2), ("select", 3), ("gemm", 4), ("attention", 5), ("rowops", 6), ("scan_tail", 7))
 
     def read_prof():
         out = {}
@@ -450,10 +450,13 @@ class _RowIds:
 
 
 class _SynthDocstore:
-    """node id -> TextNode with that row's synthetic chunk text (what a docstore lookup returns, made on demand)."""
+    """node id -> TextNode (what a docstore lookup returns), made on demand: the chunk texts come from a pool of 4096
+    distinct synthetic texts (row -> pool[row % 4096]) so that a lookup costs what a dict lookup costs."""
+
+    POOL = 4096
 
     def __init__(self, chunk_words):
-        self.chunk_words = chunk_words
+        self.texts = [synth_text(i, chunk_words) for i in range(self.POOL)]
 
     def get(self, nid, default=None):
         from tensor_truth_amd.schema import TextNode
@@ -461,7 +464,7 @@ class _SynthDocstore:
         if nid is None:
             return default
         row = int(nid[1:])
-        return TextNode(text=synth_text(row, self.chunk_words), id_=nid, metadata={"row": row})
+        return TextNode(text=self.texts[row % self.POOL], id_=nid, metadata={"row": row})
 
 
 def _run_threads(n_threads, work_items, fn):

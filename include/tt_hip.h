@@ -233,7 +233,8 @@ int tt_gemm_fp8_ex(const void* a8, const float* a_scale, const void* w8, const f
  * tt_prof_enable(1) (or a mask of 1 << id, to time only some kernels) starts recording one event pair per launch of the tracked kernels on the
  * calling thread; tt_prof_read() synchronises those events and returns total milliseconds
  * and launch count for kernel id `which` since the last enable, then keeps recording.
- * ids: 1 scan filter pass, 2 scan sample pass, 3 top-k select, 4 gemm, 5 attention, 6 row ops */
+ * ids: 1 scan filter pass, 2 scan sample pass, 3 top-k select, 4 gemm, 5 attention, 6 row ops,
+ * 7 scan tail rows (the < 256 rows behind the tiled filter pass of a 65+ query batch) */
 int tt_prof_enable(int on);
 int tt_prof_read(int which, double* total_ms_host, int* launches_host);
 

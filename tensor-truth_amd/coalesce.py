@@ -17,7 +17,7 @@ from __future__ import annotations
 
 import threading
 import time
-from typing import Any, Callable, List, Sequence
+from typing import Any, Callable, List, Optional, Sequence
 
 
 class _Slot:
@@ -32,12 +32,23 @@ class _Slot:
 
 
 class Coalescer:
-    """``run_batch(items) -> results`` (same length, same order) is called by ONE thread at a time."""
+    """``run_batch(items) -> results`` (same length, same order) is called by ONE thread at a time.
 
-    def __init__(self, run_batch: Callable[[List[Any]], Sequence[Any]], max_batch: int = 256, max_wait_s: float = 0.0):
+    Two-phase form: ``Coalescer(prepare, execute=...)`` -- ``prepare(items) -> prepared`` is the host side of a batch
+    (tokenising, packing), ``execute(prepared) -> results`` its device side.  The leader hands leadership on as soon
+    as its batch is prepared, so the NEXT batch is collected and prepared while this one is on the GPU; ``execute``
+    calls run one at a time, in batch order."""
+
+    def __init__(self, run_batch: Callable[[List[Any]], Any], max_batch: int = 256, max_wait_s: float = 0.0,
+                 execute: Optional[Callable[[Any], Sequence[Any]]] = None):
         if max_batch < 1:
             raise ValueError("max_batch must be >= 1")
         self._run = run_batch
+        self._execute = execute
+        self._exec_lock = threading.Lock()
+        self._exec_turn = 0        # batches execute in the order they were taken off the queue
+        self._exec_cv = threading.Condition(self._exec_lock)
+        self._taken = 0
         self.max_batch = max_batch
         self.max_wait_s = max_wait_s
         self._lock = threading.Lock()
@@ -69,38 +80,63 @@ class Coalescer:
             with self._lock:
                 batch = self._queue[: self.max_batch]
                 del self._queue[: len(batch)]
+                ticket = self._taken
+                self._taken += 1
+            # the queue is FIFO and a leader is either the first arrival or the promoted queue head, so its own slot is
+            # always the first item of the batch it takes
+            assert batch and batch[0] is slot
+            prepared, failure = None, None
             try:
-                results = list(self._run([s.item for s in batch]))
-                if len(results) != len(batch):
-                    raise RuntimeError(f"coalesced batch returned {len(results)} results for {len(batch)} items")
-                for s, r in zip(batch, results):
-                    s.result = r
+                prepared = self._run([s.item for s in batch])
             except BaseException as exc:  # noqa: BLE001 - every member of the batch sees the failure, like a lone call would
-                for s in batch:
-                    s.error = exc
-            with self._lock:
-                self.batches += 1
-                self.items += len(batch)
-                for s in batch:
-                    s.done = True
-                # hand over: the oldest waiter leads the next batch (the leader never serves others forever)
-                nxt = None
-                if slot.done or not self._queue:
-                    nxt = self._queue[0] if self._queue else None
-                    if nxt is None:
-                        self._running = False
-                    keep_leading = False
-                else:
-                    keep_leading = True   # own item not served yet (queue longer than max_batch): lead once more
-            for s in batch:
-                if s is not slot:
-                    s.event.set()
-            if keep_leading:
-                lead = True
-                continue
-            if nxt is not None:
-                nxt.event.set()
+                failure = exc
+            if self._execute is None:
+                self._deliver(batch, prepared, failure)
+            self._hand_over()               # two-phase: BEFORE executing -- the next batch is prepared meanwhile
+            if self._execute is not None:
+                with self._exec_cv:         # device phases run one at a time, in the order the batches were taken
+                    while self._exec_turn != ticket:
+                        self._exec_cv.wait()
+                try:
+                    if failure is None:
+                        prepared = self._execute(prepared)
+                except BaseException as exc:  # noqa: BLE001
+                    failure = exc
+                finally:
+                    with self._exec_cv:
+                        self._exec_turn += 1
+                        self._exec_cv.notify_all()
+                self._deliver(batch, prepared, failure)
+            for s in batch[1:]:
+                s.event.set()
             break
         if slot.error is not None:
             raise slot.error
         return slot.result
+
+    def _hand_over(self) -> None:
+        """The oldest waiter leads the next batch (a leader never serves others forever); nobody waiting: idle."""
+        with self._lock:
+            nxt = self._queue[0] if self._queue else None
+            if nxt is None:
+                self._running = False
+        if nxt is not None:
+            nxt.event.set()
+
+    def _deliver(self, batch, results, failure) -> None:
+        if failure is None:
+            try:
+                results = list(results)
+                if len(results) != len(batch):
+                    raise RuntimeError(f"coalesced batch returned {len(results)} results for {len(batch)} items")
+            except BaseException as exc:  # noqa: BLE001
+                failure = exc
+        with self._lock:
+            self.batches += 1
+            self.items += len(batch)
+            for i, s in enumerate(batch):
+                if failure is None:
+                    s.result = results[i]
+                else:
+                    s.error = failure
+                s.done = True

@@ -82,7 +82,8 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 }
 
 // ---- per-kernel device timing (tt_prof_enable / tt_prof_read) -----------------------------
-enum { TT_K_SCAN_FILTER = 1, TT_K_SCAN_SAMPLE = 2, TT_K_SELECT = 3, TT_K_GEMM = 4, TT_K_ATTENTION = 5, TT_K_ROWOPS = 6 };
+enum { TT_K_SCAN_FILTER = 1, TT_K_SCAN_SAMPLE = 2, TT_K_SELECT = 3, TT_K_GEMM = 4, TT_K_ATTENTION = 5, TT_K_ROWOPS = 6,
+       TT_K_SCAN_TAIL = 7 /* streaming kernel over the < 256 tail rows behind the tiled filter pass */ };
 bool tt_prof_on();
 void tt_prof_begin(int id, hipStream_t st);
 void tt_prof_end(hipStream_t st);

@@ -608,8 +608,8 @@ __device__ __forceinline__ void epilogue_all(const GemmParams& p, f32x4 (&acc)[2
 // of the tile's threshold strip (LDS, staged like a bias strip).  Survivors are rare (about k * rows / sample rows
 // per query over the whole pass) and go to the shared per-query lists with one returning atomic each -- outside the
 // main loop, where nothing is in flight behind them.  NaN scores (tombstoned rows) fail the compare.
-__device__ __forceinline__ void scan_filter_epilogue(const GemmParams& p, f32x4 (&acc)[2][2][2][4], const char* smem, int m0,
-                                                     int wm, int wn, int lane) {
+__device__ __forceinline__ void scan_filter_epilogue(const GemmParams& p, f32x4 (&acc)[2][2][2][4], const char* smem, int thr_off,
+                                                     int m0, int wm, int wn, int lane) {
     const int g = lane >> 4, l15 = lane & 15;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)smem;
 #pragma unroll
@@ -617,7 +617,7 @@ __device__ __forceinline__ void scan_filter_epilogue(const GemmParams& p, f32x4 
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
             const int q0 = wn * 64 + qn * 32 + nt * 16 + g * 4;
-            u32x4 tb = lds_read128_async<0>(lds0 + kBiasOff + q0 * 4);
+            u32x4 tb = lds_read128_async<0>(lds0 + thr_off + q0 * 4);
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tb));
             const float t[4] = {__uint_as_float(tb.x), __uint_as_float(tb.y), __uint_as_float(tb.z), __uint_as_float(tb.w)};
 #pragma unroll
@@ -926,7 +926,7 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
             for (int qn = 0; qn < 2; ++qn)
                 gemm_epilogue_wide<EPI, 2, 4>(p, acc[qm][qn], m0 + qm * 128 + wm * 64, n0 + wn * 64 + qn * 32, lane);
     } else if constexpr (EPI == TT_EPI_SCAN) {
-        scan_filter_epilogue(p, acc, smem, m0, wm, wn, lane);
+        scan_filter_epilogue(p, acc, smem, kBiasOff, m0, wm, wn, lane);
     } else if constexpr (SLOTS == 47) {
 #pragma unroll
         for (int qm = 0; qm < 2; ++qm)
@@ -1099,9 +1099,11 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_p(GemmParams p, int 
         };
         auto tile4 = [&](int t, auto bufc) {
             constexpr int B = decltype(bufc)::value;
-            const bool after_epi = t == 0 && !first;   // this wave's 16 epilogue stores are the youngest-but-copies
+            // this wave's 16 epilogue stores are the youngest-but-copies (the scan epilogue stores nothing: its rare
+            // atomics return a value, so the compiler has already waited for them -- the plain counts are right)
+            const bool after_epi = t == 0 && !first && EPI != TT_EPI_SCAN;
             // La: hi halves of K-tile t+1 (already issued, ahead of the stores, when after_epi)
-            if (!after_epi) issue_hi(t + 1);
+            if (!(t == 0 && !first)) issue_hi(t + 1);
             read_a(smem + slot_off(0, 0, B));
             read_w(wf0, smem + slot_off(1, 0, B));
             read_w(wf1, smem + slot_off(1, 1, B));
@@ -1131,8 +1133,11 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_p(GemmParams p, int 
         // of the tile loop they would stay live through the main loop
         int lane_e = lane;
         asm volatile("" : "+v"(lane_e));
-        epilogue_all<EPI, false, FP8>(p, acc, smem, kBiasOff + bpar * 1024, kScaleOff + bpar * 2048, m0, n0, wm, wn, wave, lane_e,
-                                      false, NoNext{});
+        if constexpr (EPI == TT_EPI_SCAN)
+            scan_filter_epilogue(p, acc, smem, kBiasOff + bpar * 1024, m0, wm, wn, lane_e);
+        else
+            epilogue_all<EPI, false, FP8>(p, acc, smem, kBiasOff + bpar * 1024, kScaleOff + bpar * 2048, m0, n0, wm, wn, wave, lane_e,
+                                          false, NoNext{});
         if (!has_next) break;
         v = vn; m0 = m1; n0 = n1; bpar ^= 1; first = false;
         vn = next_valid(v, m1, n1);
@@ -1434,6 +1439,19 @@ int tt_scan_gemm_launch(const uint16_t* corpus, int64_t rows, int dim, const uin
     p.sn = 1;
     const int mt_n = p.M / v3::BM3;
     int blocks = (mt_n + 31) / 32 * 32;     // super-tiles of 32 row tiles x 1 column tile
+    // persistent form (one workgroup per CU walks the row tiles, the K stream never drains): no per-tile prologue and no
+    // dispatch gap, and -- unlike the storing epilogues -- nothing of the filter epilogue sits in the vector-memory queue
+    static const int persist = [] { const char* e = getenv("TT_SCAN_GEMM_PERSIST"); return e && e[0] ? atoi(e) : 1; }();
+    const int cus = tt_cu_count_cached() / 8 * 8;
+    if (persist && blocks > cus && cus >= 8) {
+        TT_SET_MAX_LDS(v3::gemm_kernel_p<TT_EPI_SCAN>, v3::kLds3);
+        {
+            TtProfScope prof(TT_K_SCAN_FILTER, st);
+            hipLaunchKernelGGL(v3::gemm_kernel_p<TT_EPI_SCAN>, dim3(cus), dim3(v3::kThreads3), v3::kLds3, st, p, blocks);
+        }
+        TT_CHECK_LAUNCH();
+        return TT_OK;
+    }
     TT_SET_MAX_LDS((v3::gemm_kernel_v3<TT_EPI_SCAN, 4>), v3::kLds3);
     {
         TtProfScope prof(TT_K_SCAN_FILTER, st);

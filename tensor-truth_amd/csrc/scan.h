@@ -27,6 +27,7 @@ struct ScanParams {
     // first rows are one topic).  0 / 1 = contiguous.  phys_rows = rows of the shard (clamp for the last group).
     int64_t group_stride;
     int64_t phys_rows;
+    int prof_id;              // 0 = TT_K_SCAN_FILTER / TT_K_SCAN_SAMPLE by `out`; else the timing id of this launch
 };
 
 #define TT_SCAN_PRIV_SLOTS 16

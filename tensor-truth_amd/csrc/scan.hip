@@ -347,7 +347,7 @@ static int launch_one(const ScanParams& p, int blocks, int q_tiles, hipStream_t 
     auto kern = scan_kernel<D, MODE, OUT, VAR>;
     TT_SET_MAX_LDS(kern, lds);   // per instantiation, per thread, per device
     {
-        TtProfScope prof(OUT == 0 ? TT_K_SCAN_FILTER : TT_K_SCAN_SAMPLE, stream);
+        TtProfScope prof(p.prof_id ? p.prof_id : (OUT == 0 ? TT_K_SCAN_FILTER : TT_K_SCAN_SAMPLE), stream);
         hipLaunchKernelGGL(kern, dim3(blocks, q_tiles), dim3(kThreads), lds, stream, p);
     }
     TT_CHECK_LAUNCH();

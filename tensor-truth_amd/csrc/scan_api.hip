@@ -343,6 +343,7 @@ int tt_scan_topk(const void* corpus_bf16, int64_t n_rows, int dim, const void* q
             tp.cap = pl.cap;
             tp.priv = (uint2*)(ws + pl.off_priv);
             tp.priv_cnt = (int32_t*)(ws + pl.off_pcnt);
+            tp.prof_id = TT_K_SCAN_TAIL;
             rc = tt_scan_launch(tp, dim, mode, 0, 1, st);
             if (rc) return rc;
             s2.priv = tp.priv;

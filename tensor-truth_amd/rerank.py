@@ -50,33 +50,45 @@ class HipSentenceTransformerRerank:
         # concurrent predict() / postprocess_nodes() calls (one per request thread in the reference,
         # rag_service.py:343-346,617-620) share ONE tokenizer call and ONE encoder batch; scores do not depend on the
         # batch a pair travels in (tests/test_configs_gpu.py), so callers see exactly their serial results
-        self._front = Coalescer(self._predict_many, max_coalesced_calls, coalesce_wait_s) if coalesce else None
+        # two-phase: the host side of a batch (tokenise + pack) runs while the previous batch is on the GPU
+        self._front = (Coalescer(self._prepare_many, max_coalesced_calls, coalesce_wait_s, execute=self._execute_many)
+                       if coalesce else None)
 
     # ---- token-id level ---------------------------------------------------------------------------
-    def score_token_pairs(self, pair_ids: Sequence[Sequence[int]]) -> torch.Tensor:
-        """Sigmoid relevance of already tokenised ``<s> q </s></s> p </s>`` sequences, fp32 [n] (device)."""
-        outs = []
-        for lo in range(0, len(pair_ids), self.batch_pairs):
-            outs.append(self._encoder.rerank_packed(pack_tokens(pair_ids[lo:lo + self.batch_pairs], self.config,
-                                                                None, self.max_length)))
+    def _pack(self, pair_ids: Sequence[Sequence[int]]):
+        return [pack_tokens(pair_ids[lo:lo + self.batch_pairs], self.config, None, self.max_length)
+                for lo in range(0, len(pair_ids), self.batch_pairs)]
+
+    def _score_packed(self, batches) -> torch.Tensor:
+        outs = [self._encoder.rerank_packed(b) for b in batches]
         return torch.cat(outs) if outs else torch.empty(0, device=self.device)
 
-    def _predict_flat(self, pairs: Sequence[Sequence[str]]) -> List[float]:
+    def score_token_pairs(self, pair_ids: Sequence[Sequence[int]]) -> torch.Tensor:
+        """Sigmoid relevance of already tokenised ``<s> q </s></s> p </s>`` sequences, fp32 [n] (device)."""
+        return self._score_packed(self._pack(pair_ids))
+
+    def _tokenize_pairs(self, pairs: Sequence[Sequence[str]]):
         tk = self._tokenizer
         if hasattr(tk, "encode_pair_batch"):
-            ids = [e[0] for e in tk.encode_pair_batch(list(pairs), self.max_length)]
-        else:
-            ids = [tk.encode_pair(q, p, self.max_length)[0] for q, p in pairs]
-        return self.score_token_pairs(ids).cpu().tolist()
+            return [e[0] for e in tk.encode_pair_batch(list(pairs), self.max_length)]
+        return [tk.encode_pair(q, p, self.max_length)[0] for q, p in pairs]
 
-    def _predict_many(self, calls: List[Sequence[Sequence[str]]]) -> List[List[float]]:
-        """The pair lists of several concurrent callers as one batch -> each caller's scores."""
+    def _predict_flat(self, pairs: Sequence[Sequence[str]]) -> List[float]:
+        return self.score_token_pairs(self._tokenize_pairs(pairs)).cpu().tolist()
+
+    def _prepare_many(self, calls: List[Sequence[Sequence[str]]]):
+        """Host phase of a coalesced batch: the pair lists of several concurrent callers, tokenised and packed."""
         flat = [p for c in calls for p in c]
-        scores = self._predict_flat(flat) if flat else []
+        return [len(c) for c in calls], self._pack(self._tokenize_pairs(flat)) if flat else []
+
+    def _execute_many(self, prepared) -> List[List[float]]:
+        """Device phase: one forward over the packed pairs -> each caller's scores."""
+        sizes, batches = prepared
+        scores = self._score_packed(batches).cpu().tolist() if batches else []
         out, lo = [], 0
-        for c in calls:
-            out.append(scores[lo:lo + len(c)])
-            lo += len(c)
+        for n in sizes:
+            out.append(scores[lo:lo + n])
+            lo += n
         return out
 
     def predict(self, pairs: Sequence[Sequence[str]]) -> List[float]:

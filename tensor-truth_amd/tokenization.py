@@ -36,8 +36,19 @@ class HashTokenizer:
         self.vocab_size = vocab_size
         self.sp = SpecialTokens(arch)
         self._cache = {}           # word -> id (words repeat; bounded below)
+        self._text_cache = {}      # text -> ids (the same chunks are retrieved again and again; bounded, see _ids)
 
     def _ids(self, text: str) -> List[int]:
+        hit = self._text_cache.get(text)
+        if hit is not None:
+            return list(hit)
+        out = self._ids_uncached(text)
+        if len(self._text_cache) >= 65536:      # crude bound: drop everything (a few hundred MB at most before that)
+            self._text_cache.clear()
+        self._text_cache[text] = tuple(out)
+        return out
+
+    def _ids_uncached(self, text: str) -> List[int]:
         lo = self.sp.first_free
         span = self.vocab_size - lo
         cache = self._cache

@@ -12,6 +12,14 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    # the CPU oracle mostly runs small shapes: on a 256-core GPU host torch's default (one thread per core) makes every
+    # small matmul a 256-way barrier (a 3 s test took 260 s); the full-depth oracle raises the count for itself
+    try:
+        import torch
+
+        torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
+    except Exception:  # noqa: BLE001
+        pass
 
 
 @pytest.fixture(scope="session")

@@ -10,6 +10,8 @@ auto-merging retrieval -> fp8 MFMA reranker -- through the same entry points the
 
 Small model shapes (2 layers) keep the oracle in seconds; every kernel and every host path is the one the full-size
 run takes (the full-size timing of this workload is ``bench.py``'s ``config5`` leg)."""
+import math
+
 import numpy as np
 import pytest
 import torch
@@ -139,20 +141,34 @@ def test_config5_semantic_hierarchical_ingest_automerge_fp8_rerank(dev, built_li
     W_q = oracle_embed(queries)            # (bge-small-shaped test model: no query instruction for this name)
     assert emb.query_instruction == ""
     o_s, o_i, o_gap = osc.scan_topk(want_E.to(torch.bfloat16), W_q.to(torch.bfloat16), 16)
+    dense = W_q.to(torch.bfloat16).float() @ want_E.to(torch.bfloat16).float().T        # oracle score of EVERY leaf
+    row_of = {nid: r for r, nid in enumerate(index.leaf_ids)}
     base = index.as_retriever(similarity_top_k=16)
     amr = AutoMergingRetriever(base, index.docstore)
     overlaps, taus, top5 = [], [], []
-    n_sep = 0
+    n_sep = n_exact = 0
+    SCAN_TOL = 4e-3      # embeddings agree to cos >= 0.999 / 2e-3 per component: scores of unit vectors within ~4e-3
     for qi, q in enumerate(queries):
-        # ---- C. retrieval + auto-merge
+        # ---- C. retrieval + auto-merge.  The random-weight model crowds all texts together (neighbours at cos > 0.99),
+        # so WHICH rows come back is decided inside the tolerance; what must hold for every returned row, always: its
+        # score equals the oracle's score of that row, and that score would have made the oracle's top-16 (up to
+        # tolerance) -- i.e. the product's list is a valid top-16 of the oracle's scores.  Identical lists where the
+        # oracle's own ranking is clear-cut.
         hits = base.retrieve(q)
         got_ids = [h.node.id_ for h in hits]
         want_ids = [index.leaf_ids[int(j)] for j in o_i[qi]]
         overlaps.append(len(set(got_ids) & set(want_ids)) / 16.0)
-        if qi < len(probe_rows):
-            assert got_ids[0] == want_ids[0] == index.leaf_ids[probe_rows[qi]]
-        if o_gap[qi] > 2e-3:                                   # the oracle's ranking is clear-cut: identical lists
+        assert len(hits) == 16
+        for h in hits:
+            cos_prod = 1.0 + math.log(h.score) / 2.0                   # chroma mapping score = exp(-(2 - 2 cos))
+            cos_orac = float(dense[qi, row_of[h.node.id_]])
+            assert abs(cos_prod - cos_orac) <= SCAN_TOL, (qi, cos_prod, cos_orac)
+            assert cos_orac >= float(o_s[qi, -1]) - SCAN_TOL, (qi, cos_orac, float(o_s[qi, -1]))
+        if qi < len(probe_rows):                                       # a self-query scores ~1 against its own leaf
+            assert index.leaf_ids[probe_rows[qi]] in got_ids and hits[0].score > 0.98
+        if o_gap[qi] > 2 * SCAN_TOL:
             assert got_ids == want_ids
+            n_exact += 1
         merged = amr.retrieve(q)
         # the merge is host logic over (ids, scores): feeding it the product's own hit list must reproduce `merged`
         again = AutoMergingRetriever(base, index.docstore).merge(
@@ -168,14 +184,16 @@ def test_config5_semantic_hierarchical_ingest_automerge_fp8_rerank(dev, built_li
         got = torch.tensor(rr.predict([(q, t) for t in texts]))
         err = (got - want).abs().max().item()
         assert err <= FP8_BOUND_2L, f"query {qi}: fp8 score error {err}"
-        n_sep += assert_order_on_separable(want.numpy(), got.numpy(), 2 * FP8_BOUND_2L, f"config-5 query {qi}")
+        # order wherever the oracle separates two candidates by more than twice the error MEASURED on this query
+        n_sep += assert_order_on_separable(want.numpy(), got.numpy(), max(2 * err, 1e-4), f"config-5 query {qi}")
         taus.append(kendall_tau(want.numpy(), got.numpy()))
         top5.append(topn_overlap(want.numpy(), got.numpy(), min(5, len(texts))))
         # the service returns the top-n of exactly these scores
         by_score = sorted(range(len(texts)), key=lambda i: -got[i].item())[:5]
         assert [n.node.id_ for n in res.source_nodes] == [merged[i].node.id_ for i in by_score]
     print(f"config 5 composed: {index.n} leaves / {len(index.docstore)} nodes; splitter distance err {worst:.1e}, cuts equal on "
-          f"{same_cuts}/{checked_docs} docs; leaf cos min {cos.min().item():.5f}; retrieval overlap@16 mean {np.mean(overlaps):.2f}; "
+          f"{same_cuts}/{checked_docs} docs; leaf cos min {cos.min().item():.5f}; retrieval: every hit a valid oracle top-16 member within {SCAN_TOL}, overlap@16 mean {np.mean(overlaps):.2f}, {n_exact} clear-cut queries identical; "
           f"fp8 rerank vs fp32: Kendall tau mean {np.mean(taus):.2f}, top-5 overlap mean {np.mean(top5):.2f}, {n_sep} separable pairs ordered")
-    assert np.mean(overlaps) >= 0.8 and np.mean(top5) >= 0.6
+    # (overlap with the oracle's own top-16 is informational: the lists differ inside the tolerance, see stage C)
+    assert n_sep >= 10 and np.mean(overlaps) >= 0.4 and np.mean(top5) >= 0.6 and np.mean(taus) >= 0.5
     mm.ModelManager.reset_instance()

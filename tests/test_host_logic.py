@@ -602,3 +602,49 @@ def test_coalescer_batches_concurrent_callers_and_preserves_results():
     assert f.submit(2) == 2
     with pytest.raises(RuntimeError):
         Coalescer(lambda items: []).submit(1)                   # wrong result count is an error, not a hang
+
+
+def test_two_phase_coalescer_prepares_the_next_batch_while_one_executes():
+    import threading
+    import time
+
+    from tensor_truth_amd.coalesce import Coalescer
+
+    state = {"executing": False, "overlap": 0, "order": []}
+
+    def prepare(items):
+        if state["executing"]:
+            state["overlap"] += 1                      # a batch is being prepared while another one executes
+        time.sleep(0.004)
+        return list(items)
+
+    def execute(prepared):
+        assert not state["executing"]                  # device phases never overlap each other
+        state["executing"] = True
+        state["order"].append(prepared[0])
+        time.sleep(0.02)
+        state["executing"] = False
+        return [i + 100 for i in prepared]
+
+    c = Coalescer(prepare, max_batch=8, execute=execute)
+    out = {}
+
+    def worker(i):
+        out[i] = c.submit(i)
+
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(64)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=30)
+    assert all(not t.is_alive() for t in ts)
+    assert out == {i: i + 100 for i in range(64)}
+    assert state["overlap"] >= 1 and c.items == 64 and c.batches < 64
+    # failures in either phase reach exactly the callers of that batch; the front keeps working
+    boom = Coalescer(prepare, execute=lambda p: (_ for _ in ()).throw(ValueError("device")))
+    with pytest.raises(ValueError):
+        boom.submit(1)
+    ok = Coalescer(lambda items: (_ for _ in ()).throw(KeyError("host")), execute=execute)
+    with pytest.raises(KeyError):
+        ok.submit(1)
+    assert c.submit(7) == 107

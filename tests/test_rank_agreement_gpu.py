@@ -43,9 +43,11 @@ def oracle_scores():
     ocfg = oe.EncoderConfig(**SHAPE)
     W = oe.synth_weights(ocfg, seed=17)
     pairs = _pairs()
+    import os
+
+    before = torch.get_num_threads()
     try:
-        import os
-        torch.set_num_threads(max(1, min(len(os.sched_getaffinity(0)), 128)))
+        torch.set_num_threads(max(1, min(len(os.sched_getaffinity(0)), 128)))      # large matmuls: use the host's cores
     except Exception:  # noqa: BLE001
         pass
     want = torch.empty(N_QUERIES, N_PAIRS)
@@ -53,6 +55,7 @@ def oracle_scores():
         for q in range(N_QUERIES):
             ids = torch.from_numpy(pairs[q])
             want[q] = oe.rerank_scores(ids, torch.ones_like(ids), W, ocfg)     # plain fp32 math, fp32 weights
+    torch.set_num_threads(before)
     return ocfg, W, pairs, want
 
 

@@ -102,7 +102,6 @@ def test_sampled_threshold_path(dev, built_lib, n, d, q, k):
     _check(s2, i2, *want)
 
 
-@pytest.mark.parametrize("mode", ["0", "1"])
 def test_tiled_filter_pass_skips_tombstones_and_reports_overflow(dev, built_lib):
     """The 65+-query path with deleted rows (NaN tombstones, vector_index.delete) and with a clustered corpus that
     overflows the shared candidate list: NaN rows never rank, and an overflow raises the status flag (the wrapper then
