@@ -34,13 +34,18 @@ class _Slot:
 class Coalescer:
     """``run_batch(items) -> results`` (same length, same order) is called by ONE thread at a time.
 
-    Two-phase form: ``Coalescer(prepare, execute=...)`` -- ``prepare(items) -> prepared`` is the host side of a batch
-    (tokenising, packing), ``execute(prepared) -> results`` its device side.  The leader hands leadership on as soon
-    as its batch is prepared, so the NEXT batch is collected and prepared while this one is on the GPU; ``execute``
-    calls run one at a time, in batch order."""
+    Pipelined form: ``Coalescer(prepare, execute=..., finish=...)`` -- ``prepare(items) -> prepared`` is the host side
+    of a batch (tokenising, packing), ``execute(prepared) -> pending`` ENQUEUES its device side (asynchronous launches
+    on the stream), ``finish(pending) -> results`` waits for it and splits the results.  Leadership is handed on as soon
+    as a batch is prepared; ``execute`` calls run one at a time in batch order (so batches reach the stream in order,
+    back to back -- the GPU never waits for the host between them), ``finish`` runs outside every lock.  A new batch
+    is taken off the queue only while fewer than ``depth`` (2) batches are unfinished: one on the GPU, one prepared
+    right behind it -- so under load a batch collects everything that arrives during a whole batch time instead of
+    whatever arrived during the few milliseconds of a prepare."""
 
     def __init__(self, run_batch: Callable[[List[Any]], Any], max_batch: int = 256, max_wait_s: float = 0.0,
-                 execute: Optional[Callable[[Any], Sequence[Any]]] = None):
+                 execute: Optional[Callable[[Any], Any]] = None, finish: Optional[Callable[[Any], Sequence[Any]]] = None,
+                 depth: int = 2):
         if max_batch < 1:
             raise ValueError("max_batch must be >= 1")
         self._run = run_batch
@@ -49,6 +54,9 @@ class Coalescer:
         self._exec_turn = 0        # batches execute in the order they were taken off the queue
         self._exec_cv = threading.Condition(self._exec_lock)
         self._taken = 0
+        self._finished = 0
+        self._finish = finish
+        self.depth = max(1, depth)
         self.max_batch = max_batch
         self.max_wait_s = max_wait_s
         self._lock = threading.Lock()
@@ -77,6 +85,10 @@ class Coalescer:
                         if len(self._queue) >= self.max_batch:
                             break
                     time.sleep(min(2e-4, self.max_wait_s))
+            if self._execute is not None:
+                with self._exec_cv:         # pipeline depth: wait until fewer than `depth` batches are unfinished
+                    while self._taken - self._finished >= self.depth:
+                        self._exec_cv.wait()
             with self._lock:
                 batch = self._queue[: self.max_batch]
                 del self._queue[: len(batch)]
@@ -105,6 +117,15 @@ class Coalescer:
                 finally:
                     with self._exec_cv:
                         self._exec_turn += 1
+                        self._exec_cv.notify_all()
+                try:
+                    if failure is None and self._finish is not None:
+                        prepared = self._finish(prepared)
+                except BaseException as exc:  # noqa: BLE001
+                    failure = exc
+                finally:
+                    with self._exec_cv:
+                        self._finished += 1
                         self._exec_cv.notify_all()
                 self._deliver(batch, prepared, failure)
             for s in batch[1:]:

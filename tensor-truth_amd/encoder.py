@@ -381,46 +381,64 @@ def pack_token_matrix(ids2d: np.ndarray, cfg: EncoderConfig, type_ids2d: Optiona
     return PackedBatch(ids, pos, types, starts, lens, int(n_rows), int(length), int(n * length))
 
 
-class _Scratch(threading.local):
+class _Scratch:
+    """Workspace buffers keyed by (kind, device, HIP stream): launches on one stream execute in order, so every
+    forward enqueued on that stream can reuse ONE buffer -- whichever host thread enqueues it -- as long as a whole
+    forward is enqueued atomically (``Encoder._enqueue_lock``; two threads interleaving their launches over one
+    workspace would corrupt both).  Bounded by the largest batch per stream, not by the number of request threads
+    (per-thread buffers of 5-20 GB each would not fit 32 executor threads).  Growing frees the old buffer through
+    torch's stream-ordered caching allocator, which is safe for work already enqueued on the same stream."""
+
     def __init__(self):
         self.bufs = {}
+        self.lock = threading.Lock()
 
     def get(self, key, device, nbytes):
-        buf = self.bufs.get(key)
-        if buf is None or buf.numel() < nbytes + 256 or buf.device != device:
-            buf = torch.empty(nbytes + 256, dtype=torch.uint8, device=device)
-            self.bufs[key] = buf
+        stream = torch.cuda.current_stream(device).cuda_stream
+        k = (key, device.type, device.index, stream)
+        with self.lock:
+            buf = self.bufs.get(k)
+            if buf is None or buf.numel() < nbytes + 256:
+                buf = torch.empty(nbytes + 256, dtype=torch.uint8, device=device)
+                self.bufs[k] = buf
         base = (buf.data_ptr() + 255) // 256 * 256
         return buf, base
 
 
 _scratch = _Scratch()
+_ENQUEUE_LOCKS: Dict[Tuple[str, Optional[int]], threading.Lock] = {}
 
 
-class _Stager(threading.local):
-    """Per-thread ring of pinned host buffers for the token arrays of a batch.  One buffer holds every array
-    of one batch, goes to the device in ONE asynchronous copy on the compute stream, and is reused once the
-    event recorded behind that copy has fired -- so the host can pack and enqueue batch i+1 (and tokenize
-    batch i+2) while the GPU is still computing batch i."""
+class _Stager:
+    """Ring of pinned host buffers for the token arrays of a batch, shared by all threads of the process.  One buffer
+    holds every array of one batch, goes to the device in ONE asynchronous copy on the compute stream, and is reused
+    once the event recorded behind that copy has fired -- so the host can pack and enqueue batch i+1 (and tokenize
+    batch i+2) while the GPU is still computing batch i.  Process-wide rather than per
+    thread: pinning memory costs milliseconds per allocation, and under the coalescing front every request thread
+    leads a batch now and then (32 executor threads x their own rings = 128 pinned allocations on the hot path)."""
 
-    SLOTS = 4
+    SLOTS = 8
 
     def __init__(self):
         self.slots = []
         self.cursor = 0
+        self.lock = threading.Lock()
 
     def acquire(self, nbytes: int):
-        if len(self.slots) < self.SLOTS:
-            self.slots.append({"buf": None, "ev": None})
-            slot = self.slots[-1]
-        else:
-            slot = self.slots[self.cursor % self.SLOTS]
-        self.cursor += 1
+        """-> a slot whose ``lock`` is HELD: the caller fills ``buf``, issues the copy, records ``ev`` and releases it."""
+        with self.lock:
+            if len(self.slots) < self.SLOTS:
+                self.slots.append({"buf": None, "ev": None, "lock": threading.Lock()})
+                slot = self.slots[-1]
+            else:
+                slot = self.slots[self.cursor % self.SLOTS]
+            self.cursor += 1
+        slot["lock"].acquire()
         if slot["ev"] is not None:
-            slot["ev"].synchronize()
+            slot["ev"].synchronize()  # eight batches later: long fired
             slot["ev"] = None
         if slot["buf"] is None or slot["buf"].numel() < nbytes:
-            slot["buf"] = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, pin_memory=True)
+            slot["buf"] = torch.empty(max(nbytes, 4 << 20), dtype=torch.uint8, pin_memory=True)
         return slot
 
 
@@ -435,6 +453,8 @@ class Encoder:
         self.cfg = weights.cfg
         self.device = weights.device
         self.lib = _lib.load_library()
+        # one forward (scratch lookup + every launch of it) is enqueued atomically: the workspace is shared per stream
+        self._enqueue_lock = _ENQUEUE_LOCKS.setdefault((self.device.type, self.device.index), threading.Lock())
 
     def _upload(self, batch: PackedBatch):
         """Token arrays of a batch -> device int32 views (ids, pos, types | None, seq_start, seq_len): one pinned
@@ -446,16 +466,19 @@ class Encoder:
             if a is not None:
                 total += (a.size + 63) // 64 * 64          # 256-byte aligned sub-arrays
         slot = _stager.acquire(total * 4)
-        host = slot["buf"][: total * 4].view(torch.int32)
-        hn = host.numpy()
-        for a, o in zip(parts, offs):
-            if a is not None:
-                hn[o:o + a.size] = a
-        with torch.cuda.device(self.device):
-            devbuf = torch.empty(total, dtype=torch.int32, device=self.device)
-            devbuf.copy_(host, non_blocking=True)
-            slot["ev"] = torch.cuda.Event()
-            slot["ev"].record(torch.cuda.current_stream(self.device))
+        try:
+            host = slot["buf"][: total * 4].view(torch.int32)
+            hn = host.numpy()
+            for a, o in zip(parts, offs):
+                if a is not None:
+                    hn[o:o + a.size] = a
+            with torch.cuda.device(self.device):
+                devbuf = torch.empty(total, dtype=torch.int32, device=self.device)
+                devbuf.copy_(host, non_blocking=True)
+                slot["ev"] = torch.cuda.Event()
+                slot["ev"].record(torch.cuda.current_stream(self.device))
+        finally:
+            slot["lock"].release()
         return tuple(devbuf[o:o + a.size] if a is not None else None for a, o in zip(parts, offs))
 
     def forward_packed(self, batch: PackedBatch) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -464,8 +487,8 @@ class Encoder:
         ids, pos, types, starts, lens = self._upload(batch)
         hidden = torch.empty((batch.n_rows, H), dtype=torch.bfloat16, device=dev)
         need = lib.tt_encoder_workspace_bytes(ctypes.byref(self.w.struct), batch.n_rows)
-        ws, base = _scratch.get("enc", dev, need)
-        with torch.cuda.device(dev):
+        with self._enqueue_lock, torch.cuda.device(dev):
+            ws, base = _scratch.get("enc", dev, need)
             rc = lib.tt_encoder_forward(ctypes.byref(self.w.struct), ids.data_ptr(), pos.data_ptr(),
                                         types.data_ptr() if types is not None else None, starts.data_ptr(),
                                         lens.data_ptr(), len(batch.seq_len), batch.n_rows, batch.max_len,
@@ -503,8 +526,8 @@ class Encoder:
         b_pad = (B + 255) // 256 * 256
         cls = torch.empty((b_pad, H), dtype=torch.bfloat16, device=dev)
         need = lib.tt_encoder_cls_workspace_bytes(ctypes.byref(self.w.struct), batch.n_rows, B)
-        ws, base = _scratch.get("enc", dev, need)
-        with torch.cuda.device(dev):
+        with self._enqueue_lock, torch.cuda.device(dev):
+            ws, base = _scratch.get("enc", dev, need)
             rc = lib.tt_encoder_forward_cls(ctypes.byref(self.w.struct), ids.data_ptr(), pos.data_ptr(),
                                             types.data_ptr() if types is not None else None, starts.data_ptr(),
                                             lens.data_ptr(), B, batch.n_rows, batch.max_len, cls.data_ptr(), base, need,
@@ -535,8 +558,8 @@ class Encoder:
         logits = torch.empty(B, dtype=torch.float32, device=self.device) if want_logits else None
         n_pad = (B + 127) // 128 * 128
         need = 2 * ((n_pad * H * 2 + 255) // 256 * 256)
-        ws, base = _scratch.get("head", self.device, need)
-        with torch.cuda.device(self.device):
+        with self._enqueue_lock, torch.cuda.device(self.device):
+            ws, base = _scratch.get("head", self.device, need)
             rc = self.lib.tt_rerank_head(ctypes.byref(self.w.struct), hidden.data_ptr(), cls_rows.data_ptr(), B,
                                          scores.data_ptr(), logits.data_ptr() if want_logits else None, base, need,
                                          torch.cuda.current_stream(self.device).cuda_stream)

@@ -51,8 +51,8 @@ class HipSentenceTransformerRerank:
         # rag_service.py:343-346,617-620) share ONE tokenizer call and ONE encoder batch; scores do not depend on the
         # batch a pair travels in (tests/test_configs_gpu.py), so callers see exactly their serial results
         # two-phase: the host side of a batch (tokenise + pack) runs while the previous batch is on the GPU
-        self._front = (Coalescer(self._prepare_many, max_coalesced_calls, coalesce_wait_s, execute=self._execute_many)
-                       if coalesce else None)
+        self._front = (Coalescer(self._prepare_many, max_coalesced_calls, coalesce_wait_s, execute=self._enqueue_many,
+                                 finish=self._collect_many) if coalesce else None)
 
     # ---- token-id level ---------------------------------------------------------------------------
     def _pack(self, pair_ids: Sequence[Sequence[int]]):
@@ -81,10 +81,15 @@ class HipSentenceTransformerRerank:
         flat = [p for c in calls for p in c]
         return [len(c) for c in calls], self._pack(self._tokenize_pairs(flat)) if flat else []
 
-    def _execute_many(self, prepared) -> List[List[float]]:
-        """Device phase: one forward over the packed pairs -> each caller's scores."""
+    def _enqueue_many(self, prepared):
+        """Device phase: the forward over the packed pairs is ENQUEUED (asynchronous); nothing waits here."""
         sizes, batches = prepared
-        scores = self._score_packed(batches).cpu().tolist() if batches else []
+        return sizes, (self._score_packed(batches) if batches else None)
+
+    def _collect_many(self, pending) -> List[List[float]]:
+        """Wait for the scores and hand each caller its own."""
+        sizes, dev_scores = pending
+        scores = dev_scores.cpu().tolist() if dev_scores is not None else []
         out, lo = [], 0
         for n in sizes:
             out.append(scores[lo:lo + n])
