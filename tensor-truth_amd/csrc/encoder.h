@@ -27,6 +27,7 @@ struct GemmParams {
     float c8_inv_scale;
     int nt_store;             // whole-line output stores issued as streaming stores (set by the launcher)
     int sn;                   // super-tile width in N-tiles (32 tiles per super-tile: sm = 32 / sn); set by the launcher
+    int xp;                   // experiment switches of the persistent kernel (TT_GEMM_XP; see gemm.hip launch())
     // TT_EPI_SCAN: candidate lists of the filter pass (same layout as ScanParams' shared lists)
     int32_t* scan_cnt;        // [N] running candidate count per query (may exceed scan_cap)
     float* scan_scores;       // [N][scan_cap]

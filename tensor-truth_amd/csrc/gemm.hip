@@ -606,12 +606,32 @@ __device__ __forceinline__ void epilogue_all(const GemmParams& p, f32x4 (&acc)[2
 // TT_EPI_SCAN: nothing is stored.  In the swapped accumulator layout a lane holds ONE corpus row (m-tile row l & 15)
 // and four consecutive queries per 16x16 tile, so the per-query threshold filter is four compares against a float4
 // of the tile's threshold strip (LDS, staged like a bias strip).  Survivors are rare (about k * rows / sample rows
-// per query over the whole pass) and go to the shared per-query lists with one returning atomic each -- outside the
-// main loop, where nothing is in flight behind them.  NaN scores (tombstoned rows) fail the compare.
-__device__ __forceinline__ void scan_filter_epilogue(const GemmParams& p, f32x4 (&acc)[2][2][2][4], const char* smem, int thr_off,
+// per query over the whole pass: tens per tile) but each one needs a RETURNING global atomic on its query's list
+// counter; issued where they are found -- one divergent region after the other -- their round trips add up to ~20 %
+// of a tile (measured: 5.2 -> 4.8 ms per pass when a 4x larger sample quarters the survivors).  So the waves only
+// RECORD survivors, in an LDS list behind the operand slots (LDS atomic for the slot), and after one barrier the
+// first n threads append one survivor each: all global atomics of a tile are in flight together, one round trip.
+// NaN scores (tombstoned rows) fail the compare.  STAGED = false (persistent form, no workgroup barrier available
+// between its wave groups here): the direct per-survivor path.
+constexpr int kScanHitOff = kLds3;            // [0]: count, [16...): kScanHitCap x {score bits, (query << 8) | row in tile}
+constexpr int kScanHitCap = 1024;
+constexpr int kLdsScan = kLds3 + 16 + kScanHitCap * 8;
+
+__device__ __forceinline__ void scan_append(const GemmParams& p, int q, int32_t row, float v) {
+    const int pos = atomicAdd(p.scan_cnt + q, 1);
+    if (pos < p.scan_cap) {
+        p.scan_scores[(size_t)q * p.scan_cap + pos] = v;
+        p.scan_idx[(size_t)q * p.scan_cap + pos] = p.scan_idx_base + row;
+    }
+}
+
+template <bool STAGED>
+__device__ __forceinline__ void scan_filter_epilogue(const GemmParams& p, f32x4 (&acc)[2][2][2][4], char* smem, int thr_off,
                                                      int m0, int wm, int wn, int lane) {
     const int g = lane >> 4, l15 = lane & 15;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)smem;
+    int* hit_cnt = reinterpret_cast<int*>(smem + kScanHitOff);
+    uint2* hits = reinterpret_cast<uint2*>(smem + kScanHitOff + 16);
 #pragma unroll
     for (int qn = 0; qn < 2; ++qn)
 #pragma unroll
@@ -627,20 +647,30 @@ __device__ __forceinline__ void scan_filter_epilogue(const GemmParams& p, f32x4 
                     const f32x4 v = acc[qm][qn][nt][mt];
                     const bool hit = (v[0] >= t[0]) | (v[1] >= t[1]) | (v[2] >= t[2]) | (v[3] >= t[3]);
                     if (hit) {
-                        const int32_t row = m0 + qm * 128 + wm * 64 + mt * 16 + l15;
+                        const int rt = qm * 128 + wm * 64 + mt * 16 + l15;      // row inside the tile
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
                             if (v[r] >= t[r]) {
                                 const int q = q0 + r;
-                                const int pos = atomicAdd(p.scan_cnt + q, 1);
-                                if (pos < p.scan_cap) {
-                                    p.scan_scores[(size_t)q * p.scan_cap + pos] = v[r];
-                                    p.scan_idx[(size_t)q * p.scan_cap + pos] = p.scan_idx_base + row;
+                                if constexpr (STAGED) {
+                                    const int pos = atomicAdd(hit_cnt, 1);
+                                    if (pos < kScanHitCap) hits[pos] = make_uint2(__float_as_uint(v[r]), (uint32_t)((q << 8) | rt));
+                                    else scan_append(p, q, m0 + rt, v[r]);       // a tile with > 1024 survivors
+                                } else {
+                                    scan_append(p, q, m0 + rt, v[r]);
                                 }
                             }
                     }
                 }
         }
+    if constexpr (STAGED) {
+        __syncthreads();
+        const int n = *hit_cnt < kScanHitCap ? *hit_cnt : kScanHitCap;
+        for (int i = threadIdx.x; i < n; i += kThreads3) {
+            const uint2 e = hits[i];
+            scan_append(p, (int)(e.y >> 8), m0 + (int)(e.y & 255u), __uint_as_float(e.x));
+        }
+    }
 }
 
 #define TT_SLOT_END()                                         \
@@ -760,6 +790,9 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
     };
 
     cstamp(0);
+    if constexpr (EPI == TT_EPI_SCAN) {
+        if (tid == 0) *reinterpret_cast<int*>(smem + kScanHitOff) = 0;     // survivor count of this tile (see scan_filter_epilogue)
+    }
     // bias strip of this tile (256 floats = one 1-KiB copy), oldest operation of wave 0's queue
     if (wave == 0) {
         glds16(p.bias + n0, lane * 16, (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem + kBiasOff);
@@ -926,7 +959,7 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
             for (int qn = 0; qn < 2; ++qn)
                 gemm_epilogue_wide<EPI, 2, 4>(p, acc[qm][qn], m0 + qm * 128 + wm * 64, n0 + wn * 64 + qn * 32, lane);
     } else if constexpr (EPI == TT_EPI_SCAN) {
-        scan_filter_epilogue(p, acc, smem, kBiasOff, m0, wm, wn, lane);
+        scan_filter_epilogue<true>(p, acc, smem, kBiasOff, m0, wm, wn, lane);
     } else if constexpr (SLOTS == 47) {
 #pragma unroll
         for (int qm = 0; qm < 2; ++qm)
@@ -1037,6 +1070,15 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_p(GemmParams p, int 
     const bool late = wave >= 4;
     int bpar = 0;
     bool first = true;
+    // De-phasing (p.xp >> 8 = phases, in 1024-cycle units of delay per phase step): every CU of an XCD finishes its tiles at
+    // the same moment, so the XCD's 32 x 128 KiB of output arrive at its 4 MiB L2 in one burst, which has to be written
+    // back before it is accepted -- and the in-order vector-memory queue holds the next tile's copies behind those
+    // stores.  A one-time start delay by position inside the XCD (blockIdx.x / 8: workgroups b and b + 8 share an XCD)
+    // spreads the bursts over the tile period for the whole kernel (static tile lists keep the phase).
+    if (const int ph = p.xp >> 8) {
+        const int steps = ((blockIdx.x >> 3) % 32) * ph;       // x 1024 cycles
+        for (int i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(16);
+    }
     // ---- prologue of the first tile: K-tile 0 complete, K-tile 1 without its hi halves (La(0) brings them)
     stage_strips(m0, n0, bpar);
     issue_lo(0);
@@ -1107,7 +1149,8 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_p(GemmParams p, int 
             read_a(smem + slot_off(0, 0, B));
             read_w(wf0, smem + slot_off(1, 0, B));
             read_w(wf1, smem + slot_off(1, 1, B));
-            if (after_epi) wait_n(24);
+            // (xp bit 1: one more store-tolerant wait -- at La(1) the stores are still only behind hi(2'), lo(2'))
+            if (after_epi || (t == 1 && !first && EPI != TT_EPI_SCAN && (p.xp & 2))) wait_n(24);
             else wait_n((t + 1 < nk || has_next) ? 8 : 0);
             mma(acc[0][0], wf0);                       // Ca
             mma(acc[0][1], wf1);
@@ -1134,7 +1177,7 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_p(GemmParams p, int 
         int lane_e = lane;
         asm volatile("" : "+v"(lane_e));
         if constexpr (EPI == TT_EPI_SCAN)
-            scan_filter_epilogue(p, acc, smem, kBiasOff + bpar * 1024, m0, wm, wn, lane_e);
+            scan_filter_epilogue<false>(p, acc, smem, kBiasOff + bpar * 1024, m0, wm, wn, lane_e);
         else
             epilogue_all<EPI, false, FP8>(p, acc, smem, kBiasOff + bpar * 1024, kScaleOff + bpar * 2048, m0, n0, wm, wn, wave, lane_e,
                                           false, NoNext{});
@@ -1279,14 +1322,16 @@ int launch(const GemmParams& p, hipStream_t st) {
         blocks = (blocks + 7) / 8 * 8;
         // measured (M = 236800): the persistent kernel wins where the epilogue is VALU-heavy (GELU: 1.74 vs 1.78 ms), the
         // one-tile kernel with LDS-transposed full-line stores where it is store-bound (bias: 1.39 vs 1.40 ms)
-        if constexpr (EPI == TT_EPI_GELU) {
+        static const int xp = [] { const char* e = getenv("TT_GEMM_XP"); return e && e[0] ? (int)strtol(e, nullptr, 0) : 0; }();
+        if constexpr (EPI == TT_EPI_GELU || EPI == TT_EPI_BIAS) {
             const int cus = tt_cu_count_cached() / 8 * 8;
-            if (variant == 5 && (p.K / BK) % 2 == 0 && p.K / BK >= 2 && blocks > cus && cus >= 8) {
+            if (variant == 5 && (EPI == TT_EPI_GELU || (xp & 1)) && (p.K / BK) % 2 == 0 && p.K / BK >= 2 && blocks > cus && cus >= 8) {
                 TT_SET_MAX_LDS(v3::gemm_kernel_p<EPI>, v3::kLds3);
                 {
                     TtProfScope prof(TT_K_GEMM, st);
                     GemmParams q = p;
                     q.sn = SN;
+                    q.xp = xp;
                     hipLaunchKernelGGL(v3::gemm_kernel_p<EPI>, dim3(cus), dim3(v3::kThreads3), v3::kLds3, st, q, blocks);
                 }
                 TT_CHECK_LAUNCH();
@@ -1441,7 +1486,10 @@ int tt_scan_gemm_launch(const uint16_t* corpus, int64_t rows, int dim, const uin
     int blocks = (mt_n + 31) / 32 * 32;     // super-tiles of 32 row tiles x 1 column tile
     // persistent form (one workgroup per CU walks the row tiles, the K stream never drains): no per-tile prologue and no
     // dispatch gap, and -- unlike the storing epilogues -- nothing of the filter epilogue sits in the vector-memory queue
-    static const int persist = [] { const char* e = getenv("TT_SCAN_GEMM_PERSIST"); return e && e[0] ? atoi(e) : 1; }();
+    // (measured on 10M x 1024, 256 queries: 5.7 ms persistent vs 5.2 ms one tile per workgroup -- the storing epilogues'
+    // problem in reverse: here the tile ends with a workgroup-wide survivor hand-off, which the two wave groups of the
+    // persistent form cannot share)
+    static const int persist = [] { const char* e = getenv("TT_SCAN_GEMM_PERSIST"); return e && e[0] ? atoi(e) : 0; }();
     const int cus = tt_cu_count_cached() / 8 * 8;
     if (persist && blocks > cus && cus >= 8) {
         TT_SET_MAX_LDS(v3::gemm_kernel_p<TT_EPI_SCAN>, v3::kLds3);
@@ -1452,10 +1500,10 @@ int tt_scan_gemm_launch(const uint16_t* corpus, int64_t rows, int dim, const uin
         TT_CHECK_LAUNCH();
         return TT_OK;
     }
-    TT_SET_MAX_LDS((v3::gemm_kernel_v3<TT_EPI_SCAN, 4>), v3::kLds3);
+    TT_SET_MAX_LDS((v3::gemm_kernel_v3<TT_EPI_SCAN, 4>), v3::kLdsScan);
     {
         TtProfScope prof(TT_K_SCAN_FILTER, st);
-        hipLaunchKernelGGL((v3::gemm_kernel_v3<TT_EPI_SCAN, 4>), dim3(blocks), dim3(v3::kThreads3), v3::kLds3, st, p);
+        hipLaunchKernelGGL((v3::gemm_kernel_v3<TT_EPI_SCAN, 4>), dim3(blocks), dim3(v3::kThreads3), v3::kLdsScan, st, p);
     }
     TT_CHECK_LAUNCH();
     return TT_OK;

@@ -90,7 +90,8 @@ Plan make_plan(int64_t n_rows, int dim, int n_queries, int k, int cus) {
     // expected survivors ~ k * rows / sample rows per query) and a list sized for 4x that expectation.
     pl.gemm = scan_gemm_enabled() && n_queries > 64 && dim % 128 == 0 && n_rows >= 262144 && n_rows >= (int64_t)2048 * k;
     if (pl.gemm) {
-        n0 = 65536;
+        static const int64_t n0_env = [] { const char* e = getenv("TT_SCAN_GEMM_N0"); return e && e[0] ? (int64_t)atoll(e) : (int64_t)0; }();
+        n0 = n0_env > 0 ? n0_env : 131072;   // (measured, 10M x 1024 x 256 queries: 65536 -> 5.50, 131072 -> 5.35, 262144 -> 5.52 ms per batch)
         if (n0 < (int64_t)512 * k) n0 = (int64_t)512 * k;
         if (n0 > n_rows / 2) n0 = n_rows / 2 / 32 * 32;
         pl.q256 = (n_queries + 255) / 256 * 256;
