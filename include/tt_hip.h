@@ -229,6 +229,60 @@ int tt_gemm_fp8_ex(const void* a8, const float* a_scale, const void* w8, const f
                    const void* residual, void* c_bf16, void* c_fp8, float c_fp8_inv_scale, int m, int n, int k,
                    int epilogue, void* stream);
 
+/* ---- reference-precision (fp32) forward -------------------------------------------------------------------
+ * The reference's default embedder / reranker dtype is fp32 (src/tensortruth/app_utils/config_schema.py:66-76:
+ * torch_dtype None; services/model_manager.py:218-229 passes torch_dtype only when configured).  These entry points
+ * run the same encoder with fp32 weights, fp32 activations and fp32 MFMA (v_mfma_f32_32x32x2_f32, exact f32
+ * arithmetic at 1/16 of the bf16 matrix rate) for callers that ask for model_kwargs={"torch_dtype": "float32"}:
+ * scores within 1e-3 relative of the CPU reference, at interactive batch sizes (one query's candidate pairs).
+ * Same packed token layout as tt_encoder_forward; n_rows is any count >= last start + len.
+ * All weight tensors fp32, [out][in] for matrices. */
+typedef struct tt_layer_weights_f32 {
+    const float* qkv_w;  /* [3H][H] */
+    const float* qkv_b;
+    const float* o_w;    /* [H][H] */
+    const float* o_b;
+    const float* ln1_g;
+    const float* ln1_b;
+    const float* ffn1_w; /* [F][H] */
+    const float* ffn1_b;
+    const float* ffn2_w; /* [H][F] */
+    const float* ffn2_b;
+    const float* ln2_g;
+    const float* ln2_b;
+} tt_layer_weights_f32;
+
+typedef struct tt_encoder_weights_f32 {
+    int32_t hidden, layers, heads, ffn, vocab, max_pos, type_vocab;
+    float ln_eps;
+    const float* word_emb;  /* [vocab][H] */
+    const float* pos_emb;   /* [max_pos][H] */
+    const float* type_emb;  /* [type_vocab][H] */
+    const float* emb_ln_g;
+    const float* emb_ln_b;
+    const tt_layer_weights_f32* layer; /* host array [layers] */
+    const float* cls_dense_w;  /* [H][H] or NULL */
+    const float* cls_dense_b;
+    const float* cls_out_w;    /* [1][H] */
+    const float* cls_out_b;    /* [1] */
+} tt_encoder_weights_f32;
+
+size_t tt_encoder_f32_workspace_bytes(const tt_encoder_weights_f32* w, int n_rows);
+/* hidden_out: [n_rows][H] fp32 last hidden state */
+int tt_encoder_forward_f32(const tt_encoder_weights_f32* w, const int32_t* ids, const int32_t* pos,
+                           const int32_t* type_ids, const int32_t* seq_start, const int32_t* seq_len,
+                           int n_seq, int n_rows, int max_len, float* hidden_out,
+                           void* workspace, size_t workspace_bytes, void* stream);
+/* tt_embed_pool / tt_rerank_head on an fp32 hidden state (head workspace >= 2 * round_up(n_seq,128) * H * 4 bytes) */
+int tt_embed_pool_f32(const float* hidden_f32, int ld, const int32_t* rows, int n_seq, int hidden,
+                      float* out_f32, void* out_bf16, void* stream);
+int tt_rerank_head_f32(const tt_encoder_weights_f32* w, const float* hidden_f32, const int32_t* rows, int n_seq,
+                       float* scores, float* logits, void* workspace, size_t workspace_bytes, void* stream);
+/* building block (parity tests): c = epi(a . w^T + bias), fp32; any m, n % 128 == 0, k % 32 == 0;
+ * epilogue 0 bias, 1 exact-erf GELU, 2 + residual, 3 tanh */
+int tt_gemm_f32(const float* a, const float* w, const float* bias, const float* residual, float* c,
+                int m, int n, int k, int epilogue, void* stream);
+
 /* Per-kernel device timing (HIP events on the launch stream), for bench.py's roofline leg.
  * tt_prof_enable(1) (or a mask of 1 << id, to time only some kernels) starts recording one event pair per launch of the tracked kernels on the
  * calling thread; tt_prof_read() synchronises those events and returns total milliseconds

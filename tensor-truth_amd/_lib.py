@@ -64,6 +64,12 @@ SIGNATURES = {
                             c_void_p]),
     "tt_gemm_fp8_ex": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
                                c_int, c_int, c_int, c_int, c_void_p]),
+    "tt_encoder_f32_workspace_bytes": (c_size_t, [c_void_p, c_int]),
+    "tt_encoder_forward_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                       c_void_p, c_void_p, c_size_t, c_void_p]),
+    "tt_embed_pool_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "tt_rerank_head_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "tt_gemm_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "tt_prof_enable": (c_int, [c_int]),
     "tt_prof_read": (c_int, [c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int)]),
 }

@@ -16,6 +16,7 @@ import torch
 from . import weights as _weights
 from .coalesce import Coalescer
 from .encoder import Encoder, EncoderWeights, pack_tokens
+from .encoder_f32 import EncoderF32, EncoderWeightsF32, wants_float32
 from .schema import MetadataMode, NodeWithScore
 from .tokenization import load_tokenizer
 
@@ -42,10 +43,16 @@ class HipSentenceTransformerRerank:
         self.config = cfg
         # pairs are truncated by the tokenizer (longest-first, specials kept): never beyond what the model has positions for
         self.max_length = min(max_length, cfg.max_seq_len)
-        self.model = EncoderWeights(cfg, state, dev)    # `.model` is what the reference's memory accounting reads
-        # model_kwargs["gemm_dtype"] = "fp8": Q/K/V and FFN-up projections on the e4m3 matrix cores (BASELINE config 5)
-        self.model.set_gemm_dtype((model_kwargs or {}).get("gemm_dtype", "bf16"))
-        self._encoder = Encoder(self.model)
+        if wants_float32(model_kwargs):
+            # the reference's default precision (SentenceTransformerRerank builds its CrossEncoder in fp32,
+            # model_manager.py:333-337): fp32 weights / activations / MFMA, scores within 1e-3 relative of the CPU path
+            self.model = EncoderWeightsF32(cfg, state, dev)
+            self._encoder = EncoderF32(self.model)
+        else:
+            self.model = EncoderWeights(cfg, state, dev)    # `.model` is what the reference's memory accounting reads
+            # model_kwargs["gemm_dtype"] = "fp8": Q/K/V and FFN-up projections on the e4m3 matrix cores (BASELINE config 5)
+            self.model.set_gemm_dtype((model_kwargs or {}).get("gemm_dtype", "bf16"))
+            self._encoder = Encoder(self.model)
         self._tokenizer = (model_kwargs or {}).get("tokenizer") or load_tokenizer(mdir, cfg.arch, cfg.vocab_size)
         # concurrent predict() / postprocess_nodes() calls (one per request thread in the reference,
         # rag_service.py:343-346,617-620) share ONE tokenizer call and ONE encoder batch; scores do not depend on the

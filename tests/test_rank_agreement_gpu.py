@@ -115,3 +115,31 @@ def test_fp8_rank_quality_at_full_depth(dev, built_lib, oracle_scores):
     # each after 96 fp8 GEMMs): Kendall tau 0.44-0.54, top-10 overlap 0.6-0.7 -- the fp8 mode trades this much ranking
     # fidelity for 1.27x reranker throughput when candidates are this close; the floors below catch regressions.
     assert np.mean(taus) >= 0.4 and np.mean(over) >= 0.5, (taus, over)
+
+
+def test_fp32_scores_within_1e3_relative_at_full_depth(dev, built_lib, oracle_scores):
+    """The reference-precision path (model_kwargs torch_dtype=float32, csrc/f32_path.hip) at full depth: north_star's
+    "fp scores within 1e-3 relative" for all 200 pairs, and the oracle's own ranking reproduced."""
+    from tensor_truth_amd.encoder import EncoderConfig, pack_token_matrix
+    from tensor_truth_amd.encoder_f32 import EncoderF32, EncoderWeightsF32
+
+    ocfg, W, pairs, want = oracle_scores
+    cfg = EncoderConfig(**SHAPE)
+    enc = EncoderF32(EncoderWeightsF32(cfg, W, dev))
+    import time
+    got = torch.empty_like(want)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for q in range(N_QUERIES):                                   # one query's 50 pairs per call: the interactive case
+        got[q] = enc.rerank_packed(pack_token_matrix(pairs[q].astype(np.int32), cfg)).cpu()
+    dt = (time.perf_counter() - t0) / N_QUERIES
+    rel = ((got - want).abs() / want.abs()).max().item()
+    assert rel <= 1e-3, f"fp32 path: relative score error {rel}"
+    n_sep = 0
+    for q in range(N_QUERIES):
+        n_sep += assert_order_on_separable(want[q].numpy(), got[q].numpy(), 1e-4, f"fp32 query {q}")
+        assert_topn_on_separable(want[q].numpy(), got[q].numpy(), TOP_N, 1e-4, f"fp32 query {q}")
+    taus = [kendall_tau(want[q].numpy(), got[q].numpy()) for q in range(N_QUERIES)]
+    print(f"fp32 @24L: max relative score error {rel:.2e}; {n_sep} pairs separable at 1e-4 all ordered as the oracle; "
+          f"Kendall tau min {min(taus):.4f}; {dt * 1e3:.0f} ms per query of {N_PAIRS} pairs x {PAIR_TOKENS} tok")
+    assert min(taus) >= 0.995
