@@ -1,12 +1,20 @@
 #!/bin/bash
-# PMC passes (HBM traffic) + kernel stats of the bench command, for profiles/.
+# Round-2 evidence run: PMC passes (HBM traffic of the two roofline kernels), rocprofv3 --stats of the headline-only
+# bench + agreement check against the live HIP-event timing, per-shape GEMM rates.  Everything lands in gpurun_out/;
+# copy the summaries to profiles/r02_*.
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-rm -rf gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/prof_bench
-timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-fp8-leg > gpurun_out/pmc_fetch.log 2>&1
-timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-fp8-leg > gpurun_out/pmc_write.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_bench -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fp8-leg > gpurun_out/prof_bench.log 2>&1
-timeout 900 python bench.py > gpurun_out/bench.json 2> gpurun_out/bench.err
-cat gpurun_out/bench.json
-ls gpurun_out/pmc_fetch/*/ | head
+LEGS="--no-cpu-baseline --no-fp8-leg --no-surface-leg --no-config5-leg"
+rm -rf gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/prof_headline
+timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch -- python3 bench.py --steps 1 --warmup 1 $LEGS > gpurun_out/pmc_fetch.log 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write -- python3 bench.py --steps 1 --warmup 1 $LEGS > gpurun_out/pmc_write.log 2>&1
+python tools/pmc_to_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/r02_pmc_traffic.json
+find gpurun_out/pmc_fetch gpurun_out/pmc_write -name "*.csv" -delete
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_headline -- python3 bench.py --headline-only --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/r02_bench_headline.json 2> gpurun_out/bench_headline.err
+tail -2 gpurun_out/bench_headline.err
+S=$(find gpurun_out/prof_headline -name "*kernel_stats.csv" | head -1)
+cp "$S" gpurun_out/r02_bench_headline_kernel_stats.csv
+find gpurun_out/prof_headline -name "*kernel_trace.csv" -delete
+python tools/rocprof_vs_bench.py gpurun_out/r02_bench_headline_kernel_stats.csv gpurun_out/r02_bench_headline.json | tee gpurun_out/r02_rocprof_vs_bench.txt
+./tools/gemm_bench 473600 10 | tee gpurun_out/r02_gemm_shapes.log

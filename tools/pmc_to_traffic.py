@@ -36,7 +36,14 @@ def main(fetch_dir, write_dir, out):
         write = sum(float(r["Counter_Value"]) for r in wr) * 1024
         res[kind] = {"launches": len(fr), "fetch_bytes_per_launch": fetch / len(fr),
                      "write_bytes_per_launch": write / len(wr), "hbm_bytes_per_launch": (fetch + write) / len(fr)}
-    res["source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline`"
+    res["source"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/gpu_pmc_bench.sh) of `python3 bench.py --steps 1 "
+                     "--warmup 1 --no-cpu-baseline --no-fp8-leg --no-surface-leg --no-config5-leg`; FETCH_SIZE doubled (gfx950: the "
+                     "counter tallies 128-B requests at 64 B), counters in KiB")
+    # ties the file to the kernel sources it was measured on: bench.py refuses it when they differ
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    res["csrc_sha256"] = bench.csrc_sha256()
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))
 
