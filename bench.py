@@ -117,13 +117,21 @@ def main():
             raise SystemExit("--gpus N > 1 must be launched through torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback in tensor_truth_amd)")
+    # TT_BENCH_ONE_DEVICE=1 (debugging aid, never the driver's path): all ranks share GPU 0 and talk over gloo, so the
+    # multi-rank code path (sharded index, both all-gathers, merge, max-over-ranks timing) can be exercised on a 1-GPU box
+    one_device = os.environ.get("TT_BENCH_ONE_DEVICE") == "1"
+    if one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
 
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if one_device:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from tensor_truth_amd import _lib, scan as tscan
     from tensor_truth_amd.encoder import (BGE_M3, BGE_RERANKER_V2_M3, Encoder, EncoderConfig, EncoderWeights,
@@ -341,7 +349,9 @@ def main():
     # ALGORITHMIC bytes per launch = N_local * D * 2 (one pass of the shard per query batch); what the
     # kernel re-reads on top of that (one pass per 64-query tile beyond the first) is reported as reread_factor, never
     # credited to `achieved`
-    q_tiles = (Bq * world + 63) // 64
+    # (65+ queries over a shard of >= 262144 rows take the 256-query-wide tiled filter pass: one pass per 256 queries)
+    tiled = Bq * world > 64 and (hi - lo) >= 262144 and (hi - lo) >= 2048 * K
+    q_tiles = (Bq * world + 255) // 256 if tiled else (Bq * world + 63) // 64
     scan_bytes = (hi - lo) * D * 2
     scan_gbs = scan_bytes * scan_n / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
 
@@ -371,7 +381,7 @@ def main():
         "metric": "queries/sec (embed+top-k+rerank) over 10M x 1024 corpus",
         "value": world * Bq * args.steps / dt,
         "unit": "queries/s",
-        "n_gpus": world,
+        "n_gpus": world if not one_device else 1,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3,
@@ -403,7 +413,8 @@ def main():
             "algorithmic_flops_per_launch": gemm_flops_step * args.steps / max(gemm_n, 1),
         },
         "roofline_scan": {
-            "kernel": "scan_kernel (filter pass over the corpus shard)",
+            "kernel": ("gemm_kernel_v3<TT_EPI_SCAN> (tiled MFMA filter pass over the corpus shard)" if tiled
+                       else "scan_kernel (streaming filter pass over the corpus shard)"),
             "bound": "hbm", "achieved": scan_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": scan_gbs / HBM_PEAK_GBS, "traffic": traffic.get("scan_filter"),
             "launches": scan_n, "avg_launch_ms": scan_ms / max(scan_n, 1),
