@@ -186,6 +186,7 @@ def main():
         pair_ids[:, -1] = 2
         rb = pack_token_matrix(pair_ids, rr_cfg)
         tokens_step["rerank"] = rb.n_tokens
+        tokens_step["last_pairs"] = pair_ids          # (the rank-quality leg re-scores a few of these in every precision mode)
         scores = reranker.rerank_packed(rb).view(Bq, K)
         # 6. top-n by rerank score (host-visible result, as the postprocessor returns it)
         top_s, top_j = torch.topk(scores, topn, dim=1)
@@ -273,6 +274,9 @@ def main():
             step(q)
         sync_all()
         dt8 = time.perf_counter() - t2
+        quality = None
+        if rank == 0:
+            quality = rank_quality(reranker, rr_cfg, tokens_step["last_pairs"][: 4 * K], K, topn, dev)
         reranker.w.set_gemm_dtype("bf16")
         if world > 1:
             t = torch.tensor([dt8], dtype=torch.float64, device=dev)
@@ -281,7 +285,8 @@ def main():
         fp8_leg = {"queries_per_s": world * Bq * args.steps / dt8, "ms_per_step": dt8 / args.steps * 1e3,
                    "what": "all four projections of the reranker's layers in e4m3 (per-token activation / per-channel "
                            "weight scales, static calibrated scale for the FFN intermediate, fp32 accumulate); "
-                           "embedder, scan, attention and the CLS tail unchanged"}
+                           "embedder, scan, attention and the CLS tail unchanged",
+                   "rank_quality_vs_fp32": quality}
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -428,6 +433,39 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def rank_quality(reranker, rr_cfg, pair_ids, K, topn, dev):
+    """What the precision modes do to a ranking: the candidates of 4 queries (K pairs each) scored by the fp32
+    reference-precision path (same weights, fp32 math: tt_encoder_forward_f32), by the bf16 default and by the fp8 mode --
+    score error, Kendall tau and top-n overlap of bf16 and fp8 against fp32.  Synthetic random-init weights: the K
+    candidates of a query score within ~0.3 of each other, a hard case for any reduced precision."""
+    from tensor_truth_amd.encoder import pack_token_matrix
+    from tensor_truth_amd.encoder_f32 import EncoderF32, EncoderWeightsF32
+
+    n_q = len(pair_ids) // K
+    w = reranker.w
+    # the resident bf16 weights, widened: the fp32 forward then differs from the others by arithmetic precision only
+    state = w.state_dict()
+    enc32 = EncoderF32(EncoderWeightsF32(rr_cfg, state, dev))
+    batch = pack_token_matrix(pair_ids, rr_cfg)
+    s32 = torch.cat([enc32.rerank_packed(pack_token_matrix(pair_ids[q * K:(q + 1) * K], rr_cfg)) for q in range(n_q)]).cpu().view(n_q, K)
+    del enc32
+    prev = w.gemm_dtype
+    out = {"queries": n_q, "pairs_per_query": K, "reference": "fp32 path (tt_encoder_forward_f32) on the same weights"}
+    for mode in ("bf16", "fp8"):
+        w.set_gemm_dtype(mode)
+        sm = reranker.rerank_packed(batch).cpu().view(n_q, K)
+        taus, overlaps = [], []
+        for q in range(n_q):
+            a, b = s32[q].numpy().astype(np.float64), sm[q].numpy().astype(np.float64)
+            sa, sb = np.sign(a[:, None] - a[None, :]), np.sign(b[:, None] - b[None, :])
+            taus.append(float((sa * sb).sum() / (K * (K - 1))))
+            overlaps.append(len(set(np.argsort(-a)[:topn].tolist()) & set(np.argsort(-b)[:topn].tolist())) / topn)
+        out[mode] = {"max_abs_score_err": float((sm - s32).abs().max()), "kendall_tau_mean": float(np.mean(taus)),
+                     f"top{topn}_overlap_mean": float(np.mean(overlaps))}
+    w.set_gemm_dtype(prev)
+    return out
 
 
 _WORDS = None

@@ -103,15 +103,18 @@ class EncoderWeights:
         self.device = device
         sd = _strip_prefix(state)
         self._keep: List[torch.Tensor] = []
+        self._named: Dict[str, torch.Tensor] = {}     # HF name -> the resident tensor (state_dict())
 
         def mat(name):
             t = sd[name].to(device=device, dtype=torch.bfloat16).contiguous()
             self._keep.append(t)
+            self._named[name] = t
             return t
 
         def vec(name):
             t = sd[name].to(device=device, dtype=torch.float32).contiguous()
             self._keep.append(t)
+            self._named[name] = t
             return t
 
         H = cfg.hidden
@@ -137,6 +140,9 @@ class EncoderWeights:
             qkv_w = qkv_w.to(device=device, dtype=torch.bfloat16).contiguous()
             qkv_b = qkv_b.to(device=device, dtype=torch.float32).contiguous()
             self._keep += [qkv_w, qkv_b]
+            for j, nm in enumerate(("query", "key", "value")):
+                self._named[p + f"attention.self.{nm}.weight"] = qkv_w[j * H:(j + 1) * H]
+                self._named[p + f"attention.self.{nm}.bias"] = qkv_b[j * H:(j + 1) * H]
             self._qkv_w.append(qkv_w)
             L = self._layers[i]
             L.qkv_w, L.qkv_b = qkv_w.data_ptr(), qkv_b.data_ptr()
@@ -212,6 +218,11 @@ class EncoderWeights:
     def parameters(self) -> Iterable[torch.Tensor]:
         """For ModelManager-style memory accounting (reference model_manager.py:477-507)."""
         return iter(self._keep + self._fp8)
+
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        """HF checkpoint name -> the resident (bf16 / fp32) tensor: what these weights ARE after rounding to bf16,
+        e.g. to run the same model through the fp32 path (``encoder_f32.EncoderWeightsF32(cfg, w.state_dict(), dev)``)."""
+        return dict(self._named)
 
     def nbytes(self) -> int:
         return sum(t.numel() * t.element_size() for t in self._keep + self._fp8)
