@@ -133,7 +133,7 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
 
-    from tensor_truth_amd import _lib, scan as tscan
+    from tensor_truth_amd import _lib
     from tensor_truth_amd.encoder import (BGE_M3, BGE_RERANKER_V2_M3, Encoder, EncoderConfig, EncoderWeights,
                                           pack_token_matrix, pack_tokens, synthetic_state_device)
     from tensor_truth_amd.sharded import shard_bounds

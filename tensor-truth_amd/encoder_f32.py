@@ -10,15 +10,14 @@ CPU reference (north_star's tolerance), at about 1/10 of the bf16 path's through
 from __future__ import annotations
 
 import ctypes
+import threading
 from ctypes import POINTER, Structure, c_float, c_int32, c_void_p
 from typing import Dict, Iterable, List, Optional, Tuple
 
 import torch
 
 from . import _lib
-from .encoder import EncoderConfig, PackedBatch, _ENQUEUE_LOCKS, _scratch, _stager, _strip_prefix, pack_tokens  # noqa: F401
-
-import threading
+from .encoder import EncoderConfig, PackedBatch, _ENQUEUE_LOCKS, _scratch, _strip_prefix, pack_tokens
 
 
 class _LayerWF(Structure):

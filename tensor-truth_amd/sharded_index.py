@@ -24,13 +24,13 @@ from __future__ import annotations
 
 import math
 import threading
-from typing import Callable, Dict, List, Optional, Sequence, Tuple
+from typing import Callable, Dict, List, Optional, Sequence, Tuple  # noqa: F401
 
 import torch
 import torch.distributed as dist
 
 from . import sharded as _sh
-from .schema import NodeWithScore, TextNode, as_query_bundle
+from .schema import NodeWithScore, TextNode
 from .vector_index import (HipVectorIndex, HipVectorRetriever, _read_persisted, _node_from_dict)
 
 
