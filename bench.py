@@ -669,7 +669,17 @@ def cpu_baseline(args, emb_cfg, rr_cfg, embedder, reranker, corpus, q_tok, vocab
         t0 = time.perf_counter()
         e = oe.embed(q, torch.ones_like(q), W, ocfg_e)                           # 1 query x 34 tok, 24 layers
         t_q = time.perf_counter() - t0
-        # ingest leg: one reference-size CPU batch (batch_size_cpu = 16, config_schema.py:49) of chunk_len + 2 tokens
+        # how many units fit a ~20 s budget per encoder leg on THIS host: one pair first (a 256-core box takes ~2 s for it;
+        # a small host may take 10x that), then as many as the budget allows, capped at 8 pairs / one reference batch of 16
+        head = np.concatenate(([0], q_tok[0] % CPU_VOCAB, [2, 2]))
+        p1 = passage_tokens(np.arange(1), CL, CPU_VOCAB)
+        one = torch.from_numpy(np.stack([np.concatenate((head, p, [2])) for p in p1])).long()
+        t0 = time.perf_counter()
+        oe.rerank_scores(one, torch.ones_like(one), W, ocfg_r)
+        t_one = time.perf_counter() - t0
+        CPU_PAIRS = int(min(CPU_PAIRS, max(1, 20.0 / t_one)))
+        CPU_CHUNKS = int(min(CPU_CHUNKS, max(1, 20.0 / t_one)))
+        # ingest leg: a reference-size CPU batch (batch_size_cpu = 16, config_schema.py:49) of chunk_len + 2 tokens
         ctok = passage_tokens(np.arange(CPU_CHUNKS), CL, CPU_VOCAB)
         cids = torch.from_numpy(np.concatenate((np.zeros((CPU_CHUNKS, 1), np.int32), ctok,
                                                 np.full((CPU_CHUNKS, 1), 2, np.int32)), 1)).long()
@@ -680,11 +690,13 @@ def cpu_baseline(args, emb_cfg, rr_cfg, embedder, reranker, corpus, q_tok, vocab
         _, idx, _ = osc.scan_topk(host_corpus, e.to(torch.bfloat16), K)
         t_scan = time.perf_counter() - t0
         ptok = passage_tokens(idx[0, :CPU_PAIRS].numpy(), CL, CPU_VOCAB)
-        head = np.concatenate(([0], q_tok[0] % CPU_VOCAB, [2, 2]))
         ids = torch.from_numpy(np.stack([np.concatenate((head, p, [2])) for p in ptok])).long()
-        t0 = time.perf_counter()
-        oe.rerank_scores(ids, torch.ones_like(ids), W, ocfg_r)                   # 8 pairs x 292 tok, 24 layers
-        t_rr = time.perf_counter() - t0
+        if CPU_PAIRS > 1:
+            t0 = time.perf_counter()
+            oe.rerank_scores(ids, torch.ones_like(ids), W, ocfg_r)                   # CPU_PAIRS pairs x 292 tok, 24 layers
+            t_rr = time.perf_counter() - t0
+        else:
+            t_rr = t_one
     rows_per_s = rows / t_scan
     pairs_per_s = CPU_PAIRS / t_rr
     t_query = t_q + args.corpus_rows / rows_per_s + K / pairs_per_s
@@ -696,7 +708,7 @@ def cpu_baseline(args, emb_cfg, rr_cfg, embedder, reranker, corpus, q_tok, vocab
         "sample": (f"fp32 CPU oracle, torch threads={cores} of {avail} visible; every leg at full depth and width "
                    f"({emb_cfg.layers} layers x {emb_cfg.hidden}), measured, not scaled: 1 query x {q.shape[1]} tok embedded in "
                    f"{t_q:.2f}s; {CPU_CHUNKS} chunks x {cids.shape[1]} tok (one reference CPU batch) in {t_chunks:.2f}s; exact top-{K} of 1 "
-                   f"query over {rows} corpus rows in {t_scan:.2f}s; {CPU_PAIRS} pairs x {ids.shape[1]} tok reranked in {t_rr:.2f}s. "
+                   f"query over {rows} corpus rows in {t_scan:.2f}s; {CPU_PAIRS} pairs x {ids.shape[1]} tok reranked in {t_rr:.2f}s (units sized to ~20 s per encoder leg from one pair's {t_one:.2f}s). "
                    f"value = 1 / (t_query_embed + {args.corpus_rows} rows / rows_per_s + {K} pairs / pairs_per_s) = "
                    f"1 / ({t_q:.2f} + {args.corpus_rows / rows_per_s:.2f} + {K / pairs_per_s:.2f}) s"),
     }
