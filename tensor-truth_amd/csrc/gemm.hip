@@ -987,7 +987,7 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
 // next tile (La(0)) are issued BEFORE the 16 epilogue stores, so the first two waits of a non-first tile allow
 // 8 + 16 and 6 + 16 operations; by the third the stores are four slots old.
 // The residual epilogue needs all eight slots for the residual tile and stays on the one-tile-per-block kernel.
-template <int EPI, bool FP8 = false>
+template <int EPI, bool FP8 = false, bool STAMP = false>
 __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_p(GemmParams p, int nwg) {
     constexpr int ES = FP8 ? 1 : 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1070,6 +1070,19 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_p(GemmParams p, int 
     const bool late = wave >= 4;
     int bpar = 0;
     bool first = true;
+    // diagnostic build (TT_GEMM_ABLATE=8, tools/gemm_stamps_p): s_memtime of workgroup 0's waves 0 and 4 at the slot boundaries of
+    // the first K-tiles of its 2nd..7th output tile -> p.vt[(wave >= 4) * 1024 + tile_no * 128 + index]
+    int tile_no = 0;
+    unsigned long long* sdbg = reinterpret_cast<unsigned long long*>(p.vt);
+    auto pstamp = [&](int idx) {
+        if constexpr (STAMP) {
+            if (blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 4) && tile_no >= 1 && tile_no < 8 && idx < 128 && sdbg) {
+                __builtin_amdgcn_sched_barrier(0);
+                sdbg[(wave >= 4 ? 1024 : 0) + tile_no * 128 + idx] = __builtin_amdgcn_s_memtime();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
     // De-phasing (p.xp >> 8 = phases, in 1024-cycle units of delay per phase step): every CU of an XCD finishes its tiles at
     // the same moment, so the XCD's 32 x 128 KiB of output arrive at its 4 MiB L2 in one burst, which has to be written
     // back before it is accepted -- and the in-order vector-memory queue holds the next tile's copies behind those
@@ -1145,6 +1158,7 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_p(GemmParams p, int 
             // atomics return a value, so the compiler has already waited for them -- the plain counts are right)
             const bool after_epi = t == 0 && !first && EPI != TT_EPI_SCAN;
             // La: hi halves of K-tile t+1 (already issued, ahead of the stores, when after_epi)
+            pstamp(t * 4 + 0);                        // La start
             if (!(t == 0 && !first)) issue_hi(t + 1);
             read_a(smem + slot_off(0, 0, B));
             read_w(wf0, smem + slot_off(1, 0, B));
@@ -1152,9 +1166,11 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_p(GemmParams p, int 
             // (xp bit 1: one more store-tolerant wait -- at La(1) the stores are still only behind hi(2'), lo(2'))
             if (after_epi || (t == 1 && !first && EPI != TT_EPI_SCAN && (p.xp & 2))) wait_n(24);
             else wait_n((t + 1 < nk || has_next) ? 8 : 0);
+            pstamp(t * 4 + 1);                        // Ca start (past La's wait + barrier)
             mma(acc[0][0], wf0);                       // Ca
             mma(acc[0][1], wf1);
             TT_SLOT_END();
+            pstamp(t * 4 + 2);                        // Lb start
             // Lb: lo halves of K-tile t+2; the other group's epilogue of the previous tile is over: the bias
             // strip it read can be refilled for the next tile
             if (t == 0 && has_next) stage_strips(m1, n1, bpar ^ 1);
@@ -1162,6 +1178,7 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_p(GemmParams p, int 
             read_a(smem + slot_off(0, 1, B));
             if (after_epi) wait_n(22);
             else wait_n((t + 2 < nk || has_next) ? 6 : 0);
+            pstamp(t * 4 + 3);                        // Cb start
             mma(acc[1][1], wf1);                       // Cb
             mma(acc[1][0], wf0);
             TT_SLOT_END();
@@ -1170,7 +1187,21 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_p(GemmParams p, int 
             tile4(t, std::integral_constant<int, 0>{});
             tile4(t + 1, std::integral_constant<int, 1>{});
         }
+        pstamp(100);                                  // main loop done
         if (has_next) issue_hi(nk + 1);   // La(0) of the next tile, ahead of this tile's stores
+        // Tile boundary.  With the groups one slot apart THROUGH the boundary their epilogues serialise: group A converts
+        // and stores (4.3 k cycles for the bias epilogue, one wave per SIMD at half the vector issue rate) while B can only
+        // run its last 512-cycle MFMA slot and then waits at a barrier A reaches after its epilogue; then B's epilogue runs
+        // while A waits at the end of Ca(0) (stamps, tools/gemm_stamps_p: 6.3 k cycles in that one slot) -- 11.7 k of a
+        // 59.7 k-cycle K = 1024 tile.  Aligned instead: A waits ONE slot for B's last MFMAs, both groups run their
+        // epilogues side by side, and B waits one slot after it to fall behind again, exactly as at kernel start.
+        // Measured: GELU 3.45 -> 3.41 ms, bias 3.18 -> 3.16 ms (N = 4096) -- only 1-2 %, because the stamps of the aligned
+        // form show the real bound: the two epilogues together still take 8.6 k cycles, i.e. the 128 store instructions of
+        // a tile (1 KiB each) issue at ~15 B/clk/CU whoever issues them (store-ISSUE bound, MI355X_MICROARCH.md's
+        // "epilogue store tail" row); hiding them needs independent MFMA work on the CU, which one 8-wave workgroup with
+        // 128 accumulator registers per wave does not have.
+        const bool align = (p.xp & 4) == 0;    // default on (bit 2 of TT_GEMM_XP turns it OFF: the A/B switch)
+        if (align && !late) TT_SLOT_END();
 
         // the epilogue's per-lane addresses are recomputed per tile from an opaque copy of the lane id: hoisted out
         // of the tile loop they would stay live through the main loop
@@ -1181,12 +1212,17 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_p(GemmParams p, int 
         else
             epilogue_all<EPI, false, FP8>(p, acc, smem, kBiasOff + bpar * 1024, kScaleOff + bpar * 2048, m0, n0, wm, wn, wave, lane_e,
                                           false, NoNext{});
-        if (!has_next) break;
+        pstamp(101);                                  // epilogue done (stores issued)
+        ++tile_no;
+        if (!has_next) {
+            if (!align && !late) TT_SLOT_END();   // match the extra barrier the late group took up front
+            break;
+        }
+        if (align && late) TT_SLOT_END();         // fall one slot behind again
         v = vn; m0 = m1; n0 = n1; bpar ^= 1; first = false;
         vn = next_valid(v, m1, n1);
         has_next = vn < nwg;
     }
-    if (!late) TT_SLOT_END();   // match the extra barrier the late group took up front
 }
 #undef TT_SLOT_END
 }  // namespace v3
@@ -1341,6 +1377,16 @@ int launch(const GemmParams& p, hipStream_t st) {
         auto kern = v3::gemm_kernel_v3<EPI, 4>;
         if constexpr (EPI == TT_EPI_BIAS) {   // diagnostic build of the 4-slot loop with s_memtime stamps (tools/gemm_stamps)
             static const int abl = [] { const char* e = getenv("TT_GEMM_ABLATE"); return e && e[0] ? atoi(e) : 0; }();
+            if (abl == 8) {   // stamped persistent kernel (tools/gemm_stamps_p)
+                const int cus8 = tt_cu_count_cached() / 8 * 8;
+                TT_SET_MAX_LDS((v3::gemm_kernel_p<EPI, false, true>), v3::kLds3);
+                GemmParams q8 = p;
+                q8.sn = SN;
+                q8.xp = xp;
+                hipLaunchKernelGGL((v3::gemm_kernel_p<EPI, false, true>), dim3(cus8), dim3(v3::kThreads3), v3::kLds3, st, q8, blocks);
+                TT_CHECK_LAUNCH();
+                return TT_OK;
+            }
             if (abl == 6) kern = v3::gemm_kernel_v3<EPI, 46>;
             if (abl == 7) kern = v3::gemm_kernel_v3<EPI, 47>;   // chunk-major store experiment (output layout differs!)
             if (abl == 6 || abl == 7) TT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, v3::kLds3));
