@@ -381,6 +381,8 @@ def main():
                             f"this tree is {csrc_sha256()[:12]}: refused")
         else:
             traffic = {k: tj[k]["hbm_bytes_per_launch"] for k in traffic if k in tj}
+            if scan_only is not None and "scan_tiled_256q" in tj and scan_only["filter_pass"]["queries_per_launch"] == 256:
+                scan_only["filter_pass"]["traffic"] = tj["scan_tiled_256q"]["hbm_bytes_per_launch"]   # PMC, same run of passes
 
     out = {
         "metric": "queries/sec (embed+top-k+rerank) over 10M x 1024 corpus",
