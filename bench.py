@@ -153,7 +153,7 @@ def main():
     # partial top-k -> tt_topk_merge.  Node tables are lazy (ids derived from the row), see the surface leg.
     shard_rows = synth_corpus_shard(hi - lo, D, 1234 + rank, dev)
     corpus = ShardedHipVectorIndex(D, shard_rows, lo, args.corpus_rows, None, None, score_mode="cosine",
-                                   queries="partitioned")
+                                   queries="partitioned", ragged_queries=False)    # every rank brings Bq queries
     embedder = Encoder(EncoderWeights(emb_cfg, synthetic_state_device(emb_cfg, dev, seed=1), dev))
     reranker = Encoder(EncoderWeights(rr_cfg, synthetic_state_device(rr_cfg, dev, seed=2), dev))
     vocab = emb_cfg.vocab_size

@@ -43,7 +43,7 @@ def _world(group) -> Tuple[int, int]:
 class ShardedHipVectorIndex:
     def __init__(self, dim: int, local_rows: torch.Tensor, row_lo: int, n_total: int, leaf_ids: Sequence[Optional[str]],
                  docstore: Dict[str, TextNode], embed_model=None, score_mode: str = "chroma", group=None,
-                 logical_shards: int = 1, queries: str = "replicated",
+                 logical_shards: int = 1, queries: str = "replicated", ragged_queries: bool = True,
                  scan_fn: Optional[Callable] = None, merge_fn: Optional[Callable] = None):
         if queries not in ("replicated", "partitioned"):
             raise ValueError("queries must be 'replicated' or 'partitioned'")
@@ -63,6 +63,7 @@ class ShardedHipVectorIndex:
         self.score_mode = score_mode
         self.group = group
         self.queries = queries
+        self.ragged_queries = ragged_queries      # partitioned mode: ranks may bring different query counts (one extra tiny all-gather)
         # product path: the HIP scan / merge kernels.  (The gloo protocol test injects CPU stand-ins: the exchange and
         # the row bookkeeping are what it checks.)
         if scan_fn is None or merge_fn is None:
@@ -136,10 +137,25 @@ class ShardedHipVectorIndex:
             return self._local_topk(q16, k)
         with self._collective_lock:
             nq = q16.shape[0]
-            all_q = _sh.gather_queries(q16, self.group) if self.queries == "partitioned" else q16
+            if self.queries == "partitioned" and not self.ragged_queries:
+                nmax, all_q = nq, _sh.gather_queries(q16, self.group)
+            elif self.queries == "partitioned":
+                # ranks may bring different numbers of queries: agree on the largest count (one tiny all-gather), pad
+                # with zero rows (they score 0 everywhere and are dropped again), gather, scan, keep this rank's slice
+                counts = torch.zeros(world, dtype=torch.int64, device=q16.device)
+                dist.all_gather_into_tensor(counts, torch.tensor([nq], dtype=torch.int64, device=q16.device), group=self.group)
+                nmax = int(counts.max().item())
+                if nmax == 0:
+                    return (torch.empty((0, k), dtype=torch.float32, device=q16.device),
+                            torch.empty((0, k), dtype=torch.int32, device=q16.device))
+                if nq < nmax:
+                    q16 = torch.cat([q16, torch.zeros((nmax - nq, q16.shape[1]), dtype=q16.dtype, device=q16.device)], 0)
+                all_q = _sh.gather_queries(q16, self.group)
+            else:
+                nmax, all_q = nq, q16
             s, i = _sh.sharded_topk(lambda qq, kk: self._local_topk(qq, kk), self._merge, all_q, k, self.group)
             if self.queries == "partitioned":
-                s, i = s[rank * nq:(rank + 1) * nq], i[rank * nq:(rank + 1) * nq]
+                s, i = s[rank * nmax: rank * nmax + nq], i[rank * nmax: rank * nmax + nq]
             return s, i
 
     def as_retriever(self, similarity_top_k: int = 10, coalesce: bool = True, max_batch: int = 64,

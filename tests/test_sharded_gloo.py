@@ -120,6 +120,16 @@ def _retriever_worker(rank, world, port, n_total, d, k, mode, ret):
         retr = index.as_retriever(similarity_top_k=k)
         # replicated: every rank asks the same two questions; partitioned: rank r asks questions 2r, 2r+1
         mine = [0, 1] if mode == "replicated" else [2 * rank, 2 * rank + 1]
+        if mode == "partitioned":
+            # ranks may bring DIFFERENT numbers of queries to one collective round (rank 0: three, rank 1: one)
+            emb = queries[[0, 1, 2]] if rank == 0 else queries[[3]]
+            s_r, i_r = index.search(emb.float(), k)
+            want = [0, 1, 2] if rank == 0 else [3]
+            assert s_r.shape == (len(want), k)
+            ws, wi, wgap = osc.scan_topk(corpus, queries[want], k)
+            for j in range(len(want)):
+                if wgap[j] > 1e-6:
+                    assert i_r[j].tolist() == wi[j].tolist()
         out = []
         for qi in mine:
             hits = retr.retrieve(QueryBundle(query_str=f"q{qi}", embedding=queries[qi].float().tolist()))
