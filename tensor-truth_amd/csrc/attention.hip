@@ -46,7 +46,7 @@ __device__ __forceinline__ void lds_wait2n(u32x4& a, u32x4& b) {
     asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
 }
 
-template <int DH>
+template <int DH, bool STAMP = false>
 __global__ __launch_bounds__(64 * kWaves, 4) void attention_kernel(AttnParams p) {
     constexpr int RB = DH * 2;              // bytes per K row
     constexpr int CH = RB / 16;             // 16-B chunks per K row
@@ -64,6 +64,19 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attention_kernel(AttnParams p)
     // round-robin to DIFFERENT XCDs and each fetches K and V again (3.4 GB instead of 1.4 GB per launch at 800 x 292).
     // XCD-aware order (TT_ATT_XCD=1): linear id L goes to XCD L % 8, so slot t = L / 8 of an XCD walks (pair, query tile)
     // with the tile fastest -- the tiles of a pair run back to back on one XCD and share its L2.
+    // diagnostic build (tools/att_stamps): waves 0..3 of ONE workgroup (the one in the middle of the grid) stamp their phases
+    int st_i = 0;
+    auto stamp = [&]() {
+        if constexpr (STAMP) {
+            if (p.dbg && blockIdx.x == gridDim.x / 2 && (threadIdx.x & 63) == 0 && st_i < 60) {
+                __builtin_amdgcn_sched_barrier(0);
+                p.dbg[(threadIdx.x >> 6) * 64 + st_i] = __builtin_amdgcn_s_memtime();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            ++st_i;
+        }
+    };
+    stamp();                                   // 0: entry
     const int nqt = p.n_qt > 0 ? p.n_qt : -p.n_qt;
     const int L = blockIdx.x, t = L >> 3;
     // (n_qt < 0: TT_ATT_XCD=0, the plain order -- tile fastest over ALL workgroups -- kept as the A/B switch)
@@ -149,12 +162,16 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attention_kernel(AttnParams p)
     const uint32_t voff = lds0 + NPK * 1024 + (hh * DH + ql) * 16;    // + (4j + 2 s2) * DH*16 + 32*dt*16
 
     issue_tile(0);
+    stamp();                                   // 1: Q loads + tile 0 copies issued
     for (int kt = 0; kt < n_kt; ++kt) {
         const int k0 = kt * kKTile;
+        stamp();                               // 2 + 6 kt: tile top
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile kt have landed
+        stamp();                               // +1: own copies landed
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();                       // ... everyone's; and tile kt-1 is no longer read
         __builtin_amdgcn_sched_barrier(0);
+        stamp();                               // +2: past the barrier
         if (kt + 1 < n_kt) issue_tile(kt + 1);
         if (!wave_active) continue;
         const uint32_t bufo = (kt & 1) * BUF;
@@ -186,6 +203,8 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attention_kernel(AttnParams p)
                     acc_s[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[j][s]), qf[s], acc_s[j], 0, 0, 0);
             }
         }
+        if constexpr (STAMP) { asm volatile("" :: "v"(acc_s[0][0]), "v"(acc_s[1][15])); }
+        stamp();                               // +3: S = K.Q^T issued (results consumed next)
         // V fragments of the first 32 keys: in flight during the softmax
         u32x4 vf[2][2];   // [s2][dt]
         const uint32_t vaddr = voff + bufo;
@@ -248,6 +267,8 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attention_kernel(AttnParams p)
                 for (int r = 0; r < 16; ++r) acc_o[d][r] *= alpha;
         }
 
+        if constexpr (STAMP) { asm volatile("" :: "v"(acc_s[0][0]), "v"(acc_s[1][15]), "v"(l_run)); }
+        stamp();                               // +4: softmax done
         // ---- O^T += V^T . P^T ----------------------------------------------------------------------
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -279,6 +300,7 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attention_kernel(AttnParams p)
         }
     }
 
+    stamp();                                   // loop done
     // ---- normalise and store: lane = query row, registers = 4 consecutive d ------------------
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
@@ -396,7 +418,9 @@ int tt_attention_launch(const AttnParams& p, hipStream_t st) {
     static const bool xcd = [] { const char* e = getenv("TT_ATT_XCD"); return e && e[0] == '1'; }();
     q.n_qt = xcd ? n_qt : -n_qt;
     TtProfScope prof(TT_K_ATTENTION, st);
-    if (p.head_dim == 64) {
+    if (p.head_dim == 64 && p.dbg) {
+        hipLaunchKernelGGL((attention_kernel<64, true>), grid, dim3(64 * kWaves), 0, st, q);
+    } else if (p.head_dim == 64) {
         hipLaunchKernelGGL(attention_kernel<64>, grid, dim3(64 * kWaves), 0, st, q);
     } else if (p.head_dim == 32) {
         hipLaunchKernelGGL(attention_kernel<32>, grid, dim3(64 * kWaves), 0, st, q);

@@ -56,6 +56,7 @@ struct AttnParams {
     float scale;              // 1/sqrt(head_dim)
     float lazy;               // set by the launcher: log2 slack of the running softmax reference
     int n_qt;                 // set by the launcher: query tiles per sequence (grid decode)
+    unsigned long long* dbg;  // diagnostic build only (tools/att_stamps): s_memtime stamps of one workgroup; NULL otherwise
 };
 int tt_attention_launch(const AttnParams& p, hipStream_t st);
 // CLS-only variant: one query row (seq_start[b]) per sequence; out row index = sequence index

@@ -374,6 +374,19 @@ int tt_gemm_fp8_ex(const void* a8, const float* a_scale, const void* w8, const f
     return tt_gemm_launch(g, epilogue, (hipStream_t)stream);
 }
 
+// diagnostic only (not in tt_hip.h): the varlen attention with s_memtime stamps of one workgroup (tools/att_stamps)
+int tt_attention_debug_stamps(const void* qk, int ld_qk, int q_col0, int k_col0, const void* vt, int ldvt, void* out,
+                              int ld_out, const int32_t* seq_start, const int32_t* seq_len, int n_seq, int heads,
+                              int head_dim, int max_len, void* stamps, void* stream) {
+    AttnParams a{};
+    a.qk = (const uint16_t*)qk; a.ld_qk = ld_qk; a.q_col0 = q_col0; a.k_col0 = k_col0;
+    a.vt = (const uint16_t*)vt; a.ldvt = ldvt; a.out = (uint16_t*)out; a.ld_out = ld_out;
+    a.seq_start = seq_start; a.seq_len = seq_len; a.n_seq = n_seq; a.heads = heads; a.head_dim = head_dim;
+    a.max_len = max_len; a.scale = 1.0f / sqrtf((float)head_dim);
+    a.dbg = (unsigned long long*)stamps;
+    return tt_attention_launch(a, (hipStream_t)stream);
+}
+
 // diagnostic only (not in tt_hip.h): run the bias GEMM with a stamp buffer in GemmParams.vt
 int tt_gemm_debug_stamps(const void* a, const void* w, const float* bias, void* c, int m, int n, int k, void* stamps,
                          void* stream) {
