@@ -5,8 +5,10 @@
 #include <stdlib.h>
 extern "C" int tt_gemm_debug_stamps(const void*, const void*, const float*, void*, int, int, int, void*, void*);
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
-int main() {
-    int M = 65536, N = 3072, K = 1024;
+int main(int argc, char** argv) {
+    // optional: M N K (a grid of a few workgroups shows the epilogue of a CU that has the memory system to itself)
+    int M = argc > 1 ? atoi(argv[1]) : 65536, N = argc > 2 ? atoi(argv[2]) : 3072, K = argc > 3 ? atoi(argv[3]) : 1024;
+    printf("M=%d N=%d K=%d: %d workgroups\n", M, N, K, (M / 256) * (N / 256));
     const int n_blocks_max = (M / 256) * (N / 256) + 64;
     uint16_t *a, *w, *c; float* bias; unsigned long long* st;
     CK(hipMalloc(&a, (size_t)M * K * 2)); CK(hipMalloc(&w, (size_t)N * K * 2)); CK(hipMalloc(&c, (size_t)M * N * 2));
