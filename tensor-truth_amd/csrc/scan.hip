@@ -398,10 +398,12 @@ int tt_scan_launch(const ScanParams& p, int dim, int mode, int out, int blocks, 
         case 256: return launch_d<256>(p, mode, out, blocks, q_tiles, stream);
         case 384: return launch_d<384>(p, mode, out, blocks, q_tiles, stream);
         case 512: return launch_d<512>(p, mode, out, blocks, q_tiles, stream);
+        case 640: return launch_d<640>(p, mode, out, blocks, q_tiles, stream);
         case 768: return launch_d<768>(p, mode, out, blocks, q_tiles, stream);
+        case 896: return launch_d<896>(p, mode, out, blocks, q_tiles, stream);
         case 1024: return launch_d<1024>(p, mode, out, blocks, q_tiles, stream);
         default:
-            tt_set_error("tt_scan: dim %d not in the compiled set {128,256,384,512,768,1024}", dim);
+            tt_set_error("tt_scan: dim %d not in the compiled set {128,256,...,1024: multiples of 128}", dim);
             return TT_E_UNSUPPORTED;
     }
 }

@@ -65,6 +65,7 @@ def test_config_c1_toy_corpus(dev, built_lib):
 @pytest.mark.parametrize("n,d,q,k", [
     (0, 128, 3, 5), (1, 128, 1, 4), (31, 256, 2, 8), (33, 512, 5, 64), (257, 768, 63, 50),
     (1000, 1024, 65, 10), (4097, 1024, 130, 50), (300, 128, 7, 1000), (65536, 384, 4, 50),
+    (2000, 640, 9, 20), (3000, 896, 70, 33),      # every multiple of 128 the header promises (include/tt_hip.h:52)
 ])
 def test_ragged_shapes_dense_path(dev, built_lib, n, d, q, k):
     from tensor_truth_amd import scan as tscan
@@ -86,6 +87,7 @@ def test_ragged_shapes_dense_path(dev, built_lib, n, d, q, k):
     (262_144, 512, 65, 10),       # smallest shard / batch on that path, no tail
     (280_000, 128, 300, 20),      # two 256-query blocks (the second one mostly padding), narrow rows
     (270_001, 384, 100, 128),     # bge-small width, k above a sort group
+    (90_000, 640, 20, 50), (263_000, 896, 80, 10),   # the widths between the common model sizes, both filter kernels
 ])
 def test_sampled_threshold_path(dev, built_lib, n, d, q, k):
     """Shards above 65536 rows: sample -> threshold -> filtered main pass -> select."""
