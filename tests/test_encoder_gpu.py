@@ -118,24 +118,18 @@ def test_layernorm(dev, built_lib, rows, h, eps):
     assert (err <= 2 ** -7 * ref.abs() + 2e-3).all(), err.max().item()
 
 
-@pytest.mark.parametrize("align", [8, 1])
-@pytest.mark.parametrize("heads,dh,lens", [(16, 64, [16, 9, 5, 12]), (12, 32, [16, 7, 11, 3]),
-                                           (4, 64, [300, 64, 65, 129, 1]), (2, 32, [513, 128]),
-                                           (2, 64, [1100])])
-def test_attention_varlen(dev, built_lib, heads, dh, lens, align):
+def _attention_case(dev, heads, dh, lens, align, q, k, v, max_abs=2e-2, mean_abs=2e-3):
+    """q, k, v: [T, heads * dh] bf16 (rows beyond the packed sequences are padding) -> checks every sequence against fp32 softmax."""
     from tensor_truth_amd import _lib
 
     lib = _lib.load_library()
     H = heads * dh
-    g = torch.Generator().manual_seed(sum(lens) + heads)
     starts, off = [], 0
     for n in lens:
         starts.append(off)
         off += (n + align - 1) // align * align      # align 1: sequences share 8-row token groups
-    T = (off + 127) // 128 * 128
-    q = _bf(torch.randn(T, H, generator=g))
-    k = _bf(torch.randn(T, H, generator=g))
-    v = _bf(torch.randn(T, H, generator=g))
+    T = q.shape[0]
+    assert T % 128 == 0 and T >= off
     qk = torch.cat([q, k], 1).contiguous()
     vt = v.view(T // 8, 8, H).permute(0, 2, 1).contiguous()   # V8 layout [T/8][H][8]
     out = torch.zeros(T, H, dtype=torch.bfloat16, device=dev)
@@ -147,6 +141,7 @@ def test_attention_varlen(dev, built_lib, heads, dh, lens, align):
                "attention")
     torch.cuda.synchronize()
     got = out.float().cpu()
+    assert torch.isfinite(got).all()
     for s0, n in zip(starts, lens):
         qq = q[s0:s0 + n].float().view(n, heads, dh).transpose(0, 1)
         kk = k[s0:s0 + n].float().view(n, heads, dh).transpose(0, 1)
@@ -155,8 +150,62 @@ def test_attention_varlen(dev, built_lib, heads, dh, lens, align):
         ref = (p @ vv).transpose(0, 1).reshape(n, H)
         err = (got[s0:s0 + n] - ref).abs()
         # P is rounded to bf16 before the PV product: error ~ 2^-8 * sum|p v|
-        assert err.max().item() < 2e-2, f"len {n}: max err {err.max().item()}"
-        assert err.mean().item() < 2e-3
+        assert err.max().item() < max_abs, f"len {n} at row {s0}: max err {err.max().item()}"
+        assert err.mean().item() < mean_abs
+
+
+def _padded_rows(lens, align):
+    off = sum((n + align - 1) // align * align for n in lens)
+    return (off + 127) // 128 * 128
+
+
+@pytest.mark.parametrize("align", [8, 1])
+@pytest.mark.parametrize("heads,dh,lens", [(16, 64, [16, 9, 5, 12]), (12, 32, [16, 7, 11, 3]),
+                                           (4, 64, [300, 64, 65, 129, 1]), (2, 32, [513, 128]),
+                                           (2, 64, [1100])])
+def test_attention_varlen(dev, built_lib, heads, dh, lens, align):
+    H = heads * dh
+    g = torch.Generator().manual_seed(sum(lens) + heads)
+    T = _padded_rows(lens, align)
+    q, k, v = (_bf(torch.randn(T, H, generator=g)) for _ in range(3))
+    _attention_case(dev, heads, dh, lens, align, q, k, v)
+
+
+@pytest.mark.parametrize("align", [8, 1])
+@pytest.mark.parametrize("heads,dh,seed", [(16, 64, 1), (12, 32, 2), (4, 64, 3)])
+def test_attention_random_length_mix(dev, built_lib, heads, dh, seed, align):
+    """Seeded sweep: 60 sequences of 1..700 tokens packed back to back (every query-tile / key-tile remainder, sequences
+    that start inside another sequence's 8-token V group when align = 1), the bench's 292 among them."""
+    rng = np.random.default_rng(seed)
+    lens = [int(x) for x in rng.integers(1, 700, size=57)] + [292, 292, 1]
+    H = heads * dh
+    g = torch.Generator().manual_seed(seed)
+    T = _padded_rows(lens, align)
+    q, k, v = (_bf(torch.randn(T, H, generator=g)) for _ in range(3))
+    _attention_case(dev, heads, dh, lens, align, q, k, v)
+
+
+@pytest.mark.parametrize("where", ["late", "early", "every_tile"])
+def test_attention_running_maximum_under_spiked_logits(dev, built_lib, where):
+    """The kernel's softmax reference is lazy (it only moves when a tile's maximum exceeds it by 2^8, attention.hip): logits
+    that jump by tens of units between key tiles -- a spike key late in the sequence, early, or a bigger one in every tile --
+    must still normalise like the fp32 softmax."""
+    heads, dh, lens = 4, 64, [292, 320, 64, 129]
+    H = heads * dh
+    g = torch.Generator().manual_seed(7)
+    T = _padded_rows(lens, 8)
+    q = torch.randn(T, H, generator=g)
+    k = torch.randn(T, H, generator=g) * 0.3
+    v = torch.randn(T, H, generator=g)
+    starts = np.cumsum([0] + [(n + 7) // 8 * 8 for n in lens[:-1]])
+    for s0, n in zip(starts, lens):
+        # spike keys: aligned with the mean query direction of the sequence, so EVERY query scores them far above the rest
+        d = torch.nn.functional.normalize(q[s0:s0 + n].view(n, heads, dh).mean(0), dim=-1).reshape(H)
+        q[s0:s0 + n] += 6.0 * d                       # every query has a large component along d
+        spots = {"late": [n - 3], "early": [1], "every_tile": list(range(5, n, 64))}[where]
+        for j, pos in enumerate(spots):
+            k[s0 + pos] = (4.0 + 3.0 * j) * d          # logits ~ 6 * (4 + 3 j) * 8 / 8 = +24, +42, +60 ... natural units
+    _attention_case(dev, heads, dh, lens, 8, _bf(q), _bf(k), _bf(v), max_abs=4e-2, mean_abs=4e-3)
 
 
 def _load_golden(golden_dir, name):
