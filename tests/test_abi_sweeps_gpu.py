@@ -1,0 +1,87 @@
+"""Seeded random sweeps of the smaller C-ABI entry points against the CPU oracle: the shard merge (`tt_topk_merge`,
+SURVEY.md 8e), the one-pass multi-module scan (`tt_scan_topk_segmented`, row a8) and the semantic splitter's adjacent
+distances (`tt_adjacent_cosine`, row f4).  Integer / index results bit-exact, fp32 values as in the fixed-shape tests."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import scan as osc
+from test_scan_gpu import _check
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_topk_merge_random_lists(dev, built_lib, seed):
+    """Random (queries, lists, k): padding entries (-inf / -1) anywhere, exact score ties across lists (tie-break by global
+    index), fewer live candidates than k, duplicate scores inside a list."""
+    from tensor_truth_amd import scan as tscan
+
+    rng = np.random.default_rng(900 + seed)
+    q, lists, k = int(rng.integers(1, 300)), int(rng.integers(1, 17)), int(rng.integers(1, 130))
+    per = int(rng.integers(1, k + 1)) if seed % 3 == 0 else k       # lists shorter than k now and then
+    m = lists * per
+    g = torch.Generator().manual_seed(seed)
+    # scores from a small set of values -> many exact ties; global indices unique per query
+    vals = (torch.randint(0, 40, (q, m), generator=g).float() / 8.0) if seed % 2 else torch.randn(q, m, generator=g)
+    # unique global indices per query, in random order, spread over the int32 range
+    idx = torch.stack([torch.randperm(m, generator=g) * 1000 + torch.randint(0, 1000, (m,), generator=g) for _ in range(q)])
+    idx = (idx * (2_000_000 // max(m, 1))).to(torch.int32)
+    pad = torch.rand(q, m, generator=g) < 0.15
+    vals[pad] = float("-inf")
+    idx[pad] = -1
+    want_v, want_i = osc.merge_topk(vals, idx.to(torch.int64), k)
+    got_v, got_i = tscan.topk_merge(vals.to(dev), idx.to(dev), k)
+    torch.cuda.synchronize()
+    assert torch.equal(got_i.cpu().to(torch.int64), want_i), (q, lists, per, k)
+    assert torch.equal(got_v.cpu(), want_v)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_segmented_scan_random_modules(dev, built_lib, seed):
+    """Random module tables: 1..16 modules of 0..90 000 rows (empty ones, ones shorter than k, ones longer than a selection
+    piece), rows before the first and after the last module that belong to nobody."""
+    from tensor_truth_amd import scan as tscan
+
+    rng = np.random.default_rng(300 + seed)
+    n_seg = int(rng.integers(1, 17))
+    sizes = [int(rng.choice([0, int(rng.integers(1, 64)), int(rng.integers(64, 5000)), int(rng.integers(5000, 90_000))],
+                            p=[0.15, 0.2, 0.4, 0.25])) for _ in range(n_seg)]
+    lead = int(rng.integers(0, 50))
+    offsets = [lead]
+    for s in sizes:
+        offsets.append(offsets[-1] + s)
+    d = int(rng.choice([128, 384, 640, 1024]))
+    k, nq = int(rng.integers(1, 101)), int(rng.integers(1, 9))
+    n = offsets[-1] + int(rng.integers(0, 300))
+    if n == 0:
+        n = 8
+    corpus = osc.synth_corpus(n, d, seed=seed + 40)
+    queries, _ = osc.synth_queries(corpus, nq, seed=seed + 41)
+    want_s, want_i, gap = osc.scan_topk_segmented(corpus, queries, k, offsets)
+    s, i = tscan.scan_topk_segmented(corpus.to(dev), queries.to(dev), k, offsets)
+    torch.cuda.synchronize()
+    assert s.shape == (nq, n_seg, k) and i.shape == (nq, n_seg, k)
+    _check(s.reshape(nq * n_seg, k), i.reshape(nq * n_seg, k), want_s.reshape(nq * n_seg, k),
+           want_i.reshape(nq * n_seg, k), gap.reshape(-1))
+    for m, size in enumerate(sizes):
+        if size == 0:
+            assert (i[:, m] == -1).all() and torch.isinf(s[:, m]).all()
+        else:
+            assert int(i[:, m].max()) < size, "module-local index out of its module"
+
+
+@pytest.mark.parametrize("n,h", [(2, 128), (3, 384), (17, 1024), (1000, 1024), (4097, 384), (33, 768), (20_000, 1024)])
+def test_adjacent_cosine_random(dev, built_lib, n, h):
+    from tensor_truth_amd.semantic import adjacent_distances
+
+    g = torch.Generator().manual_seed(n + h)
+    e = torch.randn(n, h, generator=g)
+    e[n // 2] = e[n // 2 - 1] * 3.0 if n > 2 else e[n // 2]         # a parallel pair: distance 0 whatever the norms
+    if n > 5:
+        e[3] = -e[4]                                                  # an antiparallel pair: distance 2
+    a, b = e[:-1].double(), e[1:].double()
+    want = (1.0 - (a * b).sum(1) / (a.norm(dim=1) * b.norm(dim=1))).float()
+    got = adjacent_distances(e.to(dev)).cpu()
+    assert got.shape == want.shape
+    assert (got - want).abs().max().item() < 2e-6
