@@ -410,3 +410,49 @@ def test_8192_token_sequence_through_the_encoder(dev, built_lib):
         assert bad < 1e-3 and err.max().item() < 0.25, (b, bad, err.max().item())
         # the LAST token attends over the whole sequence too: check it separately (tail key tile + position table end)
         assert err[-1].max().item() < 0.1
+
+
+_SWEEP_SHAPES = {
+    "xlmr256": dict(arch="xlmr", vocab_size=2000, hidden=256, layers=3, heads=4, ffn=512, max_pos=300, type_vocab=1, pad_id=1, ln_eps=1e-5, num_labels=1),
+    "bert384": dict(arch="bert", vocab_size=3000, hidden=384, layers=2, heads=12, ffn=1536, max_pos=512, type_vocab=2, pad_id=0, ln_eps=1e-12),
+    "xlmr1024": dict(arch="xlmr", vocab_size=4000, hidden=1024, layers=2, heads=16, ffn=4096, max_pos=514, type_vocab=1, pad_id=1, ln_eps=1e-5, num_labels=1),
+}
+
+
+@pytest.mark.parametrize("n_seq", [1, 2, 7, 64, 300])
+@pytest.mark.parametrize("shape", sorted(_SWEEP_SHAPES))
+def test_random_batch_mixes_embed_and_rerank(dev, built_lib, shape, n_seq):
+    """Seeded sweep over batch compositions: 1..300 sequences of 1..max tokens in one packed batch (token counts from a
+    handful to ~50 k: the skinny, 128x128 and 256x256 GEMM kernels, the CLS tail with many sequences, every attention tile
+    remainder), embeddings and cross-encoder scores against the oracle emulating the same bf16 rounding points."""
+    from tensor_truth_amd.encoder import Encoder, EncoderConfig, EncoderWeights
+
+    if shape == "xlmr1024" and n_seq == 300:
+        n_seq = 128                                       # (the CPU oracle at width 1024 sets this test's run time)
+    cfg_o = oe.EncoderConfig(**_SWEEP_SHAPES[shape])
+    cfg = EncoderConfig(**cfg_o.__dict__)
+    W = oe.synth_weights(cfg_o, seed=11)
+    Wb = {k: v.to(torch.bfloat16) for k, v in W.items()}
+    rng = np.random.default_rng(n_seq * 7 + len(shape))
+    L = cfg.max_seq_len
+    lens = [int(x) for x in rng.integers(1, L + 1, size=n_seq)]
+    lens[0] = L                                           # the longest admissible sequence is always there
+    if n_seq > 2:
+        lens[1] = 1                                       # ... and a single-token one
+    seqs = [[int(t) for t in rng.integers(4, cfg.vocab_size, size=n)] for n in lens]
+    enc = Encoder(EncoderWeights(cfg, W, dev))
+    emb, _ = enc.embed(seqs)
+    scores = enc.rerank(seqs) if cfg.arch == "xlmr" else None
+    torch.cuda.synchronize()
+    ids = torch.full((n_seq, L), cfg.pad_id, dtype=torch.int64)
+    mask = torch.zeros(n_seq, L, dtype=torch.int64)
+    for b, s in enumerate(seqs):
+        ids[b, :len(s)] = torch.tensor(s)
+        mask[b, :len(s)] = 1
+    want = oe.embed(ids, mask, Wb, cfg_o, emulate_bf16=True)
+    cos = (emb.cpu() * want).sum(1)
+    assert (cos >= 0.9995).all(), (cos.min().item(), int(cos.argmin()), lens[int(cos.argmin())])
+    if scores is not None:
+        want_s = torch.sigmoid(oe.rerank_logits(ids, mask, Wb, cfg_o, emulate_bf16=True))
+        err = (scores.cpu() - want_s).abs()
+        assert err.max().item() < 1.5e-2, (err.max().item(), int(err.argmax()), lens[int(err.argmax())])
