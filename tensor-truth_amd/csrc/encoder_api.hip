@@ -145,7 +145,15 @@ static int forward_impl(const tt_encoder_weights* w, const int32_t* ids, const i
         g.A = x; g.lda = H; g.W = (const uint16_t*)lw.qkv_w; g.bias = lw.qkv_b;
         g.C = qk; g.ldc = 2 * H; g.vt = vt; g.ldvt = 8 * H; g.vt_col0 = 2 * H;
         g.M = T; g.N = 3 * H; g.K = H;
-        if (e.fp8) {   // x's e4m3 copy and row scales come from the LayerNorm that produced x
+        // TT_FP8_MASK (diagnostic, default 0xF): which projections of an fp8 forward run in e4m3 -- bit 0 QKV, 1 attention
+        // output, 2 FFN-up, 3 FFN-down (needs bit 2: the intermediate is then written as e4m3); the others stay bf16
+        // (tools/probes/fp8_sensitivity.py: rank agreement with the fp32 path per mask)
+        // TT_FP8_SKIP_FIRST / TT_FP8_SKIP_LAST: that many layers at either end stay bf16 altogether
+        const int f8mask_all = [] { const char* m = getenv("TT_FP8_MASK"); return m && m[0] ? (int)strtol(m, nullptr, 0) : 0xF; }();
+        const int f8first = [] { const char* m = getenv("TT_FP8_SKIP_FIRST"); return m && m[0] ? atoi(m) : 0; }();
+        const int f8last = [] { const char* m = getenv("TT_FP8_SKIP_LAST"); return m && m[0] ? atoi(m) : 0; }();
+        const int f8mask = (l < f8first || l >= w->layers - f8last) ? 0 : f8mask_all;
+        if (e.fp8 && (f8mask & 1)) {   // x's e4m3 copy and row scales come from the LayerNorm that produced x
             g.A = (const uint16_t*)q8; g.W = (const uint16_t*)lw.qkv_w8; g.a_scale = q8s; g.w_scale = lw.qkv_wscale; g.fp8 = 1;
         }
         if (int rc = tt_gemm_launch(g, TT_EPI_QKV, st)) return rc;
@@ -199,7 +207,7 @@ static int forward_impl(const tt_encoder_weights* w, const int32_t* ids, const i
         GemmParams go{};
         go.A = ctx; go.lda = H; go.W = (const uint16_t*)lw.o_w; go.bias = lw.o_b;
         go.residual = x; go.ldr = H; go.C = y; go.ldc = H; go.M = T; go.N = H; go.K = H;
-        if (e.fp8 && lw.o_w8 && lw.o_wscale) {   // the QKV GEMM is done with q8: reuse it for the context's e4m3 copy
+        if (e.fp8 && (f8mask & 2) && lw.o_w8 && lw.o_wscale) {   // the QKV GEMM is done with q8: reuse it for the context's e4m3 copy
             {
                 TtProfScope prof(TT_K_ROWOPS, st);
                 if (int rc = tt_quantize_rows_launch(ctx, H, T, H, q8, q8s, st)) return rc;
@@ -216,8 +224,8 @@ static int forward_impl(const tt_encoder_weights* w, const int32_t* ids, const i
         GemmParams g1{};
         g1.A = x1; g1.lda = H; g1.W = (const uint16_t*)lw.ffn1_w; g1.bias = lw.ffn1_b;
         g1.C = ffn; g1.ldc = F; g1.M = T; g1.N = F; g1.K = H;
-        const bool f8 = e.fp8 && lw.ffn2_w8 && lw.ffn2_wscale && lw.ffn_act_scale > 0.f;
-        if (e.fp8) {
+        const bool f8 = e.fp8 && (f8mask & 12) == 12 && lw.ffn2_w8 && lw.ffn2_wscale && lw.ffn_act_scale > 0.f;
+        if (e.fp8 && (f8mask & 4)) {
             g1.A = (const uint16_t*)q8; g1.W = (const uint16_t*)lw.ffn1_w8; g1.a_scale = q8s; g1.w_scale = lw.ffn1_wscale; g1.fp8 = 1;
             if (f8) {   // the intermediate is written as e4m3 (static scale) into the same buffer, half its size
                 g1.C8 = (uint8_t*)ffn; g1.c8_inv_scale = 1.0f / lw.ffn_act_scale;
