@@ -632,6 +632,7 @@ def config5_leg(args, dev, emb_cfg, rr_cfg):
             "ingest_s": t_ingest, "docs_per_s": len(docs) / t_ingest, "leaves_per_s": index.n / t_ingest,
             "sentence_groups_per_s": n_sent / t_ingest,
             "queries_per_s": len(queries) / dt, "mean_sources": float(np.mean(res)),
+            "host_peak_rss_gb": __import__("resource").getrusage(__import__("resource").RUSAGE_SELF).ru_maxrss / 1048576.0,
             "what": ("build_index(chunking_strategy='semantic_hierarchical', chunk_sizes=[512,128,64]) on the bge-m3-shaped "
                      "embedder, then 128 queries from 32 threads through build_retrieval_service: auto-merging retriever "
                      f"(top-{args.top_k}) + fp8 (e4m3) bge-reranker-v2-m3-shaped postprocessor -> top-{args.top_n}")}

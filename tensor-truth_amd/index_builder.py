@@ -67,6 +67,24 @@ def build_index(documents: Sequence, embed_model, persist_dir: Optional[str] = N
     return index
 
 
+def build_index_sharded(documents: Sequence, embed_model, group=None, queries: str = "replicated", **build_kw):
+    """BASELINE.json config 5 on N GPUs: every rank parses, splits and embeds documents ``rank, rank + world, ...`` on its own
+    GPU (replica-parallel ingest, no collective: SURVEY.md section 8e) and the rank-local leaf rows become that rank's shard
+    of ONE global index (``ShardedHipVectorIndex.from_local_index``: row counts + host side tables exchanged once, no matrix
+    row moves).  ``documents`` is the same sequence on every rank.  -> the ``ShardedHipVectorIndex`` behind the Retriever
+    surface (``as_retriever`` / ``AutoMergingRetriever`` as for a single-device index)."""
+    import torch.distributed as dist
+
+    from .sharded_index import ShardedHipVectorIndex
+
+    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank(group) if world > 1 else 0
+    if build_kw.get("persist_dir") is not None:
+        raise ValueError("build_index_sharded: persist the shards per rank (index.persist) or persist a gathered index")
+    local = build_index(list(documents)[rank::world], embed_model, **build_kw)
+    return ShardedHipVectorIndex.from_local_index(local, group=group, queries=queries)
+
+
 class HipDocumentIndex:
     """Incremental per-document index: the add / remove / inspect half of the reference's ``DocumentIndexBuilder``
     (``src/tensortruth/document_index.py:427-581``) on a ``HipVectorIndex`` -- PDF conversion, metadata extraction and

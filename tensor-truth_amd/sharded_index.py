@@ -93,6 +93,49 @@ class ShardedHipVectorIndex:
                    group=group, **kw)
 
     @classmethod
+    def from_local(cls, dim: int, local_rows: torch.Tensor, local_leaf_ids: Sequence[str], local_docstore: Dict[str, TextNode],
+                   group=None, **kw) -> "ShardedHipVectorIndex":
+        """Every rank has ingested ITS OWN share of the documents (replica-parallel ingest, SURVEY.md section 8e: "chunks
+        partitioned, no collective") and holds the rows of its own leaves: stitch the shards into one global index WITHOUT
+        moving a matrix row.  Rank r's rows become global rows [sum(n_0..n_{r-1}), + n_r) (one all-gather of the counts);
+        the host side tables -- leaf id per row, and every node's text / metadata / links, which is what turns a hit on
+        another rank's rows into a node here -- are exchanged once with ``all_gather_object`` (text only: a few hundred
+        bytes per node against 2 KiB per matrix row)."""
+        world, rank = _world(group)
+        local_leaf_ids = list(local_leaf_ids)
+        if local_rows.shape[0] != len(local_leaf_ids):
+            raise ValueError(f"{local_rows.shape[0]} local rows but {len(local_leaf_ids)} local leaf ids")
+        if world == 1:
+            return cls(dim, local_rows, 0, len(local_leaf_ids), local_leaf_ids, dict(local_docstore), group=group, **kw)
+        from .vector_index import _node_to_dict
+
+        mine = (local_leaf_ids, {nid: _node_to_dict(nd) for nid, nd in local_docstore.items()})
+        parts: List = [None] * world
+        dist.all_gather_object(parts, mine, group=group)
+        counts = [len(p[0]) for p in parts]
+        leaf_ids: List[Optional[str]] = []
+        docstore: Dict[str, TextNode] = {}
+        for r, (ids, nodes) in enumerate(parts):
+            leaf_ids.extend(ids)
+            if r == rank:
+                docstore.update(local_docstore)           # keep this rank's own node objects as they are
+            else:
+                for nid, d in nodes.items():
+                    docstore.setdefault(nid, _node_from_dict(nid, d))
+        if len(set(i for i in leaf_ids if i is not None)) != sum(1 for i in leaf_ids if i is not None):
+            raise ValueError("the ranks' leaf ids collide: every document must be ingested by exactly one rank")
+        return cls(dim, local_rows, sum(counts[:rank]), sum(counts), leaf_ids, docstore, group=group, **kw)
+
+    @classmethod
+    def from_local_index(cls, index: HipVectorIndex, group=None, **kw) -> "ShardedHipVectorIndex":
+        """``from_local`` for a rank-local ``HipVectorIndex`` (e.g. ``build_index`` over this rank's documents)."""
+        index._compact()
+        mat, leaf_ids = index.snapshot()
+        return cls.from_local(index.dim, mat.contiguous(), leaf_ids, index.docstore, group=group,
+                              embed_model=kw.pop("embed_model", index.embed_model),
+                              score_mode=kw.pop("score_mode", index.score_mode), **kw)
+
+    @classmethod
     def load(cls, persist_dir: str, device=None, embed_model=None, score_mode: str = "chroma", group=None,
              **kw) -> "ShardedHipVectorIndex":
         """``HipVectorIndex.persist``'s directory: every rank reads nodes.json and ONLY its rows of the matrix

@@ -527,6 +527,38 @@ def test_build_index_strategies_persist_and_retrieve(dev, built_lib, tmp_path, s
         build_index(docs, emb, chunking_strategy="fixed")
 
 
+def test_build_index_sharded_in_one_process_equals_build_index(dev, built_lib):
+    """``build_index_sharded`` (BASELINE config 5 on N GPUs: rank-local ingest stitched into one sharded index; the N-rank
+    exchange is covered over gloo in test_sharded_gloo.py) with no process group = the single-device build: same rows in
+    the same order, same hits through the auto-merging retriever."""
+    from tensor_truth_amd.embedding import HipHuggingFaceEmbedding
+    from tensor_truth_amd.encoder import EncoderConfig
+    from tensor_truth_amd.index_builder import build_index, build_index_sharded
+    from tensor_truth_amd.retrievers import AutoMergingRetriever
+    from tensor_truth_amd.schema import QueryBundle, TextNode
+
+    cfg = EncoderConfig(**SMALL)
+    emb = HipHuggingFaceEmbedding("test/bge-small-shaped", device="cuda", embed_batch_size=64,
+                                  model_kwargs={"encoder_config": cfg, "synthetic_seed": 12})
+    base = _texts(160)
+    docs = [TextNode(text=". ".join(base[i * 20:(i + 1) * 20]) + ".", id_=f"doc{i}", metadata={"title": f"doc {i}"}) for i in range(8)]
+    kw = dict(chunking_strategy="hierarchical", chunk_sizes=[128, 48, 24], chunk_overlap=6)
+    one = build_index(docs, emb, **kw)
+    sharded = build_index_sharded(docs, emb, **kw)
+    assert sharded.n_total == one.n and sharded.row_lo == 0
+    # node ids are fresh uuids per build: compare through the row order (texts) and the scores
+    texts_one = [one.docstore[i].text for i in one.leaf_ids]
+    texts_sh = [sharded.docstore[i].text for i in sharded.leaf_ids]
+    assert texts_one == texts_sh
+    qb = QueryBundle(query_str="probe", embedding=one.matrix[one.n // 3].float().cpu().tolist())
+    h1 = AutoMergingRetriever(one.as_retriever(similarity_top_k=6), one.docstore).retrieve(qb)
+    h2 = AutoMergingRetriever(sharded.as_retriever(similarity_top_k=6), sharded.docstore).retrieve(qb)
+    assert [h.node.text for h in h1] == [h.node.text for h in h2]
+    assert [h.score for h in h1] == [h.score for h in h2]
+    with pytest.raises(ValueError):
+        build_index_sharded(docs, emb, persist_dir="/tmp/x", **kw)
+
+
 def test_document_index_add_remove_roundtrip(dev, built_lib, tmp_path):
     """add_documents / remove_document / counters of the reference's DocumentIndexBuilder (document_index.py:427-581)."""
     from tensor_truth_amd.embedding import HipHuggingFaceEmbedding

@@ -169,3 +169,87 @@ def test_two_rank_retrieve_through_the_plugin_surface(mode):
     assert seen == want_seen
     if mode == "replicated":      # identical answers on every rank
         assert outs[0] == outs[1]
+
+
+def _from_local_worker(rank, world, port, sizes, d, k, ret):
+    """Replica-parallel ingest (BASELINE config 5 on N GPUs): every rank holds ONLY the rows and nodes of the documents it
+    ingested (ragged shard sizes, one of them empty); ShardedHipVectorIndex.from_local stitches them into one global
+    index -- counts + host side tables exchanged once, no matrix row moves.  Scan / merge = CPU oracle stand-ins."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tensor_truth_amd.schema import QueryBundle, TextNode
+        from tensor_truth_amd.sharded_index import ShardedHipVectorIndex
+
+        n_total = sum(sizes)
+        corpus = osc.synth_corpus(n_total, d, seed=21)
+        queries, _ = osc.synth_queries(corpus, 4, seed=22)
+        lo = sum(sizes[:rank])
+        hi = lo + sizes[rank]
+        # this rank's own leaves and a parent node per 5 leaves (hierarchy links must survive the exchange)
+        leaf_ids = [f"r{rank}-leaf{j}" for j in range(lo, hi)]
+        docstore = {}
+        for j, nid in zip(range(lo, hi), leaf_ids):
+            nd = TextNode(text=f"text {j}", id_=nid, metadata={"row": j, "file_name": f"f{j}.md"})
+            nd.excluded_embed_metadata_keys = ["file_name"]
+            nd.parent_id = f"r{rank}-parent{j // 5}"
+            docstore[nid] = nd
+            par = docstore.setdefault(nd.parent_id, TextNode(text=f"parent of {j // 5}", id_=nd.parent_id, metadata={}))
+            par.child_ids = list(getattr(par, "child_ids", None) or []) + [nid]
+
+        def scan_fn(rows, q16, kk, base):
+            v, i, _ = osc.scan_topk(rows, q16, kk)
+            return v, torch.where(i >= 0, i + base, i).to(torch.int32)
+
+        def merge_fn(vals, idx, kk):
+            v, i = osc.merge_topk(vals, idx.to(torch.int64), kk)
+            return v, i.to(torch.int32)
+
+        index = ShardedHipVectorIndex.from_local(d, corpus[lo:hi].contiguous(), leaf_ids, docstore, score_mode="cosine",
+                                                 scan_fn=scan_fn, merge_fn=merge_fn)
+        assert index.n_total == n_total and index.row_lo == lo and len(index.leaf_ids) == n_total
+        retr = index.as_retriever(similarity_top_k=k)
+        out = []
+        for qi in range(4):
+            hits = retr.retrieve(QueryBundle(query_str=f"q{qi}", embedding=queries[qi].float().tolist()))
+            out.append([(h.node.id_, h.node.metadata["row"], h.node.text, h.node.parent_id,
+                         list(h.node.excluded_embed_metadata_keys), h.score) for h in hits])
+        # a parent that lives on ANOTHER rank resolves here too (what AutoMergingRetriever walks)
+        other = (rank + 1) % world
+        while sizes[other] == 0:
+            other = (other + 1) % world
+        other_lo = sum(sizes[:other])
+        par = index.docstore[f"r{other}-parent{other_lo // 5}"]
+        ret.put((rank, out, len(par.child_ids) >= 1))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_three_rank_index_from_rank_local_ingest():
+    world, sizes, d, k = 3, [203, 0, 120], 128, 9
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_from_local_worker, args=(r, world, port, sizes, d, k, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = [ret.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    n_total = sum(sizes)
+    corpus = osc.synth_corpus(n_total, d, seed=21)
+    queries, _ = osc.synth_queries(corpus, 4, seed=22)
+    want_s, want_i, gap = osc.scan_topk(corpus, queries, k)
+    owner = lambda row: 0 if row < sizes[0] else 2      # noqa: E731  (rank 1 ingested nothing)
+    assert all(o[2] for o in outs)
+    assert outs[0][1] == outs[1][1] == outs[2][1]        # replicated queries: identical answers on every rank
+    for qi, hits in enumerate(outs[0][1]):
+        assert len(hits) == k
+        for nid, row, text, parent, excl, _score in hits:
+            assert nid == f"r{owner(row)}-leaf{row}" and text == f"text {row}"
+            assert parent == f"r{owner(row)}-parent{row // 5}" and excl == ["file_name"]
+        if gap[qi] > 1e-6:
+            assert [h[1] for h in hits] == want_i[qi].tolist()
+        assert torch.allclose(torch.tensor([h[5] for h in hits]), want_s[qi], rtol=1e-5, atol=1e-6)
