@@ -86,17 +86,29 @@ class HipHuggingFaceEmbedding:
         self.text_instruction = text_instruction or ""
         # texts tokenized per pipeline step (see _embed_texts): one encoder batch -- sequences are packed without
         # padding tokens, so nothing is lost by sorting by length inside a window only
-        self.pipeline_window = int((model_kwargs or {}).get("pipeline_window", max(embed_batch_size, 256)))
+        self.pipeline_window = int((model_kwargs or {}).get("pipeline_window", max(embed_batch_size, 2048)))
+        # tokens per forward pass: ``embed_batch_size`` is the reference's unit (texts per padded batch); sequences are
+        # packed without padding here, so what the GEMMs see is the TOKEN count -- 128 sentence groups of ~50 tokens are
+        # 27 row tiles, a tenth of a CU-wave.  A forward therefore takes ``embed_batch_size`` texts and keeps adding texts
+        # (shorter ones: the window is sorted by length) until it holds ``forward_tokens`` tokens; results do not depend
+        # on the batching (bit-identical embeddings, tests/test_configs_gpu.py).
+        self.forward_tokens = int((model_kwargs or {}).get("forward_tokens", 131072))
 
     # ---- token-id level (what the kernels see) ------------------------------------------------
     def embed_token_batches(self, seqs: Sequence[Sequence[int]]) -> torch.Tensor:
         """Embeds tokenised sequences -> fp32 [n, H] on the device, original order."""
         order = sorted(range(len(seqs)), key=lambda i: -len(seqs[i]))
         parts = []
-        for lo in range(0, len(order), self.embed_batch_size):
-            sel = order[lo:lo + self.embed_batch_size]
+        lo = 0
+        while lo < len(order):
+            hi, tokens = lo, 0
+            while hi < len(order) and (hi - lo < self.embed_batch_size or tokens < self.forward_tokens):
+                tokens += min(len(seqs[order[hi]]), self.max_length)
+                hi += 1
+            sel = order[lo:hi]
             emb, _ = self._encoder.embed_packed(pack_tokens([seqs[i] for i in sel], self.config, None, self.max_length))
             parts.append(emb)
+            lo = hi
         out = torch.empty((len(seqs), self.config.hidden), dtype=torch.float32, device=self.device)
         if parts:  # one scatter back to the caller's order (one small index upload per call, not per batch)
             out[torch.tensor(order, dtype=torch.int64).to(self.device, non_blocking=True)] = torch.cat(parts)

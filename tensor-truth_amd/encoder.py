@@ -12,6 +12,7 @@ option, ``model_manager.py:218-229``); there is no CPU path.
 from __future__ import annotations
 
 import ctypes
+import itertools
 import os
 import threading
 from ctypes import POINTER, Structure, c_float, c_int32, c_void_p
@@ -338,29 +339,43 @@ def pack_tokens(seqs: Sequence[Sequence[int]], cfg: EncoderConfig,
     than ``max_len`` (default: the model's limit) are truncated on the right, as the
     reference's tokenizer call does (``truncation=True``)."""
     limit = cfg.max_seq_len if max_len is None else min(max_len, cfg.max_seq_len)
-    lens = np.array([min(len(s), limit) for s in seqs], dtype=np.int64)
-    if (lens <= 0).any():
+    n_seq = len(seqs)
+    lens = np.fromiter((min(len(s), limit) for s in seqs), dtype=np.int64, count=n_seq)
+    if n_seq == 0 or (lens <= 0).any():
         raise ValueError("empty token sequence")
-    starts = np.zeros(len(seqs), dtype=np.int64)
-    off = 0
-    for i, n in enumerate(lens):
-        starts[i] = off
-        off += (int(n) + _PACK_ALIGN - 1) // _PACK_ALIGN * _PACK_ALIGN
-    n_rows = _round_rows(off)
+    # no per-sequence Python work below: one flat copy of all tokens and one scatter (a 100k-document ingest packs ~10^7
+    # sequences; the per-sequence slice / arange loop was a third of the host time of an ingest batch)
+    aligned = (lens + _PACK_ALIGN - 1) // _PACK_ALIGN * _PACK_ALIGN
+    starts = np.zeros(n_seq, dtype=np.int64)
+    np.cumsum(aligned[:-1], out=starts[1:])
+    n_rows = _round_rows(int(aligned.sum()))
+    total = int(lens.sum())
+
+    def flat_of(rows) -> np.ndarray:
+        if all(isinstance(r, np.ndarray) for r in rows):
+            return np.concatenate([np.asarray(r[:n], dtype=np.int32) for r, n in zip(rows, lens)]) if n_seq > 1 else \
+                np.asarray(rows[0][: lens[0]], dtype=np.int32)
+        return np.fromiter(itertools.chain.from_iterable(r if len(r) == n else r[:n] for r, n in zip(rows, lens)),
+                           dtype=np.int32, count=total)
+
+    first = np.zeros(n_seq, dtype=np.int64)
+    np.cumsum(lens[:-1], out=first[1:])
+    within = np.arange(total, dtype=np.int64) - np.repeat(first, lens)
+    dest = np.repeat(starts, lens) + within
+    flat = flat_of(seqs)
+    if flat.min() < 0 or flat.max() >= cfg.vocab_size:
+        raise ValueError("token id outside the vocabulary")
     ids = np.full(n_rows, cfg.pad_id, dtype=np.int32)
     pos = np.zeros(n_rows, dtype=np.int32)
-    types = np.zeros(n_rows, dtype=np.int32) if type_ids is not None else None
     pos_off = cfg.pad_id + 1 if cfg.arch == "xlmr" else 0
-    for i, s in enumerate(seqs):
-        n, st = int(lens[i]), int(starts[i])
-        ids[st:st + n] = np.asarray(s[:n], dtype=np.int32)
-        pos[st:st + n] = np.arange(n, dtype=np.int32) + pos_off
-        if types is not None:
-            types[st:st + n] = np.asarray(type_ids[i][:n], dtype=np.int32)
-    if ids.min() < 0 or ids.max() >= cfg.vocab_size:
-        raise ValueError("token id outside the vocabulary")
+    ids[dest] = flat
+    pos[dest] = within + pos_off
+    types = None
+    if type_ids is not None:
+        types = np.zeros(n_rows, dtype=np.int32)
+        types[dest] = flat_of(type_ids)
     return PackedBatch(ids, pos, types, starts.astype(np.int32), lens.astype(np.int32), int(n_rows),
-                       int(lens.max()), int(lens.sum()))
+                       int(lens.max()), total)
 
 
 def pack_token_matrix(ids2d: np.ndarray, cfg: EncoderConfig, type_ids2d: Optional[np.ndarray] = None) -> PackedBatch:

@@ -20,45 +20,81 @@ DEFAULT_CHUNK_OVERLAP = 64                  # indexing/builder.py DEFAULT_CHUNK_
 CHUNKING_STRATEGIES = ("hierarchical", "semantic", "semantic_hierarchical")   # builder.py:48-66
 
 
-def parse_documents(documents: Sequence, embed_model, chunking_strategy: str = "hierarchical",
-                    chunk_sizes: Optional[Sequence[int]] = None, chunk_overlap: Optional[int] = None,
-                    semantic_buffer_size: int = 1, semantic_breakpoint_threshold: float = 95, node_parser=None) -> List:
-    """Strategy dispatch of builder.py:383-420.  ``node_parser``: any object with ``get_nodes_from_documents``
-    (e.g. llama-index's own HierarchicalNodeParser) to use instead of the host restatement."""
+def iter_parsed(documents: Sequence, embed_model, chunking_strategy: str = "hierarchical",
+                chunk_sizes: Optional[Sequence[int]] = None, chunk_overlap: Optional[int] = None,
+                semantic_buffer_size: int = 1, semantic_breakpoint_threshold: float = 95, node_parser=None,
+                sub_batch: int = 2048):
+    """Strategy dispatch of builder.py:383-420, yielding the nodes in document order in pieces of about ``sub_batch`` inputs
+    of the (host-only) hierarchical pass, so that a caller can hand each piece's leaves to the GPU while the next piece
+    is being split.  ``node_parser``: any object with ``get_nodes_from_documents`` (e.g. llama-index's own
+    HierarchicalNodeParser) to use instead of the host restatement."""
     if chunking_strategy not in CHUNKING_STRATEGIES:
         raise ValueError(f"'{chunking_strategy}' is not a valid ChunkingStrategy")
+    documents = list(documents)
     sizes = list(chunk_sizes) if chunk_sizes is not None else list(DEFAULT_CHUNK_SIZES)
     overlap = DEFAULT_CHUNK_OVERLAP if chunk_overlap is None else chunk_overlap
     hier = node_parser or HierarchicalNodeParser.from_defaults(chunk_sizes=sizes, chunk_overlap=overlap)
+    step = max(1, sub_batch)
     if chunking_strategy == "hierarchical":
-        return hier.get_nodes_from_documents(documents)
+        for lo in range(0, len(documents), step):
+            yield hier.get_nodes_from_documents(documents[lo:lo + step])
+        return
     sem = SemanticSplitter(embed_model, buffer_size=semantic_buffer_size,
                            breakpoint_percentile_threshold=semantic_breakpoint_threshold)
     semantic_nodes = sem.get_nodes_from_documents(documents)
     if chunking_strategy == "semantic":
-        return semantic_nodes
-    return hier.get_nodes_from_documents(semantic_nodes)
+        yield semantic_nodes
+        return
+    for lo in range(0, len(semantic_nodes), step):
+        yield hier.get_nodes_from_documents(semantic_nodes[lo:lo + step])
+
+
+def parse_documents(documents: Sequence, embed_model, chunking_strategy: str = "hierarchical",
+                    chunk_sizes: Optional[Sequence[int]] = None, chunk_overlap: Optional[int] = None,
+                    semantic_buffer_size: int = 1, semantic_breakpoint_threshold: float = 95, node_parser=None) -> List:
+    """All nodes of ``documents`` (``iter_parsed`` in one list)."""
+    out: List = []
+    for nodes in iter_parsed(documents, embed_model, chunking_strategy, chunk_sizes, chunk_overlap, semantic_buffer_size,
+                             semantic_breakpoint_threshold, node_parser):
+        out.extend(nodes)
+    return out
 
 
 def build_index(documents: Sequence, embed_model, persist_dir: Optional[str] = None,
                 chunking_strategy: str = "hierarchical", chunk_sizes: Optional[Sequence[int]] = None,
                 chunk_overlap: Optional[int] = None, semantic_buffer_size: int = 1,
                 semantic_breakpoint_threshold: float = 95, embedding_model: Optional[str] = None, node_parser=None,
-                progress_callback: Optional[Callable[[str, int, int], None]] = None) -> HipVectorIndex:
-    """-> the module's HipVectorIndex (persisted under ``persist_dir`` when given)."""
+                progress_callback: Optional[Callable[[str, int, int], None]] = None,
+                window_docs: int = 8192) -> HipVectorIndex:
+    """-> the module's HipVectorIndex (persisted under ``persist_dir`` when given).
+
+    Documents are processed in windows of ``window_docs`` (parse -> docstore -> embed the leaves -> append the rows), so a
+    100k-document build (BASELINE config 5) holds one window's sentence groups and strings at a time, not all of them.
+    Every step is per document (percentile thresholds, hierarchy, metadata) and rows are appended in document order: the
+    index is the one the reference's whole-corpus order of operations (builder.py:383-442) builds.  (A second thread
+    parsing window i + 1 while this one embeds window i was measured SLOWER -- 250-255 vs 270 docs/s at 8000 documents:
+    smaller windows mean shorter forward passes, and the overlap is already there without a thread, see the loop below.)
+    ``window_docs <= 0``: one window."""
+    documents = list(documents)
+    n_docs = len(documents)
+    if chunking_strategy not in CHUNKING_STRATEGIES:
+        raise ValueError(f"'{chunking_strategy}' is not a valid ChunkingStrategy")
     if progress_callback:
-        progress_callback("parsing", 0, len(documents))
-    nodes = parse_documents(documents, embed_model, chunking_strategy, chunk_sizes, chunk_overlap,
-                            semantic_buffer_size, semantic_breakpoint_threshold, node_parser)
-    leaves = get_leaf_nodes(nodes)
-    if progress_callback:
-        progress_callback("embedding", 0, len(leaves))
+        progress_callback("parsing", 0, n_docs)
     index = HipVectorIndex(embed_model.config.hidden if hasattr(embed_model, "config") else len(embed_model.get_text_embedding("x")),
                            embed_model=embed_model)
-    index.add_to_docstore(nodes)                       # storage_context.docstore.add_documents(nodes), builder.py:430
-    index.add(leaves, show_progress=True)              # VectorStoreIndex(leaf_nodes, ...), builder.py:437-442
+    step = max(n_docs, 1) if window_docs <= 0 else window_docs
+    for lo in range(0, max(n_docs, 1), step):
+        # the leaf forward passes of one piece are only ENQUEUED by index.add (nothing below waits for the GPU except the
+        # staging ring's back-pressure), so the GPU embeds piece i while this thread splits piece i + 1
+        for nodes in iter_parsed(documents[lo:lo + step], embed_model, chunking_strategy, chunk_sizes, chunk_overlap,
+                                 semantic_buffer_size, semantic_breakpoint_threshold, node_parser):
+            index.add_to_docstore(nodes)                   # storage_context.docstore.add_documents(nodes), builder.py:430
+            index.add(get_leaf_nodes(nodes), show_progress=True)   # VectorStoreIndex(leaf_nodes, ...), builder.py:437-442
+        if progress_callback and lo + step < n_docs:
+            progress_callback("embedding", index.n, index.n)
     if progress_callback:
-        progress_callback("embedding", len(leaves), len(leaves))
+        progress_callback("embedding", index.n, index.n)
     if persist_dir is not None:
         sizes = list(chunk_sizes) if chunk_sizes is not None else list(DEFAULT_CHUNK_SIZES)
         index.persist(persist_dir, embedding_model=embedding_model or getattr(embed_model, "model_name", None),

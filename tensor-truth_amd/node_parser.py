@@ -12,6 +12,7 @@ the structure (levels, links, overlap semantics, metadata inheritance) is what t
 """
 from __future__ import annotations
 
+import functools
 import re
 from typing import Callable, Iterable, List, Optional, Sequence
 
@@ -22,7 +23,9 @@ _SENTENCE = re.compile(r"[^.!?\n]+[.!?]*\s*|\n+")
 _PARAGRAPH = re.compile(r"\n\s*\n")
 
 
+@functools.lru_cache(maxsize=1 << 16)
 def count_tokens(text: str) -> int:
+    # cached: every level of the hierarchy re-splits the text of the level above into (mostly) the same sentences
     return len(_TOKEN.findall(text))
 
 
@@ -37,47 +40,53 @@ class SentenceSplitter:
         self.chunk_size, self.chunk_overlap = chunk_size, chunk_overlap
         self._count = tokenizer or count_tokens
 
-    def _pieces(self, text: str) -> List[str]:
-        out = []
+    def _pieces(self, text: str):
+        """-> (pieces, their token counts): every piece is counted ONCE (the counter is the splitter's inner loop)."""
+        out, sizes = [], []
         for para in _PARAGRAPH.split(text):
             for m in _SENTENCE.finditer(para):
                 s = m.group(0)
                 if not s.strip():
                     continue
-                if self._count(s) <= self.chunk_size:
+                c = self._count(s)
+                if c <= self.chunk_size:
                     out.append(s)
+                    sizes.append(c)
                     continue
                 words, cur, n = re.findall(r"\S+\s*", s), [], 0      # oversized sentence: cut at words
                 for w in words:
                     c = self._count(w)
                     if cur and n + c > self.chunk_size:
                         out.append("".join(cur))
+                        sizes.append(n)
                         cur, n = [], 0
                     cur.append(w)
                     n += c
                 if cur:
                     out.append("".join(cur))
+                    sizes.append(n)
             if out and not out[-1].endswith("\n"):
-                out[-1] = out[-1] + "\n"
-        return out
+                out[-1] = out[-1] + "\n"      # (a newline is white space: the piece's token count is unchanged)
+        return out, sizes
 
     def split_text(self, text: str) -> List[str]:
-        pieces = self._pieces(text)
-        sizes = [self._count(p) for p in pieces]
-        chunks, cur, n, i = [], [], 0, 0
+        pieces, sizes = self._pieces(text)
+        chunks, cur, cur_n, n, i = [], [], [], 0, 0
         while i < len(pieces):
             if cur and n + sizes[i] > self.chunk_size:
                 chunks.append("".join(cur).strip())
-                keep, kn = [], 0                                       # overlap: trailing pieces of the closed chunk
+                keep, keep_n, kn = [], [], 0                           # overlap: trailing pieces of the closed chunk
                 for j in range(len(cur) - 1, -1, -1):
-                    c = self._count(cur[j])
+                    c = cur_n[j]
                     if kn + c > self.chunk_overlap or kn + c + sizes[i] > self.chunk_size:
                         break
                     keep.insert(0, cur[j])
+                    keep_n.insert(0, c)
                     kn += c
-                cur, n = keep, kn
+                cur, cur_n, n = keep, keep_n, kn
                 continue
             cur.append(pieces[i])
+            cur_n.append(sizes[i])
             n += sizes[i]
             i += 1
         if cur and "".join(cur).strip():

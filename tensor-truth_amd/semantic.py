@@ -82,6 +82,10 @@ class SemanticSplitter:
         straddling two documents is skipped) and its percentile threshold is taken over that slice -- the same
         cuts as one call per document (the reference's behaviour), at batch throughput: a 100k-document ingest
         (BASELINE config 5) is ~10^7 sentence groups, not 10^5 small launches."""
+        return self._finish_split(self._begin_split(texts))
+
+    def _begin_split(self, texts: Sequence[str]):
+        """Host half + ENQUEUE of the device half (group embeddings, adjacent distances): nothing here waits for the GPU."""
         sents = [split_sentences(t) for t in texts]
         spans, groups = [], []
         for ss in sents:
@@ -90,7 +94,25 @@ class SemanticSplitter:
                 groups.extend(self._groups(ss))
             else:
                 spans.append(None)
-        dist = adjacent_distances(self._embed_groups(groups)).cpu().numpy() if groups else np.zeros(0, np.float32)
+        fetch = None
+        if groups:
+            # the copy back is enqueued HERE, behind this call's own work, with an event of its own: fetching it later
+            # waits for this call only, not for whatever was enqueued after it (the next call's forward passes)
+            d = adjacent_distances(self._embed_groups(groups))
+            host = torch.empty(d.shape, dtype=d.dtype, pin_memory=True)
+            host.copy_(d, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(d.device))
+            fetch = (host, ev)
+        return texts, sents, spans, fetch
+
+    def _finish_split(self, state) -> List[List[str]]:
+        texts, sents, spans, fetch = state
+        if fetch is not None:
+            fetch[1].synchronize()
+            dist = fetch[0].numpy()
+        else:
+            dist = np.zeros(0, np.float32)
         out = []
         for text, ss, span in zip(texts, sents, spans):
             if span is None:
@@ -108,14 +130,22 @@ class SemanticSplitter:
         docs = list(documents)
         texts = [d.get_content() if hasattr(d, "get_content") else str(d) for d in docs]
         nodes: List[TextNode] = []
-        lo = 0
+        # documents per embedding call: bounded by the number of sentence groups (host memory for the strings)
+        calls, lo = [], 0
         while lo < len(docs):
-            # documents per embedding call: bounded by the number of sentence groups (host memory for the strings)
             hi, budget = lo, max_groups_per_call
             while hi < len(docs) and (hi == lo or budget > 0):
                 budget -= max(1, texts[hi].count(".") + texts[hi].count("\n"))
                 hi += 1
-            for doc, chunks in zip(docs[lo:hi], self.split_texts(texts[lo:hi])):
+            calls.append((lo, hi))
+            lo = hi
+        # software pipeline: call i + 1's sentence groups are tokenized and their forward passes enqueued BEFORE call i's
+        # distances are fetched, so the GPU embeds them while the host cuts call i's documents and builds its nodes
+        pending = self._begin_split(texts[calls[0][0]:calls[0][1]]) if calls else None
+        for ci, (lo, hi) in enumerate(calls):
+            state = pending
+            pending = self._begin_split(texts[calls[ci + 1][0]:calls[ci + 1][1]]) if ci + 1 < len(calls) else None
+            for doc, chunks in zip(docs[lo:hi], self._finish_split(state)):
                 meta = dict(getattr(doc, "metadata", {}) or {})
                 prev: Optional[TextNode] = None
                 for chunk in chunks:
@@ -136,5 +166,4 @@ class SemanticSplitter:
                             pass
                     nodes.append(nd)
                     prev = nd
-            lo = hi
         return nodes

@@ -648,3 +648,123 @@ def test_two_phase_coalescer_prepares_the_next_batch_while_one_executes():
     with pytest.raises(KeyError):
         ok.submit(1)
     assert c.submit(7) == 107
+
+
+def test_pack_tokens_vectorised_equals_the_per_sequence_loop():
+    """pack_tokens (one flat copy + one scatter) against the straightforward per-sequence restatement: ragged lengths,
+    truncation at the model limit and at max_len, token-type ids, list and ndarray rows, both position conventions."""
+    from tensor_truth_amd import encoder as enc
+
+    def reference(seqs, cfg, type_ids, max_len):
+        limit = cfg.max_seq_len if max_len is None else min(max_len, cfg.max_seq_len)
+        lens = [min(len(s), limit) for s in seqs]
+        starts, off = [], 0
+        for n in lens:
+            starts.append(off)
+            off += (n + enc._PACK_ALIGN - 1) // enc._PACK_ALIGN * enc._PACK_ALIGN
+        n_rows = enc._round_rows(off)
+        ids = np.full(n_rows, cfg.pad_id, dtype=np.int32)
+        pos = np.zeros(n_rows, dtype=np.int32)
+        types = np.zeros(n_rows, dtype=np.int32) if type_ids is not None else None
+        pos_off = cfg.pad_id + 1 if cfg.arch == "xlmr" else 0
+        for i, s in enumerate(seqs):
+            n, st = lens[i], starts[i]
+            ids[st:st + n] = np.asarray(s[:n], dtype=np.int32)
+            pos[st:st + n] = np.arange(n, dtype=np.int32) + pos_off
+            if types is not None:
+                types[st:st + n] = np.asarray(type_ids[i][:n], dtype=np.int32)
+        return ids, pos, types, np.array(starts, np.int32), np.array(lens, np.int32), n_rows
+
+    rng = np.random.default_rng(3)
+    xlmr = enc.EncoderConfig(arch="xlmr", vocab_size=500, hidden=128, layers=1, heads=2, ffn=256, max_pos=130, type_vocab=1,
+                             pad_id=1, ln_eps=1e-5)
+    bert = enc.EncoderConfig(arch="bert", vocab_size=700, hidden=128, layers=1, heads=2, ffn=256, max_pos=64, type_vocab=2,
+                             pad_id=0, ln_eps=1e-12)
+    for trial in range(40):
+        cfg = xlmr if trial % 2 else bert
+        n_seq = int(rng.integers(1, 70))
+        lens = rng.integers(1, 200, size=n_seq)
+        as_arrays = trial % 3 == 0
+        seqs = [rng.integers(0, cfg.vocab_size, size=int(n), dtype=np.int32) for n in lens]
+        tys = [rng.integers(0, 2, size=int(n) + (trial % 4 == 0), dtype=np.int32) for n in lens] if cfg.arch == "bert" else None
+        if not as_arrays:
+            seqs = [s.tolist() for s in seqs]
+            tys = [t.tolist() for t in tys] if tys is not None else None
+        max_len = None if trial % 5 else int(rng.integers(4, 50))
+        got = enc.pack_tokens(seqs, cfg, tys, max_len)
+        ids, pos, types, starts, ln, n_rows = reference(seqs, cfg, tys, max_len)
+        assert got.n_rows == n_rows and got.max_len == int(ln.max()) and got.n_tokens == int(ln.sum())
+        assert np.array_equal(got.ids, ids) and np.array_equal(got.pos, pos)
+        assert np.array_equal(got.seq_start, starts) and np.array_equal(got.seq_len, ln)
+        assert (got.types is None) == (types is None) and (types is None or np.array_equal(got.types, types))
+        assert got.ids.dtype == np.int32 and got.pos.dtype == np.int32 and got.seq_start.dtype == np.int32
+    with pytest.raises(ValueError):
+        enc.pack_tokens([[1, 2], []], xlmr)
+    with pytest.raises(ValueError):
+        enc.pack_tokens([[1, 2, 9999]], xlmr)
+
+
+def test_sentence_splitter_counts_once_but_cuts_as_before():
+    """The splitter counts each piece once and carries the counts (the counter was its inner loop: 3-4 regex passes per
+    sentence and level); the chunks must be the ones the recount-everything formulation yields."""
+    import re
+
+    from tensor_truth_amd.node_parser import _PARAGRAPH, _SENTENCE, SentenceSplitter, count_tokens
+
+    def old_split(text, chunk_size, chunk_overlap):
+        out = []
+        for para in _PARAGRAPH.split(text):
+            for m in _SENTENCE.finditer(para):
+                s = m.group(0)
+                if not s.strip():
+                    continue
+                if count_tokens(s) <= chunk_size:
+                    out.append(s)
+                    continue
+                words, cur, n = re.findall(r"\S+\s*", s), [], 0
+                for w in words:
+                    c = count_tokens(w)
+                    if cur and n + c > chunk_size:
+                        out.append("".join(cur))
+                        cur, n = [], 0
+                    cur.append(w)
+                    n += c
+                if cur:
+                    out.append("".join(cur))
+            if out and not out[-1].endswith("\n"):
+                out[-1] = out[-1] + "\n"
+        pieces = out
+        sizes = [count_tokens(p) for p in pieces]
+        chunks, cur, n, i = [], [], 0, 0
+        while i < len(pieces):
+            if cur and n + sizes[i] > chunk_size:
+                chunks.append("".join(cur).strip())
+                keep, kn = [], 0
+                for j in range(len(cur) - 1, -1, -1):
+                    c = count_tokens(cur[j])
+                    if kn + c > chunk_overlap or kn + c + sizes[i] > chunk_size:
+                        break
+                    keep.insert(0, cur[j])
+                    kn += c
+                cur, n = keep, kn
+                continue
+            cur.append(pieces[i])
+            n += sizes[i]
+            i += 1
+        if cur and "".join(cur).strip():
+            chunks.append("".join(cur).strip())
+        return [c for c in chunks if c]
+
+    rng = np.random.default_rng(8)
+    words = ["alpha", "beta,", "gamma", "delta;", "x", "supercalifragilistic", "e.g", "42", "(note)", "end"]
+    for trial in range(60):
+        sents = []
+        for _ in range(int(rng.integers(1, 40))):
+            n = int(rng.integers(1, 60 if trial % 7 else 300))
+            sents.append(" ".join(words[int(j)] for j in rng.integers(0, len(words), size=n)) + str(rng.choice([".", "!", "?", ""])))
+        text = ""
+        for s in sents:
+            text += s + str(rng.choice([" ", "  ", "\n", "\n\n", " \n \n"]))
+        size = int(rng.integers(8, 120))
+        overlap = int(rng.integers(0, size))
+        assert SentenceSplitter(size, overlap).split_text(text) == old_split(text, size, overlap), (trial, size, overlap)

@@ -295,7 +295,7 @@ def test_text_ingest_pipeline_equals_single_shot(dev, built_lib, tmp_path):
     cfg = EncoderConfig(**SMALL)
     texts = _texts(700)
     for tok in (HFTokenizer(str(tmp_path / "tokenizer.json"), "bert"), None):
-        kw = {"encoder_config": cfg, "synthetic_seed": 5, "pipeline_window": 96}
+        kw = {"encoder_config": cfg, "synthetic_seed": 5, "pipeline_window": 96, "forward_tokens": 1500}   # several forwards per window
         if tok is not None:
             kw["tokenizer"] = tok
         emb = HipHuggingFaceEmbedding("test/bge-small-shaped", device="cuda", embed_batch_size=64, model_kwargs=kw)
