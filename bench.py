@@ -57,7 +57,7 @@ def parse():
     ap.add_argument("--no-config5-leg", action="store_true", help="skip the composed BASELINE config 5 leg (semantic-hierarchical ingest + auto-merging retrieval + fp8 reranker)")
     ap.add_argument("--surface-threads", type=int, default=32)
     ap.add_argument("--surface-queries", type=int, default=256, help="queries the surface leg issues in all (N=1 only)")
-    ap.add_argument("--config5-docs", type=int, default=256)
+    ap.add_argument("--config5-docs", type=int, default=1024)
     ap.add_argument("--no-fp8-leg", action="store_true", help="skip the extra fp8-reranker timing (BASELINE config 5)")
     ap.add_argument("--headline-only", action="store_true",
                     help="run only the warm-up and timed steps (no scan-only / fp8 / ingest legs): every kernel of the process then "

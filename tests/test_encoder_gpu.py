@@ -456,3 +456,55 @@ def test_random_batch_mixes_embed_and_rerank(dev, built_lib, shape, n_seq):
         want_s = torch.sigmoid(oe.rerank_logits(ids, mask, Wb, cfg_o, emulate_bf16=True))
         err = (scores.cpu() - want_s).abs()
         assert err.max().item() < 1.5e-2, (err.max().item(), int(err.argmax()), lens[int(err.argmax())])
+
+
+def test_bench_sized_attention_sampled_sequences_and_order_equivariance(dev, built_lib):
+    """The bench's attention launch (1600 pairs x 292 tokens, 16 heads x 64): sampled sequences against the fp32 softmax,
+    and a size-independent property over the WHOLE output -- a sequence's context depends on its own rows only, so packing
+    the same sequences in another order permutes the output rows, bit for bit, whichever workgroup, CU or XCD a tile lands on."""
+    from tensor_truth_amd import _lib
+
+    lib = _lib.load_library()
+    heads, dh, n_seq, L = 16, 64, 1600, 292
+    H, stride = heads * dh, 296                       # sequences start on 8-row boundaries
+    T = (n_seq * stride + 255) // 256 * 256
+    g = torch.Generator(device=dev).manual_seed(3)
+    q = torch.randn(T, H, device=dev, generator=g).to(torch.bfloat16)
+    k = torch.randn(T, H, device=dev, generator=g).to(torch.bfloat16)
+    v = torch.randn(T, H, device=dev, generator=g).to(torch.bfloat16)
+
+    def run(q, k, v, starts):
+        qk = torch.cat([q, k], 1).contiguous()
+        vt = v.view(T // 8, 8, H).permute(0, 2, 1).contiguous()
+        out = torch.zeros(T, H, dtype=torch.bfloat16, device=dev)
+        st_d = torch.tensor(starts, dtype=torch.int32, device=dev)
+        ln_d = torch.full((n_seq,), L, dtype=torch.int32, device=dev)
+        _lib.check(lib.tt_attention_varlen(qk.data_ptr(), 2 * H, 0, H, vt.data_ptr(), 8 * H, out.data_ptr(), H, st_d.data_ptr(),
+                                           ln_d.data_ptr(), n_seq, heads, dh, L, _stream()), "attention")
+        torch.cuda.synchronize()
+        return out
+
+    starts = [i * stride for i in range(n_seq)]
+    out = run(q, k, v, starts)
+    assert bool(out.view(torch.int16).bitwise_and(0x7F80).ne(0x7F80).all()), "non-finite output"
+    for s in (0, 1, 777, n_seq - 1):
+        s0 = starts[s]
+        qq = q[s0:s0 + L].float().cpu().view(L, heads, dh).transpose(0, 1)
+        kk = k[s0:s0 + L].float().cpu().view(L, heads, dh).transpose(0, 1)
+        vv = v[s0:s0 + L].float().cpu().view(L, heads, dh).transpose(0, 1)
+        ref = (torch.softmax(qq @ kk.transpose(-1, -2) / math.sqrt(dh), dim=-1) @ vv).transpose(0, 1).reshape(L, H)
+        err = (out[s0:s0 + L].float().cpu() - ref).abs()
+        assert err.max().item() < 2e-2 and err.mean().item() < 2e-3, (s, err.max().item())
+    # the same sequences packed in a random order
+    perm = torch.randperm(n_seq, generator=torch.Generator().manual_seed(4)).tolist()
+    rows = torch.cat([torch.arange(starts[p], starts[p] + stride) for p in perm]).to(dev)
+    pad = torch.arange(n_seq * stride, T, device=dev)
+    rows = torch.cat([rows, pad])
+    out_p = run(q[rows].contiguous(), k[rows].contiguous(), v[rows].contiguous(), starts)
+    for j in (0, 5, 800, n_seq - 1):
+        a = out_p[j * stride: j * stride + L]
+        b = out[starts[perm[j]]: starts[perm[j]] + L]
+        assert torch.equal(a, b), f"sequence {perm[j]} differs when packed at slot {j}"
+    valid = torch.cat([torch.arange(i * stride, i * stride + L) for i in range(n_seq)]).to(dev)
+    want = torch.cat([torch.arange(starts[p], starts[p] + L) for p in perm]).to(dev)
+    assert torch.equal(out_p[valid], out[want])
