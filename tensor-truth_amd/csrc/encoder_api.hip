@@ -135,6 +135,16 @@ static int forward_impl(const tt_encoder_weights* w, const int32_t* ids, const i
     }
 
     const int dh = H / w->heads;
+    // TT_FP8_MASK (diagnostic, default 0xF; read per forward so that one process can sweep it): which projections of an fp8
+    // forward run in e4m3 -- bit 0 QKV, 1 attention output, 2 FFN-up, 3 FFN-down (needs bit 2: the intermediate is then
+    // written as e4m3); the others stay bf16.  TT_FP8_SKIP_FIRST / TT_FP8_SKIP_LAST: that many layers at either end stay bf16
+    // altogether (tools/probes/fp8_sensitivity.py: rank agreement with the fp32 path per setting).
+    int f8mask_all = 0xF, f8first = 0, f8last = 0;
+    if (e.fp8) {
+        if (const char* m = getenv("TT_FP8_MASK"); m && m[0]) f8mask_all = (int)strtol(m, nullptr, 0);
+        if (const char* m = getenv("TT_FP8_SKIP_FIRST"); m && m[0]) f8first = atoi(m);
+        if (const char* m = getenv("TT_FP8_SKIP_LAST"); m && m[0]) f8last = atoi(m);
+    }
     for (int l = 0; l < w->layers; ++l) {
         const tt_layer_weights& lw = w->layer[l];
         TT_CHECK_ARG(lw.qkv_w && lw.qkv_b && lw.o_w && lw.o_b && lw.ln1_g && lw.ln1_b && lw.ffn1_w && lw.ffn1_b &&
@@ -145,13 +155,6 @@ static int forward_impl(const tt_encoder_weights* w, const int32_t* ids, const i
         g.A = x; g.lda = H; g.W = (const uint16_t*)lw.qkv_w; g.bias = lw.qkv_b;
         g.C = qk; g.ldc = 2 * H; g.vt = vt; g.ldvt = 8 * H; g.vt_col0 = 2 * H;
         g.M = T; g.N = 3 * H; g.K = H;
-        // TT_FP8_MASK (diagnostic, default 0xF): which projections of an fp8 forward run in e4m3 -- bit 0 QKV, 1 attention
-        // output, 2 FFN-up, 3 FFN-down (needs bit 2: the intermediate is then written as e4m3); the others stay bf16
-        // (tools/probes/fp8_sensitivity.py: rank agreement with the fp32 path per mask)
-        // TT_FP8_SKIP_FIRST / TT_FP8_SKIP_LAST: that many layers at either end stay bf16 altogether
-        const int f8mask_all = [] { const char* m = getenv("TT_FP8_MASK"); return m && m[0] ? (int)strtol(m, nullptr, 0) : 0xF; }();
-        const int f8first = [] { const char* m = getenv("TT_FP8_SKIP_FIRST"); return m && m[0] ? atoi(m) : 0; }();
-        const int f8last = [] { const char* m = getenv("TT_FP8_SKIP_LAST"); return m && m[0] ? atoi(m) : 0; }();
         const int f8mask = (l < f8first || l >= w->layers - f8last) ? 0 : f8mask_all;
         if (e.fp8 && (f8mask & 1)) {   // x's e4m3 copy and row scales come from the LayerNorm that produced x
             g.A = (const uint16_t*)q8; g.W = (const uint16_t*)lw.qkv_w8; g.a_scale = q8s; g.w_scale = lw.qkv_wscale; g.fp8 = 1;

@@ -7,6 +7,7 @@ roundings that flip by one ulp), and (b) against the plain fp32 oracle with the 
 """
 import ctypes
 
+import numpy as np
 import pytest
 import torch
 
@@ -202,3 +203,49 @@ def test_fp8_needs_tileable_shapes(dev, built_lib):
     weights = EncoderWeights(cfg, W, dev)
     with pytest.raises(ValueError, match="multiples of 256"):
         weights.set_gemm_dtype("fp8")
+
+
+@pytest.mark.parametrize("n,k,epi", [(2048, 1024, 0), (4096, 1024, 1), (1024, 4096, 2)])
+def test_bench_sized_fp8_gemms_sampled_rows_and_row_equivariance(dev, built_lib, n, k, epi):
+    """The e4m3 GEMM kernels at the bench's M = 473 600 (BASELINE config 5's "fp8 MFMA reranker"): rows quantised on the
+    device (tt_quantize_rows_fp8), a random sample of rows against exact products of the same e4m3 values on the CPU, and
+    bit-exact row-permutation equivariance over the whole output."""
+    from tensor_truth_amd import _lib
+
+    lib = _lib.load_library()
+    m = 473_600
+    g = torch.Generator(device=dev).manual_seed(n + k + epi)
+    a = torch.randn(m, k, device=dev, generator=g).to(torch.bfloat16)
+    w = (0.05 * torch.randn(n, k, generator=torch.Generator().manual_seed(n + k))).to(torch.bfloat16)
+    bias = torch.randn(n, device=dev, generator=g)
+    res = torch.randn(m, n, device=dev, generator=g).to(torch.bfloat16) if epi == 2 else None
+    wq, sw = oe.quantize_rows_e4m3(w.float())
+    w8 = wq.to(torch.float8_e4m3fn).view(torch.uint8).to(dev)
+    swd = sw.reshape(-1).contiguous().to(dev)
+
+    def run(a_rows, res_rows):
+        a8 = torch.empty(a_rows.shape, dtype=torch.uint8, device=dev)
+        sa = torch.empty(a_rows.shape[0], dtype=torch.float32, device=dev)
+        _lib.check(lib.tt_quantize_rows_fp8(a_rows.data_ptr(), a_rows.shape[0], k, a8.data_ptr(), sa.data_ptr(), _stream()), "quantize")
+        c = torch.empty(a_rows.shape[0], n, dtype=torch.bfloat16, device=dev)
+        _lib.check(lib.tt_gemm_fp8_ex(a8.data_ptr(), sa.data_ptr(), w8.data_ptr(), swd.data_ptr(), bias.data_ptr(),
+                                      res_rows.data_ptr() if res_rows is not None else None, c.data_ptr(), None, 0.0,
+                                      a_rows.shape[0], n, k, epi, _stream()), "gemm fp8")
+        torch.cuda.synchronize()
+        return c, a8, sa
+
+    got, a8, sa = run(a, res)
+    assert bool(got.view(torch.int16).bitwise_and(0x7F80).ne(0x7F80).all()), "non-finite output"
+    rows = torch.from_numpy(np.unique(np.concatenate([np.random.default_rng(n).integers(0, m, 1024), np.arange(0, 256),
+                                                      np.arange(m - 256, m)]))).to(dev)
+    aq = a8[rows].cpu().view(torch.float8_e4m3fn).double()
+    want = (aq @ wq.double().T).float() * sa[rows].cpu()[:, None] * sw.T + bias.cpu()
+    if epi == 1:
+        want = oe.gelu_erf(want)
+    elif epi == 2:
+        want = want + res[rows].float().cpu()
+    err = (got[rows].float().cpu() - want).abs()
+    assert (err <= 2.0 ** -7 * want.abs() + 2e-3).all(), (err.max().item(), want.abs().max().item())
+    perm = torch.randperm(m, device=dev, generator=g)
+    got_p, _, _ = run(a[perm].contiguous(), res[perm].contiguous() if res is not None else None)
+    assert torch.equal(got_p, got[perm])
