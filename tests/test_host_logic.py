@@ -768,3 +768,73 @@ def test_sentence_splitter_counts_once_but_cuts_as_before():
         size = int(rng.integers(8, 120))
         overlap = int(rng.integers(0, size))
         assert SentenceSplitter(size, overlap).split_text(text) == old_split(text, size, overlap), (trial, size, overlap)
+
+
+@pytest.mark.parametrize("two_phase", [False, True])
+def test_coalescer_random_stress_every_caller_gets_its_own_answer_or_its_batch_s_error(two_phase):
+    """24 threads x 40 calls with random think times; one batch in ~12 fails (in a random phase): every caller gets exactly
+    its own result, or the error of the batch it rode in -- never another caller's value, never a hang."""
+    import random
+    import threading
+    import time
+
+    from tensor_truth_amd.coalesce import Coalescer
+
+    rnd = random.Random(5)
+    lock = threading.Lock()
+    seen_batches = []
+
+    def maybe_fail(tag, items):
+        with lock:
+            bad = rnd.random() < 0.03
+        if bad:
+            raise ValueError(f"{tag} failed for a batch of {len(items)}")
+
+    def prepare(items):
+        maybe_fail("prepare", items)
+        time.sleep(0.0005)
+        with lock:
+            seen_batches.append(len(items))
+        return list(items)
+
+    def execute(prepared):
+        maybe_fail("execute", prepared)
+        time.sleep(0.001)
+        return prepared
+
+    def finish(pending):
+        maybe_fail("finish", pending)
+        return [x * 2 + 1 for x in pending]
+
+    if two_phase:
+        c = Coalescer(prepare, max_batch=7, execute=execute, finish=finish)
+    else:
+        c = Coalescer(lambda items: finish(execute(prepare(items))), max_batch=7)
+    outcomes = []
+
+    def worker(tid):
+        r = random.Random(tid)
+        for j in range(40):
+            x = tid * 1000 + j
+            try:
+                got = c.submit(x)
+                ok = got == x * 2 + 1
+                with lock:
+                    outcomes.append(("ok" if ok else "WRONG", x, got))
+            except ValueError as e:
+                with lock:
+                    outcomes.append(("err", x, str(e)))
+            time.sleep(r.random() * 0.002)
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(24)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+        assert not t.is_alive(), "a caller is stuck"
+    assert len(outcomes) == 24 * 40
+    assert not [o for o in outcomes if o[0] == "WRONG"]
+    n_err = sum(1 for o in outcomes if o[0] == "err")
+    assert 0 < n_err < len(outcomes) // 2              # failures happened and were delivered, most calls succeeded
+    assert max(seen_batches) > 1 and max(seen_batches) <= 7
+    assert c.items == 24 * 40
