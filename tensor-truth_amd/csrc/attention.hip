@@ -57,6 +57,9 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attention_kernel(AttnParams p)
     constexpr int NPV = 8 * DH * 16 / 1024; // ... of a V tile (8 token groups x DH features x 16 B)
     constexpr int KPW = NPK / kWaves, VPW = NPV / kWaves;   // pieces per wave: 2 + 2 (dh 64), 1 + 1 (dh 32)
     constexpr int BUF = (NPK + NPV) * 1024;
+    // Two buffers: tile kt + 1 is copied while tile kt is computed.  (Three -- copies two tiles ahead, a copy needs about 3 us
+    // to land under load and a tile 2-2.5 us to compute -- cost a workgroup per CU at 48 KiB each and measured 20 % slower,
+    // 1.62 vs 1.35 ms at 1600 x 292 tokens and at every other length tried: resident waves hide more than the deeper prefetch.)
     __shared__ __attribute__((aligned(1024))) char lds[2 * BUF];
 
     // Workgroup -> (query tile, head, sequence).  The query tiles of one (sequence, head) read the same K / V rows, and
@@ -111,36 +114,65 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attention_kernel(AttnParams p)
     // their probabilities are 0) -- only the last tile can need that.
     const uint16_t* kbase = p.qk + (size_t)t0a * p.ld_qk + p.k_col0 + head * DH;
     const uint16_t* vbase = p.vt + (size_t)(t0a >> 3) * p.ldvt + (size_t)head * DH * 8;
-    int krow_l[KPW], kcol_l[KPW], vg_l[VPW], vcol_l[VPW];
-#pragma unroll
-    for (int i = 0; i < KPW; ++i) {
-        const int e = (wave * KPW + i) * 64 + lane;
-        const int r = e / CH, pos = e % CH;
-        krow_l[i] = r;
-        kcol_l[i] = (pos ^ ((r / RPB) & (CH - 1))) << 3;
+    // Copies in the SGPR-base form (wave-uniform 64-bit base + per-lane 32-bit byte offset, as the GEMM's glds16), with ONE
+    // per-lane offset register per operand.  History: through the builtin every piece carried a per-lane 64-bit address
+    // (v_mad_i64_i32 + v_lshl_add_u64 and a VGPR pair per piece and tile); with per-piece offset arrays kept across the loop
+    // the kernel, which sits at its 128-VGPR cap, spilled two of them and reloaded them INSIDE the key loop behind an
+    // s_waitcnt vmcnt(0) -- a drain of the copy queue per tile, 6 % of the bench shape's time.  Piece i of a wave is piece 0
+    // moved by 64 / CH rows (K) or 64 / DH token groups (V): a scalar step of the BASE; the K swizzle (r / RPB) & (CH - 1)
+    // advances by 4 per piece, i.e. toggles bit 2 of the chunk index (byte offset ^ 64) for odd i when CH = 8.
+    constexpr int kRowsPerPiece = 64 / CH, kGroupsPerPiece = 64 / DH > 0 ? 64 / DH : 1;
+    static_assert(KPW == 1 || CH == 8, "piece-to-piece swizzle step is written for 128-byte K rows");
+    static_assert(VPW == 1 || DH == 64, "one token group per V piece");
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+    uint32_t kvoff0, vvoff0;             // byte offsets of this lane inside the wave's piece 0 of an unclamped tile
+    {
+        const int e = wave * KPW * 64 + lane, r = e / CH, pos = e % CH;
+        kvoff0 = ((uint32_t)r * (uint32_t)p.ld_qk + (uint32_t)((pos ^ ((r / RPB) & (CH - 1))) << 3)) * 2u;
+        const int ev = wave * VPW * 64 + lane;
+        vvoff0 = ((uint32_t)(ev / DH) * (uint32_t)p.ldvt + (uint32_t)((ev % DH) * 8)) * 2u;
     }
-#pragma unroll
-    for (int i = 0; i < VPW; ++i) {
-        const int e = (wave * VPW + i) * 64 + lane;
-        vg_l[i] = e / DH;
-        vcol_l[i] = (e % DH) * 8;
-    }
+    auto sbase = [](const void* ptr) {      // keep a wave-uniform pointer in SGPRs
+        const unsigned long long b = reinterpret_cast<unsigned long long>(ptr);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+        return reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
+    };
+    auto glds16 = [](const char* base, uint32_t voff, uint32_t lds_addr) {
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(lds_addr) : "memory", "m0");
+    };
     auto issue_tile = [&](int kt) {
-        char* buf = lds + (kt & 1) * BUF;
+        const uint32_t buf = lds_base + (uint32_t)(kt & 1) * BUF;
         const bool clamp = (kt + 1) * kKTile > alen || (kt == 0 && off != 0);   // wave-uniform
+        if (!clamp) {
+#pragma unroll
+            for (int i = 0; i < KPW; ++i)
+                glds16(sbase(kbase + ((size_t)kt * kKTile + i * kRowsPerPiece) * p.ld_qk), (i & 1) ? (kvoff0 ^ 64u) : kvoff0,
+                       buf + (uint32_t)(wave * KPW + i) * 1024u);
+#pragma unroll
+            for (int i = 0; i < VPW; ++i)
+                glds16(sbase(vbase + ((size_t)kt * 8 + i * kGroupsPerPiece) * p.ldvt), vvoff0, buf + (uint32_t)(NPK + wave * VPW + i) * 1024u);
+            return;
+        }
+        // first / last tile: rows / token groups outside the sequence are clamped to its nearest one (finite values; their
+        // probabilities are 0).  The per-lane indices are recomputed here instead of living in registers across the loop.
+        const char* kb = sbase(kbase);
+        const char* vb = sbase(vbase);
+        int lane_c = lane;
+        asm volatile("" : "+v"(lane_c));
 #pragma unroll
         for (int i = 0; i < KPW; ++i) {
-            int row = kt * kKTile + krow_l[i];
-            if (clamp) row = row < off ? off : (row < alen ? row : alen - 1);   // rows of this sequence only
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kbase + (size_t)row * p.ld_qk + kcol_l[i]),
-                                             (__attribute__((address_space(3))) void*)(buf + (wave * KPW + i) * 1024), 16, 0, 0);
+            const int e = (wave * KPW + i) * 64 + lane_c, r = e / CH, pos = e % CH;
+            int row = kt * kKTile + r;
+            row = row < off ? off : (row < alen ? row : alen - 1);               // rows of this sequence only
+            glds16(kb, ((uint32_t)row * (uint32_t)p.ld_qk + (uint32_t)((pos ^ ((r / RPB) & (CH - 1))) << 3)) * 2u,
+                   buf + (uint32_t)(wave * KPW + i) * 1024u);
         }
 #pragma unroll
         for (int i = 0; i < VPW; ++i) {
-            int g8 = kt * 8 + vg_l[i];
-            if (clamp) g8 = g8 < n_g8 ? g8 : n_g8 - 1;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vbase + (size_t)g8 * p.ldvt + vcol_l[i]),
-                                             (__attribute__((address_space(3))) void*)(buf + (NPK + wave * VPW + i) * 1024), 16, 0, 0);
+            const int e = (wave * VPW + i) * 64 + lane_c;
+            int g8 = kt * 8 + e / DH;
+            g8 = g8 < n_g8 ? g8 : n_g8 - 1;
+            glds16(vb, ((uint32_t)g8 * (uint32_t)p.ldvt + (uint32_t)((e % DH) * 8)) * 2u, buf + (uint32_t)(NPK + wave * VPW + i) * 1024u);
         }
     };
 
@@ -166,7 +198,13 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attention_kernel(AttnParams p)
     for (int kt = 0; kt < n_kt; ++kt) {
         const int k0 = kt * kKTile;
         stamp();                               // 2 + 6 kt: tile top
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile kt have landed
+        // This wave's pieces of tile kt have landed.  As the BUILTIN, not inline asm: the waitcnt pass must see a vmcnt(0)
+        // on every path into the loop -- the Q fragments are ordinary global loads of the prologue, and otherwise it protects
+        // their first use in EVERY iteration with s_waitcnt vmcnt(3..0), which at run time also counts the copies of tile
+        // kt + 1 issued a moment earlier: a full drain of the prefetch per tile (the double buffer was single-buffered in
+        // effect; -2...4 % on top of the spill fix above).
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        asm volatile("" ::: "memory");
         stamp();                               // +1: own copies landed
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();                       // ... everyone's; and tile kt-1 is no longer read
