@@ -58,3 +58,14 @@ def topn_overlap(want, got, n):
     w = set(np.argsort(-np.asarray(want), kind="stable")[:n].tolist())
     g = set(np.argsort(-np.asarray(got), kind="stable")[:n].tolist())
     return len(w & g) / float(n)
+
+
+def weights_checksum(W) -> str:
+    """sha256 over the names and the first 4 KiB of every tensor of a weight dict: ties a golden fixture to its weights."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for k in sorted(W):
+        h.update(k.encode())
+        h.update(W[k].contiguous().numpy().tobytes()[:4096])
+    return h.hexdigest()

@@ -118,3 +118,26 @@ def test_scan_oracle_edge_cases():
         parts_i.append(i + r * 1000)
     mv, mi = osc.merge_topk(torch.cat(parts_v, 1), torch.cat(parts_i, 1), 20)
     assert torch.equal(mi, gi) and torch.allclose(mv, gv)
+
+
+def test_full_depth_rank_fixture_matches_the_oracle_on_sampled_pairs(golden_dir):
+    """tests/golden/rank_oracle_24L_4x50x292.npz (what the GPU suite's full-depth rerank gate compares the product with) is
+    what oracle/encoder.py computes for the same seeded weights and token ids: two of its 200 pairs are re-derived here
+    (a pair costs seconds on a few cores, all 200 cost minutes -- which is why they are a fixture)."""
+    import hashlib
+
+    import test_rank_agreement_gpu as t
+    from rank_checks import weights_checksum
+
+    z = np.load(os.path.join(golden_dir, t.GOLDEN_NAME))
+    ocfg = oe.EncoderConfig(**t.SHAPE)
+    W = oe.synth_weights(ocfg, seed=t.WEIGHT_SEED)
+    pairs = t._pairs()
+    assert str(z["pairs_sha256"]) == hashlib.sha256(pairs.tobytes()).hexdigest()
+    assert str(z["weights_sha256"]) == weights_checksum(W)
+    assert z["scores"].shape == (t.N_QUERIES, t.N_PAIRS)
+    for q, j in ((0, 0), (3, 41)):
+        ids = torch.from_numpy(pairs[q, j:j + 1])
+        with torch.no_grad():
+            got = oe.rerank_scores(ids, torch.ones_like(ids), W, ocfg)
+        assert abs(float(got[0]) - float(z["scores"][q, j])) < 2e-5, (q, j, float(got[0]), float(z["scores"][q, j]))
