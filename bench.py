@@ -26,6 +26,57 @@ import time
 # multi-process GPU work on this pool needs dmabuf IPC (RCCL otherwise fails in hipIpcGetMemHandle); must be set before HIP starts
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
+
+def launch_plan(argv, environ):
+    """`python bench.py --gpus N` with N > 1 and no rank environment: the command line of the child that starts the N
+    ranks (one process per GPU under torch.distributed.run), else None (run in this process).  Pure function of its
+    arguments: decided before torch is imported or anything touches the GPU (tests/test_bench_launcher.py)."""
+    gpus = 1
+    for i, a in enumerate(argv):
+        if a == "--gpus" and i + 1 < len(argv):
+            gpus = int(argv[i + 1])
+        elif a.startswith("--gpus="):
+            gpus = int(a.split("=", 1)[1])
+    if gpus <= 1 or "WORLD_SIZE" in environ or "RANK" in environ or "LOCAL_RANK" in environ:
+        return None
+    port = environ.get("MASTER_PORT")
+    if not port:
+        import socket
+
+        with socket.socket() as s:                  # a free port, decided by the kernel
+            s.bind(("127.0.0.1", 0))
+            port = str(s.getsockname()[1])
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(cmd):
+    """Run the ranks as a CHILD process (never exec: the driver may already hold the GPU, and a process that has touched
+    HIP must not be replaced), relay its output, re-print rank 0's JSON line last, exit with the child's code."""
+    import subprocess
+
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=None, text=True, bufsize=1)
+    line_json = None
+    for line in proc.stdout:
+        s = line.strip()
+        if s.startswith("{") and s.endswith("}") and '"metric"' in s:
+            line_json = s                             # held back: printed once, as the last line
+        else:
+            sys.stdout.write(line)
+    rc = proc.wait()
+    if line_json is not None:
+        print(line_json, flush=True)
+    elif rc == 0:
+        sys.stderr.write("bench.py: the ranks exited 0 without a JSON line\n")
+        rc = 1
+    raise SystemExit(rc)
+
+
+if __name__ == "__main__":
+    _cmd = launch_plan(sys.argv[1:], os.environ)
+    if _cmd is not None:
+        self_launch(_cmd)
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
@@ -113,8 +164,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched through torch.distributed.run (one rank per GPU)")
+        # (`python bench.py --gpus N` alone starts its own ranks: launch_plan() above; this is a rank whose launcher disagrees)
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start the ranks with --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback in tensor_truth_amd)")
     # TT_BENCH_ONE_DEVICE=1 (debugging aid, never the driver's path): all ranks share GPU 0 and talk over gloo, so the
@@ -388,7 +439,7 @@ def main():
         "metric": "queries/sec (embed+top-k+rerank) over 10M x 1024 corpus",
         "value": world * Bq * args.steps / dt,
         "unit": "queries/s",
-        "n_gpus": world if not one_device else 1,
+        "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3,
@@ -404,6 +455,7 @@ def main():
             "corpus_rows": args.corpus_rows, "dim": D, "queries_per_gpu_per_step": Bq, "top_k": K, "top_n": topn,
             "pair_tokens": args.query_len + args.chunk_len + 4, "encoder_layers": L,
             "parallelism": f"corpus row-sharded x{world}, encoders replicated",
+            "ranks_share_one_device": one_device,   # TT_BENCH_ONE_DEVICE=1 (debugging aid): all ranks on GPU 0 over gloo -- not a scaling number
             "chunks_reranked_per_s": world * Bq * K * args.steps / dt,
             "chunks_embedded_per_s": chunks_per_s,
             "embed_batch": f"{args.embed_chunks} chunks x {args.chunk_len + 2} tok per GPU (bge-m3 shape)",
