@@ -60,6 +60,7 @@ struct SelectParams {
     float* thr_out;           // optional [Q]: k-th best score (or -inf if fewer than k valid)
     int32_t* cnt_out;         // optional [Q]: number of valid outputs (<= k)
     int32_t* overflow_flag;   // optional
+    int min_valid;            // > 0: fewer than min_valid valid outputs for a query also raise *overflow_flag
     // optional segmentation of each query's list (tt_scan_topk_segmented): block (q, s) selects over
     // positions [seg_off[s], seg_off[s+1]) of query q's scores (and idx, when given), writes output row
     // q * n_seg + s; implicit indices are emitted as (position in the segment) + seg_add[s].

@@ -329,6 +329,7 @@ __global__ __launch_bounds__(kSelThreads) void select_kernel(SelectParams p) {
         p.out_scores[out_row * p.out_stride + i] = s;
         p.out_idx[out_row * p.out_stride + i] = id;
     }
+    if (p.min_valid > 0 && p.overflow_flag && tid == 0 && buf[p.min_valid - 1] == 0ull) atomicOr(p.overflow_flag, 1);
     if (p.thr_out || p.cnt_out) {
         if (tid == 0) lds_ctr[1] = 0;
         __syncthreads();

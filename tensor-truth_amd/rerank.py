@@ -89,14 +89,26 @@ class HipSentenceTransformerRerank:
         return [len(c) for c in calls], self._pack(self._tokenize_pairs(flat)) if flat else []
 
     def _enqueue_many(self, prepared):
-        """Device phase: the forward over the packed pairs is ENQUEUED (asynchronous); nothing waits here."""
+        """Device phase: the forward over the packed pairs is ENQUEUED (asynchronous), followed by the copy of its
+        scores into a pinned host buffer and an event of THIS batch; nothing waits here."""
         sizes, batches = prepared
-        return sizes, (self._score_packed(batches) if batches else None)
+        if not batches:
+            return sizes, None, None
+        dev_scores = self._score_packed(batches)
+        with torch.cuda.device(self.device):
+            host = torch.empty(dev_scores.shape, dtype=dev_scores.dtype, pin_memory=True)
+            host.copy_(dev_scores, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+        return sizes, host, ev
 
     def _collect_many(self, pending) -> List[List[float]]:
-        """Wait for the scores and hand each caller its own."""
-        sizes, dev_scores = pending
-        scores = dev_scores.cpu().tolist() if dev_scores is not None else []
+        """Wait for THIS batch's event only (the next batch's forward is already enqueued behind it: a stream-wide
+        synchronising copy would make these callers wait for that one too) and hand each caller its own scores."""
+        sizes, host, ev = pending
+        if ev is not None:
+            ev.synchronize()
+        scores = host.tolist() if host is not None else []
         out, lo = [], 0
         for n in sizes:
             out.append(scores[lo:lo + n])

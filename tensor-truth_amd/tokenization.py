@@ -96,11 +96,14 @@ class HFTokenizer:
     ``longest_first`` truncation for pairs -- a Rust tokenizer cannot be reconfigured while another thread is
     encoding with it, and the ingest pipeline tokenizes from background threads."""
 
-    def __init__(self, tokenizer_json: str, arch: str):
+    def __init__(self, tokenizer_json: Optional[str], arch: str, json_str: Optional[str] = None):
         from tokenizers import Tokenizer  # local import: optional dependency
 
         self._path = tokenizer_json
-        self.tk = Tokenizer.from_file(tokenizer_json)
+        # the serialised tokenizer is kept in memory: the pair tokenizer is built from it later, whatever has happened
+        # to the file meanwhile (and a tokenizer converted from sentencepiece files never touches the disk at all)
+        self._json = json_str if json_str is not None else open(tokenizer_json, encoding="utf-8").read()
+        self.tk = Tokenizer.from_str(self._json)
         self.tk.no_truncation()
         self.tk.no_padding()
         self._pair_tk = None
@@ -128,7 +131,7 @@ class HFTokenizer:
 
         with self._lock:
             if self._pair_tk is None or self._pair_len != max_length:
-                tk = Tokenizer.from_file(self._path)
+                tk = Tokenizer.from_str(self._json)
                 tk.no_padding()
                 tk.enable_truncation(max_length=max_length, strategy="longest_first")
                 self._pair_tk, self._pair_len = tk, max_length
@@ -161,16 +164,10 @@ def load_tokenizer(model_dir: Optional[str], arch: str, vocab_size: int):
             backend = getattr(fast, "backend_tokenizer", None)
             if backend is None:
                 raise RuntimeError("transformers returned a slow tokenizer")
-            cache = os.path.join(model_dir, "tokenizer.json")
-            try:
-                backend.save(cache)
-                return HFTokenizer(cache, arch)
-            except OSError:           # read-only model dir: keep the converted tokenizer in a temp file
-                import tempfile
-
-                tmp = os.path.join(tempfile.mkdtemp(prefix="tt_tok_"), "tokenizer.json")
-                backend.save(tmp)
-                return HFTokenizer(tmp, arch)
+            # The converted tokenizer stays in memory, nothing is written into the model directory: with one process per
+            # GPU every rank converts at the same moment (a half-written tokenizer.json would be parsed by its
+            # neighbour), and the directory may be a shared or HF-cache snapshot this package has no business editing.
+            return HFTokenizer(None, arch, json_str=backend.to_str())
         except Exception as exc:  # noqa: BLE001
             raise FileNotFoundError(
                 f"{model_dir}: no tokenizer.json, and converting its sentencepiece / vocab files failed ({exc})") from exc

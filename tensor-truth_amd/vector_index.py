@@ -189,45 +189,52 @@ class HipVectorIndex:
         ``load`` between the writes sees either the previous complete index or the new one, never a row-count
         mismatch (``HipDocumentIndex`` persists after every add / remove, document_index.py:478-581)."""
         os.makedirs(persist_dir, exist_ok=True)
-        with self._lock:
-            self._compact()                    # tombstones are not written
-            mat_host = self.matrix.cpu().view(torch.int16).numpy()
-            leaf_ids = list(self.leaf_ids)
-            nodes = {nid: _node_to_dict(nd) for nid, nd in self.docstore.items()}
-            ref_docs = {k: list(v) for k, v in self.ref_docs.items()}
-            n_rows = self.n
-        gen = _next_generation(persist_dir)
-        corpus_name = f"corpus.{gen}.bf16"
+        # One persist per directory at a time -- across the threads of this process (a lock per real path) and across
+        # processes (flock on a lock file): the snapshot, the choice of the generation, the writes and the clean-up of
+        # older generations happen inside, so two overlapping persists (HipDocumentIndex persists after every add /
+        # remove) can neither pick the same generation nor publish an older snapshot over a newer one, and nodes.json
+        # never names a matrix another call has removed.
+        with _persist_guard(persist_dir):
+            with self._lock:
+                self._compact()                    # tombstones are not written
+                mat_host = self.matrix.cpu().view(torch.int16).numpy()
+                leaf_ids = list(self.leaf_ids)
+                nodes = {nid: _node_to_dict(nd) for nid, nd in self.docstore.items()}
+                ref_docs = {k: list(v) for k, v in self.ref_docs.items()}
+                n_rows = self.n
+            gen = _next_generation(persist_dir)
+            corpus_name = f"corpus.{gen}.bf16"
 
-        def _atomic(name: str, write) -> None:
-            tmp = os.path.join(persist_dir, f".{name}.tmp.{os.getpid()}.{threading.get_ident()}")
-            write(tmp)
-            os.replace(tmp, os.path.join(persist_dir, name))
+            def _atomic(name: str, write) -> None:
+                tmp = os.path.join(persist_dir, f".{name}.tmp.{os.getpid()}.{threading.get_ident()}")
+                write(tmp)
+                os.replace(tmp, os.path.join(persist_dir, name))
 
-        _atomic(corpus_name, lambda t: mat_host.tofile(t))
-        # the reference's index_metadata.json (indexing/metadata.py:103-146) + what this store adds
-        model = embedding_model or getattr(self.embed_model, "model_name", None)
-        meta = {"embedding_model": model, "embedding_model_id": sanitize_model_id(model) if model else None,
-                "created_at": datetime.now(timezone.utc).isoformat(), "index_version": INDEX_VERSION,
-                "chunk_sizes": list(chunk_sizes) if chunk_sizes is not None else None, "chunk_overlap": chunk_overlap,
-                "chunking_strategy": chunking_strategy,
-                "embedding_dim": self.dim, "num_vectors": n_rows, "store": f"tensor_truth_amd/{corpus_name}"}
+            _atomic(corpus_name, lambda t: mat_host.tofile(t))
+            # the reference's index_metadata.json (indexing/metadata.py:103-146) + what this store adds
+            model = embedding_model or getattr(self.embed_model, "model_name", None)
+            meta = {"embedding_model": model, "embedding_model_id": sanitize_model_id(model) if model else None,
+                    "created_at": datetime.now(timezone.utc).isoformat(), "index_version": INDEX_VERSION,
+                    "chunk_sizes": list(chunk_sizes) if chunk_sizes is not None else None, "chunk_overlap": chunk_overlap,
+                    "chunking_strategy": chunking_strategy,
+                    "embedding_dim": self.dim, "num_vectors": n_rows, "store": f"tensor_truth_amd/{corpus_name}"}
 
-        def _dump(obj):
-            def w(t):
-                with open(t, "w") as f:
-                    json.dump(obj, f)
-            return w
+            def _dump(obj):
+                def w(t):
+                    with open(t, "w") as f:
+                        json.dump(obj, f)
+                return w
 
-        _atomic(INDEX_METADATA_FILENAME, _dump(meta))
-        _atomic("nodes.json", _dump({"dim": self.dim, "leaf_ids": leaf_ids, "nodes": nodes, "ref_docs": ref_docs,
-                                     "corpus_file": corpus_name, "generation": gen}))
-        for name in os.listdir(persist_dir):     # older generations: unreferenced once nodes.json has moved
-            if name.startswith("corpus.") and name.endswith(".bf16") and name != corpus_name:
-                try:
-                    os.remove(os.path.join(persist_dir, name))
-                except OSError:
-                    pass
+            _atomic(INDEX_METADATA_FILENAME, _dump(meta))
+            _atomic("nodes.json", _dump({"dim": self.dim, "leaf_ids": leaf_ids, "nodes": nodes, "ref_docs": ref_docs,
+                                         "corpus_file": corpus_name, "generation": gen}))
+            for name in os.listdir(persist_dir):     # LOWER generations only: unreferenced once nodes.json has moved
+                g = _generation_of(name)
+                if g is not None and g < gen:
+                    try:
+                        os.remove(os.path.join(persist_dir, name))
+                    except OSError:
+                        pass
 
     @classmethod
     def load(cls, persist_dir: str, device=None, embed_model=None, score_mode: str = "chroma") -> "HipVectorIndex":
@@ -285,24 +292,90 @@ def _node_from_dict(nid: str, d: dict):
     return nd
 
 
+def _generation_of(name: str):
+    """corpus.<gen>.bf16 -> gen, anything else -> None."""
+    if name.startswith("corpus.") and name.endswith(".bf16"):
+        try:
+            return int(name[len("corpus."):-len(".bf16")])
+        except ValueError:
+            return None
+    return None
+
+
 def _next_generation(persist_dir: str) -> int:
+    """One more than anything published or lying around (called under the directory's persist guard)."""
+    gen = 0
     try:
         with open(os.path.join(persist_dir, "nodes.json")) as f:
-            return int(json.load(f).get("generation", 0)) + 1
+            gen = int(json.load(f).get("generation", 0))
     except (OSError, ValueError):
-        return 1
+        pass
+    try:
+        for name in os.listdir(persist_dir):
+            g = _generation_of(name)
+            if g is not None:
+                gen = max(gen, g)
+    except OSError:
+        pass
+    return gen + 1
+
+
+_PERSIST_LOCKS: dict = {}
+_PERSIST_LOCKS_GUARD = threading.Lock()
+
+
+class _persist_guard:
+    """Serialises persist() per directory: a process-wide lock per real path + flock on ``.persist.lock`` in it."""
+
+    def __init__(self, persist_dir: str):
+        self.path = os.path.realpath(persist_dir)
+        with _PERSIST_LOCKS_GUARD:
+            self.lock = _PERSIST_LOCKS.setdefault(self.path, threading.Lock())
+        self.fh = None
+
+    def __enter__(self):
+        self.lock.acquire()
+        try:
+            import fcntl
+
+            self.fh = open(os.path.join(self.path, ".persist.lock"), "a+")
+            fcntl.flock(self.fh, fcntl.LOCK_EX)
+        except (ImportError, OSError):          # no flock on this filesystem: the in-process lock still holds
+            if self.fh is not None:
+                self.fh.close()
+                self.fh = None
+        return self
+
+    def __exit__(self, *exc):
+        try:
+            if self.fh is not None:
+                import fcntl
+
+                fcntl.flock(self.fh, fcntl.LOCK_UN)
+                self.fh.close()
+        finally:
+            self.lock.release()
+        return False
 
 
 def _read_persisted(persist_dir: str, rows=None):
     """-> (nodes.json blob, int16 [n, dim] array of the bf16 rows).  ``rows``: a slice, or a function of the row count
     returning one -- only that row range is read (the file is memory-mapped)."""
-    with open(os.path.join(persist_dir, "nodes.json")) as f:
-        blob = json.load(f)
-    path = os.path.join(persist_dir, blob.get("corpus_file", "corpus.bf16"))
-    n, dim = len(blob["leaf_ids"]), blob["dim"]
-    if os.path.getsize(path) != n * dim * 2:
-        raise ValueError(f"{path} and nodes.json disagree on the number of rows")
-    raw = np.memmap(path, dtype=np.int16, mode="r", shape=(n, dim)) if n else np.zeros((0, dim), np.int16)
+    for attempt in range(3):
+        with open(os.path.join(persist_dir, "nodes.json")) as f:
+            blob = json.load(f)
+        path = os.path.join(persist_dir, blob.get("corpus_file", "corpus.bf16"))
+        n, dim = len(blob["leaf_ids"]), blob["dim"]
+        try:
+            if os.path.getsize(path) != n * dim * 2:
+                raise ValueError(f"{path} and nodes.json disagree on the number of rows")
+            raw = np.memmap(path, dtype=np.int16, mode="r", shape=(n, dim)) if n else np.zeros((0, dim), np.int16)
+            break
+        except FileNotFoundError:
+            # a persist() published a newer generation and removed this one between our two opens: nodes.json has
+            # moved on too -- read it again
+            if attempt == 2:
+                raise
     if callable(rows):
         rows = rows(n)
     return blob, (raw[rows] if rows is not None else raw)

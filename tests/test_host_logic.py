@@ -587,7 +587,7 @@ def test_coalescer_batches_concurrent_callers_and_preserves_results():
     assert out == {i: i * i for i in range(40)}
     assert max(sizes) == 8 and sum(sizes) == 41 and len(sizes) < 41 and c.items == 41 and c.batches == len(sizes)
 
-    # a failing batch fails every member, later calls are unaffected
+    # a failing call raises, later calls are unaffected
     state = {"fail": True}
 
     def flaky(items):
@@ -772,8 +772,9 @@ def test_sentence_splitter_counts_once_but_cuts_as_before():
 
 @pytest.mark.parametrize("two_phase", [False, True])
 def test_coalescer_random_stress_every_caller_gets_its_own_answer_or_its_batch_s_error(two_phase):
-    """24 threads x 40 calls with random think times; one batch in ~12 fails (in a random phase): every caller gets exactly
-    its own result, or the error of the batch it rode in -- never another caller's value, never a hang."""
+    """24 threads x 40 calls with random think times; one batch in ~12 fails (in a random phase; the member-by-member
+    re-run that follows may fail again): every caller gets exactly its own result or an error -- never another caller's
+    value, never a hang."""
     import random
     import threading
     import time
@@ -838,3 +839,134 @@ def test_coalescer_random_stress_every_caller_gets_its_own_answer_or_its_batch_s
     assert 0 < n_err < len(outcomes) // 2              # failures happened and were delivered, most calls succeeded
     assert max(seen_batches) > 1 and max(seen_batches) <= 7
     assert c.items == 24 * 40
+
+
+@pytest.mark.parametrize("two_phase", [False, True])
+def test_coalescer_isolates_a_poisoned_item_from_the_callers_it_was_batched_with(two_phase):
+    """24 threads, one poisoned query among them: the offender alone gets the exception, the other 23 get exactly their
+    serial results although they rode in a failing batch (the reference isolates failures per call:
+    rag_engine.py:453-455, services/rag_service.py:347-350)."""
+    import threading
+    import time
+
+    from tensor_truth_amd.coalesce import Coalescer
+
+    POISON = 13
+    seen = []
+
+    def prepare(items):
+        seen.append(list(items))
+        time.sleep(0.01)
+        return list(items)
+
+    def execute(prepared):
+        if POISON in prepared:
+            raise ValueError(f"malformed query {POISON}")
+        return prepared
+
+    def finish(pending):
+        return [x * 3 for x in pending]
+
+    if two_phase:
+        c = Coalescer(prepare, max_batch=32, execute=execute, finish=finish)
+    else:
+        c = Coalescer(lambda items: finish(execute(prepare(items))), max_batch=32)
+    gate = threading.Event()
+    got, errs = {}, {}
+
+    def hold():                       # a first caller keeps the front busy so that the other 24 pile up into one batch
+        c.submit(1000)
+
+    def worker(i):
+        gate.wait()
+        try:
+            got[i] = c.submit(i)
+        except ValueError as exc:
+            errs[i] = str(exc)
+
+    h = threading.Thread(target=hold)
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(24)]
+    h.start()
+    for t in ts:
+        t.start()
+    gate.set()
+    for t in ts + [h]:
+        t.join(timeout=60)
+        assert not t.is_alive()
+    assert errs == {POISON: f"malformed query {POISON}"}
+    assert got == {i: 3 * i for i in range(24) if i != POISON}
+    assert any(POISON in b and len(b) > 1 for b in seen), "the poisoned item never shared a batch: the test proves nothing"
+    assert c.isolated >= 1 and c.items == 25
+    assert c.submit(5) == 15                                          # the front keeps working
+
+
+def test_coalescer_survives_a_base_exception_in_the_leader():
+    """A BaseException in the leader outside the guarded calls (here: inside the collection window's sleep) still
+    answers its batch, releases its execute turn and hands leadership on: later callers are served, nobody hangs."""
+    import threading
+    import time
+
+    from tensor_truth_amd import coalesce
+    from tensor_truth_amd.coalesce import Coalescer
+
+    class Boom(BaseException):
+        pass
+
+    calls = {"n": 0}
+    real_sleep = time.sleep
+
+    def bad_sleep(dt):
+        calls["n"] += 1
+        if calls["n"] == 1:
+            raise Boom()
+        real_sleep(dt)
+
+    c = Coalescer(lambda items: list(items), max_batch=4, max_wait_s=0.002, execute=lambda p: p, finish=lambda p: [x + 1 for x in p])
+    coalesce.time.sleep = bad_sleep
+    try:
+        with pytest.raises(Boom):
+            c.submit(1)
+    finally:
+        coalesce.time.sleep = real_sleep
+    out = {}
+    ts = [threading.Thread(target=lambda i=i: out.__setitem__(i, c.submit(i))) for i in range(8)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=30)
+        assert not t.is_alive(), "the front is stuck after a leader died"
+    assert out == {i: i + 1 for i in range(8)}
+
+
+def test_persist_guard_serialises_writers_of_one_directory(tmp_path):
+    """persist()'s critical section (snapshot, generation choice, writes, clean-up) is exclusive per directory -- across
+    threads (lock per real path) and processes (flock) -- and the next generation is above every file lying around, so
+    two overlapping persists can never pick the same corpus.<gen>.bf16."""
+    import threading
+    import time
+
+    from tensor_truth_amd.vector_index import _generation_of, _next_generation, _persist_guard
+
+    d = tmp_path / "ix"
+    d.mkdir()
+    inside, overlaps, gens = [0], [0], []
+
+    def writer():
+        with _persist_guard(str(d)):
+            inside[0] += 1
+            overlaps[0] += inside[0] > 1
+            g = _next_generation(str(d))
+            gens.append(g)
+            time.sleep(0.005)
+            (d / f"corpus.{g}.bf16").write_bytes(b"x")       # published matrix, nodes.json not yet moved
+            inside[0] -= 1
+
+    ts = [threading.Thread(target=writer) for _ in range(12)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=30)
+    assert overlaps[0] == 0 and sorted(gens) == list(range(1, 13))
+    with _persist_guard(str(tmp_path / "ix" / ".." / "ix")):    # same real path -> same lock object
+        assert not _persist_guard(str(d)).lock.acquire(blocking=False)
+    assert _generation_of("corpus.17.bf16") == 17 and _generation_of("corpus.bf16") is None and _generation_of("nodes.json") is None

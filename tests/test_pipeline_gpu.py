@@ -683,3 +683,57 @@ def test_import_reference_index_with_chroma_stub(dev, built_lib, tmp_path, monke
     assert [h.node.id_ for h in hits] == sorted("abc", key=lambda n: -float(vecs[n] @ base))
     merged = AutoMergingRetriever(index.as_retriever(similarity_top_k=3), index.docstore).retrieve(q)
     assert [m.node.id_ for m in merged] == ["P"]                 # all three children hit -> merged into the parent
+
+
+def test_overlapping_persists_and_loads_never_pair_a_matrix_with_foreign_node_tables(dev, built_lib, tmp_path):
+    """HipDocumentIndex persists after every add / remove: persists of one directory may overlap each other and loads.
+    Six threads persist states of different row counts while four threads load: every load sees ONE consistent
+    generation (rows = ids, row r still maps to id r's vector), no ENOENT, and the directory ends with one matrix."""
+    import os
+    import threading
+
+    from tensor_truth_amd.schema import TextNode
+    from tensor_truth_amd.vector_index import HipVectorIndex
+
+    D = 128
+    d = str(tmp_path / "ix")
+
+    def make(n, tag):
+        ix = HipVectorIndex(D, dev, None, "cosine")
+        emb = torch.zeros((n, D))
+        emb[torch.arange(n), torch.arange(n) % D] = 1.0
+        emb[:, 0] += float(tag) / 100.0                    # rows of different states differ
+        ix.add([TextNode(text=f"{tag}-{i}", id_=f"{tag}-{i}") for i in range(n)], emb)
+        return ix
+
+    states = [make(40 + 7 * t, t) for t in range(6)]
+    states[0].persist(d)
+    errors = []
+
+    def persister(t):
+        try:
+            for _ in range(6):
+                states[t].persist(d)
+        except Exception as exc:  # noqa: BLE001
+            errors.append(("persist", repr(exc)))
+
+    def loader():
+        try:
+            for _ in range(12):
+                ix = HipVectorIndex.load(d, dev, None, "cosine")
+                tag = int(ix.leaf_ids[0].split("-")[0])
+                assert ix.n == 40 + 7 * tag == len(ix.leaf_ids)
+                assert all(i.split("-")[0] == str(tag) for i in ix.leaf_ids)
+                assert torch.equal(ix.matrix.cpu(), states[tag].matrix.cpu())
+        except Exception as exc:  # noqa: BLE001
+            errors.append(("load", repr(exc)))
+
+    ts = [threading.Thread(target=persister, args=(t,)) for t in range(6)] + [threading.Thread(target=loader) for _ in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=120)
+        assert not t.is_alive()
+    assert not errors, errors
+    mats = [f for f in os.listdir(d) if f.startswith("corpus.") and f.endswith(".bf16")]
+    assert len(mats) == 1

@@ -88,6 +88,9 @@ def test_ragged_shapes_dense_path(dev, built_lib, n, d, q, k):
     (280_000, 128, 300, 20),      # two 256-query blocks (the second one mostly padding), narrow rows
     (270_001, 384, 100, 128),     # bge-small width, k above a sort group
     (90_000, 640, 20, 50), (263_000, 896, 80, 10),   # the widths between the common model sizes, both filter kernels
+    # tiny k on the tiled path: the threshold IS a sampled row's score (k = 1: the best sampled group), computed by the
+    # streaming kernel while the filter recomputes it on another MFMA shape -- the defining row must still pass
+    (262_144, 1024, 65, 1), (262_144, 1024, 80, 2), (262_144, 1024, 256, 3), (262_144, 1024, 130, 4),
 ])
 def test_sampled_threshold_path(dev, built_lib, n, d, q, k):
     """Shards above 65536 rows: sample -> threshold -> filtered main pass -> select."""
@@ -102,6 +105,26 @@ def test_sampled_threshold_path(dev, built_lib, n, d, q, k):
     # forced dense path gives the same answer
     s2, i2 = _run(tscan, dev, corpus, queries, k, exact_dense=True)
     _check(s2, i2, *want)
+
+
+def test_tiled_path_returns_a_sampled_best_row_at_k1(dev, built_lib):
+    """k = 1 on the 65+-query path with the global best row of every query INSIDE the threshold sample (262144 rows: every
+    second 32-row group is sampled): thr is that row's own score from the sample kernel, and the tiled filter's
+    recomputation of it must not fall below thr -- no query may come back empty, and no status flag."""
+    from tensor_truth_amd import scan as tscan
+
+    n, d, q = 262_144, 1024, 96
+    corpus = osc.synth_corpus(n, d, seed=5)
+    g = torch.Generator().manual_seed(6)
+    rows = (torch.randperm(n // 64, generator=g)[:q] * 64 + torch.randint(0, 32, (q,), generator=g))   # even groups: sampled
+    noise = torch.nn.functional.normalize(torch.randn(q, d, generator=g), dim=1)
+    queries = torch.nn.functional.normalize(corpus[rows].float() + 0.3 * noise, dim=1).to(torch.bfloat16)
+    want = osc.scan_topk(corpus, queries, 1)
+    assert torch.equal(want[1][:, 0], rows)
+    s, i, flag = tscan.scan_topk(corpus.to(dev), queries.to(dev), 1, return_flag=True)
+    torch.cuda.synchronize()
+    assert not flag and (i.cpu() >= 0).all()
+    _check(s, i, *want)
 
 
 def test_tiled_filter_pass_skips_tombstones_and_reports_overflow(dev, built_lib):
