@@ -283,6 +283,68 @@ int tt_rerank_head_f32(const tt_encoder_weights_f32* w, const float* hidden_f32,
 int tt_gemm_f32(const float* a, const float* w, const float* bias, const float* residual, float* c,
                 int m, int n, int k, int epilogue, void* stream);
 
+/* ---- reference precision on the bf16 matrix cores: split-bf16 ("bf16x3") forward -------------------------------------
+ * Same contract as the fp32 forward above (the unchanged reference call SentenceTransformerRerank(model=, top_n=, device=),
+ * src/tensortruth/services/model_manager.py:333-337, and HuggingFaceEmbedding with torch_dtype None,
+ * app_utils/config_schema.py:66-76, are fp32), at a third of the bf16 path's rate instead of a sixteenth: every matrix
+ * product runs on v_mfma_*_bf16 with both operands split into two bf16 planes (x = hi + lo, hi = bf16(x),
+ * lo = bf16(x - hi); a.b ~= a_hi.b_hi + a_hi.b_lo + a_lo.b_hi, fp32 accumulate), the residual stream, LayerNorm, softmax
+ * and the exact-erf GELU stay fp32.  Scores within 1e-3 relative of the CPU reference (measured ~1e-5).
+ * "Planes" = bf16 [rows][2 W]: columns [0, W) hold hi, [W, 2 W) hold lo.  Weight matrices are planes [out][2 in];
+ * embedding tables, biases, LayerNorm parameters and the classification head are fp32.  hidden a multiple of 256 (<= 1024)
+ * with head_dim 64, ffn a multiple of 256, n_rows a multiple of 256. */
+typedef struct tt_layer_weights_x3 {
+    const void* qkv_w;   /* planes [3H][2H] */
+    const float* qkv_b;
+    const void* o_w;     /* planes [H][2H] */
+    const float* o_b;
+    const float* ln1_g;
+    const float* ln1_b;
+    const void* ffn1_w;  /* planes [F][2H] */
+    const float* ffn1_b;
+    const void* ffn2_w;  /* planes [H][2F] */
+    const float* ffn2_b;
+    const float* ln2_g;
+    const float* ln2_b;
+} tt_layer_weights_x3;
+
+typedef struct tt_encoder_weights_x3 {
+    int32_t hidden, layers, heads, ffn, vocab, max_pos, type_vocab;
+    float ln_eps;
+    const float* word_emb;  /* [vocab][H] fp32 */
+    const float* pos_emb;
+    const float* type_emb;
+    const float* emb_ln_g;
+    const float* emb_ln_b;
+    const tt_layer_weights_x3* layer; /* host array [layers] */
+    const float* cls_dense_w;  /* [H][H] fp32 or NULL */
+    const float* cls_dense_b;
+    const float* cls_out_w;
+    const float* cls_out_b;
+} tt_encoder_weights_x3;
+
+size_t tt_encoder_x3_workspace_bytes(const tt_encoder_weights_x3* w, int n_rows);
+/* hidden_out: [n_rows][H] fp32 last hidden state (pool it with tt_embed_pool_f32) */
+int tt_encoder_forward_x3(const tt_encoder_weights_x3* w, const int32_t* ids, const int32_t* pos,
+                          const int32_t* type_ids, const int32_t* seq_start, const int32_t* seq_len,
+                          int n_seq, int n_rows, int max_len, float* hidden_out,
+                          void* workspace, size_t workspace_bytes, void* stream);
+/* classification head on the fp32 hidden state (workspace as tt_rerank_head_f32) */
+int tt_rerank_head_x3(const tt_encoder_weights_x3* w, const float* hidden_f32, const int32_t* rows, int n_seq,
+                      float* scores, float* logits, void* workspace, size_t workspace_bytes, void* stream);
+/* building blocks (parity tests).  tt_split_planes: fp32 [rows][cols] -> planes [rows][2 cols], cols % 4 == 0.
+ * tt_gemm_x3: a planes [m][2k], w planes [n][2k]; m, n multiples of 256, k of 64; epilogue 0 bias / 1 exact-erf GELU ->
+ * c_planes [m][2n]; epilogue 2 -> c_f32 [m][n] = a.w^T + bias + residual_f32 [m][n].
+ * tt_attention_x3: Q / K planes in one buffer (hi at q_col0 / k_col0 + head * 64, lo lo_off columns further), V in the
+ * token-blocked transposed layout of tt_attention_varlen, once per plane; context planes out (hi at head * 64, lo at
+ * out_lo_off + head * 64). */
+int tt_split_planes(const float* in_f32, int64_t rows, int cols, void* out_planes, void* stream);
+int tt_gemm_x3(const void* a_planes, const void* w_planes, const float* bias, const float* residual_f32, void* c_planes,
+               float* c_f32, int m, int n, int k, int epilogue, void* stream);
+int tt_attention_x3(const void* qk_planes, int ld_qk, int q_col0, int k_col0, int lo_off, const void* vt_hi,
+                    const void* vt_lo, int ldvt, void* out_planes, int ld_out, int out_lo_off,
+                    const int32_t* seq_start, const int32_t* seq_len, int n_seq, int heads, int max_len, void* stream);
+
 /* Per-kernel device timing (HIP events on the launch stream), for bench.py's roofline leg.
  * tt_prof_enable(1) (or a mask of 1 << id, to time only some kernels) starts recording one event pair per launch of the tracked kernels on the
  * calling thread; tt_prof_read() synchronises those events and returns total milliseconds

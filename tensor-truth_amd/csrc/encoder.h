@@ -34,6 +34,20 @@ struct GemmParams {
     int32_t* scan_idx;        // [N][scan_cap]
     int scan_cap;
     int32_t scan_idx_base;    // emitted index = scan_idx_base + A row
+    // ---- split-bf16 ("bf16x3") operands: reference precision on the bf16 matrix cores (x3_path.hip) -------------------
+    // A value x is carried as TWO bf16 planes, hi = bf16(x) and lo = bf16(x - hi) (x = hi + lo to 2^-17 relative), stored
+    // side by side in a row: A[m][0..K) = hi, A[m][K..2K) = lo (lda >= 2K), W[n][0..K) = hi, W[n][K..2K) = lo (ldw = 2K).
+    // The product runs as ONE contraction over a virtual K' = 3K: A-hi.W-hi + A-hi.W-lo + A-lo.W-hi (lo.lo, 2^-16 of the
+    // result, is dropped), fp32 accumulate -- the bf16 main loop unchanged, K-tile t reading A tile (t < nk ? t : t - nk)
+    // and W tile (t < 2nk ? t : t - 2nk).  256x256 kernels only.  Epilogues: TT_EPI_BIAS / TT_EPI_GELU (exact erf) write
+    // planes, C[m][n] = hi, C[m][c_lo_off + n] = lo; TT_EPI_RESIDUAL writes fp32, C32[m][n] = acc + bias + res32[m][n];
+    // TT_EPI_VT writes the V8 layout twice (vt = hi, vt_lo = lo).
+    int x3;
+    int ldw;                  // W row stride in elements (0 = K)
+    int c_lo_off;             // planes output: column offset of the lo plane
+    float* C32;               // fp32 output [M][ldc] (x3 residual epilogue)
+    const float* res32;       // fp32 residual [M][ldr]
+    uint16_t* vt_lo;          // lo plane of the V8 output
 };
 // Filter pass of the similarity scan for 65..256 queries per pass as a 256x256x64-tiled MFMA contraction (gemm.hip):
 // corpus [rows][dim] bf16 with rows a multiple of 256, queries256 [256][dim] bf16 (rows beyond the batch zero),

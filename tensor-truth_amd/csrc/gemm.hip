@@ -174,7 +174,7 @@ __device__ __forceinline__ void gemm_epilogue_wide(const GemmParams& p, f32x4 (&
 // ---- V^T epilogue (un-swapped accumulators: lane = feature column l&15, registers = 4 consecutive tokens)
 // permlane16_swap between the registers of n-tile 2i and 2i+1 gives every lane 8 consecutive tokens of one
 // feature: one 16-B store into the V8 buffer ([token/8][feature][8 tokens]) instead of eight 2-byte stores.
-template <int NT, int MT, bool FP8 = false>
+template <int NT, int MT, bool FP8 = false, bool X3 = false>
 __device__ __forceinline__ void gemm_epilogue_vt(const GemmParams& p, f32x4 (&acc)[NT][MT], int mw, int nw, int lane) {
     static_assert(NT % 2 == 0, "n-tiles are processed in pairs");
     const int g = lane >> 4;
@@ -209,6 +209,14 @@ __device__ __forceinline__ void gemm_epilogue_vt(const GemmParams& p, f32x4 (&ac
             o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
             o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
             *reinterpret_cast<uint4*>(col + (size_t)(m >> 3) * p.ldvt) = o;
+            if constexpr (X3) {   // lo plane: what the bf16 rounding of the hi plane left behind
+                uint4 l;
+                l.x = pack_bf16x2(v[0] - __uint_as_float(o.x << 16), v[1] - __uint_as_float(o.x & 0xFFFF0000u));
+                l.y = pack_bf16x2(v[2] - __uint_as_float(o.y << 16), v[3] - __uint_as_float(o.y & 0xFFFF0000u));
+                l.z = pack_bf16x2(v[4] - __uint_as_float(o.z << 16), v[5] - __uint_as_float(o.z & 0xFFFF0000u));
+                l.w = pack_bf16x2(v[6] - __uint_as_float(o.w << 16), v[7] - __uint_as_float(o.w & 0xFFFF0000u));
+                *reinterpret_cast<uint4*>(p.vt_lo + (size_t)(n - p.vt_col0) * 8 + (size_t)(m >> 3) * p.ldvt) = l;
+            }
         }
     }
 }
@@ -358,7 +366,7 @@ __device__ __forceinline__ void stage_half(const GemmParams& p, char* smem, int 
     // ES = bytes per element (2 bf16, 1 fp8); a K-tile is 128 bytes of every row either way
     const char* base;
     if constexpr (OPERAND == 0) base = reinterpret_cast<const char*>(p.A) + ((size_t)(m0 + half * 128) * p.lda) * ES + tile * 128;
-    else base = reinterpret_cast<const char*>(p.W) + ((size_t)(n0 + half * 32) * p.K) * ES + tile * 128;   // see w_row_of()
+    else base = reinterpret_cast<const char*>(p.W) + ((size_t)(n0 + half * 32) * (p.ldw ? p.ldw : p.K)) * ES + tile * 128;   // see w_row_of()
     // keep the base in SGPRs (otherwise hipcc folds it into per-lane 64-bit VGPR addresses and
     // pays two 64-bit vector adds per copy)
     const unsigned long long b64 = reinterpret_cast<unsigned long long>(base);
@@ -603,6 +611,94 @@ __device__ __forceinline__ void epilogue_all(const GemmParams& p, f32x4 (&acc)[2
         }
 }
 
+// ---- split-bf16 (bf16x3) epilogue: reference precision out of the bf16 main loop (GemmParams.x3) -------------------------
+// Same accumulator layout and column mapping as epilogue_all, no LDS staging (the main loop is three times as long as the
+// bf16 one, the epilogue's share a third): after the permlane16 swap a lane owns 8 consecutive columns of one row.
+//   BIAS / GELU (exact erf: the degree-7 fit above is a bf16-grade approximation): two bf16 planes, hi = bf16(v),
+//   lo = bf16(v - hi), 16 bytes each per lane;  RESIDUAL: fp32 out = acc + bias + fp32 residual, 32 bytes per lane.
+__device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+template <int EPI>
+__device__ __forceinline__ void epilogue_x3(const GemmParams& p, f32x4 (&acc)[2][2][2][4], const char* smem, int bias_off, int m0,
+                                            int n0, int wm, int wn, int lane) {
+    const int g = lane >> 4;
+    const bool odd = (g & 1) != 0;
+    const int ncol = wn * 64 + (g & ~1) * 4;
+    const int mrow = wm * 64 + (lane & 15);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)smem;
+    float4 bias[2][2][2];
+    {
+        const uint32_t baddr = lds0 + bias_off + ncol * 4;
+        u32x4 b[8];
+        b[0] = lds_read128_async<0>(baddr);        b[1] = lds_read128_async<16>(baddr);
+        b[2] = lds_read128_async<64>(baddr);       b[3] = lds_read128_async<80>(baddr);
+        b[4] = lds_read128_async<128>(baddr);      b[5] = lds_read128_async<144>(baddr);
+        b[6] = lds_read128_async<192>(baddr);      b[7] = lds_read128_async<208>(baddr);
+        lds_wait(b[0], b[1], b[2], b[3]);
+        lds_wait(b[4], b[5], b[6], b[7]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            bias[i >> 2][(i >> 1) & 1][i & 1] = float4{__uint_as_float(b[i].x), __uint_as_float(b[i].y), __uint_as_float(b[i].z),
+                                                       __uint_as_float(b[i].w)};
+    }
+#pragma unroll
+    for (int qm = 0; qm < 2; ++qm)
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+            const int m = m0 + qm * 128 + mrow + (pr * 2 + (odd ? 1 : 0)) * 16;
+            float4 r0[2][2], r1[2][2];
+            if constexpr (EPI == TT_EPI_RESIDUAL) {   // the block's 8 residual loads in flight together
+#pragma unroll
+                for (int qn = 0; qn < 2; ++qn)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+                        const float* rp = p.res32 + (size_t)m * p.ldr + n0 + qn * 32 + nt * 16 + ncol;
+                        r0[qn][nt] = *reinterpret_cast<const float4*>(rp);
+                        r1[qn][nt] = *reinterpret_cast<const float4*>(rp + 4);
+                    }
+            }
+#pragma unroll
+            for (int qn = 0; qn < 2; ++qn)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    float v[8];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[qm][qn][nt][2 * pr][k]),
+                                                                        __float_as_uint(acc[qm][qn][nt][2 * pr + 1][k]),
+                                                                        false, false);
+                        v[k] = __uint_as_float(r[0]);
+                        v[4 + k] = __uint_as_float(r[1]);
+                    }
+                    const float4 b0 = bias[qn][nt][0], b1 = bias[qn][nt][1];
+                    v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+                    v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+                    const int n = n0 + qn * 32 + nt * 16 + ncol;
+                    if constexpr (EPI == TT_EPI_RESIDUAL) {
+                        const float4 a = r0[qn][nt], b = r1[qn][nt];
+                        float* cp = p.C32 + (size_t)m * p.ldc + n;
+                        *reinterpret_cast<float4*>(cp) = float4{v[0] + a.x, v[1] + a.y, v[2] + a.z, v[3] + a.w};
+                        *reinterpret_cast<float4*>(cp + 4) = float4{v[4] + b.x, v[5] + b.y, v[6] + b.z, v[7] + b.w};
+                    } else {
+                        if constexpr (EPI == TT_EPI_GELU) {
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) v[k] = gelu_exact(v[k]);
+                        }
+                        uint4 o, l;
+                        o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
+                        o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
+                        l.x = pack_bf16x2(v[0] - __uint_as_float(o.x << 16), v[1] - __uint_as_float(o.x & 0xFFFF0000u));
+                        l.y = pack_bf16x2(v[2] - __uint_as_float(o.y << 16), v[3] - __uint_as_float(o.y & 0xFFFF0000u));
+                        l.z = pack_bf16x2(v[4] - __uint_as_float(o.z << 16), v[5] - __uint_as_float(o.z & 0xFFFF0000u));
+                        l.w = pack_bf16x2(v[6] - __uint_as_float(o.w << 16), v[7] - __uint_as_float(o.w & 0xFFFF0000u));
+                        uint16_t* cp = p.C + (size_t)m * p.ldc + n;
+                        *reinterpret_cast<uint4*>(cp) = o;
+                        *reinterpret_cast<uint4*>(cp + p.c_lo_off) = l;
+                    }
+                }
+        }
+}
+
 // TT_EPI_SCAN: nothing is stored.  In the swapped accumulator layout a lane holds ONE corpus row (m-tile row l & 15)
 // and four consecutive queries per 16x16 tile, so the per-query threshold filter is four compares against a float4
 // of the tile's threshold strip (LDS, staged like a bias strip).  Survivors are rare (about k * rows / sample rows
@@ -692,8 +788,9 @@ __device__ __forceinline__ f32x4 mfma_fp8(const bf16x8& a0, const bf16x8& a1, co
     return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
 }
 
-template <int EPI, int SLOTS, bool FP8 = false>
+template <int EPI, int SLOTS, bool FP8 = false, bool X3 = false>
 __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
+    static_assert(!(FP8 && X3), "split-bf16 operands are bf16");
     constexpr int ES = FP8 ? 1 : 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -716,7 +813,11 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
     const int tn = (sidx % supers_n) * SN + widx % SN;
     if (tm >= mt_n || tn >= nt_n) return;
     const int m0 = tm * BM3, n0 = tn * BN3;
-    const int nk = p.K * ES / 128;
+    // split-bf16 (X3): three passes over K -- hi.hi, hi.lo, lo.hi -- as ONE K stream of 3 nk1 tiles (GemmParams.x3)
+    const int nk1 = p.K * ES / 128;
+    const int nk = X3 ? 3 * nk1 : nk1;
+    auto tile_a = [&](int t) { if constexpr (X3) return t < nk1 ? t : t - nk1; else return t; };
+    auto tile_w = [&](int t) { if constexpr (X3) return t < 2 * nk1 ? t : t - 2 * nk1; else return t; };
 
     f32x4 acc[2][2][2][4];  // [qm][qn][n-tile][m-tile]
 #pragma unroll
@@ -743,7 +844,7 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
         const int r = 16 * wave + 8 * j + (lane >> 3);
         const int chunk = (lane & 7) ^ ((r >> 1) & 7);
         voffA[j] = (uint32_t)r * (uint32_t)p.lda * (uint32_t)ES + (uint32_t)chunk * 16u;
-        voffW[j] = (uint32_t)w_row_of(r) * (uint32_t)p.K * (uint32_t)ES + (uint32_t)chunk * 16u;
+        voffW[j] = (uint32_t)w_row_of(r) * (uint32_t)(p.ldw ? p.ldw : p.K) * (uint32_t)ES + (uint32_t)chunk * 16u;
     }
 
     unsigned long long* dbg0 = reinterpret_cast<unsigned long long*>(p.vt);
@@ -761,7 +862,7 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
         }
     };
     // residual tile -> LDS, four parts of (2 pieces x 2 copies) per wave; layout: see epilogue_all
-    constexpr bool kResLds = (EPI == TT_EPI_RESIDUAL);
+    constexpr bool kResLds = (EPI == TT_EPI_RESIDUAL) && !X3;   // (split-bf16: the residual is fp32, read by the epilogue)
     uint32_t voffR[2] = {0u, 0u};
     if constexpr (kResLds) {
 #pragma unroll
@@ -807,8 +908,8 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
     stage_half<1, ES>(p, smem, 1, 0, 0, wave, voffW, m0, n0);
     stage_half<0, ES>(p, smem, 1, 0, 0, wave, voffA, m0, n0);
     if (nk > 1) {
-        stage_half<0, ES>(p, smem, 0, 1, 1, wave, voffA, m0, n0);
-        stage_half<1, ES>(p, smem, 0, 1, 1, wave, voffW, m0, n0);
+        stage_half<0, ES>(p, smem, 0, 1, tile_a(1), wave, voffA, m0, n0);
+        stage_half<1, ES>(p, smem, 0, 1, tile_w(1), wave, voffW, m0, n0);
     }
     if (nk > 1) {
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // A-hi(0), A-lo(1), W-lo(1) may be in flight
@@ -897,8 +998,8 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
         // La
         stamp(t);                                  // 0: La start
         if (more1) {
-            stage_half<1, ES>(p, smem, 1, B ^ 1, t + 1, wave, voffW, m0, n0);
-            stage_half<0, ES>(p, smem, 1, B ^ 1, t + 1, wave, voffA, m0, n0);
+            stage_half<1, ES>(p, smem, 1, B ^ 1, tile_w(t + 1), wave, voffW, m0, n0);
+            stage_half<0, ES>(p, smem, 1, B ^ 1, tile_a(t + 1), wave, voffA, m0, n0);
         } else if (kResLds) {
             stage_res(1);                          // last tile (B = 1): hi slots of buffer 0
         }
@@ -918,8 +1019,8 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
         // Lb
         stamp(t);                                  // 6: Lb start
         if (more2) {
-            stage_half<0, ES>(p, smem, 0, B, t + 2, wave, voffA, m0, n0);
-            stage_half<1, ES>(p, smem, 0, B, t + 2, wave, voffW, m0, n0);
+            stage_half<0, ES>(p, smem, 0, B, tile_a(t + 2), wave, voffA, m0, n0);
+            stage_half<1, ES>(p, smem, 0, B, tile_w(t + 2), wave, voffW, m0, n0);
         } else if (kResLds) {
             stage_res(B == 0 ? 0 : 2);             // tile nk-2 (B = 0): lo slots of buffer 0; tile nk-1: of buffer 1
         }
@@ -951,7 +1052,9 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
         for (int qm = 0; qm < 2; ++qm)
 #pragma unroll
             for (int qn = 0; qn < 2; ++qn)
-                gemm_epilogue_vt<2, 4, FP8>(p, acc[qm][qn], m0 + qm * 128 + wm * 64, n0 + wn * 64 + qn * 32, lane);
+                gemm_epilogue_vt<2, 4, FP8, X3>(p, acc[qm][qn], m0 + qm * 128 + wm * 64, n0 + wn * 64 + qn * 32, lane);
+    } else if constexpr (X3) {
+        epilogue_x3<EPI>(p, acc, smem, kBiasOff, m0, n0, wm, wn, lane);
     } else if constexpr (EPI == TT_EPI_QKV) {
 #pragma unroll
         for (int qm = 0; qm < 2; ++qm)
@@ -1028,7 +1131,7 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_p(GemmParams p, int 
         const int r = 16 * wave + 8 * j + (lane >> 3);
         const int chunk = (lane & 7) ^ ((r >> 1) & 7);
         voffA[j] = (uint32_t)r * (uint32_t)p.lda * (uint32_t)ES + (uint32_t)chunk * 16u;
-        voffW[j] = (uint32_t)w_row_of(r) * (uint32_t)p.K * (uint32_t)ES + (uint32_t)chunk * 16u;
+        voffW[j] = (uint32_t)w_row_of(r) * (uint32_t)(p.ldw ? p.ldw : p.K) * (uint32_t)ES + (uint32_t)chunk * 16u;
     }
 
     int m0 = 0, n0 = 0, m1 = 0, n1 = 0;
@@ -1276,6 +1379,44 @@ int launch_fp8(const GemmParams& p, hipStream_t st) {
     }
 }
 
+// split-bf16 operands (GemmParams.x3): the 256x256 one-tile kernel, bias / GELU (planes out), residual (fp32 out), V^T
+template <int EPI>
+int launch_x3(const GemmParams& p, hipStream_t st) {
+    if constexpr (EPI == TT_EPI_BIAS || EPI == TT_EPI_GELU || EPI == TT_EPI_VT || EPI == TT_EPI_RESIDUAL) {
+        const int ldw = p.ldw ? p.ldw : p.K;
+        if (p.M % v3::BM3 || p.N % v3::BN3 || p.K % 64 || p.K < 128 || p.lda < 2 * p.K || ldw < 2 * p.K || p.lda % 8 || ldw % 8 || !p.A ||
+            !p.W || !p.bias) {
+            tt_set_error("gemm x3: M=%d N=%d K=%d lda=%d ldw=%d: M, N multiples of 256, K of 64, planes [.][>= 2K]", p.M, p.N, p.K, p.lda, ldw);
+            return TT_E_UNSUPPORTED;
+        }
+        if constexpr (EPI == TT_EPI_RESIDUAL) {
+            if (!p.C32 || !p.res32 || p.ldc % 4 || p.ldr % 4) { tt_set_error("gemm x3: residual epilogue needs fp32 C32 / res32"); return TT_E_INVALID; }
+        } else if constexpr (EPI == TT_EPI_VT) {
+            if (!p.vt || !p.vt_lo || p.ldvt % 8) { tt_set_error("gemm x3: V^T epilogue needs vt / vt_lo"); return TT_E_INVALID; }
+        } else {
+            if (!p.C || p.ldc % 8 || p.c_lo_off % 8 || p.c_lo_off < p.N) { tt_set_error("gemm x3: planes output needs C, c_lo_off >= N"); return TT_E_INVALID; }
+        }
+        const int mt_n = p.M / v3::BM3, nt_n = p.N / v3::BN3;
+        const int SN = super_sn(nt_n), SM = 32 / SN;
+        const int supers = ((mt_n + SM - 1) / SM) * ((nt_n + SN - 1) / SN);
+        int blocks = supers * SM * SN;
+        blocks = (blocks + 7) / 8 * 8;
+        TT_SET_MAX_LDS((v3::gemm_kernel_v3<EPI, 4, false, true>), v3::kLds3);
+        {
+            TtProfScope prof(TT_K_GEMM, st);
+            GemmParams q = p;
+            q.sn = SN;
+            q.ldw = ldw;
+            hipLaunchKernelGGL((v3::gemm_kernel_v3<EPI, 4, false, true>), dim3(blocks), dim3(v3::kThreads3), v3::kLds3, st, q);
+        }
+        TT_CHECK_LAUNCH();
+        return TT_OK;
+    } else {
+        tt_set_error("gemm x3: epilogue %d has no split-bf16 form", EPI);
+        return TT_E_UNSUPPORTED;
+    }
+}
+
 // ---- skinny: M <= 256 rows (one query's embedding, the CLS-row tail of the last layer, the rerank head) -----------
 // With a few dozen token rows a GEMM is a stream of the weight matrix and nothing else: the tiled kernels put
 // 16 (N = 1024) to 64 workgroups on the chip and walk K in 64-element steps behind a barrier each (8 us at K = 1024,
@@ -1433,6 +1574,15 @@ bool tt_gemm_skinny_enabled() {
 
 int tt_gemm_launch(const GemmParams& p, int epilogue, hipStream_t st) {
     if (p.M <= 0 || p.N <= 0) return TT_OK;
+    if (p.x3) {
+        switch (epilogue) {
+            case TT_EPI_BIAS: return launch_x3<TT_EPI_BIAS>(p, st);
+            case TT_EPI_GELU: return launch_x3<TT_EPI_GELU>(p, st);
+            case TT_EPI_RESIDUAL: return launch_x3<TT_EPI_RESIDUAL>(p, st);
+            case TT_EPI_VT: return launch_x3<TT_EPI_VT>(p, st);
+            default: tt_set_error("gemm x3: epilogue %d has no split-bf16 form", epilogue); return TT_E_UNSUPPORTED;
+        }
+    }
     if (p.fp8 && epilogue == TT_EPI_QKV) {
         // fp8 QKV projection: Q,K columns as a bias GEMM, V columns as un-swapped tiles stored transposed
         if (!p.vt || p.vt_col0 % v3::BN3 || (p.N - p.vt_col0) % v3::BN3 || p.ldvt % 8) {

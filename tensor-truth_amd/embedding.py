@@ -16,8 +16,8 @@ from typing import Any, Dict, List, Optional, Sequence
 import torch
 
 from . import weights as _weights
-from .encoder import Encoder, EncoderWeights, pack_tokens
-from .encoder_f32 import EncoderF32, EncoderWeightsF32, wants_float32
+from . import precision as _precision
+from .encoder import pack_tokens
 from .tokenization import load_tokenizer
 
 logger = logging.getLogger(__name__)
@@ -70,16 +70,9 @@ class HipHuggingFaceEmbedding:
         _report_unused_kwargs(model_name, model_kwargs, tokenizer_kwargs)
         cfg, state, mdir = _weights.resolve(model_name, model_kwargs, dev, want_head=False)
         self.config = cfg
-        if wants_float32(model_kwargs):
-            # model_kwargs["torch_dtype"] = float32, the reference's own default precision (config_schema.py:66-76):
-            # fp32 weights, activations and MFMA -- 1e-3-relative agreement with the CPU path, ~1/10 of the throughput
-            self._model = EncoderWeightsF32(cfg, state, dev)
-            self._encoder = EncoderF32(self._model)
-            logger.info("%s: torch_dtype=float32 -> reference-precision fp32 forward", model_name)
-        else:
-            self._model = EncoderWeights(cfg, state, dev)       # .parameters() for memory accounting
-            self._model.set_gemm_dtype((model_kwargs or {}).get("gemm_dtype", "bf16"))
-            self._encoder = Encoder(self._model)
+        # precision.resolve(): model_kwargs (torch_dtype float32 = the reference's own default, config_schema.py:66-76),
+        # ModelManager.precision, TT_PRECISION; default bf16.  (`_model.parameters()` is read by the memory accounting.)
+        self._model, self._encoder, self.precision = _precision.build_encoder(cfg, state, dev, model_kwargs, f"embedder {model_name}")
         self._tokenizer = (model_kwargs or {}).get("tokenizer") or load_tokenizer(mdir, cfg.arch, cfg.vocab_size)
         self.max_length = min(max_length or cfg.max_seq_len, cfg.max_seq_len)
         self.query_instruction = query_instruction_for(model_name) if query_instruction is None else query_instruction

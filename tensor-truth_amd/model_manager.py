@@ -81,6 +81,10 @@ class ModelManager:
         self._model_lock = threading.Lock()
         self.embedding_model_configs: Dict[str, Dict] = dict(DEFAULT_EMBEDDING_MODEL_CONFIGS)
         self.model_kwargs_overrides: Dict[str, Dict[str, Any]] = {}  # model name -> extra model_kwargs
+        # Process-level precision of the models this manager loads: None (= TT_PRECISION, else bf16), "bf16", "fp8" or
+        # "reference" -- the reference's own fp32 semantics for its unchanged calls (precision.py).  Set it before the
+        # first get_embedder / get_reranker, or call set_precision() (drops the resident models).
+        self.precision: Optional[str] = None
         self._initialized = True
 
     @classmethod
@@ -97,6 +101,23 @@ class ModelManager:
 
     def set_default_device(self, device: str) -> None:
         self._default_device = device
+
+    def set_precision(self, precision: Optional[str]) -> None:
+        """Config key for the arithmetic of every model loaded from now on (see ``precision.py``); resident models are
+        dropped so that the next ``get_*`` reloads them in the new mode."""
+        from . import precision as _p
+
+        value = None if precision is None else _p.canonical(precision)
+        if value != self.precision:
+            self.precision = value
+            self.unload_all()
+
+    def _with_precision(self, model_kwargs: Optional[Dict[str, Any]]) -> Optional[Dict[str, Any]]:
+        mk = dict(model_kwargs or {})
+        explicit = mk.get("precision") is not None or mk.get("torch_dtype") is not None or mk.get("gemm_dtype") is not None
+        if self.precision is not None and not explicit:
+            mk["precision"] = self.precision
+        return mk or None
 
     # ---- embedder ------------------------------------------------------------------------------
     def _embedding_config(self, model_name: str) -> EmbeddingModelConfig:
@@ -128,6 +149,7 @@ class ModelManager:
             logger.info("Creating embedding model: %s (batch_size=%d, dtype=%s)", model_name, batch,
                         mc.torch_dtype or "bfloat16 (HIP default)")
             model_kwargs.update(self.model_kwargs_overrides.get(model_name, {}))
+            model_kwargs = self._with_precision(model_kwargs)
             tokenizer_kwargs = {"padding_side": mc.padding_side} if mc.padding_side else None
             self._embedder = HipHuggingFaceEmbedding(model_name=model_name, device=device, model_kwargs=model_kwargs,
                                                      tokenizer_kwargs=tokenizer_kwargs, embed_batch_size=batch)
@@ -161,7 +183,7 @@ class ModelManager:
 
             self._reranker = HipSentenceTransformerRerank(
                 model=model_name, top_n=top_n, device=device,
-                model_kwargs=self.model_kwargs_overrides.get(model_name) or None)
+                model_kwargs=self._with_precision(self.model_kwargs_overrides.get(model_name)))
             self._reranker_model_name, self._reranker_top_n, self._reranker_device = model_name, top_n, device
         except Exception as e:  # noqa: BLE001
             self._reranker = None

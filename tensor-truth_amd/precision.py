@@ -1,0 +1,90 @@
+"""Which arithmetic a HIP embedder / reranker runs in, and who decides.
+
+The reference never passes a dtype to its reranker (``SentenceTransformerRerank(model=, top_n=, device=)``,
+``src/tensortruth/services/model_manager.py:333-337``) and passes one to its embedder only when the per-model config
+holds ``torch_dtype`` (``services/model_manager.py:218-229``; ``app_utils/config_schema.py:66-76``: default None), so the
+reference's own precision is fp32.  BASELINE.json's configurations name bf16 (and fp8 for config 5), which is what this
+package computes by default.  The unchanged reference calls can still get the reference's arithmetic:
+
+    mode "reference"  fp32 semantics: scores within north_star's 1e-3 relative of the CPU path.  Runs as split-bf16 on
+                      the bf16 matrix cores (``encoder_x3``, a third of the bf16 rate) when the model shape allows,
+                      else on the fp32 MFMA (``encoder_f32``).  ``TT_REFERENCE_IMPL=fp32`` forces the latter.
+    mode "bf16"       bf16 weights / activations, fp32 accumulate (default; BASELINE configs 2-4)
+    mode "fp8"        the layer projections in OCP e4m3 (BASELINE config 5's "fp8 MFMA reranker")
+
+Resolution order (first that says something): ``model_kwargs["precision"]``; ``model_kwargs["torch_dtype"]`` (float32 ->
+reference; bfloat16 / float16 -> bf16) and ``model_kwargs["gemm_dtype"]``; ``ModelManager.precision`` (a config key the
+application sets once; ModelManager puts it into the model_kwargs it builds); the process environment ``TT_PRECISION``;
+"bf16".  The active mode is logged when a model is loaded.
+"""
+from __future__ import annotations
+
+import logging
+import os
+from typing import Any, Dict, Optional, Tuple
+
+logger = logging.getLogger(__name__)
+
+MODES = ("bf16", "fp8", "reference")
+_ALIASES = {"bf16": "bf16", "bfloat16": "bf16", "fp8": "fp8", "e4m3": "fp8", "reference": "reference", "fp32": "reference",
+            "float32": "reference", "float": "reference", "bf16x3": "reference"}
+
+
+def canonical(value) -> str:
+    v = str(value).replace("torch.", "").strip().lower()
+    if v not in _ALIASES:
+        raise ValueError(f"precision {value!r}: expected one of {MODES}")
+    return _ALIASES[v]
+
+
+def resolve(model_kwargs: Optional[Dict[str, Any]] = None, environ=None) -> str:
+    mk = model_kwargs or {}
+    if mk.get("precision") is not None:
+        return canonical(mk["precision"])
+    td = mk.get("torch_dtype")
+    if td is not None:
+        t = str(td).replace("torch.", "")
+        if t in ("float32", "fp32", "float"):
+            return "reference"
+        if mk.get("gemm_dtype") is None:
+            return "bf16"          # bfloat16, and float16 / anything else the HIP path maps to bf16 (logged by the callers)
+    if mk.get("gemm_dtype") is not None:
+        return canonical(mk["gemm_dtype"])
+    env = (os.environ if environ is None else environ).get("TT_PRECISION")
+    if env:
+        return canonical(env)
+    return "bf16"
+
+
+def reference_impl(cfg, environ=None) -> str:
+    """"bf16x3" (split-bf16 on the bf16 matrix cores) where the model shape fits, else "fp32" (fp32 MFMA)."""
+    from . import encoder_x3
+
+    forced = (os.environ if environ is None else environ).get("TT_REFERENCE_IMPL", "").strip().lower()
+    if forced in ("fp32", "float32", "f32"):
+        return "fp32"
+    return "bf16x3" if encoder_x3.supports(cfg) else "fp32"
+
+
+def build_encoder(cfg, state, device, model_kwargs: Optional[Dict[str, Any]], what: str) -> Tuple[Any, Any, str]:
+    """-> (weights, encoder, description) for the resolved precision; logs it."""
+    from .encoder import Encoder, EncoderWeights
+
+    mode = resolve(model_kwargs)
+    if mode == "reference":
+        if reference_impl(cfg) == "bf16x3":
+            from .encoder_x3 import EncoderWeightsX3, EncoderX3
+
+            w = EncoderWeightsX3(cfg, state, device)
+            enc, desc = EncoderX3(w), "reference (fp32 semantics as split-bf16 on the bf16 matrix cores, fp32 residual stream)"
+        else:
+            from .encoder_f32 import EncoderF32, EncoderWeightsF32
+
+            w = EncoderWeightsF32(cfg, state, device)
+            enc, desc = EncoderF32(w), "reference (fp32 weights, activations and MFMA)"
+    else:
+        w = EncoderWeights(cfg, state, device)
+        w.set_gemm_dtype(mode)
+        enc, desc = Encoder(w), ("bf16 (fp32 accumulate)" if mode == "bf16" else "fp8 e4m3 layer projections, bf16 elsewhere")
+    logger.info("%s: precision = %s", what, desc)
+    return w, enc, desc

@@ -15,8 +15,8 @@ import torch
 
 from . import weights as _weights
 from .coalesce import Coalescer
-from .encoder import Encoder, EncoderWeights, pack_tokens
-from .encoder_f32 import EncoderF32, EncoderWeightsF32, wants_float32
+from . import precision as _precision
+from .encoder import pack_tokens
 from .schema import MetadataMode, NodeWithScore
 from .tokenization import load_tokenizer
 
@@ -43,16 +43,10 @@ class HipSentenceTransformerRerank:
         self.config = cfg
         # pairs are truncated by the tokenizer (longest-first, specials kept): never beyond what the model has positions for
         self.max_length = min(max_length, cfg.max_seq_len)
-        if wants_float32(model_kwargs):
-            # the reference's default precision (SentenceTransformerRerank builds its CrossEncoder in fp32,
-            # model_manager.py:333-337): fp32 weights / activations / MFMA, scores within 1e-3 relative of the CPU path
-            self.model = EncoderWeightsF32(cfg, state, dev)
-            self._encoder = EncoderF32(self.model)
-        else:
-            self.model = EncoderWeights(cfg, state, dev)    # `.model` is what the reference's memory accounting reads
-            # model_kwargs["gemm_dtype"] = "fp8": Q/K/V and FFN-up projections on the e4m3 matrix cores (BASELINE config 5)
-            self.model.set_gemm_dtype((model_kwargs or {}).get("gemm_dtype", "bf16"))
-            self._encoder = Encoder(self.model)
+        # precision.resolve(): model_kwargs, ModelManager.precision, TT_PRECISION -- "reference" gives the unchanged
+        # reference call (no dtype: fp32, model_manager.py:333-337) its fp32 semantics; default bf16 (BASELINE configs 2-4)
+        # (`.model` is what the reference's memory accounting reads)
+        self.model, self._encoder, self.precision = _precision.build_encoder(cfg, state, dev, model_kwargs, f"reranker {model}")
         self._tokenizer = (model_kwargs or {}).get("tokenizer") or load_tokenizer(mdir, cfg.arch, cfg.vocab_size)
         # concurrent predict() / postprocess_nodes() calls (one per request thread in the reference,
         # rag_service.py:343-346,617-620) share ONE tokenizer call and ONE encoder batch; scores do not depend on the

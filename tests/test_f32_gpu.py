@@ -96,9 +96,12 @@ def test_f32_forward_matches_the_oracle(dev, built_lib, shape):
         assert torch.allclose(scores.cpu(), torch.sigmoid(logits.cpu()), atol=1e-6)
 
 
-def test_float32_through_the_plugin_surface(dev, built_lib):
+def test_float32_through_the_plugin_surface(dev, built_lib, monkeypatch):
     """model_kwargs={"torch_dtype": "float32"} -- the string the reference's config carries (config_schema.py:66-76) and
-    the torch dtype its ModelManager maps it to (model_manager.py:218-229) -- on both plugin classes."""
+    the torch dtype its ModelManager maps it to (model_manager.py:218-229) -- on both plugin classes, on the fp32-MFMA
+    implementation of the reference precision (TT_REFERENCE_IMPL=fp32; the default for this shape is the split-bf16
+    one: tests/test_x3_gpu.py)."""
+    monkeypatch.setenv("TT_REFERENCE_IMPL", "fp32")
     from tensor_truth_amd.embedding import HipHuggingFaceEmbedding
     from tensor_truth_amd.encoder import EncoderConfig
     from tensor_truth_amd.encoder_f32 import EncoderF32

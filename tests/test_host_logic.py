@@ -970,3 +970,32 @@ def test_persist_guard_serialises_writers_of_one_directory(tmp_path):
     with _persist_guard(str(tmp_path / "ix" / ".." / "ix")):    # same real path -> same lock object
         assert not _persist_guard(str(d)).lock.acquire(blocking=False)
     assert _generation_of("corpus.17.bf16") == 17 and _generation_of("corpus.bf16") is None and _generation_of("nodes.json") is None
+
+
+def test_precision_resolution_order():
+    """precision.resolve(): explicit model_kwargs beat the ModelManager key (which arrives as model_kwargs["precision"]
+    only when nothing explicit is there), which beats TT_PRECISION, which beats the bf16 default; torch_dtype float32 is
+    the reference's own spelling of "reference" (config_schema.py:66-76)."""
+    import torch
+
+    from tensor_truth_amd import model_manager as mm
+    from tensor_truth_amd import precision as P
+
+    assert P.resolve(None, {}) == "bf16" and P.resolve({}, {"TT_PRECISION": "reference"}) == "reference"
+    assert P.resolve({"torch_dtype": "float32"}, {}) == "reference" and P.resolve({"torch_dtype": torch.float32}, {}) == "reference"
+    assert P.resolve({"torch_dtype": "bfloat16"}, {"TT_PRECISION": "reference"}) == "bf16"
+    assert P.resolve({"gemm_dtype": "fp8"}, {"TT_PRECISION": "reference"}) == "fp8"
+    assert P.resolve({"precision": "bf16", "torch_dtype": "float32"}, {}) == "bf16"
+    assert P.resolve({}, {"TT_PRECISION": "fp32"}) == "reference" and P.canonical("bf16x3") == "reference"
+    with pytest.raises(ValueError):
+        P.resolve({}, {"TT_PRECISION": "int4"})
+    mm.ModelManager.reset_instance()
+    mgr = mm.ModelManager.get_instance()
+    assert mgr._with_precision(None) is None
+    mgr.precision = "reference"
+    assert mgr._with_precision({"trust_remote_code": True}) == {"trust_remote_code": True, "precision": "reference"}
+    assert mgr._with_precision({"torch_dtype": "bfloat16"}) == {"torch_dtype": "bfloat16"}      # the per-model config wins
+    assert mgr._with_precision({"gemm_dtype": "fp8"}) == {"gemm_dtype": "fp8"}
+    with pytest.raises(ValueError):
+        mgr.set_precision("fp64")
+    mm.ModelManager.reset_instance()

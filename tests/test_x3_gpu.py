@@ -1,0 +1,234 @@
+"""GPU: reference precision on the bf16 matrix cores (split-bf16, "bf16x3": csrc/x3_path.hip, gemm.hip GemmParams.x3)
+against fp64 / the fp32 CPU oracle.  The mode exists to give the reference's unchanged calls -- which carry no dtype,
+i.e. fp32 (services/model_manager.py:333-337, app_utils/config_schema.py:66-76) -- north_star's tolerance (scores within
+1e-3 relative) at a third of the bf16 rate; full depth (4 x 50 pairs x 24 layers): test_rank_agreement_gpu.py."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import encoder as oe
+
+pytestmark = pytest.mark.gpu
+
+XLMR = dict(arch="xlmr", vocab_size=2000, hidden=256, layers=3, heads=4, ffn=512, max_pos=300, type_vocab=1, pad_id=1,
+            ln_eps=1e-5, num_labels=1)
+WIDE = dict(arch="xlmr", vocab_size=1000, hidden=1024, layers=2, heads=16, ffn=4096, max_pos=300, type_vocab=1, pad_id=1,
+            ln_eps=1e-5, num_labels=1)
+
+
+def _pad(seqs, pad):
+    L = max(len(s) for s in seqs)
+    ids = torch.full((len(seqs), L), pad, dtype=torch.int64)
+    mask = torch.zeros(len(seqs), L, dtype=torch.int64)
+    for b, s in enumerate(seqs):
+        ids[b, : len(s)] = torch.tensor(s)
+        mask[b, : len(s)] = 1
+    return ids, mask
+
+
+def _planes(x):
+    from tensor_truth_amd.encoder_x3 import split_planes
+
+    return split_planes(x)
+
+
+def _join(planes, cols):
+    return planes[:, :cols].float() + planes[:, cols:2 * cols].float()
+
+
+def test_split_planes_kernel_equals_the_torch_formula(dev, built_lib):
+    from tensor_truth_amd import _lib
+
+    lib = _lib.load_library()
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(777, 320, generator=g) * torch.logspace(-6, 3, 320)
+    out = torch.zeros((777, 640), dtype=torch.bfloat16, device=dev)
+    _lib.check(lib.tt_split_planes(x.to(dev).data_ptr(), 777, 320, out.data_ptr(), None), "tt_split_planes")
+    torch.cuda.synchronize()
+    assert torch.equal(out.cpu(), _planes(x))
+    rel = ((_join(out.cpu(), 320) - x).abs() / x.abs().clamp_min(1e-30)).max().item()
+    assert rel <= 2.0 ** -16, rel                       # hi + lo carries x to 16+ bits
+
+
+@pytest.mark.parametrize("m,n,k", [(256, 256, 128), (512, 768, 256), (256, 1024, 1024), (768, 256, 4096), (1024, 4096, 1024)])
+def test_gemm_x3_building_block(dev, built_lib, m, n, k):
+    """tt_gemm_x3 against fp64 on the operands' own (hi + lo) values: error of an fp32-accumulated product, two orders
+    below what one bf16 rounding of an operand costs (2^-9 relative)."""
+    from tensor_truth_amd import _lib
+
+    lib = _lib.load_library()
+    g = torch.Generator().manual_seed(m + n + k)
+    a, w = torch.randn(m, k, generator=g), torch.randn(n, k, generator=g) * 0.05
+    bias, res = torch.randn(n, generator=g), torch.randn(m, n, generator=g)
+    ap, wp = _planes(a), _planes(w)
+    a64, w64 = _join(ap, k).double(), _join(wp, k).double()
+    ref = a64 @ w64.T + bias.double()
+    mag = (a64.abs() @ w64.abs().T)                                    # sum |a_i w_i|: the scale rounding errors grow with
+    wants = {0: ref, 1: 0.5 * ref * (1 + torch.erf(ref / 2 ** 0.5)), 2: ref + res.double()}
+    dap, dwp, db, dr = ap.to(dev), wp.to(dev), bias.to(dev), res.to(dev)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    for epi, want in wants.items():
+        cp = torch.full((m, 2 * n), float("nan"), dtype=torch.bfloat16, device=dev)
+        c32 = torch.full((m, n), float("nan"), device=dev)
+        rc = lib.tt_gemm_x3(dap.data_ptr(), dwp.data_ptr(), db.data_ptr(), dr.data_ptr() if epi == 2 else None,
+                            cp.data_ptr() if epi != 2 else None, c32.data_ptr() if epi == 2 else None, m, n, k, epi, st)
+        _lib.check(rc, "tt_gemm_x3")
+        torch.cuda.synchronize()
+        got = c32.cpu().double() if epi == 2 else _join(cp.cpu(), n).double()
+        assert torch.isfinite(got).all()
+        # dropped lo.lo terms (2^-16 each, incoherent) + fp32 accumulation + (planes output) the 2^-17 split of the result
+        bound = mag * (2.0 ** -15 / k ** 0.5 + 2.0 ** -22) + want.abs() * 2.0 ** -16 + 1e-6
+        excess = ((got - want).abs() / bound).max().item()
+        assert excess <= 1.0, (epi, excess)
+        rel = ((got - want).abs().max() / want.abs().max()).item()
+        assert rel <= 2e-5, (epi, rel)
+    with pytest.raises(_lib.TTError):
+        _lib.check(lib.tt_gemm_x3(dap.data_ptr(), dwp.data_ptr(), db.data_ptr(), None, cp.data_ptr(), None, m, n + 64, k, 0, st), "x")
+
+
+def test_gemm_x3_is_row_permutation_equivariant_bit_for_bit(dev, built_lib):
+    from tensor_truth_amd import _lib
+
+    lib = _lib.load_library()
+    m, n, k = 2048, 1024, 1024
+    g = torch.Generator().manual_seed(9)
+    ap, wp = _planes(torch.randn(m, k, generator=g)).to(dev), _planes(torch.randn(n, k, generator=g) * 0.03).to(dev)
+    bias = torch.randn(n, generator=g).to(dev)
+    perm = torch.randperm(m, generator=g).to(dev)
+    outs = []
+    for a in (ap, ap[perm].contiguous()):
+        c = torch.empty((m, 2 * n), dtype=torch.bfloat16, device=dev)
+        _lib.check(lib.tt_gemm_x3(a.data_ptr(), wp.data_ptr(), bias.data_ptr(), None, c.data_ptr(), None, m, n, k, 1, None), "tt_gemm_x3")
+        outs.append(c)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0][perm].view(torch.int16), outs[1].view(torch.int16))
+
+
+@pytest.mark.parametrize("lens", [[292] * 7, [1, 8, 64, 65, 127, 128, 129, 300, 17, 33], [512, 31, 257]])
+def test_attention_x3_against_fp64(dev, built_lib, lens):
+    """tt_attention_x3 on ragged sequences (any start row: back-to-back packing shares 8-row token groups between
+    neighbours) against an fp64 softmax attention over the operands' (hi + lo) values."""
+    from tensor_truth_amd import _lib
+
+    lib = _lib.load_library()
+    heads, dh = 4, 64
+    H = heads * dh
+    g = torch.Generator().manual_seed(sum(lens))
+    starts, row = [], 0
+    for i, n in enumerate(lens):
+        starts.append(row)
+        row += n if i % 2 else (n + 7) // 8 * 8          # every other sequence follows its neighbour without a gap
+    T = (row + 255) // 256 * 256
+    q, k, v = (torch.randn(T, H, generator=g) * s for s in (1.5, 1.5, 1.0))
+    qp, kp, vp = _planes(q), _planes(k), _planes(v)
+    qk = torch.cat([qp[:, :H], kp[:, :H], qp[:, H:], kp[:, H:]], dim=1).contiguous()           # Q hi | K hi | Q lo | K lo
+    def v8(plane):                                                                                # [T][H] -> [T/8][H][8]
+        return plane.view(T // 8, 8, H).permute(0, 2, 1).contiguous()
+    out = torch.zeros((T, 2 * H), dtype=torch.bfloat16, device=dev)
+    ss, sl = torch.tensor(starts, dtype=torch.int32, device=dev), torch.tensor(lens, dtype=torch.int32, device=dev)
+    dq, dvh, dvl = qk.to(dev), v8(vp[:, :H]).to(dev), v8(vp[:, H:]).to(dev)
+    rc = lib.tt_attention_x3(dq.data_ptr(), 4 * H, 0, H, 2 * H, dvh.data_ptr(), dvl.data_ptr(), 8 * H, out.data_ptr(), 2 * H, H,
+                             ss.data_ptr(), sl.data_ptr(), len(lens), heads, max(lens), torch.cuda.current_stream(dev).cuda_stream)
+    _lib.check(rc, "tt_attention_x3")
+    torch.cuda.synchronize()
+    got = _join(out.cpu(), H).double()
+    q64, k64, v64 = _join(qp, H).double(), _join(kp, H).double(), _join(vp, H).double()
+    worst = 0.0
+    for s, n in zip(starts, lens):
+        for h in range(heads):
+            sl_ = slice(h * dh, (h + 1) * dh)
+            p = torch.softmax(q64[s:s + n, sl_] @ k64[s:s + n, sl_].T / 8.0, dim=1)
+            worst = max(worst, (got[s:s + n, sl_] - p @ v64[s:s + n, sl_]).abs().max().item())
+    assert worst <= 3e-5, worst                         # |ctx| ~ 1; one bf16 rounding of P alone would be 4e-3
+    used = torch.zeros(T, dtype=torch.bool)
+    for s, n in zip(starts, lens):
+        used[s:s + n] = True
+    assert not out.cpu()[~used].any()                   # rows of no sequence are not written
+
+
+@pytest.mark.parametrize("shape", [XLMR, WIDE], ids=["xlmr256", "wide1024"])
+def test_x3_forward_matches_the_fp32_oracle(dev, built_lib, shape):
+    from tensor_truth_amd.encoder import EncoderConfig, pack_tokens
+    from tensor_truth_amd.encoder_x3 import EncoderWeightsX3, EncoderX3
+
+    cfg_o, cfg = oe.EncoderConfig(**shape), EncoderConfig(**shape)
+    W = oe.synth_weights(cfg_o, seed=29)
+    g = torch.Generator().manual_seed(4)
+    lens = [n for n in (cfg.max_seq_len, 65, 129, 33, 7, 200, 100, 17)]
+    seqs = [[0] + torch.randint(4, cfg.vocab_size, (n - 2,), generator=g).tolist() + [2] for n in lens]
+    enc = EncoderX3(EncoderWeightsX3(cfg, W, dev))
+    batch = pack_tokens(seqs, cfg)
+    hidden, _ = enc.forward_packed(batch)
+    emb, emb16 = enc.embed_packed(batch)
+    scores, logits = enc.rerank_packed(batch, want_logits=True)
+    torch.cuda.synchronize()
+    ids, mask = _pad(seqs, cfg.pad_id)
+    with torch.no_grad():
+        want_h = oe.encoder_forward(ids, mask, W, cfg_o)
+        want_s = oe.rerank_scores(ids, mask, W, cfg_o)
+    hidden = hidden.cpu()
+    worst = max((hidden[int(batch.seq_start[b]):int(batch.seq_start[b]) + len(s)] - want_h[b, : len(s)]).abs().max().item()
+                for b, s in enumerate(seqs))
+    assert worst <= 5e-4, worst                          # LayerNorm-scale values (|x| ~ 1-5); the bf16 path: ~5e-2
+    assert (emb.cpu() - oe.cls_pool_normalize(want_h)).abs().max().item() <= 5e-5
+    assert torch.equal(emb16.cpu(), emb.cpu().to(torch.bfloat16))
+    rel = ((scores.cpu() - want_s).abs() / want_s.abs()).max().item()
+    assert rel <= 1e-3, rel                              # north_star: fp scores within 1e-3 relative
+    assert rel <= 2e-4, rel                              # (what this path delivers on a 2-3 layer model)
+    assert torch.allclose(scores.cpu(), torch.sigmoid(logits.cpu()), atol=1e-6)
+    # a single short sequence (64 token rows, padded to one 256-row tile) gives the same embedding as inside the batch
+    one, _ = enc.embed([seqs[4]])
+    assert (one.cpu()[0] - emb.cpu()[4]).abs().max().item() <= 2e-6
+
+
+def test_precision_selector_reaches_both_surfaces(dev, built_lib, monkeypatch):
+    """TT_PRECISION=reference (process level), ModelManager.set_precision (config key) and model_kwargs each select the
+    reference arithmetic for the UNCHANGED reference calls -- SentenceTransformerRerank(model=, top_n=, device=) carries
+    no dtype (model_manager.py:333-337); TT_REFERENCE_IMPL=fp32 picks the fp32-MFMA implementation of it."""
+    from tensor_truth_amd import model_manager as mm
+    from tensor_truth_amd.encoder import Encoder, EncoderConfig
+    from tensor_truth_amd.encoder_f32 import EncoderF32
+    from tensor_truth_amd.encoder_x3 import EncoderX3
+    from tensor_truth_amd.rerank import HipSentenceTransformerRerank
+
+    cfg, cfg_o = EncoderConfig(**XLMR), oe.EncoderConfig(**XLMR)
+    W = oe.synth_weights(cfg_o, seed=31)
+    base = {"encoder_config": cfg, "state_dict": W}
+    texts = [" ".join(f"w{(7 * i + j) % 50}" for j in range(5 + 3 * i)) for i in range(9)]
+    query = "w1 w2 w3 which one"
+
+    def scores_of(rr):
+        got = torch.tensor(rr.predict([(query, t) for t in texts]))
+        ids, mask = _pad([rr._tokenizer.encode_pair(query, t, rr.max_length)[0] for t in texts], cfg.pad_id)
+        want = oe.rerank_scores(ids, mask, W, cfg_o)
+        return ((got - want).abs() / want.abs()).max().item()
+
+    monkeypatch.delenv("TT_PRECISION", raising=False)
+    monkeypatch.delenv("TT_REFERENCE_IMPL", raising=False)
+    rr = HipSentenceTransformerRerank(model="test/xenc", top_n=3, device="cuda", model_kwargs=dict(base))
+    assert isinstance(rr._encoder, Encoder) and rr.precision.startswith("bf16")          # default unchanged
+    monkeypatch.setenv("TT_PRECISION", "reference")
+    rr = HipSentenceTransformerRerank(model="test/xenc", top_n=3, device="cuda", model_kwargs=dict(base))
+    assert isinstance(rr._encoder, EncoderX3) and scores_of(rr) <= 2e-4
+    monkeypatch.setenv("TT_REFERENCE_IMPL", "fp32")
+    rr = HipSentenceTransformerRerank(model="test/xenc", top_n=3, device="cuda", model_kwargs=dict(base))
+    assert isinstance(rr._encoder, EncoderF32) and scores_of(rr) <= 1e-4
+    monkeypatch.delenv("TT_REFERENCE_IMPL")
+    rr = HipSentenceTransformerRerank(model="test/xenc", top_n=3, device="cuda", model_kwargs={**base, "precision": "bf16"})
+    assert isinstance(rr._encoder, Encoder)                                                # an explicit kwarg beats the environment
+    monkeypatch.delenv("TT_PRECISION")
+    # the ModelManager config key, through the reference's own lifecycle calls
+    mm.ModelManager.reset_instance()
+    mgr = mm.ModelManager.get_instance()
+    mgr.model_kwargs_overrides["test/xenc"] = dict(base)
+    mgr.model_kwargs_overrides["test/emb"] = {"encoder_config": EncoderConfig(**{**XLMR, "num_labels": 0}), "state_dict": W}
+    assert isinstance(mgr.get_reranker("test/xenc", top_n=3, device="cuda")._encoder, Encoder)
+    mgr.set_precision("reference")
+    rr = mgr.get_reranker("test/xenc", top_n=3, device="cuda")
+    assert isinstance(rr._encoder, EncoderX3) and scores_of(rr) <= 2e-4
+    emb = mgr.get_embedder("test/emb", "cuda")
+    assert isinstance(emb._encoder, EncoderX3)
+    e = torch.tensor(emb.get_text_embedding_batch(texts))
+    ids, mask = _pad([emb._tokenizer.encode(t, emb.max_length) for t in texts], cfg.pad_id)
+    assert (e - oe.embed(ids, mask, W, cfg_o)).abs().max().item() <= 5e-5
+    mm.ModelManager.reset_instance()

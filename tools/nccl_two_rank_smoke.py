@@ -28,6 +28,13 @@ def parse(argv):
 def launcher(args):
     import socket
 
+    import torch      # device_count() does not initialise the GPU on this image (counting is safe before spawning)
+
+    n_dev = torch.cuda.device_count()
+    if n_dev < args.ranks:
+        print(f"nccl smoke: {args.ranks} ranks need {args.ranks} GPUs, this box has {n_dev}: RCCL cannot share a device between ranks")
+        raise SystemExit(3)
+
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
