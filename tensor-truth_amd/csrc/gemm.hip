@@ -682,7 +682,13 @@ __device__ __forceinline__ void epilogue_x3(const GemmParams& p, f32x4 (&acc)[2]
                     } else {
                         if constexpr (EPI == TT_EPI_GELU) {
 #pragma unroll
-                            for (int k = 0; k < 8; ++k) v[k] = gelu_exact(v[k]);
+                            for (int k = 0; k < 8; ++k) {
+                                v[k] = gelu_exact(v[k]);
+                                // opaque: under -ffp-contract=fast the final multiply of the GELU fuses with the "v - hi" below
+                                // in SOME unrolled copies of this block only -- the lo plane then depends on the row's position
+                                // in the tile by an ulp (found by the row-permutation test)
+                                asm("" : "+v"(v[k]));
+                            }
                         }
                         uint4 o, l;
                         o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);

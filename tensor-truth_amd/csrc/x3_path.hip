@@ -415,8 +415,9 @@ __global__ __launch_bounds__(64 * kXWaves, 2) void attention_x3_kernel(AttnX3Par
         for (int d = 0; d < DT; ++d)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const float y0 = acc_o[d][4 * g + 0] * inv, y1 = acc_o[d][4 * g + 1] * inv, y2 = acc_o[d][4 * g + 2] * inv,
-                            y3 = acc_o[d][4 * g + 3] * inv;
+                float y0 = acc_o[d][4 * g + 0] * inv, y1 = acc_o[d][4 * g + 1] * inv, y2 = acc_o[d][4 * g + 2] * inv,
+                      y3 = acc_o[d][4 * g + 3] * inv;
+                asm("" : "+v"(y0), "+v"(y1), "+v"(y2), "+v"(y3));   // opaque: no fusing of "* inv" into the "y - hi" below (see epilogue_x3)
                 uint2 hi, lo;
                 hi.x = pack_bf16x2(y0, y1);
                 hi.y = pack_bf16x2(y2, y3);

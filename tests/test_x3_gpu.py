@@ -139,7 +139,9 @@ def test_attention_x3_against_fp64(dev, built_lib, lens):
             sl_ = slice(h * dh, (h + 1) * dh)
             p = torch.softmax(q64[s:s + n, sl_] @ k64[s:s + n, sl_].T / 8.0, dim=1)
             worst = max(worst, (got[s:s + n, sl_] - p @ v64[s:s + n, sl_]).abs().max().item())
-    assert worst <= 3e-5, worst                         # |ctx| ~ 1; one bf16 rounding of P alone would be 4e-3
+    # scores S ~ N(0, 2.25^2) here: the dropped lo.lo terms of K.Q^T (2^-16 each, 64 incoherent terms of |q||k| ~ 2.25, / 8)
+    # leave ~3e-5 in S, i.e. ~3e-5 relative in P and in ctx (|ctx| ~ 1); one bf16 rounding of P alone would be 4e-3
+    assert worst <= 1e-4, worst
     used = torch.zeros(T, dtype=torch.bool)
     for s, n in zip(starts, lens):
         used[s:s + n] = True
