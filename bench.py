@@ -110,6 +110,7 @@ def parse():
     ap.add_argument("--surface-queries", type=int, default=256, help="queries the surface leg issues in all (N=1 only)")
     ap.add_argument("--config5-docs", type=int, default=1024)
     ap.add_argument("--no-fp8-leg", action="store_true", help="skip the extra fp8-reranker timing (BASELINE config 5)")
+    ap.add_argument("--no-reference-leg", action="store_true", help="skip the reference-precision (bf16x3) timing")
     ap.add_argument("--headline-only", action="store_true",
                     help="run only the warm-up and timed steps (no scan-only / fp8 / ingest legs): every kernel of the process then "
                          "belongs to the timed workload, so a rocprofv3 --stats summary of this command can be compared with "
@@ -215,7 +216,10 @@ def main():
 
     tokens_step = {"embed": 0, "rerank": 0}
 
+    enc_pair = {"embedder": embedder, "reranker": reranker}     # (the reference-precision leg swaps both)
+
     def step(q_tok):
+        embedder, reranker = enc_pair["embedder"], enc_pair["reranker"]
         # 1. embed this rank's queries: <s> q </s>
         q_ids = np.empty((Bq, args.query_len + 2), dtype=np.int32)
         q_ids[:, 0], q_ids[:, 1:-1], q_ids[:, -1] = 0, q_tok, 2
@@ -343,6 +347,47 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # ---- the reference's own precision (it passes no dtype: fp32 -- services/model_manager.py:333-337,
+    # app_utils/config_schema.py:66-76): the SAME step with both encoders in the "reference" mode (TT_PRECISION=reference),
+    # i.e. split-bf16 on the bf16 matrix cores with an fp32 residual stream (encoder_x3).  Fresh UNROUNDED fp32 weights
+    # (their lo planes are not zero: zero operands would flatter the clock).  Reported beside the headline, never as it.
+    reference_leg = None
+    if not args.no_reference_leg and not args.headline_only:
+        from tensor_truth_amd.encoder_x3 import EncoderWeightsX3, EncoderX3
+
+        quality = None
+        if rank == 0:   # accuracy: on the RESIDENT weights, against the fp32-MFMA path (before the fp32 copies are made)
+            quality = rank_quality(reranker, rr_cfg, tokens_step["last_pairs"][: 4 * K], K, topn, dev, modes=("bf16", "bf16x3"))
+        emb3 = EncoderX3(EncoderWeightsX3(emb_cfg, synthetic_state_device(emb_cfg, dev, seed=1, dtype=torch.float32), dev))
+        rr3 = EncoderX3(EncoderWeightsX3(rr_cfg, synthetic_state_device(rr_cfg, dev, seed=2, dtype=torch.float32), dev))
+        enc_pair["embedder"], enc_pair["reranker"] = emb3, rr3
+        step(queries[0])
+        sync_all()
+        lib.tt_prof_enable(1)
+        t2 = time.perf_counter()
+        for q in queries:
+            step(q)
+        sync_all()
+        dt3 = time.perf_counter() - t2
+        prof3 = read_prof()
+        lib.tt_prof_enable(0)
+        enc_pair["embedder"], enc_pair["reranker"] = embedder, reranker
+        del emb3, rr3
+        torch.cuda.empty_cache()
+        if world > 1:
+            t = torch.tensor([dt3], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt3 = float(t.item())
+        g3_ms, g3_n = prof3["gemm"]
+        reference_leg = {"queries_per_s": world * Bq * args.steps / dt3, "ms_per_step": dt3 / args.steps * 1e3,
+                         "dtype": "bf16x3 (fp32 semantics: operands as bf16 hi + lo planes, three bf16 MFMA products per product, "
+                                  "fp32 accumulate, fp32 residual stream / LayerNorm / softmax / erf-GELU)",
+                         "stage_ms_per_step": {k: v[0] / args.steps for k, v in prof3.items() if v[1]},
+                         "gemm_launches_per_step": g3_n // max(args.steps, 1),
+                         "what": "the headline step with embedder and reranker in the reference's precision "
+                                 "(TT_PRECISION=reference / ModelManager.set_precision('reference') / torch_dtype=float32)",
+                         "score_quality_vs_fp32_path": quality}
+
     chunks_per_s = None
     if not args.headline_only:
         # ---- second half of the BASELINE metric: batch chunk embedding (ingest), separately timed ----
@@ -460,6 +505,7 @@ def main():
             "chunks_embedded_per_s": chunks_per_s,
             "embed_batch": f"{args.embed_chunks} chunks x {args.chunk_len + 2} tok per GPU (bge-m3 shape)",
             "fp8_reranker": fp8_leg,
+            "reference_precision": reference_leg,
             "scan_only": scan_only,
             "plugin_surface": surface,
             "config5_composed": config5,
@@ -489,7 +535,7 @@ def main():
         dist.destroy_process_group()
 
 
-def rank_quality(reranker, rr_cfg, pair_ids, K, topn, dev):
+def rank_quality(reranker, rr_cfg, pair_ids, K, topn, dev, modes=("bf16", "fp8")):
     """What the precision modes do to a ranking: the candidates of 4 queries (K pairs each) scored by the fp32
     reference-precision path (same weights, fp32 math: tt_encoder_forward_f32), by the bf16 default and by the fp8 mode --
     score error, Kendall tau and top-n overlap of bf16 and fp8 against fp32.  Synthetic random-init weights: the K
@@ -507,17 +553,25 @@ def rank_quality(reranker, rr_cfg, pair_ids, K, topn, dev):
     del enc32
     prev = w.gemm_dtype
     out = {"queries": n_q, "pairs_per_query": K, "reference": "fp32 path (tt_encoder_forward_f32) on the same weights"}
-    for mode in ("bf16", "fp8"):
-        w.set_gemm_dtype(mode)
-        sm = reranker.rerank_packed(batch).cpu().view(n_q, K)
+    for mode in modes:
+        if mode == "bf16x3":
+            from tensor_truth_amd.encoder_x3 import EncoderWeightsX3, EncoderX3
+
+            enc3 = EncoderX3(EncoderWeightsX3(rr_cfg, state, dev))
+            sm = enc3.rerank_packed(batch).cpu().view(n_q, K)
+            del enc3
+        else:
+            w.set_gemm_dtype(mode)
+            sm = reranker.rerank_packed(batch).cpu().view(n_q, K)
         taus, overlaps = [], []
         for q in range(n_q):
             a, b = s32[q].numpy().astype(np.float64), sm[q].numpy().astype(np.float64)
             sa, sb = np.sign(a[:, None] - a[None, :]), np.sign(b[:, None] - b[None, :])
             taus.append(float((sa * sb).sum() / (K * (K - 1))))
             overlaps.append(len(set(np.argsort(-a)[:topn].tolist()) & set(np.argsort(-b)[:topn].tolist())) / topn)
-        out[mode] = {"max_abs_score_err": float((sm - s32).abs().max()), "kendall_tau_mean": float(np.mean(taus)),
-                     f"top{topn}_overlap_mean": float(np.mean(overlaps))}
+        out[mode] = {"max_abs_score_err": float((sm - s32).abs().max()),
+                     "max_rel_score_err": float(((sm - s32).abs() / s32.abs().clamp_min(1e-30)).max()),
+                     "kendall_tau_mean": float(np.mean(taus)), f"top{topn}_overlap_mean": float(np.mean(overlaps))}
     w.set_gemm_dtype(prev)
     return out
 

@@ -266,11 +266,13 @@ def synthetic_state(cfg: EncoderConfig, seed: int = 0) -> Dict[str, torch.Tensor
     return W
 
 
-def synthetic_state_device(cfg: EncoderConfig, device: torch.device, seed: int = 0) -> Dict[str, torch.Tensor]:
+def synthetic_state_device(cfg: EncoderConfig, device: torch.device, seed: int = 0,
+                           dtype: torch.dtype = torch.bfloat16) -> Dict[str, torch.Tensor]:
     """Random-init weights generated directly on the device (benchmarks: avoids building a
-    2.3 GB fp32 model on the host).  Not reproducible against the CPU oracle."""
+    2.3 GB fp32 model on the host).  Not reproducible against the CPU oracle.  ``dtype=torch.float32`` keeps the
+    matrices unrounded (the reference-precision legs: their lo planes must not be all zero)."""
     g = torch.Generator(device=device).manual_seed(seed)
-    n = lambda *s, std=0.02: (torch.randn(*s, generator=g, device=device) * std).to(torch.bfloat16)  # noqa: E731
+    n = lambda *s, std=0.02: (torch.randn(*s, generator=g, device=device) * std).to(dtype)  # noqa: E731
     H, F = cfg.hidden, cfg.ffn
     W = {
         "embeddings.word_embeddings.weight": n(cfg.vocab_size, H),
