@@ -313,6 +313,45 @@ def main():
                      "filter_pass": {"achieved_GBps_algorithmic": so_gbs, "frac_of_hbm_peak": so_gbs / HBM_PEAK_GBS,
                                      "avg_launch_ms": so_ms / max(so_n, 1), "queries_per_launch": world * nq_scan}}
 
+    # ---- the 8-GPU-shaped scan on ONE GPU: what every GPU of an 8-GPU step does per batch -- 256 gathered queries over a
+    # shard of corpus_rows / 8 rows (10M / 8 = 1.25M): sample + threshold select + tiled filter pass + tail + final select,
+    # per-stage device times from HIP events, and the whole batch as a fraction of the HBM roofline on ALGORITHMIC bytes
+    scan_shard = None
+    if world == 1 and not args.headline_only and (hi - lo) >= args.corpus_rows // 8 >= 262144:
+        from tensor_truth_amd import scan as tscan
+
+        rows8 = args.corpus_rows // 8
+        shard8 = shard_rows[:rows8]
+        q8 = torch.nn.functional.normalize(torch.randn(256, D, device=dev, generator=torch.Generator(device=dev).manual_seed(4322)), dim=1).to(torch.bfloat16)
+        tscan.scan_topk(shard8, q8, K)
+        sync_all()
+        reps = 10
+        lib.tt_prof_enable(1)
+        t3 = time.perf_counter()
+        for _ in range(reps):
+            tscan.scan_topk(shard8, q8, K)          # (the wrapper reads the overflow flag: one host sync per batch, included)
+        sync_all()
+        dt8s = (time.perf_counter() - t3) / reps
+        p8 = read_prof()
+        lib.tt_prof_enable(0)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        for _ in range(reps):
+            tscan.scan_topk(shard8, q8, K, check_overflow=False)     # device time of a batch, back to back, no host sync
+        ev1.record()
+        sync_all()
+        dev_ms = ev0.elapsed_time(ev1) / reps
+        bytes8 = rows8 * D * 2
+        scan_shard = {"rows": rows8, "queries": 256, "ms_per_batch_wall": dt8s * 1e3, "ms_per_batch_device": dev_ms,
+                      "stage_ms_per_batch": {k_: v[0] / reps for k_, v in p8.items() if v[1] and k_.startswith(("scan", "select"))},
+                      "launches_per_batch": {k_: v[1] // reps for k_, v in p8.items() if v[1] and k_.startswith(("scan", "select"))},
+                      "algorithmic_bytes_per_batch": bytes8,
+                      "frac_of_hbm_peak_per_batch": bytes8 / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                      "frac_of_hbm_peak_filter_pass": (bytes8 / (p8["scan_filter"][0] / max(p8["scan_filter"][1], 1) * 1e-3) / 1e9 / HBM_PEAK_GBS
+                                                       if p8["scan_filter"][1] else None),
+                      "what": f"one GPU's share of an 8-GPU step: exact top-{K} of 256 gathered queries over {rows8} x {D} rows "
+                              "(no collective); frac = rows * dim * 2 bytes / device time of the WHOLE batch / 8 TB/s"}
+
     # ---- BASELINE config 5's "fp8 MFMA reranker": the same steps with the cross-encoder's Q/K/V and FFN-up
     # projections on e4m3 operands.  Reported beside the headline (which stays bf16), never as it.
     fp8_leg = None
@@ -427,8 +466,8 @@ def main():
     # the reference's executor threads do (rag_engine.py:418-424, api/routes/chat.py:367-374); the coalescing front
     # merges them into shared embed / scan / rerank batches.  Strings in, NodeWithScore out; the SAME resident corpus.
     surface = None
-    if world == 1 and not args.headline_only and not args.no_surface_leg:
-        surface = surface_leg(args, dev, shard_rows, emb_cfg, rr_cfg)
+    if not args.headline_only and not args.no_surface_leg:
+        surface = surface_leg(args, dev, shard_rows, emb_cfg, rr_cfg, world, rank, lo)
     config5 = None
     if world == 1 and not args.headline_only and not args.no_config5_leg:
         config5 = config5_leg(args, dev, emb_cfg, rr_cfg)
@@ -507,6 +546,7 @@ def main():
             "fp8_reranker": fp8_leg,
             "reference_precision": reference_leg,
             "scan_only": scan_only,
+            "scan_only_shard": scan_shard,
             "plugin_surface": surface,
             "config5_composed": config5,
         },
@@ -650,7 +690,10 @@ def _run_threads(n_threads, work_items, fn):
     return dt, out
 
 
-def surface_leg(args, dev, shard_rows, emb_cfg, rr_cfg):
+def surface_leg(args, dev, shard_rows, emb_cfg, rr_cfg, world=1, rank=0, row_lo=0):
+    """world > 1: every rank runs its OWN request threads against the row-sharded index; the retriever's lock-step tick front
+    keeps the ranks' collective rounds aligned, each rank embeds and reranks only its own callers' queries
+    (sharded_index._TickFront).  Reported rate = all ranks' queries / the slowest rank's time."""
     from tensor_truth_amd.embedding import HipHuggingFaceEmbedding
     from tensor_truth_amd.rerank import HipSentenceTransformerRerank
     from tensor_truth_amd.schema import QueryBundle
@@ -661,11 +704,11 @@ def surface_leg(args, dev, shard_rows, emb_cfg, rr_cfg):
                                   model_kwargs={"encoder_config": emb_cfg, "synthetic_seed": 1})
     rr = HipSentenceTransformerRerank(model="BAAI/bge-reranker-v2-m3", top_n=topn, device=str(dev), batch_pairs=4096,
                                       model_kwargs={"encoder_config": rr_cfg, "synthetic_seed": 2})
-    n = shard_rows.shape[0]
-    index = ShardedHipVectorIndex(shard_rows.shape[1], shard_rows, 0, n, _RowIds(n), _SynthDocstore(args.chunk_len),
-                                  embed_model=emb, score_mode="cosine")
-    retr = index.as_retriever(similarity_top_k=K, max_batch=64)
-    queries = [synth_text(10_000_000_000 + i, args.query_len) for i in range(args.surface_queries)]
+    n = shard_rows.shape[0] if world == 1 else args.corpus_rows
+    index = ShardedHipVectorIndex(shard_rows.shape[1], shard_rows, row_lo, n, _RowIds(n), _SynthDocstore(args.chunk_len),
+                                  embed_model=emb, score_mode="cosine", queries="partitioned" if world > 1 else "replicated")
+    retr = index.as_retriever(similarity_top_k=K, max_batch=64 if world == 1 else max(8, 256 // world))
+    queries = [synth_text(10_000_000_000 + 1_000_000 * rank + i, args.query_len) for i in range(args.surface_queries)]
 
     def one(q):
         nodes = retr.retrieve(q)
@@ -673,7 +716,12 @@ def surface_leg(args, dev, shard_rows, emb_cfg, rr_cfg):
 
     one(queries[0])                                    # warm-up (tokenizer cache, workspaces)
     _run_threads(args.surface_threads, queries[: args.surface_threads], one)
-    b_r0, b_x0 = retr._front.batches, rr._front.batches
+    scan_batches = (lambda: retr._front.batches) if retr._tick is None else (lambda: retr._tick.rounds)
+    b_r0, b_x0 = scan_batches(), rr._front.batches
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.barrier()
     dt, res = _run_threads(args.surface_threads, queries, one)
     assert all(len(r) == topn for r in res)
     t1 = time.perf_counter()
@@ -681,8 +729,14 @@ def surface_leg(args, dev, shard_rows, emb_cfg, rr_cfg):
         one(q)
     torch.cuda.synchronize()
     lat = (time.perf_counter() - t1) / 8
-    return {"queries_per_s": len(queries) / dt, "threads": args.surface_threads, "queries": len(queries),
-            "scan_batches": retr._front.batches - b_r0, "rerank_batches": rr._front.batches - b_x0,
+    n_scan, n_rr = scan_batches() - b_r0, rr._front.batches - b_x0
+    if world > 1:
+        retr.close(timeout=600)                    # leave the lock-step front (every rank does)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return {"queries_per_s": world * len(queries) / dt, "threads": args.surface_threads, "queries": world * len(queries),
+            "ranks": world, "scan_batches": n_scan, "rerank_batches": n_rr,
             "single_caller_ms_per_query": lat * 1e3,
             "what": (f"{args.surface_threads} threads each calling retriever.retrieve(str) (top-{K} over the resident "
                      f"{n} x {shard_rows.shape[1]} corpus) then reranker.postprocess_nodes(nodes, QueryBundle) -> top-{topn}; "

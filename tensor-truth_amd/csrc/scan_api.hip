@@ -92,6 +92,11 @@ Plan make_plan(int64_t n_rows, int dim, int n_queries, int k, int cus) {
     if (pl.gemm) {
         static const int64_t n0_env = [] { const char* e = getenv("TT_SCAN_GEMM_N0"); return e && e[0] ? (int64_t)atoll(e) : (int64_t)0; }();
         n0 = n0_env > 0 ? n0_env : 131072;   // (measured, 10M x 1024 x 256 queries: 65536 -> 5.50, 131072 -> 5.35, 262144 -> 5.52 ms per batch)
+        // ... in proportion to the shard: the sample pass and its selection are a fixed cost per batch (0.3 ms at 131072 rows),
+        // a third of the whole batch on the 1.25M-row shard of an 8-GPU step; expected survivors per query ~ k * rows / n0 stay
+        // at or below the 10M-row figure (1.25M rows: 32768 sample rows, 38 k survivors per query instead of 76 k)
+        if (n0_env <= 0)
+            while (n0 > 32768 && n0 * 64 > n_rows) n0 /= 2;
         if (n0 < (int64_t)512 * k) n0 = (int64_t)512 * k;
         if (n0 > n_rows / 2) n0 = n_rows / 2 / 32 * 32;
         pl.q256 = (n_queries + 255) / 256 * 256;

@@ -16,14 +16,17 @@ not belong on one device (or when one process per GPU serves it):
 * ``logical_shards > 1`` cuts the local rows once more and merges the pieces through the same merge kernel: one GPU
   exercises the whole protocol (tests), and a single process can hold several shards.
 
-Collectives are issued under a lock in call order; SPMD callers must make their ``retrieve`` calls in the same order
-on every rank (a coalescing front keeps that true for concurrent request threads only if the requests themselves are
-replicated in order -- hence the default mode).
+Collectives are issued under a lock in call order.  ``queries="replicated"``: SPMD callers make their ``retrieve`` calls
+in the same order on every rank (one collective round per call).  ``queries="partitioned"`` behind ``as_retriever`` on
+several ranks: a lock-step TICK front (``_TickFront``) -- every rank serves its own request threads, the ranks' rounds are
+kept aligned by one tiny all-gather per tick, concurrent callers of a rank share its rounds, and query embedding and the
+rerank above it are partitioned over the GPUs (throughput scales with the ranks; ``replicated`` buys capacity only).
 """
 from __future__ import annotations
 
 import math
 import threading
+import time
 from typing import Callable, Dict, List, Optional, Sequence, Tuple  # noqa: F401
 
 import torch
@@ -73,6 +76,7 @@ class ShardedHipVectorIndex:
             merge_fn = merge_fn or _scan.topk_merge
         self._scan, self._merge = scan_fn, merge_fn
         self._collective_lock = threading.Lock()
+        self._tick_fronts = 0                      # live _TickFront threads (they own this index's collectives)
         n_local = local_rows.shape[0]
         pieces = max(1, min(int(logical_shards), max(n_local, 1)))
         self._shards: List[Tuple[torch.Tensor, int]] = []
@@ -171,53 +175,217 @@ class ShardedHipVectorIndex:
         i = torch.cat([p[1] for p in parts], dim=1)
         return self._merge(s, i, k)
 
+    def _unit_bf16(self, query_emb: torch.Tensor) -> torch.Tensor:
+        q = query_emb.to(self.device, dtype=torch.float32)
+        return (q / q.norm(dim=1, keepdim=True).clamp_min(1e-12)).to(torch.bfloat16).contiguous()
+
     def search(self, query_emb: torch.Tensor, k: int):
         """query_emb [Q, D] (this rank's queries) -> (cosine scores [Q, k] fp32, GLOBAL rows [Q, k] int32) for them."""
-        q = query_emb.to(self.device, dtype=torch.float32)
-        q16 = (q / q.norm(dim=1, keepdim=True).clamp_min(1e-12)).to(torch.bfloat16).contiguous()
+        q16 = self._unit_bf16(query_emb)
         world, rank = _world(self.group)
         if world == 1:
             return self._local_topk(q16, k)
+        if self._tick_fronts:
+            raise RuntimeError("this index is being served by a lock-step tick front (as_retriever at world > 1, "
+                               "queries='partitioned'): a direct search() would interleave its collectives with the front's; "
+                               "go through retrieve(), or close() the retriever first")
         with self._collective_lock:
             nq = q16.shape[0]
             if self.queries == "partitioned" and not self.ragged_queries:
-                nmax, all_q = nq, _sh.gather_queries(q16, self.group)
-            elif self.queries == "partitioned":
-                # ranks may bring different numbers of queries: agree on the largest count (one tiny all-gather), pad
-                # with zero rows (they score 0 everywhere and are dropped again), gather, scan, keep this rank's slice
+                return self._round_partitioned(q16, k, nq)
+            if self.queries == "partitioned":
+                # ranks may bring different numbers of queries: agree on the largest count (one tiny all-gather)
                 counts = torch.zeros(world, dtype=torch.int64, device=q16.device)
                 dist.all_gather_into_tensor(counts, torch.tensor([nq], dtype=torch.int64, device=q16.device), group=self.group)
-                nmax = int(counts.max().item())
-                if nmax == 0:
-                    return (torch.empty((0, k), dtype=torch.float32, device=q16.device),
-                            torch.empty((0, k), dtype=torch.int32, device=q16.device))
-                if nq < nmax:
-                    q16 = torch.cat([q16, torch.zeros((nmax - nq, q16.shape[1]), dtype=q16.dtype, device=q16.device)], 0)
-                all_q = _sh.gather_queries(q16, self.group)
-            else:
-                nmax, all_q = nq, q16
-            s, i = _sh.sharded_topk(lambda qq, kk: self._local_topk(qq, kk), self._merge, all_q, k, self.group)
-            if self.queries == "partitioned":
-                s, i = s[rank * nmax: rank * nmax + nq], i[rank * nmax: rank * nmax + nq]
-            return s, i
+                return self._round_partitioned(q16, k, int(counts.max().item()))
+            return _sh.sharded_topk(lambda qq, kk: self._local_topk(qq, kk), self._merge, q16, k, self.group)
+
+    def _round_partitioned(self, q16: torch.Tensor, k: int, nmax: int):
+        """One collective round in which rank r brings q16[r] ([nq_r, D] unit bf16, nq_r <= nmax, nmax agreed beforehand):
+        pad to nmax with zero rows (they score 0 everywhere and are dropped again), all-gather the queries, every shard
+        scans the whole gathered batch, ONE all-gather of the packed partial top-k, merge, keep this rank's slice."""
+        world, rank = _world(self.group)
+        nq = q16.shape[0]
+        if nmax == 0:
+            return (torch.empty((0, k), dtype=torch.float32, device=q16.device),
+                    torch.empty((0, k), dtype=torch.int32, device=q16.device))
+        if nq < nmax:
+            q16 = torch.cat([q16, torch.zeros((nmax - nq, q16.shape[1]), dtype=q16.dtype, device=q16.device)], 0)
+        all_q = _sh.gather_queries(q16, self.group)
+        s, i = _sh.sharded_topk(lambda qq, kk: self._local_topk(qq, kk), self._merge, all_q, k, self.group)
+        return s[rank * nmax: rank * nmax + nq], i[rank * nmax: rank * nmax + nq]
 
     def as_retriever(self, similarity_top_k: int = 10, coalesce: bool = True, max_batch: int = 64,
                      max_wait_s: float = 0.0, **_kw) -> "ShardedHipVectorRetriever":
-        # concurrent callers are merged into one collective round only in single-process use: across ranks the batches
-        # formed by independent coalescers need not line up, so the front is off whenever a process group is live
+        """One process (world 1): the leader/follower coalescer of ``HipVectorRetriever``.  Several ranks with
+        ``queries="partitioned"``: a TICK front (``_TickFront``) -- every rank queues its own callers and all ranks run
+        collective rounds in lock step, so coalescing stays on and each rank embeds (and, above this retriever, reranks)
+        only ITS OWN callers' queries: N GPUs serve N times the queries, not N copies of the same ones.
+        ``queries="replicated"`` keeps one collective round per call (the front end hands every rank the same request)."""
         if self.leaf_ids is None or self.docstore is None:
             raise ValueError("this ShardedHipVectorIndex was built without node tables (search-only)")
         world, _ = _world(self.group)
+        tick = coalesce and world > 1 and self.queries == "partitioned"
         return ShardedHipVectorRetriever(self, similarity_top_k, coalesce=coalesce and world == 1, max_batch=max_batch,
-                                         max_wait_s=max_wait_s)
+                                         max_wait_s=max_wait_s, tick=tick)
 
     # what HipVectorRetriever's shared code reads
     def snapshot(self):
         return None, self.leaf_ids
 
 
+class _TickSlot:
+    __slots__ = ("bundle", "event", "result", "error")
+
+    def __init__(self, bundle):
+        self.bundle, self.event, self.result, self.error = bundle, threading.Event(), None, None
+
+
+class _TickFront:
+    """Lock-step serving front for a row-sharded index with one process per GPU ("pairs can be scattered
+    to all 8 GPUs regardless of which shard found them").
+
+    Every rank runs ONE tick thread.  A tick: take up to ``max_batch`` queued callers; embed THEIR queries on this GPU;
+    all-gather (query count, closing flag) -- the only collective of an idle tick; if any rank brought queries: all-gather
+    the padded query blocks, every shard scans the gathered batch, one all-gather of the packed partial top-k, merge,
+    and each rank turns ITS slice into nodes for its own callers.  Ranks therefore always issue the same collectives in
+    the same order whatever their callers do, concurrent callers of a rank share its rounds (coalescing stays on), and
+    embedding -- and the reranker above -- only ever see a rank's own queries.  A query whose embedding fails is answered
+    with its exception before the round; it never reaches a collective.  ``close()`` raises this rank's closing flag;
+    the thread keeps serving the other ranks' rounds (they need this shard) until every rank has raised its own."""
+
+    def __init__(self, retriever: "ShardedHipVectorRetriever", max_batch: int, idle_sleep_s: float = 2e-4):
+        self.retriever, self.index = retriever, retriever.index
+        self.max_batch = max(1, int(max_batch))
+        self.idle_sleep_s = idle_sleep_s
+        self._lock = threading.Lock()
+        self._queue: List[_TickSlot] = []
+        self._closing = False
+        self._dead: Optional[BaseException] = None
+        self.ticks = self.rounds = self.items = 0
+        self.index._tick_fronts += 1
+        self._thread = threading.Thread(target=self._loop, name="tt-tick-front", daemon=True)
+        self._thread.start()
+
+    def submit(self, bundle):
+        slot = _TickSlot(bundle)
+        with self._lock:
+            if self._closing or self._dead is not None:
+                raise RuntimeError("the sharded retriever's serving front is closed") from self._dead
+            self._queue.append(slot)
+        slot.event.wait()
+        if slot.error is not None:
+            raise slot.error
+        return slot.result
+
+    def close(self, timeout: Optional[float] = None) -> None:
+        with self._lock:
+            self._closing = True
+        self._thread.join(timeout)
+
+    def _embed_own(self, batch: List[_TickSlot]):
+        """-> (slots that go into the round, their unit bf16 embeddings [n, D]); failures are answered here."""
+        r = self.retriever
+        try:
+            return batch, self.index._unit_bf16(r._query_matrix([s.bundle for s in batch]))
+        except Exception as first:  # noqa: BLE001 - isolate the offender(s): each query alone
+            if len(batch) == 1:
+                batch[0].error = first
+                batch[0].event.set()
+                return [], None
+        good, rows = [], []
+        for s in batch:
+            try:
+                rows.append(self.index._unit_bf16(r._query_matrix([s.bundle])))
+                good.append(s)
+            except Exception as exc:  # noqa: BLE001
+                s.error = exc
+                s.event.set()
+        return good, (torch.cat(rows, 0) if rows else None)
+
+    def _loop(self) -> None:
+        idx, r = self.index, self.retriever
+        world, rank = _world(idx.group)
+        dev = idx.device
+        batch: List[_TickSlot] = []
+        if dev.type == "cuda":
+            torch.cuda.set_device(dev)         # (the current device is per thread)
+        try:
+            while True:
+                with self._lock:
+                    batch = self._queue[: self.max_batch]
+                    del self._queue[: len(batch)]
+                    closing = self._closing and not self._queue
+                q16 = None
+                if batch:
+                    batch, q16 = self._embed_own(batch)
+                nq = len(batch)
+                flags = torch.zeros((world, 2), dtype=torch.int64, device=dev)
+                with idx._collective_lock:
+                    dist.all_gather_into_tensor(flags.view(-1), torch.tensor([nq, 1 if (closing and nq == 0) else 0],
+                                                                             dtype=torch.int64, device=dev), group=idx.group)
+                    flags_h = flags.cpu()
+                    nmax = int(flags_h[:, 0].max().item())
+                    self.ticks += 1
+                    if nmax == 0:
+                        if bool(flags_h[:, 1].all().item()):
+                            return                                   # every rank is closing and idle: all leave at this tick
+                        hits = None
+                    else:
+                        k = min(r.similarity_top_k, idx.n_total)
+                        if q16 is None:
+                            q16 = torch.zeros((0, idx.dim), dtype=torch.bfloat16, device=dev)
+                        hits = idx._round_partitioned(q16, k, nmax) if k >= 1 else None
+                        self.rounds += 1
+                if nmax == 0:
+                    time.sleep(self.idle_sleep_s)
+                    continue
+                if batch:
+                    if hits is None:
+                        results = [[] for _ in batch]
+                    else:
+                        scores, rows = hits[0].cpu().tolist(), hits[1].cpu().tolist()
+                        results = [r.nodes_from_hits(s_, r_, idx.leaf_ids) for s_, r_ in zip(scores, rows)]
+                    self.items += len(batch)
+                    for s_, res in zip(batch, results):
+                        s_.result = res
+                        s_.event.set()
+                    batch = []
+        except BaseException as exc:  # noqa: BLE001 - a failed collective: nobody may wait forever
+            with self._lock:
+                self._dead = exc
+                self._closing = True
+                pending = batch + self._queue
+                self._queue = []
+            for s_ in pending:
+                if not s_.event.is_set():
+                    s_.error = RuntimeError(f"sharded serving front stopped: {exc!r}")
+                    s_.event.set()
+        finally:
+            idx._tick_fronts -= 1
+
+
 class ShardedHipVectorRetriever(HipVectorRetriever):
     """``retrieve(query)`` over the sharded index: same surface, same node construction as ``HipVectorRetriever``."""
+
+    def __init__(self, index, similarity_top_k: int = 10, coalesce: bool = True, max_batch: int = 64, max_wait_s: float = 0.0,
+                 tick: bool = False):
+        super().__init__(index, similarity_top_k, coalesce=coalesce, max_batch=max_batch, max_wait_s=max_wait_s)
+        self._tick = _TickFront(self, max_batch) if tick else None
+
+    def retrieve(self, query) -> List[NodeWithScore]:
+        if self._tick is not None:
+            from .schema import as_query_bundle
+
+            return self._tick.submit(as_query_bundle(query))
+        return super().retrieve(query)
+
+    _retrieve = retrieve
+
+    def close(self, timeout: Optional[float] = None) -> None:
+        """Leave the lock-step serving front (multi-rank ``queries="partitioned"`` only; SPMD: every rank calls it)."""
+        if self._tick is not None:
+            self._tick.close(timeout)
 
     def _retrieve_batch(self, bundles) -> List[List[NodeWithScore]]:
         idx = self.index

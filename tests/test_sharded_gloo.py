@@ -117,10 +117,9 @@ def _retriever_worker(rank, world, port, n_total, d, k, mode, ret):
 
         index = ShardedHipVectorIndex(d, corpus[lo:hi].contiguous(), lo, n_total, leaf_ids, docstore, score_mode="cosine",
                                       logical_shards=3, queries=mode, scan_fn=scan_fn, merge_fn=merge_fn)
-        retr = index.as_retriever(similarity_top_k=k)
         # replicated: every rank asks the same two questions; partitioned: rank r asks questions 2r, 2r+1
         mine = [0, 1] if mode == "replicated" else [2 * rank, 2 * rank + 1]
-        if mode == "partitioned":
+        if mode == "partitioned":    # (direct search() rounds: before the retriever's lock-step front owns the collectives)
             # ranks may bring DIFFERENT numbers of queries to one collective round (rank 0: three, rank 1: one)
             emb = queries[[0, 1, 2]] if rank == 0 else queries[[3]]
             s_r, i_r = index.search(emb.float(), k)
@@ -130,10 +129,15 @@ def _retriever_worker(rank, world, port, n_total, d, k, mode, ret):
             for j in range(len(want)):
                 if wgap[j] > 1e-6:
                     assert i_r[j].tolist() == wi[j].tolist()
+        retr = index.as_retriever(similarity_top_k=k)
+        if mode == "partitioned":
+            with pytest.raises(RuntimeError):
+                index.search(queries[[0]].float(), k)          # the front owns the collectives now
         out = []
         for qi in mine:
             hits = retr.retrieve(QueryBundle(query_str=f"q{qi}", embedding=queries[qi].float().tolist()))
             out.append((qi, [(h.node.id_, h.score, h.node.metadata["row"]) for h in hits]))
+        retr.close(timeout=120)
         ret.put((rank, out))
     finally:
         dist.destroy_process_group()
@@ -253,3 +257,99 @@ def test_three_rank_index_from_rank_local_ingest():
         if gap[qi] > 1e-6:
             assert [h[1] for h in hits] == want_i[qi].tolist()
         assert torch.allclose(torch.tensor([h[5] for h in hits]), want_s[qi], rtol=1e-5, atol=1e-6)
+
+
+def _tick_worker(rank, world, port, n_total, d, k, ret):
+    """The multi-rank serving front: every rank has ITS OWN request threads (different counts, different questions, one
+    rank idle for a while, one malformed query), the ranks' collective rounds stay aligned by the tick protocol, and
+    every caller gets the serial answer.  Scan / merge = CPU oracle stand-ins (the kernels need a GPU)."""
+    import threading
+    import time
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tensor_truth_amd.schema import QueryBundle, TextNode
+        from tensor_truth_amd.sharded import shard_bounds
+        from tensor_truth_amd.sharded_index import ShardedHipVectorIndex
+
+        corpus = osc.synth_corpus(n_total, d, seed=7)
+        queries, _ = osc.synth_queries(corpus, 24, seed=9)
+        lo, hi = shard_bounds(n_total, world, rank)
+        leaf_ids = [f"leaf{j}" for j in range(n_total)]
+        docstore = {nid: TextNode(text=f"text {j}", id_=nid, metadata={"row": j}) for j, nid in enumerate(leaf_ids)}
+
+        def scan_fn(rows, q16, kk, base):
+            v, i, _ = osc.scan_topk(rows, q16, kk)
+            return v, torch.where(i >= 0, i + base, i).to(torch.int32)
+
+        def merge_fn(vals, idx, kk):
+            v, i = osc.merge_topk(vals, idx.to(torch.int64), kk)
+            return v, i.to(torch.int32)
+
+        index = ShardedHipVectorIndex(d, corpus[lo:hi].contiguous(), lo, n_total, leaf_ids, docstore, score_mode="cosine",
+                                      queries="partitioned", scan_fn=scan_fn, merge_fn=merge_fn)
+        retr = index.as_retriever(similarity_top_k=k, max_batch=4)
+        assert retr._tick is not None                      # coalescing stays ON at world > 1
+        # rank 0: 5 threads x 3 questions (0..14); rank 1: idle for a moment, then 2 threads x 2 questions (15..18) + one malformed
+        mine = {0: [[3 * t + j for j in range(3)] for t in range(5)], 1: [[15, 16], [17, 18]]}[rank]
+        out, errs = {}, []
+        lock = threading.Lock()
+
+        def caller(qs):
+            for qi in qs:
+                hits = retr.retrieve(QueryBundle(query_str=f"q{qi}", embedding=queries[qi].float().tolist()))
+                with lock:
+                    out[qi] = [(h.node.id_, h.score, h.node.metadata["row"]) for h in hits]
+
+        def bad_caller():
+            try:
+                retr.retrieve(QueryBundle(query_str="no embedding and the index has no embed_model"))
+            except Exception as exc:  # noqa: BLE001
+                errs.append(type(exc).__name__)
+
+        threads = [threading.Thread(target=caller, args=(qs,)) for qs in mine]
+        if rank == 1:
+            time.sleep(0.3)                                   # rank 0's rounds run with rank 1 bringing no queries
+            threads.append(threading.Thread(target=bad_caller))
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=120)
+            assert not t.is_alive()
+        front = retr._tick
+        retr.close(timeout=120)                               # rank 1 closes early and keeps scanning for rank 0 until it closes too
+        assert not front._thread.is_alive()
+        with pytest.raises(RuntimeError):
+            retr.retrieve(QueryBundle(query_str="late", embedding=queries[0].float().tolist()))
+        ret.put((rank, out, errs, front.rounds, front.items))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_tick_front_serves_different_callers_per_rank():
+    world, n_total, d, k = 2, 555, 128, 7
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_tick_worker, args=(r, world, port, n_total, d, k, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = {o[0]: o[1:] for o in (ret.get(timeout=240) for _ in procs)}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    corpus = osc.synth_corpus(n_total, d, seed=7)
+    queries, _ = osc.synth_queries(corpus, 24, seed=9)
+    want_s, want_i, gap = osc.scan_topk(corpus, queries, k)
+    assert set(outs[0][0]) == set(range(15)) and set(outs[1][0]) == {15, 16, 17, 18}     # every caller answered, on its own rank
+    for rank in (0, 1):
+        for qi, hits in outs[rank][0].items():
+            assert len(hits) == k and all(h[0] == f"leaf{h[2]}" for h in hits)
+            if gap[qi] > 1e-6:
+                assert [h[2] for h in hits] == want_i[qi].tolist()
+            assert torch.allclose(torch.tensor([h[1] for h in hits]), want_s[qi], rtol=1e-5, atol=1e-6)
+    assert outs[0][1] == [] and outs[1][1] == ["ValueError"]          # the malformed query failed alone, before any collective
+    assert outs[0][2] == outs[1][2]                                    # both ranks ran the same collective rounds
+    assert outs[0][3] == 15 and outs[1][3] == 4 and outs[0][2] < 19    # rounds were shared by concurrent callers
