@@ -52,7 +52,8 @@ def launch_plan(argv, environ):
 
 def self_launch(cmd):
     """Run the ranks as a CHILD process (never exec: the driver may already hold the GPU, and a process that has touched
-    HIP must not be replaced), relay its output, re-print rank 0's JSON line last, exit with the child's code."""
+    HIP must not be replaced); the ranks' other output goes to stderr, rank 0's JSON line is the one line on stdout;
+    exit with the child's code."""
     import subprocess
 
     proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=None, text=True, bufsize=1)
@@ -60,9 +61,9 @@ def self_launch(cmd):
     for line in proc.stdout:
         s = line.strip()
         if s.startswith("{") and s.endswith("}") and '"metric"' in s:
-            line_json = s                             # held back: printed once, as the last line
+            line_json = s                             # held back: printed once, as the ONLY line on stdout
         else:
-            sys.stdout.write(line)
+            sys.stderr.write(line)                    # (gloo / launcher chatter of the ranks)
     rc = proc.wait()
     if line_json is not None:
         print(line_json, flush=True)

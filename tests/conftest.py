@@ -22,6 +22,21 @@ def pytest_configure(config):
         pass
 
 
+@pytest.fixture(autouse=True)
+def _restore_torch_threads():
+    """A test may raise torch's CPU thread count for a large oracle matmul (256 on the GPU host); left in place it makes
+    every later small CPU op a 256-way barrier (the x3 tests took 100 s instead of 1 s behind the full-size scan test)."""
+    try:
+        import torch
+    except Exception:  # noqa: BLE001
+        yield
+        return
+    before = torch.get_num_threads()
+    yield
+    if torch.get_num_threads() != before:
+        torch.set_num_threads(before)
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN

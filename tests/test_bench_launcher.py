@@ -52,5 +52,5 @@ def test_self_launch_relays_json_last_and_exit_code(tmp_path):
     for rc in (0, 7):
         r = subprocess.run([sys.executable, str(driver), str(rc)], capture_output=True, text=True, timeout=300)
         assert r.returncode == rc
-        lines = r.stdout.strip().splitlines()
-        assert lines[-1].startswith('{"metric"') and lines[:-1] == ["noise before", "noise after"]
+        assert r.stdout.strip().splitlines() == ['{"metric": "m", "value": 1.0, "n_gpus": 2}']     # the one line on stdout
+        assert r.stderr.strip().splitlines()[-2:] == ["noise before", "noise after"]
