@@ -496,29 +496,46 @@ def main():
     scan_bytes = (hi - lo) * D * 2
     scan_gbs = scan_bytes * scan_n / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
 
-    # HBM traffic per launch: PMC counters cannot be read from inside this process; profiles/r02_pmc_traffic.json holds
-    # them for exactly this default single-GPU command (tools/gpu_pmc_bench.sh + tools/pmc_to_traffic.py: separate
+    # HBM traffic per launch: PMC counters cannot be read from inside this process; profiles/r03_pmc_traffic.json holds
+    # them for exactly this default single-GPU command (tools/gpu_pmc_bench_r03.sh + tools/pmc_to_traffic.py: separate
     # --pmc passes, FETCH_SIZE doubled per the gfx950 rule).  The file records the hash of the kernel sources it was
     # measured on; a file from other sources is REFUSED (traffic null + the reason), so the number cannot go stale.
     traffic = {"gemm": None, "scan_filter": None}
     traffic_note = None
     default_cfg = (world == 1 and args.corpus_rows == 10_000_000 and D == 1024 and Bq == 32 and K == 50
                    and args.chunk_len == 256 and args.query_len == 32 and L == 24)
-    tpath = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
     if not default_cfg:
         traffic_note = "not the default single-GPU configuration the PMC passes were collected on"
     elif not os.path.exists(tpath):
-        traffic_note = "profiles/r02_pmc_traffic.json not collected for this tree"
+        traffic_note = "profiles/r03_pmc_traffic.json not collected for this tree"
     else:
         with open(tpath) as f:
             tj = json.load(f)
         if tj.get("csrc_sha256") != csrc_sha256():
-            traffic_note = (f"profiles/r02_pmc_traffic.json was measured on kernel sources {str(tj.get('csrc_sha256'))[:12]}, "
+            traffic_note = (f"profiles/r03_pmc_traffic.json was measured on kernel sources {str(tj.get('csrc_sha256'))[:12]}, "
                             f"this tree is {csrc_sha256()[:12]}: refused")
         else:
             traffic = {k: tj[k]["hbm_bytes_per_launch"] for k in traffic if k in tj}
             if scan_only is not None and "scan_tiled_256q" in tj and scan_only["filter_pass"]["queries_per_launch"] == 256:
                 scan_only["filter_pass"]["traffic"] = tj["scan_tiled_256q"]["hbm_bytes_per_launch"]   # PMC, same run of passes
+
+    # matrix-core utilisation (north_star: "evidenced by ... MFMA-utilisation counters"): SQ_VALU_MFMA_BUSY_CYCLES over kernel
+    # cycles x SIMDs from a --pmc pass of this command on these kernel sources (tools/gpu_pmc_bench_r03.sh -> tools/pmc_to_mfma.py)
+    mfma_busy, mfma_scan, mfma_note = None, None, None
+    mpath = os.path.join(ROOT, "profiles", "r03_pmc_mfma.json")
+    if not default_cfg:
+        mfma_note = "not the default single-GPU configuration the PMC pass was collected on"
+    elif not os.path.exists(mpath):
+        mfma_note = "profiles/r03_pmc_mfma.json not collected for this tree"
+    else:
+        with open(mpath) as f:
+            mj = json.load(f)
+        if mj.get("csrc_sha256") != csrc_sha256():
+            mfma_note = f"profiles/r03_pmc_mfma.json was measured on kernel sources {str(mj.get('csrc_sha256'))[:12]}: refused"
+        else:
+            mfma_busy = {k: v["mfma_busy"] for k, v in mj.items() if isinstance(v, dict) and "mfma_busy" in v}
+            mfma_scan = mfma_busy.get("scan_tiled_filter_pass")
 
     out = {
         "metric": "queries/sec (embed+top-k+rerank) over 10M x 1024 corpus",
@@ -557,6 +574,10 @@ def main():
             "frac": gemm_tf / MFMA_BF16_PEAK_TF, "traffic": traffic.get("gemm"), "traffic_note": traffic_note,
             "launches": gemm_n, "avg_launch_ms": gemm_ms / max(gemm_n, 1),
             "algorithmic_flops_per_launch": gemm_flops_step * args.steps / max(gemm_n, 1),
+            "mfma_busy": mfma_busy, "mfma_busy_note": mfma_note,
+            # what the chip sustains on this data with NO operand traffic: a stream of nothing but v_mfma_f32_16x16x32_bf16
+            # (tools/gemm4w_bench variant 14, profiles/r03_gemm_4wave_ab.log) -- the clock it holds under an MFMA-only load
+            "mfma_only_stream_TFLOPs": 1803.0,
         },
         "roofline_scan": {
             "kernel": ("gemm_kernel_v3<TT_EPI_SCAN> (tiled MFMA filter pass over the corpus shard)" if tiled
