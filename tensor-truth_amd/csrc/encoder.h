@@ -48,6 +48,7 @@ struct GemmParams {
     float* C32;               // fp32 output [M][ldc] (x3 residual epilogue)
     const float* res32;       // fp32 residual [M][ldr]
     uint16_t* vt_lo;          // lo plane of the V8 output
+    int x3_zero_lo;           // diagnostic (TT_X3_ROUND_MASK): planes outputs are written with lo = 0, i.e. rounded to bf16
 };
 // Filter pass of the similarity scan for 65..256 queries per pass as a 256x256x64-tiled MFMA contraction (gemm.hip):
 // corpus [rows][dim] bf16 with rows a multiple of 256, queries256 [256][dim] bf16 (rows beyond the batch zero),

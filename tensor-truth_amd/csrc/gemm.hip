@@ -215,6 +215,7 @@ __device__ __forceinline__ void gemm_epilogue_vt(const GemmParams& p, f32x4 (&ac
                 l.y = pack_bf16x2(v[2] - __uint_as_float(o.y << 16), v[3] - __uint_as_float(o.y & 0xFFFF0000u));
                 l.z = pack_bf16x2(v[4] - __uint_as_float(o.z << 16), v[5] - __uint_as_float(o.z & 0xFFFF0000u));
                 l.w = pack_bf16x2(v[6] - __uint_as_float(o.w << 16), v[7] - __uint_as_float(o.w & 0xFFFF0000u));
+                if (p.x3_zero_lo) l = uint4{0u, 0u, 0u, 0u};
                 *reinterpret_cast<uint4*>(p.vt_lo + (size_t)(n - p.vt_col0) * 8 + (size_t)(m >> 3) * p.ldvt) = l;
             }
         }
@@ -697,6 +698,7 @@ __device__ __forceinline__ void epilogue_x3(const GemmParams& p, f32x4 (&acc)[2]
                         l.y = pack_bf16x2(v[2] - __uint_as_float(o.y << 16), v[3] - __uint_as_float(o.y & 0xFFFF0000u));
                         l.z = pack_bf16x2(v[4] - __uint_as_float(o.z << 16), v[5] - __uint_as_float(o.z & 0xFFFF0000u));
                         l.w = pack_bf16x2(v[6] - __uint_as_float(o.w << 16), v[7] - __uint_as_float(o.w & 0xFFFF0000u));
+                        if (p.x3_zero_lo) l = uint4{0u, 0u, 0u, 0u};
                         uint16_t* cp = p.C + (size_t)m * p.ldc + n;
                         *reinterpret_cast<uint4*>(cp) = o;
                         *reinterpret_cast<uint4*>(cp + p.c_lo_off) = l;

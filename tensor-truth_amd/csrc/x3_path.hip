@@ -41,8 +41,16 @@ __device__ __forceinline__ float wave_sum_x(float v) {
 
 // LayerNorm of a row held as x[c] (float4 = elements 256 c + 4 lane ...), two-pass fp32 statistics; writes the fp32 row
 // (out32, may be NULL) and its two bf16 planes (planes[0..H) = hi, planes[H..2H) = lo; may be NULL)
+__device__ __forceinline__ float rbf(float v) { return __uint_as_float(pack_bf16x2(v, 0.f) << 16); }   // round to bf16, kept as fp32
+
+// flags (diagnostic, TT_X3_ROUND_MASK): 1 = the input row is rounded to bf16 first, 2 = the output is rounded to bf16
 __device__ __forceinline__ void ln_row_x3(float4 (&x)[kMaxC4], int nc, int H, const float* gamma, const float* beta, float eps,
-                                          float* out32, uint16_t* planes, int lane) {
+                                          float* out32, uint16_t* planes, int lane, int flags = 0) {
+    if (flags & 1) {
+#pragma unroll
+        for (int c = 0; c < kMaxC4; ++c)
+            if (c < nc) x[c] = float4{rbf(x[c].x), rbf(x[c].y), rbf(x[c].z), rbf(x[c].w)};
+    }
     float s = 0.f;
 #pragma unroll
     for (int c = 0; c < kMaxC4; ++c)
@@ -62,8 +70,9 @@ __device__ __forceinline__ void ln_row_x3(float4 (&x)[kMaxC4], int nc, int H, co
             const int e0 = 256 * c + 4 * lane;
             const float4 g = *reinterpret_cast<const float4*>(gamma + e0);
             const float4 b = *reinterpret_cast<const float4*>(beta + e0);
-            const float4 y = float4{(x[c].x - mean) * rstd * g.x + b.x, (x[c].y - mean) * rstd * g.y + b.y,
-                                    (x[c].z - mean) * rstd * g.z + b.z, (x[c].w - mean) * rstd * g.w + b.w};
+            float4 y = float4{(x[c].x - mean) * rstd * g.x + b.x, (x[c].y - mean) * rstd * g.y + b.y,
+                              (x[c].z - mean) * rstd * g.z + b.z, (x[c].w - mean) * rstd * g.w + b.w};
+            if (flags & 2) y = float4{rbf(y.x), rbf(y.y), rbf(y.z), rbf(y.w)};
             if (out32) *reinterpret_cast<float4*>(out32 + e0) = y;
             if (planes) {
                 uint2 hi, lo;
@@ -81,7 +90,7 @@ __global__ __launch_bounds__(kRowThreadsX) void embed_ln_x3_kernel(const int32_t
                                                                     const float* word, const float* posemb, const float* typeemb,
                                                                     const float* gamma, const float* beta, float* out32,
                                                                     uint16_t* planes, int T, int H, int vocab, int max_pos,
-                                                                    int type_vocab, float eps) {
+                                                                    int type_vocab, float eps, int flags) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= T) return;
     int id = ids[row], p = pos[row], t = type ? type[row] : 0;
@@ -99,11 +108,11 @@ __global__ __launch_bounds__(kRowThreadsX) void embed_ln_x3_kernel(const int32_t
             const float4 d = *reinterpret_cast<const float4*>(typeemb + (size_t)t * H + e0);
             x[c] = float4{a.x + b.x + d.x, a.y + b.y + d.y, a.z + b.z + d.z, a.w + b.w + d.w};
         }
-    ln_row_x3(x, nc, H, gamma, beta, eps, out32 + (size_t)row * H, planes + (size_t)row * 2 * H, lane);
+    ln_row_x3(x, nc, H, gamma, beta, eps, out32 + (size_t)row * H, planes + (size_t)row * 2 * H, lane, flags & 2);
 }
 
 __global__ __launch_bounds__(kRowThreadsX) void layernorm_x3_kernel(const float* in, float* out32, uint16_t* planes, const float* gamma,
-                                                                     const float* beta, int rows, int H, float eps) {
+                                                                     const float* beta, int rows, int H, float eps, int flags) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
     const int nc = H / 256;
@@ -111,7 +120,8 @@ __global__ __launch_bounds__(kRowThreadsX) void layernorm_x3_kernel(const float*
 #pragma unroll
     for (int c = 0; c < kMaxC4; ++c)
         if (c < nc) x[c] = *reinterpret_cast<const float4*>(in + (size_t)row * H + 256 * c + 4 * lane);
-    ln_row_x3(x, nc, H, gamma, beta, eps, out32 ? out32 + (size_t)row * H : nullptr, planes ? planes + (size_t)row * 2 * H : nullptr, lane);
+    ln_row_x3(x, nc, H, gamma, beta, eps, out32 ? out32 + (size_t)row * H : nullptr, planes ? planes + (size_t)row * 2 * H : nullptr, lane,
+              flags);
 }
 
 // fp32 [rows][cols] -> planes [rows][2 cols] (tests, and callers that bring fp32 activations)
@@ -150,6 +160,7 @@ struct AttnX3Params {
     int ld_qk, q_col0, k_col0, lo_off, ldvt, ld_out, out_lo_off;
     float scale, lazy;
     int n_qt;
+    int round_flags;          // diagnostic (TT_X3_ROUND_MASK): 1 = probabilities rounded to bf16 (P lo = 0), 2 = context rounded (lo = 0)
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -395,6 +406,7 @@ __global__ __launch_bounds__(64 * kXWaves, 2) void attention_x3_kernel(AttnX3Par
                 pl.y = pack_bf16x2(e[2] - __uint_as_float(ph.y << 16), e[3] - __uint_as_float(ph.y & 0xFFFF0000u));
                 pl.z = pack_bf16x2(e[4] - __uint_as_float(ph.z << 16), e[5] - __uint_as_float(ph.z & 0xFFFF0000u));
                 pl.w = pack_bf16x2(e[6] - __uint_as_float(ph.w << 16), e[7] - __uint_as_float(ph.w & 0xFFFF0000u));
+                if (p.round_flags & 1) pl = uint4{0u, 0u, 0u, 0u};
                 const bf16x8 pfh = __builtin_bit_cast(bf16x8, ph), pfl = __builtin_bit_cast(bf16x8, pl);
 #pragma unroll
                 for (int d = 0; d < DT; ++d) {
@@ -423,6 +435,7 @@ __global__ __launch_bounds__(64 * kXWaves, 2) void attention_x3_kernel(AttnX3Par
                 hi.y = pack_bf16x2(y2, y3);
                 lo.x = pack_bf16x2(y0 - __uint_as_float(hi.x << 16), y1 - __uint_as_float(hi.x & 0xFFFF0000u));
                 lo.y = pack_bf16x2(y2 - __uint_as_float(hi.y << 16), y3 - __uint_as_float(hi.y & 0xFFFF0000u));
+                if (p.round_flags & 2) lo = uint2{0u, 0u};
                 *reinterpret_cast<uint2*>(op + 32 * d + 8 * g + 4 * hh) = hi;
                 *reinterpret_cast<uint2*>(op + p.out_lo_off + 32 * d + 8 * g + 4 * hh) = lo;
             }
@@ -522,11 +535,20 @@ int tt_encoder_forward_x3(const tt_encoder_weights_x3* w, const int32_t* ids, co
     uint16_t* ffn = (uint16_t*)(ws + e.off_ffn);
     TT_CHECK_HIP(hipMemsetAsync(ctx, 0, (size_t)T * 2 * H * 2, st));    // rows of no sequence are never written by attention
 
+    // TT_X3_ROUND_MASK (diagnostic, default 0; read per forward): re-introduce ONE of the bf16 path's rounding points at a time
+    // into this fp32-grade forward -- the error budget of the bf16 mode (tools/probes/bf16_error_budget.py).  bit 1: Q / K / V
+    // projections' outputs, 2: softmax probabilities, 3: attention context, 4: pre-LayerNorm sums (attention output + residual,
+    // FFN output + residual), 5: LayerNorm outputs (incl. the embedding LayerNorm; the residual branch reads the rounded copy, as
+    // in the bf16 path), 6: FFN intermediate (GELU output).  (Bit 0, bf16 WEIGHTS, is applied where the planes are made:
+    // encoder_x3.EncoderWeightsX3(round_weights=True).)
+    int rmask = 0;
+    if (const char* m = getenv("TT_X3_ROUND_MASK"); m && m[0]) rmask = (int)strtol(m, nullptr, 0);
+    const int ln_out = (rmask & 32) ? 2 : 0, ln_in = (rmask & 16) ? 1 : 0;
     float* x = w->layers == 0 ? hidden_out : xa;
     {
         TtProfScope prof(TT_K_ROWOPS, st);
         hipLaunchKernelGGL(embed_ln_x3_kernel, row_grid_x(T), dim3(kRowThreadsX), 0, st, ids, pos, type_ids, w->word_emb, w->pos_emb,
-                           w->type_emb, w->emb_ln_g, w->emb_ln_b, x, xpl, T, H, w->vocab, w->max_pos, w->type_vocab, w->ln_eps);
+                           w->type_emb, w->emb_ln_g, w->emb_ln_b, x, xpl, T, H, w->vocab, w->max_pos, w->type_vocab, w->ln_eps, ln_out);
         TT_CHECK_LAUNCH();
     }
     for (int l = 0; l < w->layers; ++l) {
@@ -538,6 +560,7 @@ int tt_encoder_forward_x3(const tt_encoder_weights_x3* w, const int32_t* ids, co
         g.x3 = 1;
         g.A = xpl; g.lda = 2 * H; g.W = (const uint16_t*)lw.qkv_w; g.ldw = 2 * H; g.bias = lw.qkv_b;
         g.C = qk; g.ldc = 4 * H; g.c_lo_off = 2 * H; g.M = T; g.N = 2 * H; g.K = H;
+        g.x3_zero_lo = (rmask & 2) ? 1 : 0;
         if (int rc = tt_gemm_launch(g, TT_EPI_BIAS, st)) return rc;
         GemmParams gv = g;
         gv.W = (const uint16_t*)lw.qkv_w + (size_t)2 * H * 2 * H;
@@ -548,6 +571,7 @@ int tt_encoder_forward_x3(const tt_encoder_weights_x3* w, const int32_t* ids, co
         a.qk = qk; a.ld_qk = 4 * H; a.q_col0 = 0; a.k_col0 = H; a.lo_off = 2 * H; a.vt = vt; a.vt_lo = vtlo; a.ldvt = 8 * H;
         a.out = ctx; a.ld_out = 2 * H; a.out_lo_off = H; a.seq_start = seq_start; a.seq_len = seq_len;
         a.n_seq = n_seq; a.heads = w->heads; a.max_len = max_len; a.scale = 0.125f;
+        a.round_flags = ((rmask & 4) ? 1 : 0) | ((rmask & 8) ? 2 : 0);
         if (int rc = attention_x3_launch(a, st)) return rc;
         GemmParams go{};
         go.x3 = 1;
@@ -557,13 +581,15 @@ int tt_encoder_forward_x3(const tt_encoder_weights_x3* w, const int32_t* ids, co
         float* x1 = (x == xa) ? xb : xa;
         {
             TtProfScope prof(TT_K_ROWOPS, st);
-            hipLaunchKernelGGL(layernorm_x3_kernel, row_grid_x(T), dim3(kRowThreadsX), 0, st, y, x1, xpl, lw.ln1_g, lw.ln1_b, T, H, w->ln_eps);
+            hipLaunchKernelGGL(layernorm_x3_kernel, row_grid_x(T), dim3(kRowThreadsX), 0, st, y, x1, xpl, lw.ln1_g, lw.ln1_b, T, H, w->ln_eps,
+                               ln_in | ln_out);
             TT_CHECK_LAUNCH();
         }
         GemmParams g1{};
         g1.x3 = 1;
         g1.A = xpl; g1.lda = 2 * H; g1.W = (const uint16_t*)lw.ffn1_w; g1.ldw = 2 * H; g1.bias = lw.ffn1_b;
         g1.C = ffn; g1.ldc = 2 * F; g1.c_lo_off = F; g1.M = T; g1.N = F; g1.K = H;
+        g1.x3_zero_lo = (rmask & 64) ? 1 : 0;
         if (int rc = tt_gemm_launch(g1, TT_EPI_GELU, st)) return rc;
         GemmParams g2{};
         g2.x3 = 1;
@@ -575,7 +601,7 @@ int tt_encoder_forward_x3(const tt_encoder_weights_x3* w, const int32_t* ids, co
         {
             TtProfScope prof(TT_K_ROWOPS, st);
             hipLaunchKernelGGL(layernorm_x3_kernel, row_grid_x(T), dim3(kRowThreadsX), 0, st, y, dst, last ? (uint16_t*)nullptr : xpl,
-                               lw.ln2_g, lw.ln2_b, T, H, w->ln_eps);
+                               lw.ln2_g, lw.ln2_b, T, H, w->ln_eps, ln_in | ln_out);
             TT_CHECK_LAUNCH();
         }
         x = dst;

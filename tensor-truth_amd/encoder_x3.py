@@ -60,7 +60,9 @@ class EncoderWeightsX3:
 
     gemm_dtype = "bf16x3"
 
-    def __init__(self, cfg: EncoderConfig, state: Dict[str, torch.Tensor], device: torch.device):
+    def __init__(self, cfg: EncoderConfig, state: Dict[str, torch.Tensor], device: torch.device, round_weights: bool = False):
+        """``round_weights`` (diagnostic, tools/probes/bf16_error_budget.py): every tensor the bf16 path keeps in bf16 -- the
+        matrices and the embedding tables -- is rounded to bf16 first, i.e. the weights' share of the bf16 mode's error."""
         if device.type != "cuda":
             raise RuntimeError("EncoderWeightsX3 need a HIP device; tensor_truth_amd has no CPU path")
         if not supports(cfg):
@@ -75,13 +77,16 @@ class EncoderWeightsX3:
             return x
 
         def planes(x):
+            if round_weights:
+                x = x.to(torch.bfloat16)
             x = split_planes(x.to(device=device))
             self._keep.append(x)
             return x
 
         H = cfg.hidden
-        word, pos, typ = t(sd["embeddings.word_embeddings.weight"]), t(sd["embeddings.position_embeddings.weight"]), \
-            t(sd["embeddings.token_type_embeddings.weight"])
+        rt = (lambda x: t(x.to(torch.bfloat16))) if round_weights else t
+        word, pos, typ = rt(sd["embeddings.word_embeddings.weight"]), rt(sd["embeddings.position_embeddings.weight"]), \
+            rt(sd["embeddings.token_type_embeddings.weight"])
         if word.shape != (cfg.vocab_size, H) or pos.shape != (cfg.max_pos, H):
             raise ValueError(f"embedding tables {tuple(word.shape)} / {tuple(pos.shape)} do not match {cfg}")
         self._layers = (_LayerWX * max(cfg.layers, 1))()
@@ -105,8 +110,8 @@ class EncoderWeightsX3:
         if cfg.num_labels:
             if cfg.num_labels != 1:
                 raise ValueError("only single-label (sigmoid) cross-encoder heads are supported")
-            w.cls_dense_w, w.cls_dense_b = t(sd["classifier.dense.weight"]).data_ptr(), t(sd["classifier.dense.bias"]).data_ptr()
-            w.cls_out_w, w.cls_out_b = t(sd["classifier.out_proj.weight"]).data_ptr(), t(sd["classifier.out_proj.bias"]).data_ptr()
+            w.cls_dense_w, w.cls_dense_b = rt(sd["classifier.dense.weight"]).data_ptr(), t(sd["classifier.dense.bias"]).data_ptr()
+            w.cls_out_w, w.cls_out_b = rt(sd["classifier.out_proj.weight"]).data_ptr(), t(sd["classifier.out_proj.bias"]).data_ptr()
         self.struct = w
 
     def set_gemm_dtype(self, dtype: str) -> None:
