@@ -145,7 +145,7 @@ def test_config5_semantic_hierarchical_ingest_automerge_fp8_rerank(dev, built_li
     row_of = {nid: r for r, nid in enumerate(index.leaf_ids)}
     base = index.as_retriever(similarity_top_k=16)
     amr = AutoMergingRetriever(base, index.docstore)
-    overlaps, taus, top5 = [], [], []
+    overlaps, taus, top5, taus16 = [], [], [], []
     n_sep = n_exact = 0
     SCAN_TOL = 4e-3      # embeddings agree to cos >= 0.999 / 2e-3 per component: scores of unit vectors within ~4e-3
     for qi, q in enumerate(queries):
@@ -184,6 +184,14 @@ def test_config5_semantic_hierarchical_ingest_automerge_fp8_rerank(dev, built_li
         got = torch.tensor(rr.predict([(q, t) for t in texts]))
         err = (got - want).abs().max().item()
         assert err <= FP8_BOUND_2L, f"query {qi}: fp8 score error {err}"
+        # ... and the same candidates through the bf16 reranker (the PRIMARY mode; fp8 is the labelled throughput variant)
+        rr.model.set_gemm_dtype("bf16")
+        got16 = torch.tensor(rr.predict([(q, t) for t in texts]))
+        rr.model.set_gemm_dtype("fp8")
+        err16 = (got16 - want).abs().max().item()
+        assert err16 <= 2e-2, f"query {qi}: bf16 score error {err16}"
+        assert_order_on_separable(want.numpy(), got16.numpy(), max(2 * err16, 1e-4), f"config-5 query {qi} (bf16)")
+        taus16.append(kendall_tau(want.numpy(), got16.numpy()))
         # order wherever the oracle separates two candidates by more than twice the error MEASURED on this query
         n_sep += assert_order_on_separable(want.numpy(), got.numpy(), max(2 * err, 1e-4), f"config-5 query {qi}")
         taus.append(kendall_tau(want.numpy(), got.numpy()))
@@ -193,7 +201,9 @@ def test_config5_semantic_hierarchical_ingest_automerge_fp8_rerank(dev, built_li
         assert [n.node.id_ for n in res.source_nodes] == [merged[i].node.id_ for i in by_score]
     print(f"config 5 composed: {index.n} leaves / {len(index.docstore)} nodes; splitter distance err {worst:.1e}, cuts equal on "
           f"{same_cuts}/{checked_docs} docs; leaf cos min {cos.min().item():.5f}; retrieval: every hit a valid oracle top-16 member within {SCAN_TOL}, overlap@16 mean {np.mean(overlaps):.2f}, {n_exact} clear-cut queries identical; "
-          f"fp8 rerank vs fp32: Kendall tau mean {np.mean(taus):.2f}, top-5 overlap mean {np.mean(top5):.2f}, {n_sep} separable pairs ordered")
+          f"fp8 rerank vs fp32: Kendall tau mean {np.mean(taus):.2f}, top-5 overlap mean {np.mean(top5):.2f}, {n_sep} separable pairs ordered; "
+          f"bf16 rerank vs fp32: Kendall tau mean {np.mean(taus16):.2f}")
+    assert np.mean(taus16) >= np.mean(taus) - 0.05 and np.mean(taus16) >= 0.8
     # (overlap with the oracle's own top-16 is informational: the lists differ inside the tolerance, see stage C)
     assert n_sep >= 1 and np.mean(overlaps) >= 0.4 and np.mean(top5) >= 0.6 and np.mean(taus) >= 0.5
     mm.ModelManager.reset_instance()
