@@ -1387,11 +1387,130 @@ int launch_fp8(const GemmParams& p, hipStream_t st) {
     }
 }
 
+// ---- skinny: M <= 256 rows (one query's embedding, the CLS-row tail of the last layer, the rerank head) -----------
+// With a few dozen token rows a GEMM is a stream of the weight matrix and nothing else: the tiled kernels put
+// 16 (N = 1024) to 64 workgroups on the chip and walk K in 64-element steps behind a barrier each (8 us at K = 1024,
+// 30 us at K = 4096, times 6 GEMMs x 24 layers = most of a query embedding's 3.4 ms).  Here ONE WAVE owns 16 output
+// columns x 64 rows x all of K: no LDS, no barrier, operands straight from global memory into MFMA fragments (a
+// fragment is 16 contiguous bytes of a K-contiguous row in both operands), kPf K-steps of loads in flight per wave,
+// N/16 x M/64 waves per launch.  The activations (<= 256 x K) are re-read by every wave from L2.
+// Same instruction, operand order and K order as the tiled kernels, same epilogue code: results are bit-identical
+// to theirs, so an embedding does not depend on whether the text was embedded alone or in a large batch.
+constexpr int kPf = 8;
+
+// split-bf16 epilogue of one wave's tile (skinny kernel): same values, same operations as epilogue_x3
+template <int EPI, int NT, int MT>
+__device__ __forceinline__ void gemm_epilogue_tile_x3(const GemmParams& p, f32x4 (&acc)[NT][MT], int mw, int nw, int lane) {
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const int n = nw + i * 16 + (lane >> 4) * 4;
+        const float4 b4 = *reinterpret_cast<const float4*>(p.bias + n);
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+            const int m = mw + j * 16 + (lane & 15);
+            float v[4] = {acc[i][j][0] + b4.x, acc[i][j][1] + b4.y, acc[i][j][2] + b4.z, acc[i][j][3] + b4.w};
+            if constexpr (EPI == TT_EPI_RESIDUAL) {
+                const float4 r = *reinterpret_cast<const float4*>(p.res32 + (size_t)m * p.ldr + n);
+                *reinterpret_cast<float4*>(p.C32 + (size_t)m * p.ldc + n) = float4{v[0] + r.x, v[1] + r.y, v[2] + r.z, v[3] + r.w};
+            } else {
+                if constexpr (EPI == TT_EPI_GELU) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        v[k] = v3::gelu_exact(v[k]);
+                        asm("" : "+v"(v[k]));          // (see epilogue_x3)
+                    }
+                }
+                uint2 o, l;
+                o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
+                l.x = pack_bf16x2(v[0] - __uint_as_float(o.x << 16), v[1] - __uint_as_float(o.x & 0xFFFF0000u));
+                l.y = pack_bf16x2(v[2] - __uint_as_float(o.y << 16), v[3] - __uint_as_float(o.y & 0xFFFF0000u));
+                if (p.x3_zero_lo) l = uint2{0u, 0u};
+                if constexpr (EPI == TT_EPI_VT) {      // every column is a V feature: V8 layout, hi and lo planes
+                    const size_t at = (size_t)(m >> 3) * p.ldvt + (size_t)(n - p.vt_col0) * 8 + (m & 7);
+                    p.vt[at] = (uint16_t)(o.x & 0xFFFFu);       p.vt[at + 8] = (uint16_t)(o.x >> 16);
+                    p.vt[at + 16] = (uint16_t)(o.y & 0xFFFFu);  p.vt[at + 24] = (uint16_t)(o.y >> 16);
+                    p.vt_lo[at] = (uint16_t)(l.x & 0xFFFFu);      p.vt_lo[at + 8] = (uint16_t)(l.x >> 16);
+                    p.vt_lo[at + 16] = (uint16_t)(l.y & 0xFFFFu); p.vt_lo[at + 24] = (uint16_t)(l.y >> 16);
+                } else {
+                    uint16_t* cp = p.C + (size_t)m * p.ldc + n;
+                    *reinterpret_cast<uint2*>(cp) = o;
+                    *reinterpret_cast<uint2*>(cp + p.c_lo_off) = l;
+                }
+            }
+        }
+    }
+}
+
+// X3: split-bf16 operands (GemmParams.x3) -- the same loop over the virtual K stream of 3 K (hi.hi, hi.lo, lo.hi), in the
+// tiled kernel's order, so a row's result does not depend on which kernel computed it
+template <int EPI, bool X3 = false>
+__global__ __launch_bounds__(64) void gemm_skinny_kernel(GemmParams p) {
+    const int lane = threadIdx.x;
+    const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 64;
+    const int frow = lane & 15, fchk = lane >> 4;
+    const uint16_t* wp = p.W + (size_t)(n0 + frow) * (X3 ? p.ldw : p.K) + fchk * 8;
+    const uint16_t* ap = p.A + (size_t)(m0 + frow) * p.lda + fchk * 8;
+    const size_t a16 = (size_t)16 * p.lda;
+    f32x4 acc[1][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[0][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 wb[kPf], ab[kPf][4];
+    const int nks1 = p.K / 32;
+    const int nks = X3 ? 3 * nks1 : nks1;
+    auto step_a = [&](int s) { if constexpr (X3) return s < nks1 ? s : s - nks1; else return s; };
+    auto step_w = [&](int s) { if constexpr (X3) return s < 2 * nks1 ? s : s - 2 * nks1; else return s; };
+#pragma unroll
+    for (int s = 0; s < kPf; ++s)
+        if (s < nks) {
+            wb[s] = *reinterpret_cast<const bf16x8*>(wp + step_w(s) * 32);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ab[s][j] = *reinterpret_cast<const bf16x8*>(ap + j * a16 + step_a(s) * 32);
+        }
+    for (int ks = 0; ks < nks; ks += kPf) {
+#pragma unroll
+        for (int s = 0; s < kPf; ++s) {
+            if (ks + s < nks) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[s], ab[s][j], acc[0][j], 0, 0, 0);
+                const int nx = ks + s + kPf;
+                if (nx < nks) {
+                    wb[s] = *reinterpret_cast<const bf16x8*>(wp + step_w(nx) * 32);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) ab[s][j] = *reinterpret_cast<const bf16x8*>(ap + j * a16 + step_a(nx) * 32);
+                }
+            }
+        }
+    }
+    if constexpr (X3) gemm_epilogue_tile_x3<EPI, 1, 4>(p, acc, m0, n0, lane);
+    else gemm_epilogue_tile<EPI, 1, 4>(p, acc, m0, n0, lane);
+}
+
 // split-bf16 operands (GemmParams.x3): the 256x256 one-tile kernel, bias / GELU (planes out), residual (fp32 out), V^T
 template <int EPI>
 int launch_x3(const GemmParams& p, hipStream_t st) {
     if constexpr (EPI == TT_EPI_BIAS || EPI == TT_EPI_GELU || EPI == TT_EPI_VT || EPI == TT_EPI_RESIDUAL) {
         const int ldw = p.ldw ? p.ldw : p.K;
+        // up to 256 rows (one query's embedding): the weight-streaming skinny kernel on the same virtual K stream -- a
+        // 256-row tile grid would put 4-16 workgroups on the chip (11.5 ms per 24-layer forward instead of ~3)
+        if (tt_gemm_skinny_enabled() && p.M > 0 && p.M <= 256 && p.M % 64 == 0 && p.N % 16 == 0 && p.K % 32 == 0 && p.lda >= 2 * p.K &&
+            ldw >= 2 * p.K && p.lda % 8 == 0 && ldw % 8 == 0 && p.A && p.W && p.bias) {
+            if constexpr (EPI == TT_EPI_RESIDUAL) {
+                if (!p.C32 || !p.res32 || p.ldc % 4 || p.ldr % 4) { tt_set_error("gemm x3: residual epilogue needs fp32 C32 / res32"); return TT_E_INVALID; }
+            } else if constexpr (EPI == TT_EPI_VT) {
+                if (!p.vt || !p.vt_lo) { tt_set_error("gemm x3: V^T epilogue needs vt / vt_lo"); return TT_E_INVALID; }
+            } else {
+                if (!p.C || p.ldc % 4 || p.c_lo_off % 4 || p.c_lo_off < p.N) { tt_set_error("gemm x3: planes output needs C, c_lo_off >= N"); return TT_E_INVALID; }
+            }
+            GemmParams q = p;
+            q.ldw = ldw;
+            {
+                TtProfScope prof(TT_K_GEMM, st);
+                hipLaunchKernelGGL((gemm_skinny_kernel<EPI, true>), dim3(p.N / 16, p.M / 64), dim3(64), 0, st, q);
+            }
+            TT_CHECK_LAUNCH();
+            return TT_OK;
+        }
         if (p.M % v3::BM3 || p.N % v3::BN3 || p.K % 64 || p.K < 128 || p.lda < 2 * p.K || ldw < 2 * p.K || p.lda % 8 || ldw % 8 || !p.A ||
             !p.W || !p.bias) {
             tt_set_error("gemm x3: M=%d N=%d K=%d lda=%d ldw=%d: M, N multiples of 256, K of 64, planes [.][>= 2K]", p.M, p.N, p.K, p.lda, ldw);
@@ -1423,55 +1542,6 @@ int launch_x3(const GemmParams& p, hipStream_t st) {
         tt_set_error("gemm x3: epilogue %d has no split-bf16 form", EPI);
         return TT_E_UNSUPPORTED;
     }
-}
-
-// ---- skinny: M <= 256 rows (one query's embedding, the CLS-row tail of the last layer, the rerank head) -----------
-// With a few dozen token rows a GEMM is a stream of the weight matrix and nothing else: the tiled kernels put
-// 16 (N = 1024) to 64 workgroups on the chip and walk K in 64-element steps behind a barrier each (8 us at K = 1024,
-// 30 us at K = 4096, times 6 GEMMs x 24 layers = most of a query embedding's 3.4 ms).  Here ONE WAVE owns 16 output
-// columns x 64 rows x all of K: no LDS, no barrier, operands straight from global memory into MFMA fragments (a
-// fragment is 16 contiguous bytes of a K-contiguous row in both operands), kPf K-steps of loads in flight per wave,
-// N/16 x M/64 waves per launch.  The activations (<= 256 x K) are re-read by every wave from L2.
-// Same instruction, operand order and K order as the tiled kernels, same epilogue code: results are bit-identical
-// to theirs, so an embedding does not depend on whether the text was embedded alone or in a large batch.
-constexpr int kPf = 8;
-template <int EPI>
-__global__ __launch_bounds__(64) void gemm_skinny_kernel(GemmParams p) {
-    const int lane = threadIdx.x;
-    const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 64;
-    const int frow = lane & 15, fchk = lane >> 4;
-    const uint16_t* wp = p.W + (size_t)(n0 + frow) * p.K + fchk * 8;
-    const uint16_t* ap = p.A + (size_t)(m0 + frow) * p.lda + fchk * 8;
-    const size_t a16 = (size_t)16 * p.lda;
-    f32x4 acc[1][4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[0][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    bf16x8 wb[kPf], ab[kPf][4];
-    const int nks = p.K / 32;
-#pragma unroll
-    for (int s = 0; s < kPf; ++s)
-        if (s < nks) {
-            wb[s] = *reinterpret_cast<const bf16x8*>(wp + s * 32);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) ab[s][j] = *reinterpret_cast<const bf16x8*>(ap + j * a16 + s * 32);
-        }
-    for (int ks = 0; ks < nks; ks += kPf) {
-#pragma unroll
-        for (int s = 0; s < kPf; ++s) {
-            if (ks + s < nks) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[s], ab[s][j], acc[0][j], 0, 0, 0);
-                const int nx = ks + s + kPf;
-                if (nx < nks) {
-                    wb[s] = *reinterpret_cast<const bf16x8*>(wp + nx * 32);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) ab[s][j] = *reinterpret_cast<const bf16x8*>(ap + j * a16 + nx * 32);
-                }
-            }
-        }
-    }
-    gemm_epilogue_tile<EPI, 1, 4>(p, acc, m0, n0, lane);
 }
 
 bool skinny_shape(const GemmParams& p) {

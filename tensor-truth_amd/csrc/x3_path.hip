@@ -512,7 +512,8 @@ int tt_encoder_forward_x3(const tt_encoder_weights_x3* w, const int32_t* ids, co
                           const int32_t* seq_start, const int32_t* seq_len, int n_seq, int n_rows, int max_len,
                           float* hidden_out, void* workspace, size_t workspace_bytes, void* stream) {
     if (int rc = check_weights_x3(w)) return rc;
-    TT_CHECK_ARG(n_rows > 0 && n_rows % 256 == 0, "n_rows=%d must be a positive multiple of 256", n_rows);
+    TT_CHECK_ARG(n_rows > 0 && (n_rows % 256 == 0 || (n_rows < 256 && n_rows % 64 == 0)),
+                 "n_rows=%d must be a positive multiple of 256 (or 64 / 128 / 192: skinny GEMMs)", n_rows);
     TT_CHECK_ARG(n_seq > 0 && max_len > 0, "n_seq=%d max_len=%d", n_seq, max_len);
     TT_CHECK_ARG(ids && pos && seq_start && seq_len && hidden_out, "null pointer");
     const X3Ws e = x3_plan(w, n_rows);

@@ -126,7 +126,10 @@ class EncoderWeightsX3:
 
 
 def _pad_rows(batch: PackedBatch, multiple: int = 256) -> PackedBatch:
-    """The split-bf16 GEMMs run whole 256-row tiles: a short batch (one query: 64 rows) is padded with rows of no sequence."""
+    """The tiled split-bf16 GEMMs run whole 256-row tiles; up to 256 rows (one query: 64 rows) the projections run as
+    weight-streaming skinny GEMMs on multiples of 64 rows (``encoder._round_rows`` packs exactly that)."""
+    if batch.n_rows <= 256 and batch.n_rows % 64 == 0:
+        return batch
     n = (batch.n_rows + multiple - 1) // multiple * multiple
     if n == batch.n_rows:
         return batch

@@ -1,5 +1,5 @@
 """Interactive case (BASELINE config 3: one query, 1M x 1024 corpus, top-50, rerank 50 -> 10): wall-clock latency of
-each stage with a device sync after it, median of 20.  Usage: python tools/probes/single_query_latency.py [rows] [queries]"""
+each stage with a device sync after it, median of 20.  Usage: python tools/probes/single_query_latency.py [rows] [queries] [reference]"""
 import statistics
 import sys
 import time
@@ -18,8 +18,14 @@ Bq = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(0)
 corpus = B.synth_corpus_shard(N, 1024, 1234, dev)
-emb = Encoder(EncoderWeights(BGE_M3, synthetic_state_device(BGE_M3, dev, seed=1), dev))
-rr = Encoder(EncoderWeights(BGE_RERANKER_V2_M3, synthetic_state_device(BGE_RERANKER_V2_M3, dev, seed=2), dev))
+if len(sys.argv) > 3 and sys.argv[3] == "reference":      # both encoders in the reference precision (split-bf16, encoder_x3)
+    from tensor_truth_amd.encoder_x3 import EncoderWeightsX3, EncoderX3
+
+    emb = EncoderX3(EncoderWeightsX3(BGE_M3, synthetic_state_device(BGE_M3, dev, seed=1, dtype=torch.float32), dev))
+    rr = EncoderX3(EncoderWeightsX3(BGE_RERANKER_V2_M3, synthetic_state_device(BGE_RERANKER_V2_M3, dev, seed=2, dtype=torch.float32), dev))
+else:
+    emb = Encoder(EncoderWeights(BGE_M3, synthetic_state_device(BGE_M3, dev, seed=1), dev))
+    rr = Encoder(EncoderWeights(BGE_RERANKER_V2_M3, synthetic_state_device(BGE_RERANKER_V2_M3, dev, seed=2), dev))
 rng = np.random.default_rng(777)
 vocab = BGE_M3.vocab_size
 K, QL, CL = 50, 32, 256
