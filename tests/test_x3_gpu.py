@@ -50,7 +50,8 @@ def test_split_planes_kernel_equals_the_torch_formula(dev, built_lib):
     assert rel <= 2.0 ** -16, rel                       # hi + lo carries x to 16+ bits
 
 
-@pytest.mark.parametrize("m,n,k", [(256, 256, 128), (512, 768, 256), (256, 1024, 1024), (768, 256, 4096), (1024, 4096, 1024)])
+@pytest.mark.parametrize("m,n,k", [(256, 256, 128), (512, 768, 256), (256, 1024, 1024), (768, 256, 4096), (1024, 4096, 1024),
+                                   (64, 1024, 1024), (192, 4096, 1024), (128, 1024, 4096)])      # <= 256 rows: the skinny kernel
 def test_gemm_x3_building_block(dev, built_lib, m, n, k):
     """tt_gemm_x3 against fp64 on the operands' own (hi + lo) values: error of an fp32-accumulated product, two orders
     below what one bf16 rounding of an operand costs (2^-9 relative)."""
@@ -83,7 +84,7 @@ def test_gemm_x3_building_block(dev, built_lib, m, n, k):
         rel = ((got - want).abs().max() / want.abs().max()).item()
         assert rel <= 2e-5, (epi, rel)
     with pytest.raises(_lib.TTError):
-        _lib.check(lib.tt_gemm_x3(dap.data_ptr(), dwp.data_ptr(), db.data_ptr(), None, cp.data_ptr(), None, m, n + 64, k, 0, st), "x")
+        _lib.check(lib.tt_gemm_x3(dap.data_ptr(), dwp.data_ptr(), db.data_ptr(), None, cp.data_ptr(), None, m, n + 8, k, 0, st), "x")
 
 
 def test_gemm_x3_is_row_permutation_equivariant_bit_for_bit(dev, built_lib):
