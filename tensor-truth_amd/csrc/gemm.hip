@@ -720,6 +720,13 @@ __device__ __forceinline__ void epilogue_x3(const GemmParams& p, f32x4 (&acc)[2]
 constexpr int kScanHitOff = kLds3;            // [0]: count, [16...): kScanHitCap x {score bits, (query << 8) | row in tile}
 constexpr int kScanHitCap = 1024;
 constexpr int kLdsScan = kLds3 + 16 + kScanHitCap * 8;
+// MODE 2: wave-private lists (round 3): every wave records ITS survivors in its own LDS list (count + kScanWaveCap entries)
+// and appends them itself once its compares are done -- the same "all atomics of a tile in flight together", but with no
+// workgroup barrier and no shared counter, so the two wave groups of the PERSISTENT kernel (one slot apart through the tile
+// boundary, no common barrier there) can use it: the persistent form then saves the per-tile prologue and dispatch gap.
+constexpr int kScanWaveCap = 120;             // survivors per wave and tile before falling back to direct appends (expected: ~3)
+constexpr int kScanWaveBytes = 16 + kScanWaveCap * 8;      // 976 B
+constexpr int kLdsScanW = kLds3 + 8 * 1024;   // 8 waves x 1 KiB
 
 __device__ __forceinline__ void scan_append(const GemmParams& p, int q, int32_t row, float v) {
     const int pos = atomicAdd(p.scan_cnt + q, 1);
@@ -729,13 +736,17 @@ __device__ __forceinline__ void scan_append(const GemmParams& p, int q, int32_t 
     }
 }
 
-template <bool STAGED>
+// MODE 0: direct per-survivor appends; 1: workgroup-shared LDS list + one barrier; 2: wave-private LDS lists, no barrier
+template <int MODE>
 __device__ __forceinline__ void scan_filter_epilogue(const GemmParams& p, f32x4 (&acc)[2][2][2][4], char* smem, int thr_off,
                                                      int m0, int wm, int wn, int lane) {
     const int g = lane >> 4, l15 = lane & 15;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)smem;
-    int* hit_cnt = reinterpret_cast<int*>(smem + kScanHitOff);
-    uint2* hits = reinterpret_cast<uint2*>(smem + kScanHitOff + 16);
+    const int wave_id = wm * 4 + wn;
+    char* hbase = MODE == 2 ? smem + kScanHitOff + wave_id * 1024 : smem + kScanHitOff;
+    int* hit_cnt = reinterpret_cast<int*>(hbase);
+    uint2* hits = reinterpret_cast<uint2*>(hbase + 16);
+    constexpr int kCap = MODE == 2 ? kScanWaveCap : kScanHitCap;
 #pragma unroll
     for (int qn = 0; qn < 2; ++qn)
 #pragma unroll
@@ -756,10 +767,10 @@ __device__ __forceinline__ void scan_filter_epilogue(const GemmParams& p, f32x4 
                         for (int r = 0; r < 4; ++r)
                             if (v[r] >= t[r]) {
                                 const int q = q0 + r;
-                                if constexpr (STAGED) {
+                                if constexpr (MODE != 0) {
                                     const int pos = atomicAdd(hit_cnt, 1);
-                                    if (pos < kScanHitCap) hits[pos] = make_uint2(__float_as_uint(v[r]), (uint32_t)((q << 8) | rt));
-                                    else scan_append(p, q, m0 + rt, v[r]);       // a tile with > 1024 survivors
+                                    if (pos < kCap) hits[pos] = make_uint2(__float_as_uint(v[r]), (uint32_t)((q << 8) | rt));
+                                    else scan_append(p, q, m0 + rt, v[r]);       // more survivors than the list holds
                                 } else {
                                     scan_append(p, q, m0 + rt, v[r]);
                                 }
@@ -767,13 +778,25 @@ __device__ __forceinline__ void scan_filter_epilogue(const GemmParams& p, f32x4 
                     }
                 }
         }
-    if constexpr (STAGED) {
+    if constexpr (MODE == 1) {
         __syncthreads();
         const int n = *hit_cnt < kScanHitCap ? *hit_cnt : kScanHitCap;
         for (int i = threadIdx.x; i < n; i += kThreads3) {
             const uint2 e = hits[i];
             scan_append(p, (int)(e.y >> 8), m0 + (int)(e.y & 255u), __uint_as_float(e.x));
         }
+    } else if constexpr (MODE == 2) {
+        // wave-synchronous: this wave's LDS atomics and list writes are complete once its lgkm counter is drained
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        int n = *reinterpret_cast<volatile int*>(hit_cnt);
+        n = n < kScanWaveCap ? n : kScanWaveCap;
+        for (int i = lane; i < n; i += 64) {
+            const uint2 e = hits[i];
+            scan_append(p, (int)(e.y >> 8), m0 + (int)(e.y & 255u), __uint_as_float(e.x));
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) *reinterpret_cast<volatile int*>(hit_cnt) = 0;     // ready for this wave's next tile
     }
 }
 
@@ -900,7 +923,9 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
 
     cstamp(0);
     if constexpr (EPI == TT_EPI_SCAN) {
-        if (tid == 0) *reinterpret_cast<int*>(smem + kScanHitOff) = 0;     // survivor count of this tile (see scan_filter_epilogue)
+        // survivor counts of this tile: the shared list's, or (wave-private lists, p.xp bit 16) one per wave
+        if (tid == 0) *reinterpret_cast<int*>(smem + kScanHitOff) = 0;
+        if ((p.xp & 0x10000) && lane == 0) *reinterpret_cast<int*>(smem + kScanHitOff + wave * 1024) = 0;
     }
     // bias strip of this tile (256 floats = one 1-KiB copy), oldest operation of wave 0's queue
     if (wave == 0) {
@@ -1070,7 +1095,8 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
             for (int qn = 0; qn < 2; ++qn)
                 gemm_epilogue_wide<EPI, 2, 4>(p, acc[qm][qn], m0 + qm * 128 + wm * 64, n0 + wn * 64 + qn * 32, lane);
     } else if constexpr (EPI == TT_EPI_SCAN) {
-        scan_filter_epilogue<true>(p, acc, smem, kBiasOff, m0, wm, wn, lane);
+        if (p.xp & 0x10000) scan_filter_epilogue<2>(p, acc, smem, kBiasOff, m0, wm, wn, lane);
+        else scan_filter_epilogue<1>(p, acc, smem, kBiasOff, m0, wm, wn, lane);
     } else if constexpr (SLOTS == 47) {
 #pragma unroll
         for (int qm = 0; qm < 2; ++qm)
@@ -1203,6 +1229,9 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_p(GemmParams p, int 
         const int steps = ((blockIdx.x >> 3) % 32) * ph;       // x 1024 cycles
         for (int i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(16);
     }
+    if constexpr (EPI == TT_EPI_SCAN) {     // wave-private survivor lists (scan_filter_epilogue<2>): this wave's count
+        if (lane == 0) *reinterpret_cast<int*>(smem + kScanHitOff + wave * 1024) = 0;
+    }
     // ---- prologue of the first tile: K-tile 0 complete, K-tile 1 without its hi halves (La(0) brings them)
     stage_strips(m0, n0, bpar);
     issue_lo(0);
@@ -1319,7 +1348,7 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_p(GemmParams p, int 
         int lane_e = lane;
         asm volatile("" : "+v"(lane_e));
         if constexpr (EPI == TT_EPI_SCAN)
-            scan_filter_epilogue<false>(p, acc, smem, kBiasOff + bpar * 1024, m0, wm, wn, lane_e);
+            scan_filter_epilogue<2>(p, acc, smem, kBiasOff + bpar * 1024, m0, wm, wn, lane_e);
         else
             epilogue_all<EPI, false, FP8>(p, acc, smem, kBiasOff + bpar * 1024, kScaleOff + bpar * 2048, m0, n0, wm, wn, wave, lane_e,
                                           false, NoNext{});
@@ -1734,6 +1763,9 @@ int tt_gemm_launch(const GemmParams& p, int epilogue, hipStream_t st) {
     }
 }
 
+#ifndef TT_SCAN_PERSIST_DEFAULT
+#define TT_SCAN_PERSIST_DEFAULT 1        // persistent + wave-private lists: -3.6 % per batch (profiles/r03_scan_wave_private_ab.log)
+#endif
 int tt_scan_gemm_launch(const uint16_t* corpus, int64_t rows, int dim, const uint16_t* queries256, const float* thr256,
                         int32_t* cnt, float* cand_scores, int32_t* cand_idx, int cap, int32_t idx_base, hipStream_t st) {
     if (rows <= 0) return TT_OK;
@@ -1763,21 +1795,28 @@ int tt_scan_gemm_launch(const uint16_t* corpus, int64_t rows, int dim, const uin
     // (measured on 10M x 1024, 256 queries: 5.7 ms persistent vs 5.2 ms one tile per workgroup -- the storing epilogues'
     // problem in reverse: here the tile ends with a workgroup-wide survivor hand-off, which the two wave groups of the
     // persistent form cannot share)
-    static const int persist = [] { const char* e = getenv("TT_SCAN_GEMM_PERSIST"); return e && e[0] ? atoi(e) : 0; }();
+    // Round 3: survivors go to WAVE-PRIVATE LDS lists (scan_filter_epilogue<2>: no workgroup barrier), which is what the
+    // persistent form needs.  TT_SCAN_GEMM_PERSIST: 1 = persistent + wave-private lists, 2 = one tile per workgroup +
+    // wave-private lists, 0 = one tile per workgroup + the workgroup-shared list (round 2's form), default = see below.
+    static const int persist = [] { const char* e = getenv("TT_SCAN_GEMM_PERSIST"); return e && e[0] ? atoi(e) : TT_SCAN_PERSIST_DEFAULT; }();
     const int cus = tt_cu_count_cached() / 8 * 8;
-    if (persist && blocks > cus && cus >= 8) {
-        TT_SET_MAX_LDS(v3::gemm_kernel_p<TT_EPI_SCAN>, v3::kLds3);
+    if (persist == 1 && blocks > cus && cus >= 8) {
+        static const int sxp = [] { const char* e = getenv("TT_SCAN_GEMM_XP"); return e && e[0] ? (int)strtol(e, nullptr, 0) : 0; }();
+        p.xp = sxp;      // (experiment switches of the persistent kernel: bit 2 = wave groups NOT aligned at the tile boundary)
+        TT_SET_MAX_LDS(v3::gemm_kernel_p<TT_EPI_SCAN>, v3::kLdsScanW);
         {
             TtProfScope prof(TT_K_SCAN_FILTER, st);
-            hipLaunchKernelGGL(v3::gemm_kernel_p<TT_EPI_SCAN>, dim3(cus), dim3(v3::kThreads3), v3::kLds3, st, p, blocks);
+            hipLaunchKernelGGL(v3::gemm_kernel_p<TT_EPI_SCAN>, dim3(cus), dim3(v3::kThreads3), v3::kLdsScanW, st, p, blocks);
         }
         TT_CHECK_LAUNCH();
         return TT_OK;
     }
-    TT_SET_MAX_LDS((v3::gemm_kernel_v3<TT_EPI_SCAN, 4>), v3::kLdsScan);
+    if (persist != 0) p.xp |= 0x10000;      // wave-private lists in the one-tile kernel
+    constexpr int kLdsOne = v3::kLdsScan > v3::kLdsScanW ? v3::kLdsScan : v3::kLdsScanW;
+    TT_SET_MAX_LDS((v3::gemm_kernel_v3<TT_EPI_SCAN, 4>), kLdsOne);
     {
         TtProfScope prof(TT_K_SCAN_FILTER, st);
-        hipLaunchKernelGGL((v3::gemm_kernel_v3<TT_EPI_SCAN, 4>), dim3(blocks), dim3(v3::kThreads3), v3::kLdsScan, st, p);
+        hipLaunchKernelGGL((v3::gemm_kernel_v3<TT_EPI_SCAN, 4>), dim3(blocks), dim3(v3::kThreads3), kLdsOne, st, p);
     }
     TT_CHECK_LAUNCH();
     return TT_OK;
