@@ -207,3 +207,91 @@ def test_config5_semantic_hierarchical_ingest_automerge_fp8_rerank(dev, built_li
     # (overlap with the oracle's own top-16 is informational: the lists differ inside the tolerance, see stage C)
     assert n_sep >= 1 and np.mean(overlaps) >= 0.4 and np.mean(top5) >= 0.6 and np.mean(taus) >= 0.5
     mm.ModelManager.reset_instance()
+
+
+def test_config5_retrieval_stage_is_decidable_in_the_reference_precision(dev, built_lib, tmp_path):
+    """Stages A-C again with the embedder in the reference's own precision (``precision="reference"``: fp32 semantics) against
+    the plain fp32 oracle.  In bf16 the random-weight model's neighbours sit inside the comparison tolerance, so the bf16 test
+    above can only check membership-within-tolerance; here product and oracle embeddings agree to ~1e-5, the bf16 rows of the
+    index matrix come out (almost) bit-identical, and the lists themselves must agree: same semantic cuts, same leaves, the
+    same ordered top-16 wherever the oracle separates rank 16 from rank 17 by more than 2e-4, the same auto-merged result."""
+    from tensor_truth_amd import model_manager as mm
+    from tensor_truth_amd.encoder import EncoderConfig
+    from tensor_truth_amd.index_builder import build_index
+    from tensor_truth_amd.retrievers import AutoMergingRetriever
+    from tensor_truth_amd.schema import MetadataMode, NodeWithScore
+    from tensor_truth_amd.semantic import SemanticSplitter, adjacent_distances, breakpoints_from_distances, split_sentences
+
+    cfg, ocfg = EncoderConfig(**SMALL), oe.EncoderConfig(**SMALL)
+    mm.ModelManager.reset_instance()
+    mgr = mm.ModelManager.get_instance()
+    mgr.set_precision("reference")                                  # the config key: every model this manager loads
+    mgr.model_kwargs_overrides["test/bge-small-shaped"] = {"encoder_config": cfg, "synthetic_seed": 51, "pipeline_window": 64}
+    emb = mgr.get_embedder("test/bge-small-shaped", "cuda")
+    assert emb.precision.startswith("reference")
+    W_e = oe.synth_weights(ocfg, seed=51)                          # plain fp32, no emulation
+
+    def oracle_embed(texts):
+        seqs = [emb._tokenizer.encode(t, emb.max_length) for t in texts]
+        out = []
+        for lo in range(0, len(seqs), 256):
+            ids, mask = _pad(seqs[lo:lo + 256], cfg.pad_id)
+            out.append(oe.embed(ids, mask, W_e, ocfg))
+        return torch.cat(out)
+
+    docs = _docs()
+    index = build_index(docs, emb, persist_dir=str(tmp_path / "m"), chunking_strategy="semantic_hierarchical",
+                        chunk_sizes=[96, 40, 20], chunk_overlap=4, semantic_buffer_size=1, semantic_breakpoint_threshold=80)
+    # A. semantic cuts: identical on every document whose oracle distances are clear of the percentile threshold by 1e-4
+    sp = SemanticSplitter(emb, buffer_size=1, breakpoint_percentile_threshold=80)
+    worst, same, decisive_docs = 0.0, 0, 0
+    for doc in docs[:12]:
+        groups = sp._groups(split_sentences(doc.get_content()))
+        got_d = adjacent_distances(emb._embed_texts(groups, "")).cpu()
+        e = oracle_embed(groups)
+        want_d = 1 - torch.nn.functional.cosine_similarity(e[:-1], e[1:], dim=1)
+        worst = max(worst, (got_d - want_d).abs().max().item())
+        thr = float(np.percentile(want_d.numpy().astype(np.float64), 80))
+        equal = breakpoints_from_distances(got_d.tolist(), 80) == breakpoints_from_distances(want_d.tolist(), 80)
+        same += equal
+        if bool(((want_d - thr).abs() > 1e-4).all()):
+            decisive_docs += 1
+            assert equal, "semantic cuts differ although every oracle distance is clear of the threshold by 1e-4"
+    assert worst < 5e-5, worst
+    assert decisive_docs >= 6 and same >= 10, (decisive_docs, same)
+    # B. leaf embeddings
+    rows = [index.docstore[nid] for nid in index.leaf_ids]
+    want_E = oracle_embed([nd.get_content(metadata_mode=MetadataMode.EMBED) for nd in rows])
+    got_E = index.matrix.float().cpu()
+    same_bits = (got_E == want_E.to(torch.bfloat16).float()).float().mean().item()
+    assert same_bits > 0.99, same_bits                              # the bf16 rows of the matrix, element for element
+    # C. retrieval + auto-merge against the oracle's exact scan of ITS matrix
+    probe_rows = [7, len(rows) // 3, len(rows) // 2, len(rows) - 5]
+    queries = [rows[r].get_content(metadata_mode=MetadataMode.EMBED) for r in probe_rows] + [" ".join(t[:6]) for t in TOPICS] + \
+              [" ".join(TOPICS[i % 4][j] for j in (i % 7, (i + 3) % 10, (2 * i + 1) % 10, 9 - i % 5)) for i in range(12)]
+    W_q = oracle_embed(queries).to(torch.bfloat16)
+    K = 16
+    o_s, o_i, _ = osc.scan_topk(want_E.to(torch.bfloat16), W_q, K + 1)
+    base = index.as_retriever(similarity_top_k=K)
+    amr = AutoMergingRetriever(base, index.docstore)
+    n_identical = n_decidable = 0
+    for qi, q in enumerate(queries):
+        hits = base.retrieve(q)
+        got_ids = [h.node.id_ for h in hits]
+        want_ids = [index.leaf_ids[int(j)] for j in o_i[qi, :K]]
+        gaps = (o_s[qi, :-1] - o_s[qi, 1:])                         # adjacent oracle gaps down to rank 17
+        decidable = bool((gaps > 2e-4).all())
+        n_decidable += decidable
+        n_identical += got_ids == want_ids
+        if decidable:
+            assert got_ids == want_ids, f"query {qi}: ordered top-{K} differs although every oracle gap exceeds 2e-4"
+            merged = amr.retrieve(q)
+            oracle_hits = [NodeWithScore(node=index.docstore[i], score=h.score) for i, h in zip(want_ids, hits)]
+            again = AutoMergingRetriever(base, index.docstore).merge(oracle_hits)
+            assert [m.node.id_ for m in merged] == [m.node.id_ for m in again]
+        assert set(got_ids) >= set(want_ids[: K // 2]) or not decidable
+    print(f"config 5, reference precision: splitter distance err {worst:.1e}, cuts equal on {same}/12 docs ({decisive_docs} decisive); "
+          f"{same_bits:.4f} of the matrix elements bit-identical to the oracle's bf16 rows; ordered top-{K} identical on "
+          f"{n_identical}/{len(queries)} queries, required (all gaps > 2e-4) on {n_decidable}")
+    assert n_decidable >= 3 and n_identical >= len(queries) // 2
+    mm.ModelManager.reset_instance()
