@@ -246,7 +246,7 @@ def test_config5_retrieval_stage_is_decidable_in_the_reference_precision(dev, bu
                         chunk_sizes=[96, 40, 20], chunk_overlap=4, semantic_buffer_size=1, semantic_breakpoint_threshold=80)
     # A. semantic cuts: identical on every document whose oracle distances are clear of the percentile threshold by 1e-4
     sp = SemanticSplitter(emb, buffer_size=1, breakpoint_percentile_threshold=80)
-    worst, same, decisive_docs = 0.0, 0, 0
+    worst, same, decisive_docs, gaps_seen = 0.0, 0, 0, []
     for doc in docs[:12]:
         groups = sp._groups(split_sentences(doc.get_content()))
         got_d = adjacent_distances(emb._embed_texts(groups, "")).cpu()
@@ -260,11 +260,16 @@ def test_config5_retrieval_stage_is_decidable_in_the_reference_precision(dev, bu
         # can carry a distance across it, i.e. unless the nearest distance on the OTHER side of it is closer than 2e-4
         srt = np.sort(want_d.numpy().astype(np.float64))
         above, below = srt[srt > thr], srt[srt <= thr]
-        if len(above) and len(below) and above.min() - below.max() > 2e-4:
-            decisive_docs += 1
-            assert equal, "semantic cuts differ although the distances around the threshold are 2e-4 apart"
+        if len(above) and len(below):
+            gaps_seen.append((float(above.min() - below.max()), bool(equal)))
     assert worst < 5e-5, worst
-    assert decisive_docs >= 6 and same >= 10, (decisive_docs, same)
+    # (this toy model's distances sit within ~1e-3 of each other: a document counts as decided when the two distances that
+    # straddle the threshold are further apart than four times the worst error measured above)
+    for gap, equal in gaps_seen:
+        if gap > 4 * worst:
+            decisive_docs += 1
+            assert equal, f"semantic cuts differ although the distances around the threshold are {gap:.1e} apart (error {worst:.1e})"
+    assert same >= 11, (same, decisive_docs, gaps_seen)
     # B. leaf embeddings
     rows = [index.docstore[nid] for nid in index.leaf_ids]
     want_E = oracle_embed([nd.get_content(metadata_mode=MetadataMode.EMBED) for nd in rows])
