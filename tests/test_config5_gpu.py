@@ -216,7 +216,7 @@ def test_config5_retrieval_stage_is_decidable_in_the_reference_precision(dev, bu
     the plain fp32 oracle.  In bf16 the random-weight model's neighbours sit inside the comparison tolerance, so the bf16 test
     above can only check membership-within-tolerance; here product and oracle embeddings agree to ~1e-5, the bf16 rows of the
     index matrix come out (almost) bit-identical, and the lists themselves must agree: same semantic cuts, same leaves, the
-    same ordered top-16 wherever the oracle separates rank 16 from rank 17 by more than 2e-4, the same auto-merged result."""
+    same ordered top-16 wherever the oracle's adjacent scores down to rank 17 are more than 1e-5 apart, the same auto-merged result."""
     from tensor_truth_amd import model_manager as mm
     from tensor_truth_amd.encoder import EncoderConfig
     from tensor_truth_amd.index_builder import build_index
@@ -291,11 +291,13 @@ def test_config5_retrieval_stage_is_decidable_in_the_reference_precision(dev, bu
         got_ids = [h.node.id_ for h in hits]
         want_ids = [index.leaf_ids[int(j)] for j in o_i[qi, :K]]
         gaps = (o_s[qi, :-1] - o_s[qi, 1:])                         # adjacent oracle gaps down to rank 17
-        decidable = bool((gaps > 2e-4).all())
+        # both sides scan (almost) the same bf16 matrix exactly, so the lists can only differ where the oracle's own scores tie
+        # or where one of the few differing matrix elements moves a score: decidable = every adjacent gap above 1e-5
+        decidable = bool((gaps > 1e-5).all())
         n_decidable += decidable
         n_identical += got_ids == want_ids
         if decidable:
-            assert got_ids == want_ids, f"query {qi}: ordered top-{K} differs although every oracle gap exceeds 2e-4"
+            assert got_ids == want_ids, f"query {qi}: ordered top-{K} differs although every oracle gap exceeds 1e-5"
             merged = amr.retrieve(q)
             oracle_hits = [NodeWithScore(node=index.docstore[i], score=h.score) for i, h in zip(want_ids, hits)]
             again = AutoMergingRetriever(base, index.docstore).merge(oracle_hits)
@@ -303,6 +305,6 @@ def test_config5_retrieval_stage_is_decidable_in_the_reference_precision(dev, bu
         assert set(got_ids) >= set(want_ids[: K // 2]) or not decidable
     print(f"config 5, reference precision: splitter distance err {worst:.1e}, cuts equal on {same}/12 docs ({decisive_docs} decisive); "
           f"{same_bits:.4f} of the matrix elements bit-identical to the oracle's bf16 rows; ordered top-{K} identical on "
-          f"{n_identical}/{len(queries)} queries, required (all gaps > 2e-4) on {n_decidable}")
+          f"{n_identical}/{len(queries)} queries, required (all gaps > 1e-5) on {n_decidable}")
     assert n_decidable >= 3 and n_identical >= len(queries) // 2
     mm.ModelManager.reset_instance()
