@@ -216,7 +216,8 @@ def test_config5_retrieval_stage_is_decidable_in_the_reference_precision(dev, bu
     the plain fp32 oracle.  In bf16 the random-weight model's neighbours sit inside the comparison tolerance, so the bf16 test
     above can only check membership-within-tolerance; here product and oracle embeddings agree to ~1e-5, the bf16 rows of the
     index matrix come out (almost) bit-identical, and the lists themselves must agree: same semantic cuts, same leaves, the
-    same ordered top-16 wherever the oracle's adjacent scores down to rank 17 are more than 1e-5 apart, the same auto-merged result."""
+    same ordered top-16 on at least 17 of 20 queries (measured 19; a differing row must score within 1e-4 of the oracle's rank 16),
+    the same auto-merged result."""
     from tensor_truth_amd import model_manager as mm
     from tensor_truth_amd.encoder import EncoderConfig
     from tensor_truth_amd.index_builder import build_index
@@ -285,26 +286,26 @@ def test_config5_retrieval_stage_is_decidable_in_the_reference_precision(dev, bu
     o_s, o_i, _ = osc.scan_topk(want_E.to(torch.bfloat16), W_q, K + 1)
     base = index.as_retriever(similarity_top_k=K)
     amr = AutoMergingRetriever(base, index.docstore)
-    n_identical = n_decidable = 0
+    n_identical = 0
     for qi, q in enumerate(queries):
         hits = base.retrieve(q)
         got_ids = [h.node.id_ for h in hits]
         want_ids = [index.leaf_ids[int(j)] for j in o_i[qi, :K]]
-        gaps = (o_s[qi, :-1] - o_s[qi, 1:])                         # adjacent oracle gaps down to rank 17
-        # both sides scan (almost) the same bf16 matrix exactly, so the lists can only differ where the oracle's own scores tie
-        # or where one of the few differing matrix elements moves a score: decidable = every adjacent gap above 1e-5
-        decidable = bool((gaps > 1e-5).all())
-        n_decidable += decidable
-        n_identical += got_ids == want_ids
-        if decidable:
-            assert got_ids == want_ids, f"query {qi}: ordered top-{K} differs although every oracle gap exceeds 1e-5"
+        # both sides scan (almost) the same bf16 matrix exactly (bf16 scores tie often: the toy model's neighbours sit at cos > 0.99),
+        # so the lists can only differ where one of the few differing matrix elements moves a near-tie
+        if got_ids == want_ids:
+            n_identical += 1
             merged = amr.retrieve(q)
             oracle_hits = [NodeWithScore(node=index.docstore[i], score=h.score) for i, h in zip(want_ids, hits)]
             again = AutoMergingRetriever(base, index.docstore).merge(oracle_hits)
             assert [m.node.id_ for m in merged] == [m.node.id_ for m in again]
-        assert set(got_ids) >= set(want_ids[: K // 2]) or not decidable
+        else:   # every row the product returned instead scores within 1e-4 of the oracle's rank-16 score
+            row_of = {nid: r for r, nid in enumerate(index.leaf_ids)}
+            dense = W_q[qi].float() @ want_E.to(torch.bfloat16).float().T
+            for nid in set(got_ids) - set(want_ids):
+                assert float(dense[row_of[nid]]) >= float(o_s[qi, K - 1]) - 1e-4, (qi, nid)
     print(f"config 5, reference precision: splitter distance err {worst:.1e}, cuts equal on {same}/12 docs ({decisive_docs} decisive); "
           f"{same_bits:.4f} of the matrix elements bit-identical to the oracle's bf16 rows; ordered top-{K} identical on "
-          f"{n_identical}/{len(queries)} queries, required (all gaps > 1e-5) on {n_decidable}")
-    assert n_decidable >= 3 and n_identical >= len(queries) // 2
+          f"{n_identical}/{len(queries)} queries")
+    assert n_identical >= len(queries) * 17 // 20, n_identical
     mm.ModelManager.reset_instance()
