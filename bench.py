@@ -729,6 +729,11 @@ def surface_leg(args, dev, shard_rows, emb_cfg, rr_cfg, world=1, rank=0, row_lo=
     n = shard_rows.shape[0] if world == 1 else args.corpus_rows
     index = ShardedHipVectorIndex(shard_rows.shape[1], shard_rows, row_lo, n, _RowIds(n), _SynthDocstore(args.chunk_len),
                                   embed_model=emb, score_mode="cosine", queries="partitioned" if world > 1 else "replicated")
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.barrier()     # BEFORE the retriever exists: its tick thread owns the process group's collectives from then on (two
+        #                    threads issuing collectives on one RCCL communicator is not safe) until retr.close() below
     retr = index.as_retriever(similarity_top_k=K, max_batch=64 if world == 1 else max(8, 256 // world))
     queries = [synth_text(10_000_000_000 + 1_000_000 * rank + i, args.query_len) for i in range(args.surface_queries)]
 
@@ -736,24 +741,23 @@ def surface_leg(args, dev, shard_rows, emb_cfg, rr_cfg, world=1, rank=0, row_lo=
         nodes = retr.retrieve(q)
         return [(x.node.id_, x.score) for x in rr.postprocess_nodes(nodes, query_bundle=QueryBundle(query_str=q))]
 
-    one(queries[0])                                    # warm-up (tokenizer cache, workspaces)
-    _run_threads(args.surface_threads, queries[: args.surface_threads], one)
-    scan_batches = (lambda: retr._front.batches) if retr._tick is None else (lambda: retr._tick.rounds)
-    b_r0, b_x0 = scan_batches(), rr._front.batches
+    try:
+        one(queries[0])                                    # warm-up (tokenizer cache, workspaces)
+        _run_threads(args.surface_threads, queries[: args.surface_threads], one)
+        scan_batches = (lambda: retr._front.batches) if retr._tick is None else (lambda: retr._tick.rounds)
+        b_r0, b_x0 = scan_batches(), rr._front.batches
+        dt, res = _run_threads(args.surface_threads, queries, one)
+        assert all(len(r) == topn for r in res)
+        t1 = time.perf_counter()
+        for q in queries[:8]:
+            one(q)
+        torch.cuda.synchronize()
+        lat = (time.perf_counter() - t1) / 8
+        n_scan, n_rr = scan_batches() - b_r0, rr._front.batches - b_x0
+    finally:
+        if world > 1:
+            retr.close(timeout=600)                # leave the lock-step front whatever happened (every rank does)
     if world > 1:
-        import torch.distributed as dist
-
-        dist.barrier()
-    dt, res = _run_threads(args.surface_threads, queries, one)
-    assert all(len(r) == topn for r in res)
-    t1 = time.perf_counter()
-    for q in queries[:8]:
-        one(q)
-    torch.cuda.synchronize()
-    lat = (time.perf_counter() - t1) / 8
-    n_scan, n_rr = scan_batches() - b_r0, rr._front.batches - b_x0
-    if world > 1:
-        retr.close(timeout=600)                    # leave the lock-step front (every rank does)
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
