@@ -105,7 +105,7 @@ def test_gemm_x3_is_row_permutation_equivariant_bit_for_bit(dev, built_lib):
     assert torch.equal(outs[0][perm].view(torch.int16), outs[1].view(torch.int16))
 
 
-@pytest.mark.parametrize("lens", [[292] * 7, [1, 8, 64, 65, 127, 128, 129, 300, 17, 33], [512, 31, 257]])
+@pytest.mark.parametrize("lens", [[292] * 7, [1, 8, 64, 65, 127, 128, 129, 300, 17, 33], [512, 31, 257], [1100, 40, 2049]])
 def test_attention_x3_against_fp64(dev, built_lib, lens):
     """tt_attention_x3 on ragged sequences (any start row: back-to-back packing shares 8-row token groups between
     neighbours) against an fp64 softmax attention over the operands' (hi + lo) values."""

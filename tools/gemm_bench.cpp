@@ -58,6 +58,33 @@ int main(int argc, char** argv) {
         double fl = 2.0 * M * s.n * s.k;
         printf("%-16s M=%d N=%d K=%d  %.3f ms  %.1f TF/s\n", s.name, M, s.n, s.k, ms, fl / (ms * 1e-3) / 1e12);
     }
+    // split-bf16 ("bf16x3", the reference precision): the same shapes over hi / lo planes, three MFMA products per product
+    {
+        uint16_t *ap, *wp, *cp; float *c32, *r32;
+        size_t maxAp = (size_t)M * 2 * 4096, maxWp = (size_t)4096 * 2 * 4096;
+        CK(hipMalloc(&ap, maxAp * 2)); CK(hipMalloc(&wp, maxWp * 2)); CK(hipMalloc(&cp, (size_t)M * 2 * 4096 * 2));
+        CK(hipMalloc(&c32, (size_t)M * 1024 * 4)); CK(hipMalloc(&r32, (size_t)M * 1024 * 4));
+        fill_bf16<<<2048, 256>>>(ap, maxAp, 11, 1.0f);
+        fill_bf16<<<2048, 256>>>(wp, maxWp, 12, 0.05f);
+        fill_bf16<<<2048, 256>>>((uint16_t*)r32, (size_t)M * 1024 * 2, 13, 1.0f);
+        CK(hipDeviceSynchronize());
+        struct SX { int n, k, epi; const char* name; } sx[] = {{2048, 1024, 0, "x3 q,k proj (planes)"}, {1024, 1024, 2, "x3 o-proj (+res fp32)"},
+                                                               {4096, 1024, 1, "x3 ffn-up (erf gelu)"}, {1024, 4096, 2, "x3 ffn-down (+res)"},
+                                                               {4096, 1024, 0, "x3 ffn-up shape, bias"}};
+        for (auto& s : sx) {
+            auto run = [&]() { return tt_gemm_x3(ap, wp, bias, s.epi == 2 ? r32 : nullptr, s.epi == 2 ? nullptr : cp, s.epi == 2 ? c32 : nullptr, M, s.n, s.k, s.epi, st); };
+            for (int i = 0; i < 3; ++i) { int rc = run(); if (rc) { fprintf(stderr, "rc=%d %s\n", rc, tt_last_error()); return 1; } }
+            CK(hipStreamSynchronize(st));
+            CK(hipEventRecord(e0, st));
+            for (int i = 0; i < iters; ++i) run();
+            CK(hipEventRecord(e1, st));
+            CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= iters;
+            double fl = 3.0 * 2.0 * M * s.n * s.k;
+            printf("%-24s M=%d N=%d K=%d  %.3f ms  %.1f TF/s of bf16 MFMA work\n", s.name, M, s.n, s.k, ms, fl / (ms * 1e-3) / 1e12);
+        }
+        CK(hipFree(ap)); CK(hipFree(wp)); CK(hipFree(cp)); CK(hipFree(c32)); CK(hipFree(r32));
+    }
     // fp8 (e4m3) forms of the two projections the fp8 mode moves to the fp8 matrix cores
     {
         uint8_t *a8, *w8; float *sa, *sw;
