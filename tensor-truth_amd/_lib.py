@@ -98,6 +98,10 @@ def load_library():
                 f"or `make -C {os.path.join(_HERE, 'csrc')}` (needs hipcc, --offload-arch=gfx950). "
                 "tensor_truth_amd has no CPU fallback."
             )
+        # torch FIRST: its wheel carries its own copy of the HIP runtime, and whichever copy initialises second in a process sees
+        # "no ROCm-capable device" -- the library's launches must land on the runtime torch's tensors and streams live in
+        import torch  # noqa: F401
+
         lib = ctypes.CDLL(path)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the .so is stale
