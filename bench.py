@@ -350,6 +350,10 @@ def main():
                       "frac_of_hbm_peak_per_batch": bytes8 / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                       "frac_of_hbm_peak_filter_pass": (bytes8 / (p8["scan_filter"][0] / max(p8["scan_filter"][1], 1) * 1e-3) / 1e9 / HBM_PEAK_GBS
                                                        if p8["scan_filter"][1] else None),
+                      # at 256 queries the pass sits on the machine's ridge (256 FLOP per corpus byte vs 2.5 PF / 8 TB/s = 312): the
+                      # contraction itself, rows * dim * 256 * 2 flops, against the bf16 MFMA peak, for the same device time
+                      "mfma_TFLOPs_per_batch": rows8 * D * 256 * 2 / (dev_ms * 1e-3) / 1e12,
+                      "frac_of_mfma_peak_per_batch": rows8 * D * 256 * 2 / (dev_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TF,
                       "what": f"one GPU's share of an 8-GPU step: exact top-{K} of 256 gathered queries over {rows8} x {D} rows "
                               "(no collective); frac = rows * dim * 2 bytes / device time of the WHOLE batch / 8 TB/s"}
 
@@ -901,6 +905,7 @@ def cpu_baseline(args, emb_cfg, rr_cfg, embedder, reranker, corpus, q_tok, vocab
     t_query = t_q + args.corpus_rows / rows_per_s + K / pairs_per_s
     return {
         "value": 1.0 / t_query, "unit": "queries/s", "cores": cores, "kind": "port",
+        "composed": True,      # value = one query composed from the three measured per-unit rates below (formula in `sample`)
         "per_unit": {"query_embeddings_per_s": 1.0 / t_q, "chunks_embedded_per_s": CPU_CHUNKS / t_chunks,
                      "scan_rows_per_s": rows_per_s, "scan_GBps": rows_per_s * args.dim * 2 / 1e9,
                      "pairs_reranked_per_s": pairs_per_s},
