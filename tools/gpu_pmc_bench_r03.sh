@@ -15,6 +15,7 @@ timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFM
 python tools/pmc_to_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/r03_pmc_traffic.json
 python tools/pmc_to_mfma.py gpurun_out/pmc_mfma gpurun_out/r03_pmc_mfma.json
 find gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_mfma -name "*.csv" -delete
+# (headline stats + gemm shapes: see below)
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_headline -- python3 bench.py --headline-only --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/r03_bench_headline.json 2> gpurun_out/bench_headline.err
 tail -2 gpurun_out/bench_headline.err
 S=$(find gpurun_out/prof_headline -name "*kernel_stats.csv" | head -1)

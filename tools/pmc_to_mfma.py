@@ -32,16 +32,19 @@ def main(pmc_dir, out):
         n = d["name"]
         if "GRBM_GUI_ACTIVE" not in d:
             continue
-        if "gemm_kernel_v3<6" in n:
+        if "gemm_kernel_v3<6" in n or "gemm_kernel_p<6" in n:
             fam["scan_tiled_filter_pass"].append(d)
         elif "attention_kernel" in n and "cls" not in n:
             if d["grid"] * 1 >= 1000 * 256:
                 fam["attention (rerank batch)"].append(d)
         elif "gemm_kernel" in n and "skinny" not in n:
+            if "gemm_kernel_p<1" in n:                     # (persistent: grid = one workgroup per CU; only big batches take it)
+                fam["gemm ffn-up + gelu (persistent)"].append(d)
+                continue
             if d["grid"] < big // 8:
                 continue                                   # query-embedding / CLS-tail sized launches
-            if "gemm_kernel_p<1" in n:
-                fam["gemm ffn-up + gelu (persistent)"].append(d)
+            if False:
+                pass
             elif "gemm_kernel_v3<5" in n:
                 fam["gemm v projection (V^T epilogue)"].append(d)
             elif "gemm_kernel_v3<2" in n:

@@ -37,15 +37,16 @@ def main(fetch_dir, write_dir, out):
         res[kind] = {"launches": len(fr), "fetch_bytes_per_launch": fetch / len(fr),
                      "write_bytes_per_launch": write / len(wr), "hbm_bytes_per_launch": (fetch + write) / len(fr)}
     # the 256-query tiled filter pass of the scan-only leg (gemm_kernel_v3<TT_EPI_SCAN = 6, ...>): last of its launches
-    fr = [r for r in load(fetch_dir, "FETCH_SIZE") if "gemm_kernel_v3<6" in r["Kernel_Name"]]
-    wr = [r for r in load(write_dir, "WRITE_SIZE") if "gemm_kernel_v3<6" in r["Kernel_Name"]]
+    is_scan = lambda r: "gemm_kernel_v3<6" in r["Kernel_Name"] or "gemm_kernel_p<6" in r["Kernel_Name"]   # noqa: E731 (one-tile / persistent form)
+    fr = [r for r in load(fetch_dir, "FETCH_SIZE") if is_scan(r)]
+    wr = [r for r in load(write_dir, "WRITE_SIZE") if is_scan(r)]
     if fr and wr:
         fetch = float(fr[-1]["Counter_Value"]) * 1024 * 2
         write = float(wr[-1]["Counter_Value"]) * 1024
         res["scan_tiled_256q"] = {"launches": 1, "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write,
                                   "hbm_bytes_per_launch": fetch + write}
-    res["source"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/gpu_pmc_bench.sh) of `python3 bench.py --steps 1 "
-                     "--warmup 1 --no-cpu-baseline --no-fp8-leg --no-surface-leg --no-config5-leg`; FETCH_SIZE doubled (gfx950: the "
+    res["source"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/gpu_pmc_bench_r03.sh) of `python3 bench.py --steps 1 "
+                     "--warmup 1 --no-cpu-baseline --no-fp8-leg --no-reference-leg --no-surface-leg --no-config5-leg`; FETCH_SIZE doubled (gfx950: the "
                      "counter tallies 128-B requests at 64 B), counters in KiB")
     # ties the file to the kernel sources it was measured on: bench.py refuses it when they differ
     import os
