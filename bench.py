@@ -523,6 +523,8 @@ def main():
             traffic = {k: tj[k]["hbm_bytes_per_launch"] for k in traffic if k in tj}
             if scan_only is not None and "scan_tiled_256q" in tj and scan_only["filter_pass"]["queries_per_launch"] == 256:
                 scan_only["filter_pass"]["traffic"] = tj["scan_tiled_256q"]["hbm_bytes_per_launch"]   # PMC, same run of passes
+            if scan_shard is not None and "scan_tiled_256q_shard" in tj:
+                scan_shard["filter_pass_traffic"] = tj["scan_tiled_256q_shard"]["hbm_bytes_per_launch"]
 
     # matrix-core utilisation (north_star: "evidenced by ... MFMA-utilisation counters"): SQ_VALU_MFMA_BUSY_CYCLES over kernel
     # cycles x SIMDs from a --pmc pass of this command on these kernel sources (tools/gpu_pmc_bench_r03.sh -> tools/pmc_to_mfma.py)

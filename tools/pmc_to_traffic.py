@@ -41,10 +41,14 @@ def main(fetch_dir, write_dir, out):
     fr = [r for r in load(fetch_dir, "FETCH_SIZE") if is_scan(r)]
     wr = [r for r in load(write_dir, "WRITE_SIZE") if is_scan(r)]
     if fr and wr:
-        fetch = float(fr[-1]["Counter_Value"]) * 1024 * 2
-        write = float(wr[-1]["Counter_Value"]) * 1024
-        res["scan_tiled_256q"] = {"launches": 1, "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write,
-                                  "hbm_bytes_per_launch": fetch + write}
+        # the process runs the tiled pass at two sizes (same kernel, same grid in the persistent form): over the whole corpus
+        # (scan_only leg) and over corpus / 8 rows (scan_only_shard leg) -- told apart by the bytes they fetch
+        order = sorted(range(len(fr)), key=lambda i: float(fr[i]["Counter_Value"]))
+        for name, i in (("scan_tiled_256q", order[-1]), ("scan_tiled_256q_shard", order[0])):
+            fetch = float(fr[i]["Counter_Value"]) * 1024 * 2
+            write = float(wr[i]["Counter_Value"]) * 1024
+            res[name] = {"launches": 1, "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write,
+                         "hbm_bytes_per_launch": fetch + write}
     res["source"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/gpu_pmc_bench_r03.sh) of `python3 bench.py --steps 1 "
                      "--warmup 1 --no-cpu-baseline --no-fp8-leg --no-reference-leg --no-surface-leg --no-config5-leg`; FETCH_SIZE doubled (gfx950: the "
                      "counter tallies 128-B requests at 64 B), counters in KiB")
