@@ -366,7 +366,8 @@ __device__ __forceinline__ void stage_half(const GemmParams& p, char* smem, int 
     char* dst = smem + slot_off(OPERAND, half, buf);
     // ES = bytes per element (2 bf16, 1 fp8); a K-tile is 128 bytes of every row either way
     const char* base;
-    if constexpr (OPERAND == 0) base = reinterpret_cast<const char*>(p.A) + ((size_t)(m0 + half * 128) * p.lda) * ES + tile * 128;
+    // (p.xp bit 17, TT_GEMM_DEBUG_A0: every tile reads the A rows of row-block 0 -- wrong results, all A reads L2 hits: what the A misses cost)
+    if constexpr (OPERAND == 0) base = reinterpret_cast<const char*>(p.A) + ((size_t)(((p.xp & 0x20000) ? 0 : m0) + half * 128) * p.lda) * ES + tile * 128;
     else base = reinterpret_cast<const char*>(p.W) + ((size_t)(n0 + half * 32) * (p.ldw ? p.ldw : p.K)) * ES + tile * 128;   // see w_row_of()
     // keep the base in SGPRs (otherwise hipcc folds it into per-lane 64-bit VGPR addresses and
     // pays two 64-bit vector adds per copy)
@@ -881,7 +882,7 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
     unsigned long long* dbg0 = reinterpret_cast<unsigned long long*>(p.vt);
     auto cstamp = [&](int slot) {
         if constexpr (SLOTS == 46) {
-            if (blockIdx.x == 0 && tid == 0 && dbg0) dbg0[20 + slot] = __builtin_amdgcn_s_memtime();
+            if ((int)blockIdx.x == (p.xp >> 20) && tid == 0 && dbg0) dbg0[20 + slot] = __builtin_amdgcn_s_memtime();   // stamped workgroup: TT_GEMM_STAMP_BLOCK
             // every workgroup: entry / exit time and where it ran (tools/gemm_stamps: dispatch gaps per CU)
             if ((slot == 0 || slot == 3) && tid == 0 && dbg0) {
                 unsigned long long* rec = dbg0 + 256 + (size_t)blockIdx.x * 4;
@@ -1008,7 +1009,7 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
     int dbg_i = 0;
     auto stamp = [&](int t) {
         if constexpr (SLOTS == 46) {
-            if (blockIdx.x == 0 && t == 6 && (lane == 0) && dbg) {
+            if ((int)blockIdx.x == (p.xp >> 20) && t == 6 && (lane == 0) && dbg) {
                 __builtin_amdgcn_sched_barrier(0);
                 dbg[wave * 32 + dbg_i] = __builtin_amdgcn_s_memtime();
                 ++dbg_i;
@@ -1646,6 +1647,10 @@ int launch(const GemmParams& p, hipStream_t st) {
         static const int nts = [] { const char* e = getenv("TT_GEMM_NT_STORE"); return e && e[0] ? atoi(e) : 1; }();
         q.nt_store = nts;
         q.sn = SN;
+        static const bool a0 = [] { const char* e = getenv("TT_GEMM_DEBUG_A0"); return e && e[0] == '1'; }();
+        if (a0) q.xp |= 0x20000;
+        static const int stamp_block = [] { const char* e = getenv("TT_GEMM_STAMP_BLOCK"); return e && e[0] ? atoi(e) : 0; }();
+        q.xp |= stamp_block << 20;
         {
             TtProfScope prof(TT_K_GEMM, st);
             hipLaunchKernelGGL(kern, dim3(blocks), dim3(v3::kThreads3), v3::kLds3, st, q);
