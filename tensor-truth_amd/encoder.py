@@ -52,10 +52,18 @@ BGE_RERANKER_V2_M3 = EncoderConfig(num_labels=1)
 BGE_SMALL_EN_V15 = EncoderConfig(arch="bert", vocab_size=30522, hidden=384, layers=12, heads=12, ffn=1536,
                                  max_pos=512, type_vocab=2, pad_id=0, ln_eps=1e-12)
 
+# the other two rerankers the reference offers out of the box (app_utils/config_schema.py:83-87): XLM-R base with the same
+# head as v2-m3, and a 6-layer BERT (MiniLM) whose head is BertForSequenceClassification's pooler + classifier
+BGE_RERANKER_BASE = EncoderConfig(vocab_size=250002, hidden=768, layers=12, heads=12, ffn=3072, max_pos=514, num_labels=1)
+MS_MARCO_MINILM_L6_V2 = EncoderConfig(arch="bert", vocab_size=30522, hidden=384, layers=6, heads=12, ffn=1536, max_pos=512,
+                                      type_vocab=2, pad_id=0, ln_eps=1e-12, num_labels=1)
+
 KNOWN_CONFIGS = {
     "BAAI/bge-m3": BGE_M3,
     "BAAI/bge-reranker-v2-m3": BGE_RERANKER_V2_M3,
     "BAAI/bge-small-en-v1.5": BGE_SMALL_EN_V15,
+    "BAAI/bge-reranker-base": BGE_RERANKER_BASE,
+    "cross-encoder/ms-marco-MiniLM-L-6-v2": MS_MARCO_MINILM_L6_V2,
 }
 
 
@@ -85,6 +93,12 @@ def _strip_prefix(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
                 k = k[len(pre):]
                 break
         out[k] = v
+    # BertForSequenceClassification (cross-encoder/ms-marco-MiniLM-L-6-v2, the third of the reference's out-of-the-box
+    # rerankers, config_schema.py:83-87): logits = classifier(tanh(pooler.dense(h[CLS]))) -- the same dense -> tanh -> projection
+    # as RobertaClassificationHead's classifier.dense / classifier.out_proj, under other names
+    if "classifier.dense.weight" not in out and "pooler.dense.weight" in out and "classifier.weight" in out:
+        out["classifier.dense.weight"], out["classifier.dense.bias"] = out["pooler.dense.weight"], out["pooler.dense.bias"]
+        out["classifier.out_proj.weight"], out["classifier.out_proj.bias"] = out["classifier.weight"], out["classifier.bias"]
     return out
 
 

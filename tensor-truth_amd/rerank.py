@@ -41,6 +41,10 @@ class HipSentenceTransformerRerank:
         if not cfg.num_labels:
             raise ValueError(f"'{model}' has no classification head (not a cross-encoder)")
         self.config = cfg
+        # CrossEncoder.predict's activation: sigmoid for the BGE rerankers, raw logits for checkpoints that say so (ms-marco)
+        self.activation = _weights.head_activation(model, mdir, model_kwargs)
+        # BERT cross-encoders mark the passage segment with token type 1 (XLM-R has a single type)
+        self._use_types = cfg.arch == "bert" and cfg.type_vocab > 1
         # pairs are truncated by the tokenizer (longest-first, specials kept): never beyond what the model has positions for
         self.max_length = min(max_length, cfg.max_seq_len)
         # precision.resolve(): model_kwargs, ModelManager.precision, TT_PRECISION -- "reference" gives the unchanged
@@ -56,31 +60,44 @@ class HipSentenceTransformerRerank:
                                  finish=self._collect_many) if coalesce else None)
 
     # ---- token-id level ---------------------------------------------------------------------------
-    def _pack(self, pair_ids: Sequence[Sequence[int]]):
-        return [pack_tokens(pair_ids[lo:lo + self.batch_pairs], self.config, None, self.max_length)
+    def _pack(self, pair_ids: Sequence[Sequence[int]], type_ids: Optional[Sequence[Sequence[int]]] = None):
+        if not self._use_types:
+            type_ids = None
+        return [pack_tokens(pair_ids[lo:lo + self.batch_pairs], self.config,
+                            None if type_ids is None else type_ids[lo:lo + self.batch_pairs], self.max_length)
                 for lo in range(0, len(pair_ids), self.batch_pairs)]
 
     def _score_packed(self, batches) -> torch.Tensor:
-        outs = [self._encoder.rerank_packed(b) for b in batches]
+        if self.activation == "identity":
+            outs = [self._encoder.rerank_packed(b, want_logits=True)[1] for b in batches]
+        else:
+            outs = [self._encoder.rerank_packed(b) for b in batches]
         return torch.cat(outs) if outs else torch.empty(0, device=self.device)
 
-    def score_token_pairs(self, pair_ids: Sequence[Sequence[int]]) -> torch.Tensor:
-        """Sigmoid relevance of already tokenised ``<s> q </s></s> p </s>`` sequences, fp32 [n] (device)."""
-        return self._score_packed(self._pack(pair_ids))
+    def score_token_pairs(self, pair_ids: Sequence[Sequence[int]],
+                          type_ids: Optional[Sequence[Sequence[int]]] = None) -> torch.Tensor:
+        """Relevance (sigmoid, or the raw logit for ``activation == "identity"``) of already tokenised
+        ``<s> q </s></s> p </s>`` / ``[CLS] q [SEP] p [SEP]`` sequences, fp32 [n] (device).  ``type_ids``: BERT segment ids."""
+        if self._use_types and type_ids is None:
+            raise ValueError("a BERT cross-encoder needs the pairs' token type ids (0 for [CLS] q [SEP], 1 for p [SEP])")
+        return self._score_packed(self._pack(pair_ids, type_ids))
 
     def _tokenize_pairs(self, pairs: Sequence[Sequence[str]]):
+        """-> (ids per pair, token type ids per pair)."""
         tk = self._tokenizer
         if hasattr(tk, "encode_pair_batch"):
-            return [e[0] for e in tk.encode_pair_batch(list(pairs), self.max_length)]
-        return [tk.encode_pair(q, p, self.max_length)[0] for q, p in pairs]
+            enc = tk.encode_pair_batch(list(pairs), self.max_length)
+        else:
+            enc = [tk.encode_pair(q, p, self.max_length) for q, p in pairs]
+        return [e[0] for e in enc], [e[1] for e in enc]
 
     def _predict_flat(self, pairs: Sequence[Sequence[str]]) -> List[float]:
-        return self.score_token_pairs(self._tokenize_pairs(pairs)).cpu().tolist()
+        return self.score_token_pairs(*self._tokenize_pairs(pairs)).cpu().tolist()
 
     def _prepare_many(self, calls: List[Sequence[Sequence[str]]]):
         """Host phase of a coalesced batch: the pair lists of several concurrent callers, tokenised and packed."""
         flat = [p for c in calls for p in c]
-        return [len(c) for c in calls], self._pack(self._tokenize_pairs(flat)) if flat else []
+        return [len(c) for c in calls], self._pack(*self._tokenize_pairs(flat)) if flat else []
 
     def _enqueue_many(self, prepared):
         """Device phase: the forward over the packed pairs is ENQUEUED (asynchronous), followed by the copy of its
@@ -110,7 +127,7 @@ class HipSentenceTransformerRerank:
         return out
 
     def predict(self, pairs: Sequence[Sequence[str]]) -> List[float]:
-        """CrossEncoder.predict: [(query, passage), ...] -> sigmoid scores."""
+        """CrossEncoder.predict: [(query, passage), ...] -> scores (sigmoid, or logits where the checkpoint says Identity)."""
         pairs = list(pairs)
         if not pairs:
             return []

@@ -36,6 +36,35 @@ def _config_from_hf(d: dict, num_labels_default: int = 0) -> EncoderConfig:
         ln_eps=d.get("layer_norm_eps", 1e-5), num_labels=num_labels)
 
 
+def head_activation(model_name: str, model_dir: Optional[str], model_kwargs: Optional[dict]) -> str:
+    """What ``CrossEncoder.predict`` applies to a single-label head's logit ([UPSTREAM-K], sentence-transformers): the
+    activation named in the checkpoint's config.json (``sbert_ce_default_activation_function``, or
+    ``sentence_transformers.activation_fn`` in newer exports), else Sigmoid.  The BGE rerankers carry none (sigmoid
+    scores in (0, 1)); the ``cross-encoder/ms-marco-*`` checkpoints name ``torch.nn.modules.linear.Identity`` and are
+    scored by their raw logits.  ``model_kwargs["activation"]`` ("sigmoid" / "identity") overrides."""
+    mk = model_kwargs or {}
+    if mk.get("activation"):
+        act = str(mk["activation"]).lower()
+        if act not in ("sigmoid", "identity"):
+            raise ValueError("model_kwargs['activation'] must be 'sigmoid' or 'identity'")
+        return act
+    name = None
+    if model_dir and os.path.exists(os.path.join(model_dir, "config.json")):
+        with open(os.path.join(model_dir, "config.json")) as f:
+            d = json.load(f)
+        name = d.get("sbert_ce_default_activation_function") or (d.get("sentence_transformers") or {}).get("activation_fn")
+    elif model_name.startswith("cross-encoder/ms-marco-"):
+        name = "torch.nn.modules.linear.Identity"      # synthetic weights under the real name: the real checkpoint's setting
+    if name is None:
+        return "sigmoid"
+    tail = str(name).rsplit(".", 1)[-1].lower()
+    if tail == "identity":
+        return "identity"
+    if tail == "sigmoid":
+        return "sigmoid"
+    raise ValueError(f"cross-encoder activation '{name}' is not supported (Sigmoid or Identity)")
+
+
 def find_model_dir(model_name: str, model_kwargs: Optional[dict]) -> Optional[str]:
     mk = model_kwargs or {}
     cands = []

@@ -164,3 +164,136 @@ def test_bi_encoder_checkpoint_vs_transformers(dev, built_lib, tmp_path, arch):
     cos = (got * want).sum(dim=1)
     assert cos.min().item() >= 0.999 and (got - want).abs().max().item() <= 1e-2, (cos.min().item(), (got - want).abs().max().item())
     assert (got.norm(dim=1) - 1).abs().max() < 1e-3
+
+
+def test_bert_cross_encoder_checkpoint_vs_transformers(dev, built_lib, tmp_path):
+    """The third reranker the reference offers out of the box (``cross-encoder/ms-marco-MiniLM-L-6-v2``,
+    app_utils/config_schema.py:83-87) is a BertForSequenceClassification: pooler.dense -> tanh -> classifier on [CLS], token
+    type 1 on the passage segment, and a config.json that tells CrossEncoder to return the raw logit (Identity).  A tiny
+    random-init checkpoint of that class, upstream forward in fp32 on the CPU as the reference."""
+    import json
+
+    from transformers import BertConfig, BertForSequenceClassification
+
+    from tensor_truth_amd.rerank import HipSentenceTransformerRerank
+    from tensor_truth_amd.tokenization import HashTokenizer
+
+    torch.manual_seed(5)
+    cfg = BertConfig(vocab_size=1500, hidden_size=384, num_hidden_layers=3, num_attention_heads=12, intermediate_size=1536,
+                     max_position_embeddings=160, type_vocab_size=2, pad_token_id=0, num_labels=1,
+                     hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, classifier_dropout=0.0)
+    model = BertForSequenceClassification(cfg).eval()
+    _perturb_layernorms(model, 2)
+    with torch.no_grad():
+        model.bert.embeddings.token_type_embeddings.weight.mul_(4.0)       # make a wrong / missing segment id visible
+    rng = np.random.default_rng(1)
+    seqs, types = [], []
+    for _ in range(24):
+        na, nb = int(rng.integers(3, 20)), int(rng.integers(4, 120))
+        a, b = rng.integers(5, 1500, size=na).tolist(), rng.integers(5, 1500, size=nb).tolist()
+        seqs.append([101 % 1500] + a + [102 % 1500] + b + [102 % 1500])
+        types.append([0] * (na + 2) + [1] * (nb + 1))
+    ids, mask = _padded(seqs, 0)
+    tt, _ = _padded(types, 0)
+    with torch.no_grad():
+        raw = model(input_ids=ids, attention_mask=mask, token_type_ids=tt).logits[:, 0]
+        k = 1.5 / raw.std()
+        model.classifier.weight.mul_(k)
+        model.classifier.bias.mul_(k)
+        model.classifier.bias.sub_(model(input_ids=ids, attention_mask=mask, token_type_ids=tt).logits[:, 0].mean())
+        want_logit = model(input_ids=ids, attention_mask=mask, token_type_ids=tt).logits[:, 0]
+        no_types = model(input_ids=ids, attention_mask=mask).logits[:, 0]
+    assert (want_logit - no_types).abs().max().item() > 0.3          # the segment ids matter in this checkpoint
+    mdir = tmp_path / "minilm"
+    model.save_pretrained(str(mdir), safe_serialization=True)
+    tk = HashTokenizer("bert", 1500)
+    # (a) no activation named in config.json: CrossEncoder's default for one label, sigmoid
+    rr = HipSentenceTransformerRerank(model=str(mdir), top_n=3, device="cuda", model_kwargs={"tokenizer": tk})
+    assert rr.config.arch == "bert" and rr.config.num_labels == 1 and rr.config.type_vocab == 2 and rr.activation == "sigmoid"
+    with pytest.raises(ValueError):
+        rr.score_token_pairs(seqs)                                   # a BERT cross-encoder without segment ids: refused
+    got = rr.score_token_pairs(seqs, types).cpu()
+    # bf16 forward: the standardised head (weights x k, a bias that cancels a mean logit of several units) turns the 2^-9
+    # rounding of its weights into a common shift of every logit by ~0.1-0.2; the fp32-grade mode below pins the mapping
+    # itself at 2e-3, here the bound is what that shift allows
+    assert (got - torch.sigmoid(want_logit)).abs().max().item() < 8e-2
+    assert torch.corrcoef(torch.stack([got, torch.sigmoid(want_logit)]))[0, 1].item() > 0.995
+    # (b) the ms-marco checkpoints' config.json: Identity -> scores are the raw logits
+    conf = json.loads((mdir / "config.json").read_text())
+    conf["sbert_ce_default_activation_function"] = "torch.nn.modules.linear.Identity"
+    (mdir / "config.json").write_text(json.dumps(conf))
+    rr_id = HipSentenceTransformerRerank(model=str(mdir), top_n=3, device="cuda", model_kwargs={"tokenizer": tk})
+    assert rr_id.activation == "identity"
+    got_l = rr_id.score_token_pairs(seqs, types).cpu()
+    d = got_l - want_logit
+    assert abs(d.mean().item()) < 0.35 and (d - d.mean()).abs().max().item() < 0.15, (d, float(k))   # common shift / per-pair noise
+    assert got_l.min().item() < -0.5 and got_l.max().item() > 1.0    # raw logits, not probabilities
+    from rank_checks import assert_order_on_separable
+    assert assert_order_on_separable(want_logit.numpy(), got_l.numpy(), 0.3, "BERT cross-encoder order") >= 20
+    # the reference precision (TT_PRECISION=reference / torch_dtype=float32) on the same checkpoint
+    rr_ref = HipSentenceTransformerRerank(model=str(mdir), top_n=3, device="cuda",
+                                          model_kwargs={"tokenizer": tk, "precision": "reference"})
+    got_ref = rr_ref.score_token_pairs(seqs, types).cpu()
+    assert (got_ref - want_logit).abs().max().item() < 2e-3 * max(1.0, want_logit.abs().max().item())
+
+    # ---- from strings through the postprocessor surface: [CLS] q [SEP] p [SEP], segment 1 on the passage, longest-first
+    from tokenizers import Tokenizer, models, pre_tokenizers, processors
+
+    from tensor_truth_amd.schema import NodeWithScore, QueryBundle, TextNode
+
+    words = [f"w{i}" for i in range(1300)]
+    vocab = {"[PAD]": 0, "[UNK]": 1, "[CLS]": 2, "[SEP]": 3, **{w: 5 + i for i, w in enumerate(words)}}
+    tkj = Tokenizer(models.WordLevel(vocab, unk_token="[UNK]"))
+    tkj.pre_tokenizer = pre_tokenizers.Whitespace()
+    tkj.post_processor = processors.TemplateProcessing(single="[CLS] $A [SEP]", pair="[CLS] $A [SEP] $B:1 [SEP]:1",
+                                                       special_tokens=[("[CLS]", 2), ("[SEP]", 3)])
+    tkj.save(str(mdir / "tokenizer.json"))
+    rr2 = HipSentenceTransformerRerank(model=str(mdir), top_n=4, device="cuda")
+    query = " ".join(words[i] for i in rng.integers(0, 1300, size=7))
+    passages = [" ".join(words[i] for i in rng.integers(0, 1300, size=int(n))) for n in rng.integers(5, 220, size=12)]
+    nodes = [NodeWithScore(node=TextNode(text=p, id_=f"p{i}"), score=0.5) for i, p in enumerate(passages)]
+    ranked = rr2.postprocess_nodes(nodes, query_bundle=QueryBundle(query_str=query))
+    tkj.enable_truncation(max_length=160, strategy="longest_first")
+    encs = [tkj.encode(query, p) for p in passages]
+    assert max(len(e.ids) for e in encs) == 160
+    ids2, mask2 = _padded([e.ids for e in encs], 0)
+    tt2, _ = _padded([e.type_ids for e in encs], 0)
+    with torch.no_grad():
+        want2 = model(input_ids=ids2, attention_mask=mask2, token_type_ids=tt2).logits[:, 0]
+    by_id = {f"p{i}": float(want2[i]) for i in range(12)}
+    assert len(ranked) == 4 and all(isinstance(n.score, float) for n in ranked)
+    assert [n.score for n in ranked] == sorted((n.score for n in ranked), reverse=True)
+    assert max(abs(n.score - by_id[n.node.id_]) for n in ranked) < 0.4          # (common shift of the bf16 head, see above)
+    top4 = sorted(by_id, key=by_id.get, reverse=True)[:4]
+    gaps_ok = sorted(by_id.values(), reverse=True)[3] - sorted(by_id.values(), reverse=True)[4] > 0.3
+    assert not gaps_ok or [n.node.id_ for n in ranked][:4] == top4 or set(n.node.id_ for n in ranked) == set(top4)
+
+
+def test_xlmr_base_reranker_shape_vs_oracle(dev, built_lib):
+    """``BAAI/bge-reranker-base`` (the second out-of-the-box reranker): XLM-R base -- 768 wide, 12 heads, 3072 FFN; here at
+    3 of its 12 layers with seeded synthetic weights against the fp32 CPU oracle (the 768-wide GEMM / LayerNorm / head
+    launches are what this pins; depth is covered by the v2-m3 tests)."""
+    from dataclasses import replace
+
+    from oracle import encoder as oe
+    from tensor_truth_amd.encoder import BGE_RERANKER_BASE, KNOWN_CONFIGS
+    from tensor_truth_amd.rerank import HipSentenceTransformerRerank
+    from tensor_truth_amd.tokenization import HashTokenizer
+
+    assert KNOWN_CONFIGS["BAAI/bge-reranker-base"] is BGE_RERANKER_BASE
+    cfg = replace(BGE_RERANKER_BASE, layers=3, vocab_size=4000)
+    ocfg = oe.EncoderConfig(**cfg.__dict__)
+    W = oe.synth_weights(ocfg, seed=21)
+    rng = np.random.default_rng(4)
+    seqs = _ragged(rng, 20, 8, 300, 4000, 0, 2)
+    ids, mask = _padded(seqs, 1)
+    with torch.no_grad():
+        want = oe.rerank_scores(ids, mask, W, ocfg)
+    for precision, bound in (("bf16", 2e-2), ("reference", 1e-4)):
+        rr = HipSentenceTransformerRerank(model="BAAI/bge-reranker-base", top_n=3, device="cuda",
+                                          model_kwargs={"encoder_config": cfg, "state_dict": W, "precision": precision,
+                                                        "tokenizer": HashTokenizer("xlmr", 4000)})
+        assert rr.activation == "sigmoid" and rr.precision.startswith(precision)
+        assert precision != "reference" or "split-bf16" in rr.precision          # 768 = 12 heads x 64: the bf16x3 kernels take it
+        got = rr.score_token_pairs(seqs).cpu()
+        assert (got - want).abs().max().item() < bound, precision

@@ -999,3 +999,47 @@ def test_precision_resolution_order():
     with pytest.raises(ValueError):
         mgr.set_precision("fp64")
     mm.ModelManager.reset_instance()
+
+
+def test_reranker_family_host_side(tmp_path):
+    """The reference's three out-of-the-box rerankers (app_utils/config_schema.py:83-87): known configs, the BERT
+    sequence-classification head under the XLM-R head's names, the activation CrossEncoder.predict applies, BERT pair
+    token types."""
+    import json
+
+    import torch
+
+    from tensor_truth_amd import weights
+    from tensor_truth_amd.encoder import KNOWN_CONFIGS, _strip_prefix
+    from tensor_truth_amd.tokenization import HashTokenizer
+
+    base, mini = KNOWN_CONFIGS["BAAI/bge-reranker-base"], KNOWN_CONFIGS["cross-encoder/ms-marco-MiniLM-L-6-v2"]
+    assert (base.arch, base.hidden, base.layers, base.heads, base.ffn, base.num_labels, base.max_seq_len) == ("xlmr", 768, 12, 12, 3072, 1, 512)
+    assert (mini.arch, mini.hidden, mini.layers, mini.heads, mini.type_vocab, mini.num_labels, mini.max_seq_len) == ("bert", 384, 6, 12, 2, 1, 512)
+    sd = {"bert.pooler.dense.weight": torch.ones(4, 4), "bert.pooler.dense.bias": torch.zeros(4),
+          "classifier.weight": torch.full((1, 4), 2.0), "classifier.bias": torch.zeros(1),
+          "bert.embeddings.word_embeddings.weight": torch.zeros(8, 4)}
+    out = _strip_prefix(sd)
+    assert out["classifier.dense.weight"] is sd["bert.pooler.dense.weight"] and out["classifier.out_proj.weight"] is sd["classifier.weight"]
+    assert "embeddings.word_embeddings.weight" in out
+    xl = _strip_prefix({"roberta.embeddings.word_embeddings.weight": torch.zeros(1), "classifier.dense.weight": torch.zeros(1)})
+    assert "classifier.out_proj.weight" not in xl                                    # an XLM-R head is left as it is
+    # activation: explicit override > config.json > the ms-marco name > sigmoid
+    assert weights.head_activation("BAAI/bge-reranker-v2-m3", None, None) == "sigmoid"
+    assert weights.head_activation("cross-encoder/ms-marco-MiniLM-L-6-v2", None, {"synthetic_seed": 1}) == "identity"
+    assert weights.head_activation("cross-encoder/ms-marco-MiniLM-L-6-v2", None, {"activation": "sigmoid"}) == "sigmoid"
+    d = tmp_path / "m"
+    d.mkdir()
+    (d / "config.json").write_text(json.dumps({"sbert_ce_default_activation_function": "torch.nn.modules.linear.Identity"}))
+    assert weights.head_activation("x/y", str(d), None) == "identity"
+    (d / "config.json").write_text(json.dumps({"sentence_transformers": {"activation_fn": "torch.nn.modules.activation.Sigmoid"}}))
+    assert weights.head_activation("x/y", str(d), None) == "sigmoid"
+    (d / "config.json").write_text(json.dumps({"sbert_ce_default_activation_function": "torch.nn.modules.activation.Tanh"}))
+    with pytest.raises(ValueError):
+        weights.head_activation("x/y", str(d), None)
+    with pytest.raises(ValueError):
+        weights.head_activation("x/y", None, {"activation": "softmax"})
+    ids, types = HashTokenizer("bert", 3000).encode_pair("alpha beta", "gamma delta epsilon", 64)
+    assert len(ids) == 8 and types == [0, 0, 0, 0, 1, 1, 1, 1]                       # [CLS] a b [SEP] | c d e [SEP]
+    ids, types = HashTokenizer("xlmr", 3000).encode_pair("alpha beta", "gamma delta epsilon", 64)
+    assert len(ids) == 9 and set(types) == {0}                                       # <s> a b </s></s> c d e </s>
