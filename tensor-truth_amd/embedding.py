@@ -70,6 +70,11 @@ class HipHuggingFaceEmbedding:
         _report_unused_kwargs(model_name, model_kwargs, tokenizer_kwargs)
         cfg, state, mdir = _weights.resolve(model_name, model_kwargs, dev, want_head=False)
         self.config = cfg
+        pooling = _weights.pooling_mode(mdir)
+        if pooling != "cls":
+            # no silent wrong vectors: the kernels implement the CLS + L2-norm path of the BGE family (tt_embed_pool)
+            raise NotImplementedError(f"{model_name}: the checkpoint declares sentence-transformers pooling '{pooling}'; "
+                                      f"tensor_truth_amd embeds with CLS pooling + L2 normalisation only")
         # precision.resolve(): model_kwargs (torch_dtype float32 = the reference's own default, config_schema.py:66-76),
         # ModelManager.precision, TT_PRECISION; default bf16.  (`_model.parameters()` is read by the memory accounting.)
         self._model, self._encoder, self.precision = _precision.build_encoder(cfg, state, dev, model_kwargs, f"embedder {model_name}")

@@ -65,6 +65,22 @@ def head_activation(model_name: str, model_dir: Optional[str], model_kwargs: Opt
     raise ValueError(f"cross-encoder activation '{name}' is not supported (Sigmoid or Identity)")
 
 
+def pooling_mode(model_dir: Optional[str]) -> str:
+    """The sentence-transformers pooling a checkpoint directory declares (``1_Pooling/config.json``): "cls", "mean", ... ;
+    "cls" when the directory declares nothing (the BGE models the reference defaults to are CLS + Normalize)."""
+    if not model_dir:
+        return "cls"
+    pc = os.path.join(model_dir, "1_Pooling", "config.json")
+    if not os.path.exists(pc):
+        return "cls"
+    with open(pc) as f:
+        d = json.load(f)
+    on = [k[len("pooling_mode_"):] for k, v in d.items() if k.startswith("pooling_mode_") and v is True]
+    if on == ["cls_token"]:
+        return "cls"
+    return "+".join(sorted(on)) or "none"
+
+
 def find_model_dir(model_name: str, model_kwargs: Optional[dict]) -> Optional[str]:
     mk = model_kwargs or {}
     cands = []

@@ -1043,3 +1043,20 @@ def test_reranker_family_host_side(tmp_path):
     assert len(ids) == 8 and types == [0, 0, 0, 0, 1, 1, 1, 1]                       # [CLS] a b [SEP] | c d e [SEP]
     ids, types = HashTokenizer("xlmr", 3000).encode_pair("alpha beta", "gamma delta epsilon", 64)
     assert len(ids) == 9 and set(types) == {0}                                       # <s> a b </s></s> c d e </s>
+
+
+def test_pooling_mode_of_a_checkpoint_directory(tmp_path):
+    """An embedding checkpoint that declares anything but CLS pooling must not be embedded with CLS pooling silently."""
+    import json
+
+    from tensor_truth_amd import weights
+
+    assert weights.pooling_mode(None) == "cls" and weights.pooling_mode(str(tmp_path)) == "cls"
+    (tmp_path / "1_Pooling").mkdir()
+    conf = {"word_embedding_dimension": 384, "pooling_mode_cls_token": True, "pooling_mode_mean_tokens": False,
+            "pooling_mode_max_tokens": False, "include_prompt": True}
+    (tmp_path / "1_Pooling" / "config.json").write_text(json.dumps(conf))
+    assert weights.pooling_mode(str(tmp_path)) == "cls"
+    conf.update(pooling_mode_cls_token=False, pooling_mode_mean_tokens=True)
+    (tmp_path / "1_Pooling" / "config.json").write_text(json.dumps(conf))
+    assert weights.pooling_mode(str(tmp_path)) == "mean_tokens"
