@@ -1421,12 +1421,12 @@ int launch_fp8(const GemmParams& p, hipStream_t st) {
 // With a few dozen token rows a GEMM is a stream of the weight matrix and nothing else: the tiled kernels put
 // 16 (N = 1024) to 64 workgroups on the chip and walk K in 64-element steps behind a barrier each (8 us at K = 1024,
 // 30 us at K = 4096, times 6 GEMMs x 24 layers = most of a query embedding's 3.4 ms).  Here ONE WAVE owns 16 output
-// columns x 64 rows x all of K: no LDS, no barrier, operands straight from global memory into MFMA fragments (a
-// fragment is 16 contiguous bytes of a K-contiguous row in both operands), kPf K-steps of loads in flight per wave,
-// N/16 x M/64 waves per launch.  The activations (<= 256 x K) are re-read by every wave from L2.
+// columns x 16 rows x all of K: no LDS, no barrier, operands straight from global memory into MFMA fragments (a
+// fragment is 16 contiguous bytes of a K-contiguous row in both operands), 24 K-steps of loads in flight per wave,
+// N/16 x M/16 waves per launch.  The activations (<= 256 x K) and, by the row tiles of a column block, the weights
+// are re-read from L2.  (Rounds 1-2: 16 columns x 64 rows per wave, 8 steps in flight -- TT_GEMM_SKINNY_MT=4.)
 // Same instruction, operand order and K order as the tiled kernels, same epilogue code: results are bit-identical
 // to theirs, so an embedding does not depend on whether the text was embedded alone or in a large batch.
-constexpr int kPf = 8;
 
 // split-bf16 epilogue of one wave's tile (skinny kernel): same values, same operations as epilogue_x3
 template <int EPI, int NT, int MT>
@@ -1473,47 +1473,56 @@ __device__ __forceinline__ void gemm_epilogue_tile_x3(const GemmParams& p, f32x4
 
 // X3: split-bf16 operands (GemmParams.x3) -- the same loop over the virtual K stream of 3 K (hi.hi, hi.lo, lo.hi), in the
 // tiled kernel's order, so a row's result does not depend on which kernel computed it
-template <int EPI, bool X3 = false>
+// MT row tiles of 16 per wave, PF K-steps of loads in flight.  Round 3: one row tile per wave and 24 steps in flight (a
+// query's 64 padded rows on 4 x N/16 waves instead of N/16: the N = 1024 GEMMs had 64 waves on 256 CUs, each waiting for its
+// own 8 loads, 0.44 TB/s of weights); the MFMA chain of a 16 x 16 output tile is the same either way, so the bits are too.
+template <int EPI, bool X3 = false, int MT = 1, int PF = 24>
 __global__ __launch_bounds__(64) void gemm_skinny_kernel(GemmParams p) {
     const int lane = threadIdx.x;
-    const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 64;
+    const int n0 = blockIdx.x * 16, m0 = blockIdx.y * (16 * MT);
     const int frow = lane & 15, fchk = lane >> 4;
     const uint16_t* wp = p.W + (size_t)(n0 + frow) * (X3 ? p.ldw : p.K) + fchk * 8;
     const uint16_t* ap = p.A + (size_t)(m0 + frow) * p.lda + fchk * 8;
     const size_t a16 = (size_t)16 * p.lda;
-    f32x4 acc[1][4];
+    f32x4 acc[1][MT];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[0][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    bf16x8 wb[kPf], ab[kPf][4];
+    for (int j = 0; j < MT; ++j) acc[0][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 wb[PF], ab[PF][MT];
     const int nks1 = p.K / 32;
     const int nks = X3 ? 3 * nks1 : nks1;
     auto step_a = [&](int s) { if constexpr (X3) return s < nks1 ? s : s - nks1; else return s; };
     auto step_w = [&](int s) { if constexpr (X3) return s < 2 * nks1 ? s : s - 2 * nks1; else return s; };
 #pragma unroll
-    for (int s = 0; s < kPf; ++s)
+    for (int s = 0; s < PF; ++s)
         if (s < nks) {
             wb[s] = *reinterpret_cast<const bf16x8*>(wp + step_w(s) * 32);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) ab[s][j] = *reinterpret_cast<const bf16x8*>(ap + j * a16 + step_a(s) * 32);
+            for (int j = 0; j < MT; ++j) ab[s][j] = *reinterpret_cast<const bf16x8*>(ap + j * a16 + step_a(s) * 32);
         }
-    for (int ks = 0; ks < nks; ks += kPf) {
+    for (int ks = 0; ks < nks; ks += PF) {
 #pragma unroll
-        for (int s = 0; s < kPf; ++s) {
+        for (int s = 0; s < PF; ++s) {
             if (ks + s < nks) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < MT; ++j)
                     acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[s], ab[s][j], acc[0][j], 0, 0, 0);
-                const int nx = ks + s + kPf;
+                const int nx = ks + s + PF;
                 if (nx < nks) {
                     wb[s] = *reinterpret_cast<const bf16x8*>(wp + step_w(nx) * 32);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) ab[s][j] = *reinterpret_cast<const bf16x8*>(ap + j * a16 + step_a(nx) * 32);
+                    for (int j = 0; j < MT; ++j) ab[s][j] = *reinterpret_cast<const bf16x8*>(ap + j * a16 + step_a(nx) * 32);
                 }
             }
         }
     }
-    if constexpr (X3) gemm_epilogue_tile_x3<EPI, 1, 4>(p, acc, m0, n0, lane);
-    else gemm_epilogue_tile<EPI, 1, 4>(p, acc, m0, n0, lane);
+    if constexpr (X3) gemm_epilogue_tile_x3<EPI, 1, MT>(p, acc, m0, n0, lane);
+    else gemm_epilogue_tile<EPI, 1, MT>(p, acc, m0, n0, lane);
+}
+
+// TT_GEMM_SKINNY_MT=4: round 2's shape (four row tiles per wave, 8 steps in flight), the A/B switch
+inline bool skinny_mt4() {
+    static const bool on = [] { const char* e = getenv("TT_GEMM_SKINNY_MT"); return e && e[0] == '4'; }();
+    return on;
 }
 
 // split-bf16 operands (GemmParams.x3): the 256x256 one-tile kernel, bias / GELU (planes out), residual (fp32 out), V^T
@@ -1536,7 +1545,8 @@ int launch_x3(const GemmParams& p, hipStream_t st) {
             q.ldw = ldw;
             {
                 TtProfScope prof(TT_K_GEMM, st);
-                hipLaunchKernelGGL((gemm_skinny_kernel<EPI, true>), dim3(p.N / 16, p.M / 64), dim3(64), 0, st, q);
+                if (skinny_mt4()) hipLaunchKernelGGL((gemm_skinny_kernel<EPI, true, 4, 8>), dim3(p.N / 16, p.M / 64), dim3(64), 0, st, q);
+                else hipLaunchKernelGGL((gemm_skinny_kernel<EPI, true>), dim3(p.N / 16, p.M / 16), dim3(64), 0, st, q);
             }
             TT_CHECK_LAUNCH();
             return TT_OK;
@@ -1582,7 +1592,8 @@ template <int EPI>
 int launch_skinny(const GemmParams& p, hipStream_t st) {
     {
         TtProfScope prof(TT_K_GEMM, st);
-        hipLaunchKernelGGL(gemm_skinny_kernel<EPI>, dim3(p.N / 16, p.M / 64), dim3(64), 0, st, p);
+        if (skinny_mt4()) hipLaunchKernelGGL((gemm_skinny_kernel<EPI, false, 4, 8>), dim3(p.N / 16, p.M / 64), dim3(64), 0, st, p);
+        else hipLaunchKernelGGL((gemm_skinny_kernel<EPI, false>), dim3(p.N / 16, p.M / 16), dim3(64), 0, st, p);
     }
     TT_CHECK_LAUNCH();
     return TT_OK;
