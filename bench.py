@@ -181,10 +181,13 @@ def main():
 
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        import datetime
+
+        # (rank 0 alone runs the accuracy / CPU legs while the others wait at a barrier: keep the collective watchdog well above that)
         if one_device:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=datetime.timedelta(minutes=30))
         else:
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(minutes=30))
 
     from tensor_truth_amd import _lib
     from tensor_truth_amd.encoder import (BGE_M3, BGE_RERANKER_V2_M3, Encoder, EncoderConfig, EncoderWeights,
