@@ -189,6 +189,15 @@ int tt_encoder_forward_cls(const tt_encoder_weights* w, const int32_t* ids, cons
 int tt_embed_pool(const void* hidden_bf16, int ld, const int32_t* rows, int n_seq, int hidden,
                   float* out_f32, void* out_bf16, void* stream);
 
+/* sentence-transformers Pooling(mean) + Normalize for checkpoints whose 1_Pooling/config.json says so (e5, all-MiniLM, gte ...;
+ * the reference loads any HuggingFace embedding model its config names, services/model_manager.py:188-272):
+ * out[b] = mean over the sequence's rows [seq_start[b], seq_start[b] + seq_len[b]) of h, L2-normalised.  hidden: the FULL last
+ * hidden state (tt_encoder_forward / _f32 / _x3), bf16 or fp32. */
+int tt_embed_pool_mean(const void* hidden_bf16, int ld, const int32_t* seq_start, const int32_t* seq_len, int n_seq, int hidden,
+                       float* out_f32, void* out_bf16, void* stream);
+int tt_embed_pool_mean_f32(const float* hidden_f32, int ld, const int32_t* seq_start, const int32_t* seq_len, int n_seq, int hidden,
+                           float* out_f32, void* out_bf16, void* stream);
+
 /* XLMRobertaClassificationHead + CrossEncoder sigmoid on the CLS rows:
  * scores[b] = sigmoid(out_proj(tanh(dense(h[rows[b]])))) ; logits optional.
  * workspace >= 2 * round_up(n_seq,128) * H * 2 bytes. */

@@ -188,9 +188,18 @@ def cls_pool_normalize(hidden: torch.Tensor) -> torch.Tensor:
     return c / c.norm(dim=-1, keepdim=True).clamp_min(1e-12)
 
 
-def embed(ids, mask, W, cfg, emulate_bf16=False, type_ids=None, emulate_fp8=False) -> torch.Tensor:
-    """Token ids -> L2-normalised CLS embeddings [B, H] fp32 (reference a2/a4)."""
-    return cls_pool_normalize(encoder_forward(ids, mask, W, cfg, emulate_bf16, type_ids, emulate_fp8=emulate_fp8))
+def mean_pool_normalize(hidden: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+    """sentence-transformers Pooling(mean) + Normalize ([UPSTREAM-K] sentence_transformers/models/Pooling.py): the sum of
+    the un-masked token states over the number of un-masked tokens (clamped at 1e-9), then h/||h||_2 (eps 1e-12)."""
+    m = mask.to(torch.float32).unsqueeze(-1)
+    c = (hidden.to(torch.float32) * m).sum(dim=1) / m.sum(dim=1).clamp_min(1e-9)
+    return c / c.norm(dim=-1, keepdim=True).clamp_min(1e-12)
+
+
+def embed(ids, mask, W, cfg, emulate_bf16=False, type_ids=None, emulate_fp8=False, pooling="cls") -> torch.Tensor:
+    """Token ids -> L2-normalised embeddings [B, H] fp32 (reference a2/a4); ``pooling`` "cls" (BGE) or "mean"."""
+    h = encoder_forward(ids, mask, W, cfg, emulate_bf16, type_ids, emulate_fp8=emulate_fp8)
+    return mean_pool_normalize(h, mask) if pooling == "mean" else cls_pool_normalize(h)
 
 
 def rerank_logits(ids, mask, W, cfg, emulate_bf16=False, emulate_fp8=False, ffn_act_scales=None) -> torch.Tensor:

@@ -105,6 +105,8 @@ int tt_cls_pool_l2norm_launch(const uint16_t* hidden, int ld, const int32_t* row
                               uint16_t* out_bf16, hipStream_t st);
 
 // gather rows: dst[b][:] = src[rows[b]][:]  (bf16, H elements), rows beyond n zero-filled up to n_pad
+int tt_mean_pool_l2norm_launch(const void* hidden, int is_f32, int ld, const int32_t* seq_start, const int32_t* seq_len, int n, int H,
+                               float* out_f32, uint16_t* out_bf16, hipStream_t st);
 int tt_gather_rows_launch(const uint16_t* src, int ld, const int32_t* rows, int n, int n_pad, int H, uint16_t* dst,
                           hipStream_t st);
 

@@ -296,6 +296,26 @@ int tt_embed_pool(const void* hidden_bf16, int ld, const int32_t* rows, int n_se
                                      (uint16_t*)out_bf16, (hipStream_t)stream);
 }
 
+int tt_embed_pool_mean(const void* hidden_bf16, int ld, const int32_t* seq_start, const int32_t* seq_len, int n_seq, int hidden,
+                       float* out_f32, void* out_bf16, void* stream) {
+    TT_CHECK_ARG(n_seq >= 0, "n_seq=%d", n_seq);
+    if (n_seq == 0) return TT_OK;
+    TT_CHECK_ARG(hidden_bf16 && seq_start && seq_len && out_f32 && ld >= hidden && ld % 8 == 0, "bad argument");
+    TtProfScope prof(TT_K_ROWOPS, (hipStream_t)stream);
+    return tt_mean_pool_l2norm_launch(hidden_bf16, 0, ld, seq_start, seq_len, n_seq, hidden, out_f32, (uint16_t*)out_bf16,
+                                      (hipStream_t)stream);
+}
+
+int tt_embed_pool_mean_f32(const float* hidden_f32, int ld, const int32_t* seq_start, const int32_t* seq_len, int n_seq, int hidden,
+                           float* out_f32, void* out_bf16, void* stream) {
+    TT_CHECK_ARG(n_seq >= 0, "n_seq=%d", n_seq);
+    if (n_seq == 0) return TT_OK;
+    TT_CHECK_ARG(hidden_f32 && seq_start && seq_len && out_f32 && ld >= hidden && ld % 4 == 0, "bad argument");
+    TtProfScope prof(TT_K_ROWOPS, (hipStream_t)stream);
+    return tt_mean_pool_l2norm_launch(hidden_f32, 1, ld, seq_start, seq_len, n_seq, hidden, out_f32, (uint16_t*)out_bf16,
+                                      (hipStream_t)stream);
+}
+
 int tt_rerank_head(const tt_encoder_weights* w, const void* hidden_bf16, const int32_t* rows, int n_seq,
                    float* scores, float* logits, void* workspace, size_t workspace_bytes, void* stream) {
     if (int rc = check_weights(w)) return rc;

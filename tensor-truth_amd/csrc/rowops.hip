@@ -222,6 +222,65 @@ __global__ __launch_bounds__(kRowThreads) void cls_pool_kernel(const uint16_t* h
     }
 }
 
+// sentence-transformers Pooling(mean) + Normalize: the mean of a sequence's token rows (padding never exists here: sequences are
+// packed), L2-normalised.  One wave per sequence walks its rows (a 256-token chunk is 512 KiB), fp32 sums in the token order.
+template <bool F32>
+__global__ __launch_bounds__(kRowThreads) void mean_pool_kernel(const void* hidden, int ld, const int32_t* seq_start,
+                                                               const int32_t* seq_len, int n, int H, float* out_f32,
+                                                               uint16_t* out_bf16) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * (kRowThreads / 64) + (threadIdx.x >> 6);
+    if (b >= n) return;
+    const int nch = H / 8;
+    const int t0 = seq_start[b], len = seq_len[b];
+    float acc[kMaxChunks][8];
+#pragma unroll
+    for (int c = 0; c < kMaxChunks; ++c)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[c][i] = 0.f;
+    for (int t = 0; t < len; ++t) {
+#pragma unroll
+        for (int c = 0; c < kMaxChunks; ++c) {
+            const int ch = lane + 64 * c;
+            if (ch < nch) {
+                float x[8];
+                if constexpr (F32) {
+                    const float* src = static_cast<const float*>(hidden) + (size_t)(t0 + t) * ld + ch * 8;
+                    const float4 a = *reinterpret_cast<const float4*>(src), bq = *reinterpret_cast<const float4*>(src + 4);
+                    x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = bq.x; x[5] = bq.y; x[6] = bq.z; x[7] = bq.w;
+                } else {
+                    unpack8(*reinterpret_cast<const uint4*>(static_cast<const uint16_t*>(hidden) + (size_t)(t0 + t) * ld + ch * 8), x);
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[c][i] += x[i];
+            }
+        }
+    }
+    const float inv_len = 1.0f / (float)(len > 0 ? len : 1);
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < kMaxChunks; ++c)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            acc[c][i] *= inv_len;
+            if (lane + 64 * c < nch) ss += acc[c][i] * acc[c][i];
+        }
+    const float inv = 1.0f / fmaxf(sqrtf(wave_sum(ss)), 1e-12f);
+#pragma unroll
+    for (int c = 0; c < kMaxChunks; ++c) {
+        const int ch = lane + 64 * c;
+        if (ch < nch) {
+            float y[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) y[i] = acc[c][i] * inv;
+            float* o = out_f32 + (size_t)b * H + ch * 8;
+            *reinterpret_cast<float4*>(o) = make_float4(y[0], y[1], y[2], y[3]);
+            *reinterpret_cast<float4*>(o + 4) = make_float4(y[4], y[5], y[6], y[7]);
+            if (out_bf16) *reinterpret_cast<uint4*>(out_bf16 + (size_t)b * H + ch * 8) = pack8(y);
+        }
+    }
+}
+
 __global__ __launch_bounds__(kRowThreads) void gather_rows_kernel(const uint16_t* src, int ld, const int32_t* rows, int n,
                                                                  int n_pad, int H, uint16_t* dst) {
     const int lane = threadIdx.x & 63;
@@ -385,6 +444,16 @@ int tt_cls_pool_l2norm_launch(const uint16_t* hidden, int ld, const int32_t* row
     if (n <= 0) return TT_OK;
     if (int rc = check_h(H)) return rc;
     hipLaunchKernelGGL(cls_pool_kernel, row_grid(n), dim3(kRowThreads), 0, st, hidden, ld, rows, n, H, out_f32, out_bf16);
+    TT_CHECK_LAUNCH();
+    return TT_OK;
+}
+
+int tt_mean_pool_l2norm_launch(const void* hidden, int is_f32, int ld, const int32_t* seq_start, const int32_t* seq_len, int n, int H,
+                               float* out_f32, uint16_t* out_bf16, hipStream_t st) {
+    if (n <= 0) return TT_OK;
+    if (int rc = check_h(H)) return rc;
+    if (is_f32) hipLaunchKernelGGL(mean_pool_kernel<true>, row_grid(n), dim3(kRowThreads), 0, st, hidden, ld, seq_start, seq_len, n, H, out_f32, out_bf16);
+    else hipLaunchKernelGGL(mean_pool_kernel<false>, row_grid(n), dim3(kRowThreads), 0, st, hidden, ld, seq_start, seq_len, n, H, out_f32, out_bf16);
     TT_CHECK_LAUNCH();
     return TT_OK;
 }

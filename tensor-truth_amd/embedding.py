@@ -70,11 +70,15 @@ class HipHuggingFaceEmbedding:
         _report_unused_kwargs(model_name, model_kwargs, tokenizer_kwargs)
         cfg, state, mdir = _weights.resolve(model_name, model_kwargs, dev, want_head=False)
         self.config = cfg
-        pooling = _weights.pooling_mode(mdir)
-        if pooling != "cls":
-            # no silent wrong vectors: the kernels implement the CLS + L2-norm path of the BGE family (tt_embed_pool)
-            raise NotImplementedError(f"{model_name}: the checkpoint declares sentence-transformers pooling '{pooling}'; "
-                                      f"tensor_truth_amd embeds with CLS pooling + L2 normalisation only")
+        # sentence-transformers pooling: what the checkpoint directory declares (1_Pooling/config.json), unless the caller says
+        # (model_kwargs["pooling"]); "cls" for the BGE family the reference defaults to, "mean" for e5 / all-MiniLM / gte ...
+        pooling = (model_kwargs or {}).get("pooling") or _weights.pooling_mode(mdir)
+        pooling = {"cls_token": "cls", "mean_tokens": "mean"}.get(pooling, pooling)
+        if pooling not in ("cls", "mean"):
+            # no silent wrong vectors: anything else (max, weighted mean, last token ...) has no kernel here
+            raise NotImplementedError(f"{model_name}: sentence-transformers pooling '{pooling}' is not supported "
+                                      f"(CLS and mean pooling, both followed by L2 normalisation, are)")
+        self.pooling = pooling
         # precision.resolve(): model_kwargs (torch_dtype float32 = the reference's own default, config_schema.py:66-76),
         # ModelManager.precision, TT_PRECISION; default bf16.  (`_model.parameters()` is read by the memory accounting.)
         self._model, self._encoder, self.precision = _precision.build_encoder(cfg, state, dev, model_kwargs, f"embedder {model_name}")
@@ -104,7 +108,8 @@ class HipHuggingFaceEmbedding:
                 tokens += min(len(seqs[order[hi]]), self.max_length)
                 hi += 1
             sel = order[lo:hi]
-            emb, _ = self._encoder.embed_packed(pack_tokens([seqs[i] for i in sel], self.config, None, self.max_length))
+            emb, _ = self._encoder.embed_packed(pack_tokens([seqs[i] for i in sel], self.config, None, self.max_length),
+                                                pooling=self.pooling)
             parts.append(emb)
             lo = hi
         out = torch.empty((len(seqs), self.config.hidden), dtype=torch.float32, device=self.device)

@@ -523,8 +523,8 @@ class Encoder:
             slot["lock"].release()
         return tuple(devbuf[o:o + a.size] if a is not None else None for a, o in zip(parts, offs))
 
-    def forward_packed(self, batch: PackedBatch) -> Tuple[torch.Tensor, torch.Tensor]:
-        """-> (hidden [n_rows, H] bf16, cls_rows [B] int32 device tensor)."""
+    def forward_packed(self, batch: PackedBatch, want_lens: bool = False):
+        """-> (hidden [n_rows, H] bf16, cls_rows [B] int32 device tensor[, seq_len [B] int32 device tensor])."""
         lib, dev, H = self.lib, self.device, self.cfg.hidden
         ids, pos, types, starts, lens = self._upload(batch)
         hidden = torch.empty((batch.n_rows, H), dtype=torch.bfloat16, device=dev)
@@ -536,7 +536,7 @@ class Encoder:
                                         lens.data_ptr(), len(batch.seq_len), batch.n_rows, batch.max_len,
                                         hidden.data_ptr(), base, need, torch.cuda.current_stream(dev).cuda_stream)
         _lib.check(rc, "tt_encoder_forward")
-        return hidden, starts
+        return (hidden, starts, lens) if want_lens else (hidden, starts)
 
     def calibrate_fp8(self, batch: PackedBatch, margin: float = 2.0) -> List[float]:
         """One bf16 forward over ``batch`` that records max |GELU output| per layer (``ffn_absmax_out`` hook) and sets
@@ -578,12 +578,22 @@ class Encoder:
         rows = torch.arange(B, dtype=torch.int32, device=dev)
         return cls, rows
 
-    def embed_packed(self, batch: PackedBatch) -> Tuple[torch.Tensor, torch.Tensor]:
-        """-> (embeddings fp32 [B, H] L2-normalised, same rounded to bf16)."""
-        hidden, cls_rows = self.cls_hidden_packed(batch)
+    def embed_packed(self, batch: PackedBatch, pooling: str = "cls") -> Tuple[torch.Tensor, torch.Tensor]:
+        """-> (embeddings fp32 [B, H] L2-normalised, same rounded to bf16).  ``pooling``: "cls" (the BGE family: the last layer
+        runs for the CLS rows only) or "mean" (sentence-transformers mean pooling over a sequence's tokens: full last layer)."""
         B, H = len(batch.seq_len), self.cfg.hidden
         out = torch.empty((B, H), dtype=torch.float32, device=self.device)
         out16 = torch.empty((B, H), dtype=torch.bfloat16, device=self.device)
+        if pooling == "mean":
+            hidden, starts, lens = self.forward_packed(batch, want_lens=True)
+            with torch.cuda.device(self.device):
+                rc = self.lib.tt_embed_pool_mean(hidden.data_ptr(), H, starts.data_ptr(), lens.data_ptr(), B, H, out.data_ptr(),
+                                                 out16.data_ptr(), torch.cuda.current_stream(self.device).cuda_stream)
+            _lib.check(rc, "tt_embed_pool_mean")
+            return out, out16
+        if pooling != "cls":
+            raise ValueError(f"pooling '{pooling}' (supported: 'cls', 'mean')")
+        hidden, cls_rows = self.cls_hidden_packed(batch)
         with torch.cuda.device(self.device):
             rc = self.lib.tt_embed_pool(hidden.data_ptr(), H, cls_rows.data_ptr(), B, H, out.data_ptr(), out16.data_ptr(),
                                         torch.cuda.current_stream(self.device).cuda_stream)

@@ -158,8 +158,8 @@ class EncoderX3:
 
         return Encoder._upload(self, batch)       # same pinned staging ring, one async copy
 
-    def forward_packed(self, batch: PackedBatch) -> Tuple[torch.Tensor, torch.Tensor]:
-        """-> (hidden [n_rows, H] fp32, seq_start [B] int32 device tensor)."""
+    def forward_packed(self, batch: PackedBatch, want_lens: bool = False):
+        """-> (hidden [n_rows, H] fp32, seq_start [B] int32 device tensor[, seq_len [B] int32 device tensor])."""
         lib, dev, H = self.lib, self.device, self.cfg.hidden
         batch = _pad_rows(batch)
         ids, pos, types, starts, lens = self._upload(batch)
@@ -172,13 +172,22 @@ class EncoderX3:
                                            lens.data_ptr(), len(batch.seq_len), batch.n_rows, batch.max_len,
                                            hidden.data_ptr(), base, need, torch.cuda.current_stream(dev).cuda_stream)
         _lib.check(rc, "tt_encoder_forward_x3")
-        return hidden, starts
+        return (hidden, starts, lens) if want_lens else (hidden, starts)
 
-    def embed_packed(self, batch: PackedBatch) -> Tuple[torch.Tensor, torch.Tensor]:
-        hidden, rows = self.forward_packed(batch)
+    def embed_packed(self, batch: PackedBatch, pooling: str = "cls") -> Tuple[torch.Tensor, torch.Tensor]:
         B, H = len(batch.seq_len), self.cfg.hidden
         out = torch.empty((B, H), dtype=torch.float32, device=self.device)
         out16 = torch.empty((B, H), dtype=torch.bfloat16, device=self.device)
+        if pooling == "mean":
+            hidden, starts, lens = self.forward_packed(batch, want_lens=True)
+            with torch.cuda.device(self.device):
+                rc = self.lib.tt_embed_pool_mean_f32(hidden.data_ptr(), H, starts.data_ptr(), lens.data_ptr(), B, H, out.data_ptr(),
+                                                     out16.data_ptr(), torch.cuda.current_stream(self.device).cuda_stream)
+            _lib.check(rc, "tt_embed_pool_mean_f32")
+            return out, out16
+        if pooling != "cls":
+            raise ValueError(f"pooling '{pooling}' (supported: 'cls', 'mean')")
+        hidden, rows = self.forward_packed(batch)
         with torch.cuda.device(self.device):
             rc = self.lib.tt_embed_pool_f32(hidden.data_ptr(), H, rows.data_ptr(), B, H, out.data_ptr(), out16.data_ptr(),
                                             torch.cuda.current_stream(self.device).cuda_stream)

@@ -165,6 +165,32 @@ def test_bi_encoder_checkpoint_vs_transformers(dev, built_lib, tmp_path, arch):
     assert cos.min().item() >= 0.999 and (got - want).abs().max().item() <= 1e-2, (cos.min().item(), (got - want).abs().max().item())
     assert (got.norm(dim=1) - 1).abs().max() < 1e-3
 
+    # ---- a checkpoint that declares MEAN pooling (e5 / all-MiniLM / gte style: 1_Pooling/config.json): Pooling(mean) + Normalize,
+    #      in the default precision and in the reference precision (split-bf16 for the 256-wide XLM-R shape, fp32 MFMA for BERT-384)
+    import json
+
+    assert emb.pooling == "cls"
+    (d / "1_Pooling").mkdir()
+    (d / "1_Pooling" / "config.json").write_text(json.dumps({
+        "word_embedding_dimension": cfg.hidden_size, "pooling_mode_cls_token": False, "pooling_mode_mean_tokens": True,
+        "pooling_mode_max_tokens": False, "pooling_mode_mean_sqrt_len_tokens": False}))
+    m = mask.unsqueeze(-1).float()
+    want_mean = torch.nn.functional.normalize((hidden * m).sum(1) / m.sum(1), p=2, dim=1)
+    assert (want_mean - want).abs().max().item() > 0.05                      # the two poolings differ on this checkpoint
+    for precision, cos_min, err_max in (("bf16", 0.999, 1e-2), ("reference", 0.999999, 2e-4)):
+        emb_m = HipHuggingFaceEmbedding(str(d), device="cuda", embed_batch_size=16,
+                                        model_kwargs={"tokenizer": HashTokenizer(arch, cfg.vocab_size), "precision": precision})
+        assert emb_m.pooling == "mean"
+        got_m = emb_m.embed_token_batches(seqs).cpu()
+        cos_m = (got_m * want_mean).sum(dim=1)
+        assert cos_m.min().item() >= cos_min and (got_m - want_mean).abs().max().item() <= err_max, \
+            (precision, cos_m.min().item(), (got_m - want_mean).abs().max().item())
+        assert (got_m.norm(dim=1) - 1).abs().max() < 1e-3
+    # anything else (max pooling ...) is refused, not approximated
+    (d / "1_Pooling" / "config.json").write_text(json.dumps({"pooling_mode_cls_token": False, "pooling_mode_max_tokens": True}))
+    with pytest.raises(NotImplementedError):
+        HipHuggingFaceEmbedding(str(d), device="cuda", model_kwargs={"tokenizer": HashTokenizer(arch, cfg.vocab_size)})
+
 
 def test_bert_cross_encoder_checkpoint_vs_transformers(dev, built_lib, tmp_path):
     """The third reranker the reference offers out of the box (``cross-encoder/ms-marco-MiniLM-L-6-v2``,

@@ -1060,3 +1060,20 @@ def test_pooling_mode_of_a_checkpoint_directory(tmp_path):
     conf.update(pooling_mode_cls_token=False, pooling_mode_mean_tokens=True)
     (tmp_path / "1_Pooling" / "config.json").write_text(json.dumps(conf))
     assert weights.pooling_mode(str(tmp_path)) == "mean_tokens"
+
+
+def test_oracle_mean_pooling_matches_the_formula_on_ragged_masks():
+    """oracle.encoder.mean_pool_normalize: masked mean over the sequence, then L2 norm -- padding rows must not count."""
+    import torch
+
+    from oracle import encoder as oe
+
+    g = torch.Generator().manual_seed(0)
+    h = torch.randn(3, 7, 16, generator=g)
+    mask = torch.tensor([[1, 1, 1, 1, 1, 1, 1], [1, 1, 1, 0, 0, 0, 0], [1, 0, 0, 0, 0, 0, 0]])
+    got = oe.mean_pool_normalize(h, mask)
+    for b, n in enumerate((7, 3, 1)):
+        want = h[b, :n].mean(0)
+        want = want / want.norm()
+        assert torch.allclose(got[b], want, atol=1e-6)
+    assert torch.allclose(got[2], oe.cls_pool_normalize(h)[2], atol=1e-6)      # one token: mean pooling = CLS pooling
