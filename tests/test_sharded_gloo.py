@@ -46,7 +46,9 @@ def _worker(rank, world, port, n_total, d, q, k, ret):
         want_q = torch.cat([queries[r::world] for r in range(world)], 0)
         ok_q = torch.equal(allq.view(torch.int16), want_q.view(torch.int16))
         if rank == 0:
-            ret.put((s, i, ok_q))
+            # numpy, not torch: a tensor travels through the queue as a handle into THIS process's sharing server, and
+            # the parent may unpickle it after this process has exited (FileNotFoundError, seen once in a CPU-suite run)
+            ret.put((s.numpy(), i.numpy(), ok_q))
         else:
             ret.put((None, None, ok_q))
     finally:
@@ -67,7 +69,7 @@ def test_two_rank_sharded_search_equals_global(n_total, k):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(o[2] for o in outs)
-    s, i = next((o[0], o[1]) for o in outs if o[0] is not None)
+    s, i = next((torch.from_numpy(o[0]), torch.from_numpy(o[1])) for o in outs if o[0] is not None)
     corpus = osc.synth_corpus(n_total, d, seed=99)
     queries, _ = osc.synth_queries(corpus, q, seed=5)
     want_s, want_i, gap = osc.scan_topk(corpus, queries, k)
