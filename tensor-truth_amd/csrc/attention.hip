@@ -46,7 +46,11 @@ __device__ __forceinline__ void lds_wait2n(u32x4& a, u32x4& b) {
     asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
 }
 
-template <int DH, bool STAMP = false>
+// ABL (diagnostic builds, TT_ATT_ABLATE, wrong results by design -- what each part of the key-tile loop costs): 1 = no
+// exponentials (the scaled difference goes on as the "probability"), 2 = no softmax at all (no mask, maximum, FMAs,
+// exponentials, sums or rescale: the raw scores are packed as P), 3 = 2 without the V reads and the P.V MFMAs,
+// 4 = everything, but every workgroup reads the K / V rows of sequence 0 (L2 hits: what the K / V misses cost)
+template <int DH, bool STAMP = false, int ABL = 0>
 __global__ __launch_bounds__(64 * kWaves, 4) void attention_kernel(AttnParams p) {
     constexpr int RB = DH * 2;              // bytes per K row
     constexpr int CH = RB / 16;             // 16-B chunks per K row
@@ -112,8 +116,9 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attention_kernel(AttnParams p)
     // ---- staging: wave w copies K pieces w*KPW.. and V pieces w*VPW.. of each tile.  Per-lane row / token-group
     // indices are loop constants; rows / groups beyond the sequence are clamped to its last one (finite values;
     // their probabilities are 0) -- only the last tile can need that.
-    const uint16_t* kbase = p.qk + (size_t)t0a * p.ld_qk + p.k_col0 + head * DH;
-    const uint16_t* vbase = p.vt + (size_t)(t0a >> 3) * p.ldvt + (size_t)head * DH * 8;
+    const int t0kv = (ABL == 4) ? (p.seq_start[0] & ~7) : t0a;
+    const uint16_t* kbase = p.qk + (size_t)t0kv * p.ld_qk + p.k_col0 + head * DH;
+    const uint16_t* vbase = p.vt + (size_t)(t0kv >> 3) * p.ldvt + (size_t)head * DH * 8;
     // Copies in the SGPR-base form (wave-uniform 64-bit base + per-lane 32-bit byte offset, as the GEMM's glds16), with ONE
     // per-lane offset register per operand.  History: through the builtin every piece carried a per-lane 64-bit address
     // (v_mad_i64_i32 + v_lshl_add_u64 and a VGPR pair per piece and tile); with per-piece offset arrays kept across the loop
@@ -243,6 +248,16 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attention_kernel(AttnParams p)
         }
         if constexpr (STAMP) { asm volatile("" :: "v"(acc_s[0][0]), "v"(acc_s[1][15])); }
         stamp();                               // +3: S = K.Q^T issued (results consumed next)
+        if constexpr (ABL == 3) {   // S only: keep the 32 scores alive, nothing else happens in this tile
+            asm volatile("" :: "v"(acc_s[0][0]), "v"(acc_s[0][1]), "v"(acc_s[0][2]), "v"(acc_s[0][3]), "v"(acc_s[0][4]), "v"(acc_s[0][5]),
+                         "v"(acc_s[0][6]), "v"(acc_s[0][7]), "v"(acc_s[0][8]), "v"(acc_s[0][9]), "v"(acc_s[0][10]), "v"(acc_s[0][11]),
+                         "v"(acc_s[0][12]), "v"(acc_s[0][13]), "v"(acc_s[0][14]), "v"(acc_s[0][15]));
+            asm volatile("" :: "v"(acc_s[1][0]), "v"(acc_s[1][1]), "v"(acc_s[1][2]), "v"(acc_s[1][3]), "v"(acc_s[1][4]), "v"(acc_s[1][5]),
+                         "v"(acc_s[1][6]), "v"(acc_s[1][7]), "v"(acc_s[1][8]), "v"(acc_s[1][9]), "v"(acc_s[1][10]), "v"(acc_s[1][11]),
+                         "v"(acc_s[1][12]), "v"(acc_s[1][13]), "v"(acc_s[1][14]), "v"(acc_s[1][15]));
+            l_run = 1.f;
+            continue;
+        }
         // V fragments of the first 32 keys: in flight during the softmax
         u32x4 vf[2][2];   // [s2][dt]
         const uint32_t vaddr = voff + bufo;
@@ -250,6 +265,8 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attention_kernel(AttnParams p)
         if constexpr (DT == 2) vf[0][1] = lds_read128_async<512>(vaddr);
         vf[1][0] = lds_read128_async<2 * DH * 16>(vaddr);
         if constexpr (DT == 2) vf[1][1] = lds_read128_async<2 * DH * 16 + 512>(vaddr);
+        if constexpr (ABL == 2) l_run = 1.f;
+        if constexpr (ABL != 2) {
 
         // ---- mask the tail, running max, exponentials --------------------------------------------
         // The softmax scale (and log2 e) is folded into one FMA per score: p = 2^(s*sc - m), with m
@@ -292,7 +309,7 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attention_kernel(AttnParams p)
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
                 const f32x2 t = f32x2{acc_s[j][r], acc_s[j][r + 1]} * sc2 - mn2;
-                const f32x2 e = f32x2{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+                const f32x2 e = (ABL == 1) ? t : f32x2{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
                 acc_s[j][r] = e.x;
                 acc_s[j][r + 1] = e.y;
                 psum2 += e;
@@ -304,6 +321,7 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attention_kernel(AttnParams p)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc_o[d][r] *= alpha;
         }
+        }   // ABL != 2
 
         if constexpr (STAMP) { asm volatile("" :: "v"(acc_s[0][0]), "v"(acc_s[1][15]), "v"(l_run)); }
         stamp();                               // +4: softmax done
@@ -459,7 +477,12 @@ int tt_attention_launch(const AttnParams& p, hipStream_t st) {
     if (p.head_dim == 64 && p.dbg) {
         hipLaunchKernelGGL((attention_kernel<64, true>), grid, dim3(64 * kWaves), 0, st, q);
     } else if (p.head_dim == 64) {
-        hipLaunchKernelGGL(attention_kernel<64>, grid, dim3(64 * kWaves), 0, st, q);
+        static const int abl = [] { const char* e = getenv("TT_ATT_ABLATE"); return e && e[0] ? atoi(e) : 0; }();
+        if (abl == 1) hipLaunchKernelGGL((attention_kernel<64, false, 1>), grid, dim3(64 * kWaves), 0, st, q);
+        else if (abl == 2) hipLaunchKernelGGL((attention_kernel<64, false, 2>), grid, dim3(64 * kWaves), 0, st, q);
+        else if (abl == 3) hipLaunchKernelGGL((attention_kernel<64, false, 3>), grid, dim3(64 * kWaves), 0, st, q);
+        else if (abl == 4) hipLaunchKernelGGL((attention_kernel<64, false, 4>), grid, dim3(64 * kWaves), 0, st, q);
+        else hipLaunchKernelGGL(attention_kernel<64>, grid, dim3(64 * kWaves), 0, st, q);
     } else if (p.head_dim == 32) {
         hipLaunchKernelGGL(attention_kernel<32>, grid, dim3(64 * kWaves), 0, st, q);
     } else {

@@ -1,0 +1,14 @@
+#!/bin/bash
+# What each part of the attention key-tile loop costs: diagnostic builds of attention_kernel (TT_ATT_ABLATE, wrong results by
+# design) timed stand-alone on the bench shape (1600 sequences x 292 tokens, 16 heads x 64).
+cd "$GRAFT_REPO_ROOT" || exit 1
+mkdir -p gpurun_out
+export LD_LIBRARY_PATH=$PWD/tensor-truth_amd:$LD_LIBRARY_PATH
+make -C tools att_bench > /dev/null 2>&1
+{
+for r in 1 2; do for a in 0 1 2 3 4; do
+  echo "== TT_ATT_ABLATE=$a (round $r)"
+  TT_ATT_ABLATE=$a timeout 120 tools/att_bench 1600 292 2>&1 | tail -2
+done; done
+for a in 0 4; do echo "== TT_ATT_ABLATE=$a with TT_ATT_XCD=1"; TT_ATT_XCD=1 TT_ATT_ABLATE=$a timeout 120 tools/att_bench 1600 292 2>&1 | tail -1; done
+} 2>&1 | tee gpurun_out/att_ablate.log
