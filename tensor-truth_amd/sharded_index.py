@@ -43,6 +43,14 @@ def _world(group) -> Tuple[int, int]:
     return 1, 0
 
 
+class ShardRoundError(RuntimeError):
+    """A rank's local scan failed inside a collective round.  The failing rank still takes part in the round's all-gather
+    (with a poisoned partial list), so EVERY rank raises this for the round's queries and nobody is left waiting in a collective."""
+
+
+_POISON = -2          # row id marking a rank's partial list as "my scan failed" (-1 is ordinary padding)
+
+
 class ShardedHipVectorIndex:
     def __init__(self, dim: int, local_rows: torch.Tensor, row_lo: int, n_total: int, leaf_ids: Sequence[Optional[str]],
                  docstore: Dict[str, TextNode], embed_model=None, score_mode: str = "chroma", group=None,
@@ -175,6 +183,27 @@ class ShardedHipVectorIndex:
         i = torch.cat([p[1] for p in parts], dim=1)
         return self._merge(s, i, k)
 
+    def _collective_topk(self, q16: torch.Tensor, k: int):
+        """Local scan of the (identical on every rank) batch -> ONE all-gather of the packed partial lists -> merge.  A local
+        scan that raises is carried through the collective as a poisoned list: all ranks then raise ``ShardRoundError``
+        together (the failing rank with its own exception as the cause) and the next round starts aligned."""
+        world, rank = _world(self.group)
+        err = None
+        try:
+            s, i = self._local_topk(q16, k)
+        except Exception as exc:  # noqa: BLE001 - reported to every rank below
+            err = exc
+            s = torch.zeros((q16.shape[0], k), dtype=torch.float32, device=q16.device)
+            i = torch.full((q16.shape[0], k), _POISON, dtype=torch.int32, device=q16.device)
+        all_s, all_i = _sh.gather_partials(s, i, self.group)
+        bad = (all_i[:1, ::k] == _POISON).cpu().tolist()[0] if all_i.shape[0] else [False] * world   # first slot of every rank's block
+        if err is not None or any(bad):
+            failed = [r for r, b in enumerate(bad) if b] or [rank]
+            raise ShardRoundError(f"shard scan failed on rank(s) {failed}: the round's queries have no complete result") from err
+        if all_s.shape[1] == k:
+            return all_s, all_i
+        return self._merge(all_s, all_i, k)
+
     def _unit_bf16(self, query_emb: torch.Tensor) -> torch.Tensor:
         q = query_emb.to(self.device, dtype=torch.float32)
         return (q / q.norm(dim=1, keepdim=True).clamp_min(1e-12)).to(torch.bfloat16).contiguous()
@@ -198,7 +227,7 @@ class ShardedHipVectorIndex:
                 counts = torch.zeros(world, dtype=torch.int64, device=q16.device)
                 dist.all_gather_into_tensor(counts, torch.tensor([nq], dtype=torch.int64, device=q16.device), group=self.group)
                 return self._round_partitioned(q16, k, int(counts.max().item()))
-            return _sh.sharded_topk(lambda qq, kk: self._local_topk(qq, kk), self._merge, q16, k, self.group)
+            return self._collective_topk(q16, k)
 
     def _round_partitioned(self, q16: torch.Tensor, k: int, nmax: int):
         """One collective round in which rank r brings q16[r] ([nq_r, D] unit bf16, nq_r <= nmax, nmax agreed beforehand):
@@ -212,7 +241,7 @@ class ShardedHipVectorIndex:
         if nq < nmax:
             q16 = torch.cat([q16, torch.zeros((nmax - nq, q16.shape[1]), dtype=q16.dtype, device=q16.device)], 0)
         all_q = _sh.gather_queries(q16, self.group)
-        s, i = _sh.sharded_topk(lambda qq, kk: self._local_topk(qq, kk), self._merge, all_q, k, self.group)
+        s, i = self._collective_topk(all_q, k)
         return s[rank * nmax: rank * nmax + nq], i[rank * nmax: rank * nmax + nq]
 
     def as_retriever(self, similarity_top_k: int = 10, coalesce: bool = True, max_batch: int = 64,
@@ -251,7 +280,9 @@ class _TickFront:
     and each rank turns ITS slice into nodes for its own callers.  Ranks therefore always issue the same collectives in
     the same order whatever their callers do, concurrent callers of a rank share its rounds (coalescing stays on), and
     embedding -- and the reranker above -- only ever see a rank's own queries.  A query whose embedding fails is answered
-    with its exception before the round; it never reaches a collective.  ``close()`` raises this rank's closing flag;
+    with its exception before the round; it never reaches a collective.  A shard scan that fails INSIDE a round is carried through
+    the round's all-gather as a poisoned list: the round's callers on every rank get ``ShardRoundError`` and the next tick starts
+    aligned (a rank that simply stopped would leave the others in a collective for the process group's timeout).  ``close()`` raises this rank's closing flag;
     the thread keeps serving the other ranks' rounds (they need this shard) until every rank has raised its own."""
 
     def __init__(self, retriever: "ShardedHipVectorRetriever", max_batch: int, idle_sleep_s: float = 2e-4):
@@ -316,7 +347,7 @@ class _TickFront:
                     batch = self._queue[: self.max_batch]
                     del self._queue[: len(batch)]
                     closing = self._closing and not self._queue
-                q16 = None
+                q16, round_error = None, None
                 if batch:
                     batch, q16 = self._embed_own(batch)
                 nq = len(batch)
@@ -335,11 +366,19 @@ class _TickFront:
                         k = min(r.similarity_top_k, idx.n_total)
                         if q16 is None:
                             q16 = torch.zeros((0, idx.dim), dtype=torch.bfloat16, device=dev)
-                        hits = idx._round_partitioned(q16, k, nmax) if k >= 1 else None
+                        try:
+                            hits = idx._round_partitioned(q16, k, nmax) if k >= 1 else None
+                        except ShardRoundError as exc:      # raised by EVERY rank in this round: the protocol stays aligned
+                            round_error, hits = exc, None
                         self.rounds += 1
                 if nmax == 0:
                     time.sleep(self.idle_sleep_s)
                     continue
+                if batch and round_error is not None:           # this round's callers fail, the front lives on
+                    for s_ in batch:
+                        s_.error = round_error
+                        s_.event.set()
+                    batch = []
                 if batch:
                     if hits is None:
                         results = [[] for _ in batch]

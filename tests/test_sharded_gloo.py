@@ -355,3 +355,92 @@ def test_two_rank_tick_front_serves_different_callers_per_rank():
     assert outs[0][1] == [] and outs[1][1] == ["ValueError"]          # the malformed query failed alone, before any collective
     assert outs[0][2] == outs[1][2]                                    # both ranks ran the same collective rounds
     assert outs[0][3] == 15 and outs[1][3] == 4 and outs[0][2] < 19    # rounds were shared by concurrent callers
+
+
+def _poison_worker(rank, world, port, n_total, d, k, ret):
+    """A shard scan that fails inside a collective round: the failing rank completes the round with a poisoned partial list, the
+    round's callers on EVERY rank get ShardRoundError, nobody hangs in a collective, and the front serves the next queries."""
+    import threading
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tensor_truth_amd.schema import QueryBundle, TextNode
+        from tensor_truth_amd.sharded import shard_bounds
+        from tensor_truth_amd.sharded_index import ShardedHipVectorIndex, ShardRoundError
+
+        corpus = osc.synth_corpus(n_total, d, seed=17)
+        queries, _ = osc.synth_queries(corpus, 12, seed=19)
+        lo, hi = shard_bounds(n_total, world, rank)
+        leaf_ids = [f"leaf{j}" for j in range(n_total)]
+        docstore = {nid: TextNode(text=f"text {j}", id_=nid, metadata={"row": j}) for j, nid in enumerate(leaf_ids)}
+        calls = {"n": 0}
+
+        def scan_fn(rows, q16, kk, base):
+            calls["n"] += 1
+            if rank == 1 and calls["n"] == 2:
+                raise RuntimeError("boom: device error in the shard scan")
+            v, i, _ = osc.scan_topk(rows, q16, kk)
+            return v, torch.where(i >= 0, i + base, i).to(torch.int32)
+
+        def merge_fn(vals, idx, kk):
+            v, i = osc.merge_topk(vals, idx.to(torch.int64), kk)
+            return v, i.to(torch.int32)
+
+        index = ShardedHipVectorIndex(d, corpus[lo:hi].contiguous(), lo, n_total, leaf_ids, docstore, score_mode="cosine",
+                                      queries="partitioned", scan_fn=scan_fn, merge_fn=merge_fn)
+        retr = index.as_retriever(similarity_top_k=k, max_batch=4)
+        out, errs = {}, []
+
+        def caller(qs):
+            for qi in qs:
+                try:
+                    hits = retr.retrieve(QueryBundle(query_str=f"q{qi}", embedding=queries[qi].float().tolist()))
+                    out[qi] = [h.node.metadata["row"] for h in hits]
+                except ShardRoundError as exc:
+                    errs.append((qi, type(exc).__name__, repr(exc.__cause__)))
+
+        t = threading.Thread(target=caller, args=([6 * rank + j for j in range(6)],))
+        t.start()
+        t.join(timeout=120)
+        assert not t.is_alive()
+        front = retr._tick
+        assert front._dead is None                      # the front survived the failed round ...
+        late = retr.retrieve(QueryBundle(query_str="late", embedding=queries[rank].float().tolist()))   # ... and still serves
+        retr.close(timeout=120)
+        assert not front._thread.is_alive()
+        ret.put((rank, out, errs, [h.node.metadata["row"] for h in late], front.rounds, calls["n"]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_tick_front_survives_a_failed_shard_scan():
+    world, n_total, d, k = 2, 400, 64, 5
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_poison_worker, args=(r, world, port, n_total, d, k, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = {o[0]: o[1:] for o in (ret.get(timeout=240) for _ in procs)}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    corpus = osc.synth_corpus(n_total, d, seed=17)
+    queries, _ = osc.synth_queries(corpus, 12, seed=19)
+    _, want_i, gap = osc.scan_topk(corpus, queries, k)
+    n_err = 0
+    for rank in (0, 1):
+        out, errs, late, rounds, n_scans = outs[rank]
+        n_err += len(errs)
+        assert set(out) | {e[0] for e in errs} == set(range(6 * rank, 6 * rank + 6))        # every call returned or raised
+        for qi, rows in out.items():
+            if gap[qi] > 1e-6:
+                assert rows == want_i[qi].tolist()
+        if gap[rank] > 1e-6:
+            assert late == want_i[rank].tolist()
+        assert all(e[1] == "ShardRoundError" for e in errs)
+    assert 1 <= n_err <= 2                                   # the poisoned round held one or two callers (one per rank at most)
+    assert any("boom" in e[2] for e in outs[1][1]) or not outs[1][1]                        # rank 1's own callers see the cause
+    assert outs[0][3] == outs[1][3]                          # the ranks stayed in lock step
