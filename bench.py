@@ -112,6 +112,7 @@ def parse():
     ap.add_argument("--config5-docs", type=int, default=1024)
     ap.add_argument("--no-fp8-leg", action="store_true", help="skip the extra fp8-reranker timing (BASELINE config 5)")
     ap.add_argument("--no-reference-leg", action="store_true", help="skip the reference-precision (bf16x3) timing")
+    ap.add_argument("--no-fp16-leg", action="store_true", help="skip the fp16-mode timing")
     ap.add_argument("--headline-only", action="store_true",
                     help="run only the warm-up and timed steps (no scan-only / fp8 / ingest legs): every kernel of the process then "
                          "belongs to the timed workload, so a rocprofv3 --stats summary of this command can be compared with "
@@ -435,6 +436,42 @@ def main():
                                  "(TT_PRECISION=reference / ModelManager.set_precision('reference') / torch_dtype=float32)",
                          "score_quality_vs_fp32_path": quality}
 
+    # ---- the fp16 mode (precision="fp16" / the reference's torch_dtype: "float16"): the SAME step with both encoders on IEEE
+    # fp16 elements and v_mfma_*_f16 -- the bf16 rate, scores several times closer to the reference.  A labelled variant
+    # beside the headline (BASELINE's configurations name bf16), never the headline.
+    fp16_leg = None
+    if not args.no_fp16_leg and not args.headline_only:
+        quality16 = None
+        if rank == 0:
+            quality16 = rank_quality(reranker, rr_cfg, tokens_step["last_pairs"][: 4 * K], K, topn, dev, modes=("bf16", "fp16"))
+        emb16 = Encoder(EncoderWeights(emb_cfg, synthetic_state_device(emb_cfg, dev, seed=1), dev, dtype=torch.float16))
+        rr16 = Encoder(EncoderWeights(rr_cfg, synthetic_state_device(rr_cfg, dev, seed=2), dev, dtype=torch.float16))
+        enc_pair["embedder"], enc_pair["reranker"] = emb16, rr16
+        step(queries[0])
+        sync_all()
+        lib.tt_prof_enable(1)
+        t2 = time.perf_counter()
+        for q in queries:
+            step(q)
+        sync_all()
+        dt16 = time.perf_counter() - t2
+        prof16 = read_prof()
+        lib.tt_prof_enable(0)
+        enc_pair["embedder"], enc_pair["reranker"] = embedder, reranker
+        del emb16, rr16
+        torch.cuda.empty_cache()
+        if world > 1:
+            t = torch.tensor([dt16], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt16 = float(t.item())
+        fp16_leg = {"queries_per_s": world * Bq * args.steps / dt16, "ms_per_step": dt16 / args.steps * 1e3,
+                    "dtype": "fp16 (IEEE half activations and weights, v_mfma_*_f16, fp32 accumulate, fp32 LayerNorm / softmax / GELU "
+                             "arithmetic; outputs saturate at +-65504)",
+                    "stage_ms_per_step": {k: v[0] / args.steps for k, v in prof16.items() if v[1]},
+                    "what": "the headline step with embedder and reranker in the fp16 mode (TT_PRECISION=fp16 / "
+                            "ModelManager.set_precision('fp16') / torch_dtype=float16)",
+                    "score_quality_vs_fp32_path": quality16}
+
     chunks_per_s = None
     if not args.headline_only:
         # ---- second half of the BASELINE metric: batch chunk embedding (ingest), separately timed ----
@@ -572,6 +609,7 @@ def main():
             "embed_batch": f"{args.embed_chunks} chunks x {args.chunk_len + 2} tok per GPU (bge-m3 shape)",
             "fp8_reranker": fp8_leg,
             "reference_precision": reference_leg,
+            "fp16_mode": fp16_leg,
             "scan_only": scan_only,
             "scan_only_shard": scan_shard,
             "plugin_surface": surface,
@@ -631,6 +669,12 @@ def rank_quality(reranker, rr_cfg, pair_ids, K, topn, dev, modes=("bf16", "fp8")
             enc3 = EncoderX3(EncoderWeightsX3(rr_cfg, state, dev))
             sm = enc3.rerank_packed(batch).cpu().view(n_q, K)
             del enc3
+        elif mode == "fp16":
+            from tensor_truth_amd.encoder import Encoder, EncoderWeights
+
+            enc16 = Encoder(EncoderWeights(rr_cfg, state, dev, dtype=torch.float16))
+            sm = enc16.rerank_packed(batch).cpu().view(n_q, K)
+            del enc16
         else:
             w.set_gemm_dtype(mode)
             sm = reranker.rerank_packed(batch).cpu().view(n_q, K)

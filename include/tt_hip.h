@@ -292,6 +292,37 @@ int tt_rerank_head_f32(const tt_encoder_weights_f32* w, const float* hidden_f32,
 int tt_gemm_f32(const float* a, const float* w, const float* bias, const float* residual, float* c,
                 int m, int n, int k, int epilogue, void* stream);
 
+/* ---- fp16 compute mode (round 3): the same forward with IEEE fp16 activations / weights and v_mfma_*_f16 ---------------------
+ * Same weight struct (the matrices then point at fp16 data: word / position / type tables, all projections, the head), same
+ * workspace sizes, same argument meaning as the functions they twin; hidden states and V^T are fp16.  Values beyond +-65504
+ * saturate at the GEMM / LayerNorm outputs instead of becoming infinite.  No fp8 projections, no split planes in this mode.
+ * (FlagEmbedding loads these very models with use_fp16=True by default; the reference's torch_dtype: "float16",
+ * app_utils/config_schema.py:66-76, lands here instead of being mapped to bf16.) */
+size_t tt_encoder_workspace_bytes_f16(const tt_encoder_weights* w, int n_rows);
+size_t tt_encoder_cls_workspace_bytes_f16(const tt_encoder_weights* w, int n_rows, int n_seq);
+int tt_encoder_forward_f16(const tt_encoder_weights* w, const int32_t* ids, const int32_t* pos,
+                           const int32_t* type_ids, const int32_t* seq_start, const int32_t* seq_len,
+                           int n_seq, int n_rows, int max_len, void* hidden_out,
+                           void* workspace, size_t workspace_bytes, void* stream);
+int tt_encoder_forward_cls_f16(const tt_encoder_weights* w, const int32_t* ids, const int32_t* pos,
+                               const int32_t* type_ids, const int32_t* seq_start, const int32_t* seq_len,
+                               int n_seq, int n_rows, int max_len, void* cls_out,
+                               void* workspace, size_t workspace_bytes, void* stream);
+int tt_embed_pool_f16(const void* hidden_f16, int ld, const int32_t* rows, int n_seq, int hidden, float* out_f32,
+                      void* out_f16, void* stream);
+int tt_embed_pool_mean_f16(const void* hidden_f16, int ld, const int32_t* seq_start, const int32_t* seq_len, int n_seq, int hidden,
+                           float* out_f32, void* out_f16, void* stream);
+int tt_rerank_head_f16(const tt_encoder_weights* w, const void* hidden_f16, const int32_t* rows, int n_seq,
+                       float* scores, float* logits, void* workspace, size_t workspace_bytes, void* stream);
+/* building blocks (parity tests) */
+int tt_gemm_f16(const void* a, const void* w, const float* bias, const void* residual, void* c,
+                int m, int n, int k, int epilogue, void* stream);
+int tt_layernorm_f16(const void* in, void* out, const float* gamma, const float* beta, int rows, int hidden,
+                     float eps, void* stream);
+int tt_attention_varlen_f16(const void* qk, int ld_qk, int q_col0, int k_col0, const void* vt, int ldvt, void* out,
+                            int ld_out, const int32_t* seq_start, const int32_t* seq_len, int n_seq, int heads,
+                            int head_dim, int max_len, void* stream);
+
 /* ---- reference precision on the bf16 matrix cores: split-bf16 ("bf16x3") forward -------------------------------------
  * Same contract as the fp32 forward above (the unchanged reference call SentenceTransformerRerank(model=, top_n=, device=),
  * src/tensortruth/services/model_manager.py:333-337, and HuggingFaceEmbedding with torch_dtype None,

@@ -68,8 +68,28 @@ BGE_SMALL_EN = EncoderConfig(
 )
 
 
+# element type the "emulate_bf16" rounding points round to: bfloat16 (the HIP path's default mode), or float16 for its fp16
+# mode (tests set it around a call with ``rounding_dtype``)
+_ROUND_DTYPE = torch.bfloat16
+
+
+class rounding_dtype:
+    """``with rounding_dtype(torch.float16): encoder_forward(..., emulate_bf16=True)`` emulates the fp16 mode's rounding points."""
+
+    def __init__(self, dtype):
+        self.dtype = dtype
+
+    def __enter__(self):
+        global _ROUND_DTYPE
+        self.prev, _ROUND_DTYPE = _ROUND_DTYPE, self.dtype
+
+    def __exit__(self, *exc):
+        global _ROUND_DTYPE
+        _ROUND_DTYPE = self.prev
+
+
 def _rnd(x: torch.Tensor, on: bool) -> torch.Tensor:
-    return x.to(torch.bfloat16).to(torch.float32) if on else x
+    return x.to(_ROUND_DTYPE).to(torch.float32) if on else x
 
 
 def position_ids(mask: torch.Tensor, cfg: EncoderConfig) -> torch.Tensor:

@@ -53,6 +53,20 @@ SIGNATURES = {
     "tt_embed_pool": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "tt_embed_pool_mean": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "tt_embed_pool_mean_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    # fp16 twins of the 16-bit path (same signatures)
+    "tt_encoder_workspace_bytes_f16": (c_size_t, [c_void_p, c_int]),
+    "tt_encoder_cls_workspace_bytes_f16": (c_size_t, [c_void_p, c_int, c_int]),
+    "tt_encoder_forward_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                   c_void_p, c_void_p, c_size_t, c_void_p]),
+    "tt_encoder_forward_cls_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                       c_void_p, c_void_p, c_size_t, c_void_p]),
+    "tt_embed_pool_f16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "tt_embed_pool_mean_f16": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "tt_rerank_head_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "tt_gemm_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "tt_layernorm_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
+    "tt_attention_varlen_f16": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p,
+                                    c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "tt_rerank_head": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "tt_adjacent_cosine": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "tt_gemm_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

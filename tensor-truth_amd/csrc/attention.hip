@@ -107,9 +107,9 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attention_kernel(AttnParams p)
     const int q_row = (qt * kWaves + wave) * 32 + ql;      // row inside the sequence
     const int q_row_c = q_row < len ? q_row : len - 1;     // clamp: result discarded
     const uint16_t* qp = p.qk + (size_t)(t0 + q_row_c) * p.ld_qk + p.q_col0 + head * DH + hh * 8;
-    bf16x8 qf[KS];
+    ex8 qf[KS];
 #pragma unroll
-    for (int s = 0; s < KS; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + s * 16);
+    for (int s = 0; s < KS; ++s) qf[s] = *reinterpret_cast<const ex8*>(qp + s * 16);
 
     const int n_kt = (alen + kKTile - 1) / kKTile;
     const int n_g8 = (alen + 7) >> 3;
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attention_kernel(AttnParams p)
                 for (int r = 0; r < 16; ++r) acc_s[j][r] = 0.f;
 #pragma unroll
                 for (int s = 0; s < KS; ++s)
-                    acc_s[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[j][s]), qf[s], acc_s[j], 0, 0, 0);
+                    acc_s[j] = TT_MFMA_32x32x16(__builtin_bit_cast(ex8, kf[j][s]), qf[s], acc_s[j]);
             }
         }
         if constexpr (STAMP) { asm volatile("" :: "v"(acc_s[0][0]), "v"(acc_s[1][15])); }
@@ -330,11 +330,11 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attention_kernel(AttnParams p)
         for (int j = 0; j < 2; ++j) {
             if constexpr (DT == 2) lds_wait4n<0>(vf[0][0], vf[0][1], vf[1][0], vf[1][1]);
             else lds_wait2n<0>(vf[0][0], vf[1][0]);
-            bf16x8 va[2][2];
+            ex8 va[2][2];
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-                for (int d = 0; d < DT; ++d) va[s2][d] = __builtin_bit_cast(bf16x8, vf[s2][d]);
+                for (int d = 0; d < DT; ++d) va[s2][d] = __builtin_bit_cast(ex8, vf[s2][d]);
             if (j == 0) {   // next 32 keys' fragments, in flight during these MFMAs
                 vf[0][0] = lds_read128_async<4 * DH * 16>(vaddr);
                 if constexpr (DT == 2) vf[0][1] = lds_read128_async<4 * DH * 16 + 512>(vaddr);
@@ -344,14 +344,14 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attention_kernel(AttnParams p)
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 uint4 pb;
-                pb.x = pack_bf16x2(acc_s[j][8 * s2 + 0], acc_s[j][8 * s2 + 1]);
-                pb.y = pack_bf16x2(acc_s[j][8 * s2 + 2], acc_s[j][8 * s2 + 3]);
-                pb.z = pack_bf16x2(acc_s[j][8 * s2 + 4], acc_s[j][8 * s2 + 5]);
-                pb.w = pack_bf16x2(acc_s[j][8 * s2 + 6], acc_s[j][8 * s2 + 7]);
-                const bf16x8 pf = __builtin_bit_cast(bf16x8, pb);
+                pb.x = pack_e2_inrange(acc_s[j][8 * s2 + 0], acc_s[j][8 * s2 + 1]);
+                pb.y = pack_e2_inrange(acc_s[j][8 * s2 + 2], acc_s[j][8 * s2 + 3]);
+                pb.z = pack_e2_inrange(acc_s[j][8 * s2 + 4], acc_s[j][8 * s2 + 5]);
+                pb.w = pack_e2_inrange(acc_s[j][8 * s2 + 6], acc_s[j][8 * s2 + 7]);
+                const ex8 pf = __builtin_bit_cast(ex8, pb);
 #pragma unroll
                 for (int d = 0; d < DT; ++d)
-                    acc_o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[s2][d], pf, acc_o[d], 0, 0, 0);
+                    acc_o[d] = TT_MFMA_32x32x16(va[s2][d], pf, acc_o[d]);
             }
         }
     }
@@ -367,8 +367,8 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attention_kernel(AttnParams p)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 uint2 o;
-                o.x = pack_bf16x2(acc_o[d][4 * g + 0] * inv, acc_o[d][4 * g + 1] * inv);
-                o.y = pack_bf16x2(acc_o[d][4 * g + 2] * inv, acc_o[d][4 * g + 3] * inv);
+                o.x = pack_e2(acc_o[d][4 * g + 0] * inv, acc_o[d][4 * g + 1] * inv);
+                o.y = pack_e2(acc_o[d][4 * g + 2] * inv, acc_o[d][4 * g + 3] * inv);
                 *reinterpret_cast<uint2*>(op + 32 * d + 8 * g + 4 * hh) = o;
             }
     }
@@ -393,10 +393,10 @@ __global__ __launch_bounds__(64) void attention_cls_kernel(AttnParams p) {
 #pragma unroll
         for (int c = 0; c < DH / 8; ++c) {
             const uint4 u = *reinterpret_cast<const uint4*>(qp + c * 8);
-            q[c * 8 + 0] = __uint_as_float(u.x << 16); q[c * 8 + 1] = __uint_as_float(u.x & 0xFFFF0000u);
-            q[c * 8 + 2] = __uint_as_float(u.y << 16); q[c * 8 + 3] = __uint_as_float(u.y & 0xFFFF0000u);
-            q[c * 8 + 4] = __uint_as_float(u.z << 16); q[c * 8 + 5] = __uint_as_float(u.z & 0xFFFF0000u);
-            q[c * 8 + 6] = __uint_as_float(u.w << 16); q[c * 8 + 7] = __uint_as_float(u.w & 0xFFFF0000u);
+            q[c * 8 + 0] = elo(u.x); q[c * 8 + 1] = ehi(u.x);
+            q[c * 8 + 2] = elo(u.y); q[c * 8 + 3] = ehi(u.y);
+            q[c * 8 + 4] = elo(u.z); q[c * 8 + 5] = ehi(u.z);
+            q[c * 8 + 6] = elo(u.w); q[c * 8 + 7] = ehi(u.w);
         }
     }
     const float sc = p.scale * 1.4426950408889634f;
@@ -407,14 +407,14 @@ __global__ __launch_bounds__(64) void attention_cls_kernel(AttnParams p) {
 #pragma unroll
         for (int c = 0; c < DH / 8; ++c) {
             const uint4 u = *reinterpret_cast<const uint4*>(kp + c * 8);
-            acc = fmaf(q[c * 8 + 0], __uint_as_float(u.x << 16), acc);
-            acc = fmaf(q[c * 8 + 1], __uint_as_float(u.x & 0xFFFF0000u), acc);
-            acc = fmaf(q[c * 8 + 2], __uint_as_float(u.y << 16), acc);
-            acc = fmaf(q[c * 8 + 3], __uint_as_float(u.y & 0xFFFF0000u), acc);
-            acc = fmaf(q[c * 8 + 4], __uint_as_float(u.z << 16), acc);
-            acc = fmaf(q[c * 8 + 5], __uint_as_float(u.z & 0xFFFF0000u), acc);
-            acc = fmaf(q[c * 8 + 6], __uint_as_float(u.w << 16), acc);
-            acc = fmaf(q[c * 8 + 7], __uint_as_float(u.w & 0xFFFF0000u), acc);
+            acc = fmaf(q[c * 8 + 0], elo(u.x), acc);
+            acc = fmaf(q[c * 8 + 1], ehi(u.x), acc);
+            acc = fmaf(q[c * 8 + 2], elo(u.y), acc);
+            acc = fmaf(q[c * 8 + 3], ehi(u.y), acc);
+            acc = fmaf(q[c * 8 + 4], elo(u.z), acc);
+            acc = fmaf(q[c * 8 + 5], ehi(u.z), acc);
+            acc = fmaf(q[c * 8 + 6], elo(u.w), acc);
+            acc = fmaf(q[c * 8 + 7], ehi(u.w), acc);
         }
         acc *= sc;
         probs[j] = acc;
@@ -441,13 +441,13 @@ __global__ __launch_bounds__(64) void attention_cls_kernel(AttnParams p) {
         const uint4 u = *reinterpret_cast<const uint4*>(p.vt + (size_t)(t0a / 8 + g8) * p.ldvt + (size_t)(head * DH + d) * 8);
         const float4 pa = *reinterpret_cast<const float4*>(probs + g8 * 8);
         const float4 pb = *reinterpret_cast<const float4*>(probs + g8 * 8 + 4);
-        o = fmaf(pa.x, __uint_as_float(u.x << 16), o); o = fmaf(pa.y, __uint_as_float(u.x & 0xFFFF0000u), o);
-        o = fmaf(pa.z, __uint_as_float(u.y << 16), o); o = fmaf(pa.w, __uint_as_float(u.y & 0xFFFF0000u), o);
-        o = fmaf(pb.x, __uint_as_float(u.z << 16), o); o = fmaf(pb.y, __uint_as_float(u.z & 0xFFFF0000u), o);
-        o = fmaf(pb.z, __uint_as_float(u.w << 16), o); o = fmaf(pb.w, __uint_as_float(u.w & 0xFFFF0000u), o);
+        o = fmaf(pa.x, elo(u.x), o); o = fmaf(pa.y, ehi(u.x), o);
+        o = fmaf(pa.z, elo(u.y), o); o = fmaf(pa.w, ehi(u.y), o);
+        o = fmaf(pb.x, elo(u.z), o); o = fmaf(pb.y, ehi(u.z), o);
+        o = fmaf(pb.z, elo(u.w), o); o = fmaf(pb.w, ehi(u.w), o);
     }
     if constexpr (PARTS == 2) o += __shfl_xor(o, 32, 64);
-    if (part == 0) p.out[(size_t)seq * p.ld_out + head * DH + d] = f32_to_bf16_bits(o / sum);
+    if (part == 0) p.out[(size_t)seq * p.ld_out + head * DH + d] = f32_to_ebits(o / sum);
 }
 
 }  // namespace

@@ -7,6 +7,20 @@
 
 #include "../../include/tt_hip.h"
 
+// ---- element type of the 16-bit encoder path ---------------------------------------------------------------------------
+// gemm.hip, attention.hip, rowops.hip and encoder_api.hip are compiled TWICE: as they are (bf16 activations and weights,
+// v_mfma_*_bf16) and with -DTT_F16=1 (IEEE fp16, v_mfma_*_f16: the same matrix rate, three more mantissa bits at every
+// rounding point -- FlagEmbedding's own default for these models, `precision="fp16"` here).  The second set's external
+// functions carry an _f16 suffix (f16_names.h); everything that is not element arithmetic -- tile shapes, LDS images,
+// copy schedules, the wait counts -- is the same source.  Code that is bf16 by definition (the split-bf16 planes, the fp8
+// path's quantiser inputs, the scan) keeps the explicit bf16 helper names below and is dead code in the second set.
+#ifndef TT_F16
+#define TT_F16 0
+#endif
+#if TT_F16
+#include "f16_names.h"
+#endif
+
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -80,6 +94,39 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
     const bf16x2_t v = __builtin_convertvector(f32x2{lo, hi}, bf16x2_t);
     return __builtin_bit_cast(uint32_t, v);
 }
+
+// ---- the element helpers the twice-compiled files use (see TT_F16 above) ---------------------------------------------------
+constexpr bool kF16 = TT_F16 != 0;
+#if TT_F16
+typedef __attribute__((ext_vector_type(8))) _Float16 ex8;            // one MFMA operand fragment (8 elements per lane)
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+// low / high 16 bits of a dword as an element
+__device__ __forceinline__ float elo(uint32_t u) { return (float)__builtin_bit_cast(f16x2_t, u).x; }
+__device__ __forceinline__ float ehi(uint32_t u) { return (float)__builtin_bit_cast(f16x2_t, u).y; }
+__device__ __forceinline__ float ebits_to_f32(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
+// round to nearest even; finite values beyond the format's range saturate at +-65504 instead of becoming infinite
+__device__ __forceinline__ float e_sat(float f) { return __builtin_amdgcn_fmed3f(f, -65504.0f, 65504.0f); }
+__device__ __forceinline__ uint16_t f32_to_ebits(float f) { return __builtin_bit_cast(uint16_t, (_Float16)e_sat(f)); }
+__device__ __forceinline__ uint32_t pack_e2(float lo, float hi) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{e_sat(lo), e_sat(hi)}, f16x2_t));
+}
+// values known to be in range (softmax probabilities): no clamp
+__device__ __forceinline__ uint32_t pack_e2_inrange(float lo, float hi) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{lo, hi}, f16x2_t));
+}
+#define TT_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
+#define TT_MFMA_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+#else
+typedef bf16x8 ex8;
+__device__ __forceinline__ float elo(uint32_t u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float ehi(uint32_t u) { return __uint_as_float(u & 0xFFFF0000u); }
+__device__ __forceinline__ float ebits_to_f32(uint16_t h) { return bf16_bits_to_f32(h); }
+__device__ __forceinline__ uint16_t f32_to_ebits(float f) { return f32_to_bf16_bits(f); }
+__device__ __forceinline__ uint32_t pack_e2(float lo, float hi) { return pack_bf16x2(lo, hi); }
+__device__ __forceinline__ uint32_t pack_e2_inrange(float lo, float hi) { return pack_bf16x2(lo, hi); }
+#define TT_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+#define TT_MFMA_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+#endif
 
 // ---- per-kernel device timing (tt_prof_enable / tt_prof_read) -----------------------------
 enum { TT_K_SCAN_FILTER = 1, TT_K_SCAN_SAMPLE = 2, TT_K_SELECT = 3, TT_K_GEMM = 4, TT_K_ATTENTION = 5, TT_K_ROWOPS = 6,

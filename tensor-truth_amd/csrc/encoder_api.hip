@@ -26,6 +26,7 @@ struct EncWs {
 
 // every layer carries fp8 projections and the shapes fit the fp8 GEMM tiles
 bool fp8_ready(const tt_encoder_weights* w, int n_rows) {
+    if constexpr (kF16) return false;      // (the fp16 instantiation has no e4m3 projections)
     if (w->layers <= 0 || w->hidden % 256 || w->ffn % 256 || n_rows % 256) return false;
     for (int l = 0; l < w->layers; ++l) {
         const tt_layer_weights& lw = w->layer[l];
@@ -306,6 +307,7 @@ int tt_embed_pool_mean(const void* hidden_bf16, int ld, const int32_t* seq_start
                                       (hipStream_t)stream);
 }
 
+#if !TT_F16   // bf16 instantiation only
 int tt_embed_pool_mean_f32(const float* hidden_f32, int ld, const int32_t* seq_start, const int32_t* seq_len, int n_seq, int hidden,
                            float* out_f32, void* out_bf16, void* stream) {
     TT_CHECK_ARG(n_seq >= 0, "n_seq=%d", n_seq);
@@ -316,6 +318,7 @@ int tt_embed_pool_mean_f32(const float* hidden_f32, int ld, const int32_t* seq_s
                                       (hipStream_t)stream);
 }
 
+#endif
 int tt_rerank_head(const tt_encoder_weights* w, const void* hidden_bf16, const int32_t* rows, int n_seq,
                    float* scores, float* logits, void* workspace, size_t workspace_bytes, void* stream) {
     if (int rc = check_weights(w)) return rc;
@@ -345,6 +348,7 @@ int tt_rerank_head(const tt_encoder_weights* w, const void* hidden_bf16, const i
     return tt_head_out_sigmoid_launch(t, H, (const uint16_t*)w->cls_out_w, w->cls_out_b, n_seq, H, scores, logits, st);
 }
 
+#if !TT_F16   // bf16 instantiation only
 int tt_adjacent_cosine(const float* emb_f32, int n, int hidden, float* out_dist, void* stream) {
     TT_CHECK_ARG(n >= 0, "n=%d", n);
     if (n <= 1) return TT_OK;
@@ -353,6 +357,7 @@ int tt_adjacent_cosine(const float* emb_f32, int n, int hidden, float* out_dist,
     return tt_adjacent_cosine_launch(emb_f32, n, hidden, out_dist, (hipStream_t)stream);
 }
 
+#endif
 int tt_gemm_bf16(const void* a, const void* w, const float* bias, const void* residual, void* c, int m, int n,
                  int k, int epilogue, void* stream) {
     TT_CHECK_ARG(epilogue >= TT_EPI_BIAS && epilogue <= TT_EPI_TANH, "epilogue %d", epilogue);
@@ -367,6 +372,7 @@ int tt_gemm_bf16(const void* a, const void* w, const float* bias, const void* re
     return tt_gemm_launch(g, epilogue, (hipStream_t)stream);
 }
 
+#if !TT_F16   // bf16 instantiation only
 int tt_quantize_rows_fp8(const void* in_bf16, int rows, int cols, void* out_fp8, float* out_scale, void* stream) {
     TT_CHECK_ARG(in_bf16 && out_fp8 && out_scale, "null pointer");
     return tt_quantize_rows_launch((const uint16_t*)in_bf16, cols, rows, cols, (uint8_t*)out_fp8, out_scale, (hipStream_t)stream);
@@ -406,6 +412,8 @@ int tt_gemm_fp8_ex(const void* a8, const float* a_scale, const void* w8, const f
 }
 
 // diagnostic only (not in tt_hip.h): the varlen attention with s_memtime stamps of one workgroup (tools/att_stamps)
+#endif
+#if !TT_F16   // bf16 instantiation only
 int tt_attention_debug_stamps(const void* qk, int ld_qk, int q_col0, int k_col0, const void* vt, int ldvt, void* out,
                               int ld_out, const int32_t* seq_start, const int32_t* seq_len, int n_seq, int heads,
                               int head_dim, int max_len, void* stamps, void* stream) {
@@ -427,6 +435,7 @@ int tt_gemm_debug_stamps(const void* a, const void* w, const float* bias, void* 
     return tt_gemm_launch(g, TT_EPI_BIAS, (hipStream_t)stream);
 }
 
+#endif
 int tt_layernorm_bf16(const void* in, void* out, const float* gamma, const float* beta, int rows, int hidden,
                       float eps, void* stream) {
     TT_CHECK_ARG(in && out && gamma && beta, "null pointer");

@@ -70,29 +70,36 @@ __device__ __forceinline__ void gemm_epilogue_tile(const GemmParams& p, f32x4 (&
                 v0 = tanhf(v0); v1 = tanhf(v1); v2 = tanhf(v2); v3 = tanhf(v3);
             } else if constexpr (EPI == TT_EPI_RESIDUAL) {
                 const uint2 r = *reinterpret_cast<const uint2*>(p.residual + (size_t)m * p.ldr + n);
-                v0 += __uint_as_float(r.x << 16);
-                v1 += __uint_as_float(r.x & 0xFFFF0000u);
-                v2 += __uint_as_float(r.y << 16);
-                v3 += __uint_as_float(r.y & 0xFFFF0000u);
+                v0 += elo(r.x);
+                v1 += ehi(r.x);
+                v2 += elo(r.y);
+                v3 += ehi(r.y);
             }
             if constexpr (EPI == TT_EPI_QKV) {
                 if (n >= p.vt_col0) {
                     // V third: store transposed, VT[n - vt_col0][m]
                     // V8 layout: vt[(m / 8) * ldvt + feature * 8 + m % 8]
                     uint16_t* vt = p.vt + (size_t)(m >> 3) * p.ldvt + (size_t)(n - p.vt_col0) * 8 + (m & 7);
-                    vt[0] = f32_to_bf16_bits(v0);
-                    vt[8] = f32_to_bf16_bits(v1);
-                    vt[16] = f32_to_bf16_bits(v2);
-                    vt[24] = f32_to_bf16_bits(v3);
+                    vt[0] = f32_to_ebits(v0);
+                    vt[8] = f32_to_ebits(v1);
+                    vt[16] = f32_to_ebits(v2);
+                    vt[24] = f32_to_ebits(v3);
                     continue;
                 }
             }
             uint2 o;
-            o.x = pack_bf16x2(v0, v1);
-            o.y = pack_bf16x2(v2, v3);
+            o.x = pack_e2(v0, v1);
+            o.y = pack_e2(v2, v3);
             *reinterpret_cast<uint2*>(p.C + (size_t)m * p.ldc + n) = o;
         }
     }
+}
+
+// split-bf16 planes are bf16 whatever the element type of this build is
+template <bool X3>
+__device__ __forceinline__ uint32_t pack_sel(float lo, float hi) {
+    if constexpr (X3) return pack_bf16x2(lo, hi);
+    else return pack_e2(lo, hi);
 }
 
 template <int EPI>
@@ -124,10 +131,10 @@ __device__ __forceinline__ void gemm_epilogue_wide(const GemmParams& p, f32x4 (&
                     const int m = mw + j * 16 + (lane & 15);
                     const float4 b4 = *reinterpret_cast<const float4*>(p.bias + n);
                     uint16_t* vt = p.vt + (size_t)(m >> 3) * p.ldvt + (size_t)(n - p.vt_col0) * 8 + (m & 7);
-                    vt[0] = f32_to_bf16_bits(acc[i][j][0] + b4.x);
-                    vt[8] = f32_to_bf16_bits(acc[i][j][1] + b4.y);
-                    vt[16] = f32_to_bf16_bits(acc[i][j][2] + b4.z);
-                    vt[24] = f32_to_bf16_bits(acc[i][j][3] + b4.w);
+                    vt[0] = f32_to_ebits(acc[i][j][0] + b4.x);
+                    vt[8] = f32_to_ebits(acc[i][j][1] + b4.y);
+                    vt[16] = f32_to_ebits(acc[i][j][2] + b4.z);
+                    vt[24] = f32_to_ebits(acc[i][j][3] + b4.w);
                 }
                 continue;
             }
@@ -157,14 +164,14 @@ __device__ __forceinline__ void gemm_epilogue_wide(const GemmParams& p, f32x4 (&
                 for (int k = 0; k < 8; ++k) v[k] = tanhf(v[k]);
             } else if constexpr (EPI == TT_EPI_RESIDUAL) {
                 const uint4 r = *reinterpret_cast<const uint4*>(p.residual + (size_t)m * p.ldr + n);
-                v[0] += __uint_as_float(r.x << 16); v[1] += __uint_as_float(r.x & 0xFFFF0000u);
-                v[2] += __uint_as_float(r.y << 16); v[3] += __uint_as_float(r.y & 0xFFFF0000u);
-                v[4] += __uint_as_float(r.z << 16); v[5] += __uint_as_float(r.z & 0xFFFF0000u);
-                v[6] += __uint_as_float(r.w << 16); v[7] += __uint_as_float(r.w & 0xFFFF0000u);
+                v[0] += elo(r.x); v[1] += ehi(r.x);
+                v[2] += elo(r.y); v[3] += ehi(r.y);
+                v[4] += elo(r.z); v[5] += ehi(r.z);
+                v[6] += elo(r.w); v[7] += ehi(r.w);
             }
             uint4 o;
-            o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
-            o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
+            o.x = pack_e2(v[0], v[1]); o.y = pack_e2(v[2], v[3]);
+            o.z = pack_e2(v[4], v[5]); o.w = pack_e2(v[6], v[7]);
             if constexpr (CM) *reinterpret_cast<uint4*>(p.C + ((size_t)(n >> 3) * p.M + m) * 8) = o;
             else *reinterpret_cast<uint4*>(p.C + (size_t)m * p.ldc + n) = o;
         }
@@ -206,8 +213,8 @@ __device__ __forceinline__ void gemm_epilogue_vt(const GemmParams& p, f32x4 (&ac
 #pragma unroll
             for (int k = 0; k < 8; ++k) v[k] += b;
             uint4 o;
-            o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
-            o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
+            o.x = pack_sel<X3>(v[0], v[1]); o.y = pack_sel<X3>(v[2], v[3]);
+            o.z = pack_sel<X3>(v[4], v[5]); o.w = pack_sel<X3>(v[6], v[7]);
             *reinterpret_cast<uint4*>(col + (size_t)(m >> 3) * p.ldvt) = o;
             if constexpr (X3) {   // lo plane: what the bf16 rounding of the hi plane left behind
                 uint4 l;
@@ -293,19 +300,19 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_kernel(GemmParams p) {
         const char* tW = cur + kTileBytes;
 #pragma unroll
         for (int ss = 0; ss < 2; ++ss) {
-            bf16x8 wf[4], xf[4];
+            ex8 wf[4], xf[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int rw = wn * 64 + i * 16 + frow;
-                wf[i] = *reinterpret_cast<const bf16x8*>(tW + rw * 128 + (((4 * ss + fchk) ^ ((rw >> 1) & 7)) << 4));
+                wf[i] = *reinterpret_cast<const ex8*>(tW + rw * 128 + (((4 * ss + fchk) ^ ((rw >> 1) & 7)) << 4));
                 const int ra = wm * 64 + i * 16 + frow;
-                xf[i] = *reinterpret_cast<const bf16x8*>(tA + ra * 128 + (((4 * ss + fchk) ^ ((ra >> 1) & 7)) << 4));
+                xf[i] = *reinterpret_cast<const ex8*>(tA + ra * 128 + (((4 * ss + fchk) ^ ((ra >> 1) & 7)) << 4));
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = TT_MFMA_16x16x32(wf[i], xf[j], acc[i][j]);
         }
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): next tile landed
         __syncthreads();
@@ -550,16 +557,16 @@ __device__ __forceinline__ void epilogue_all(const GemmParams& p, f32x4 (&acc)[2
                         for (int k = 0; k < 8; ++k) v[k] = tanhf(v[k]);
                     } else if constexpr (EPI == TT_EPI_RESIDUAL) {
                         const u32x4 r = res[qn][nt];
-                        v[0] += __uint_as_float(r.x << 16); v[1] += __uint_as_float(r.x & 0xFFFF0000u);
-                        v[2] += __uint_as_float(r.y << 16); v[3] += __uint_as_float(r.y & 0xFFFF0000u);
-                        v[4] += __uint_as_float(r.z << 16); v[5] += __uint_as_float(r.z & 0xFFFF0000u);
-                        v[6] += __uint_as_float(r.w << 16); v[7] += __uint_as_float(r.w & 0xFFFF0000u);
+                        v[0] += elo(r.x); v[1] += ehi(r.x);
+                        v[2] += elo(r.y); v[3] += ehi(r.y);
+                        v[4] += elo(r.z); v[5] += ehi(r.z);
+                        v[6] += elo(r.w); v[7] += ehi(r.w);
                     }
                     const int m = m0 + qm * 128 + mrow + (pr * 2 + (odd ? 1 : 0)) * 16;
                     const int n = n0 + qn * 32 + nt * 16 + ncol;
                     uint4 o;
-                    o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
-                    o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
+                    o.x = pack_e2(v[0], v[1]); o.y = pack_e2(v[2], v[3]);
+                    o.z = pack_e2(v[4], v[5]); o.w = pack_e2(v[6], v[7]);
                     if constexpr (STAGE) {
                         lds_write128_async(raddr[qn][nt] + kOffB[qm * 2 + pr], o);
                     } else {
@@ -809,12 +816,12 @@ __device__ __forceinline__ void scan_filter_epilogue(const GemmParams& p, f32x4 
     } while (0)
 
 typedef int v8i __attribute__((ext_vector_type(8)));
-struct Frag2 { bf16x8 lo, hi; };
+struct Frag2 { ex8 lo, hi; };
 // one K = 128 step of e4m3 products (v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales: twice the cycles of
 // the bf16 16x16x32 form at four times the K).  Lane (row, g) supplies bytes [16 g, 16 g + 16) and
 // [64 + 16 g, 64 + 16 g + 16) of its row's 128-byte K-tile for BOTH operands -- the two fragments the bf16 path
 // reads -- which is a permutation of k the instruction applies to both operands alike.
-__device__ __forceinline__ f32x4 mfma_fp8(const bf16x8& a0, const bf16x8& a1, const bf16x8& b0, const bf16x8& b1, f32x4 c) {
+__device__ __forceinline__ f32x4 mfma_fp8(const ex8& a0, const ex8& a1, const ex8& b0, const ex8& b1, f32x4 c) {
     const v8i a = __builtin_bit_cast(v8i, Frag2{a0, a1});
     const v8i b = __builtin_bit_cast(v8i, Frag2{b0, b1});
     return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
@@ -955,26 +962,26 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
     const bool late = wave >= 4;   // (grouping by SIMD parity instead, both waves of a SIMD in the same slot: -36 %)
     if (late) TT_SLOT_END();   // waves 4-7 run one slot behind
 
-    bf16x8 xf[4][2], wf0[2][2], wf1[2][2];
+    ex8 xf[4][2], wf0[2][2], wf1[2][2];
 
     auto read_a = [&](const char* base) {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
-            xf[mt][0] = *reinterpret_cast<const bf16x8*>(base + a_row0 + mt * 2048 + off0);
-            xf[mt][1] = *reinterpret_cast<const bf16x8*>(base + a_row0 + mt * 2048 + off1);
+            xf[mt][0] = *reinterpret_cast<const ex8*>(base + a_row0 + mt * 2048 + off0);
+            xf[mt][1] = *reinterpret_cast<const ex8*>(base + a_row0 + mt * 2048 + off1);
         }
     };
-    auto read_w = [&](bf16x8(&wf)[2][2], const char* base) {
+    auto read_w = [&](ex8(&wf)[2][2], const char* base) {
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
-            wf[nt][0] = *reinterpret_cast<const bf16x8*>(base + w_row0 + nt * 2048 + off0);
-            wf[nt][1] = *reinterpret_cast<const bf16x8*>(base + w_row0 + nt * 2048 + off1);
+            wf[nt][0] = *reinterpret_cast<const ex8*>(base + w_row0 + nt * 2048 + off0);
+            wf[nt][1] = *reinterpret_cast<const ex8*>(base + w_row0 + nt * 2048 + off1);
         }
     };
     // Tiles of the V third of a QKV projection are produced un-swapped (a = X, b = W): a lane then holds 4
     // consecutive TOKENS of one feature, which is what the transposed V^T store wants.
     constexpr bool vblk = (EPI == TT_EPI_VT);
-    auto mma = [&](f32x4(&c)[2][4], const bf16x8(&wf)[2][2]) {
+    auto mma = [&](f32x4(&c)[2][4], const ex8(&wf)[2][2]) {
         __builtin_amdgcn_s_setprio(1);
         if constexpr (FP8) {
 #pragma unroll
@@ -991,7 +998,7 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
                 for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                     for (int mt = 0; mt < 4; ++mt)
-                        c[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[mt][ss], wf[nt][ss], c[nt][mt], 0, 0, 0);
+                        c[nt][mt] = TT_MFMA_16x16x32(xf[mt][ss], wf[nt][ss], c[nt][mt]);
         } else {
 #pragma unroll
             for (int ss = 0; ss < 2; ++ss)
@@ -999,7 +1006,7 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
                 for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                     for (int mt = 0; mt < 4; ++mt)
-                        c[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt][ss], xf[mt][ss], c[nt][mt], 0, 0, 0);
+                        c[nt][mt] = TT_MFMA_16x16x32(wf[nt][ss], xf[mt][ss], c[nt][mt]);
         }
         __builtin_amdgcn_s_setprio(0);
     };
@@ -1252,22 +1259,22 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_p(GemmParams p, int 
                 for (int c = 0; c < 2; ++c)
 #pragma unroll
                     for (int d = 0; d < 4; ++d) acc[a][b][c][d] = f32x4{0.f, 0.f, 0.f, 0.f};
-        bf16x8 xf[4][2], wf0[2][2], wf1[2][2];
+        ex8 xf[4][2], wf0[2][2], wf1[2][2];
         auto read_a = [&](const char* base) {
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
-                xf[mt][0] = *reinterpret_cast<const bf16x8*>(base + a_row0 + mt * 2048 + off0);
-                xf[mt][1] = *reinterpret_cast<const bf16x8*>(base + a_row0 + mt * 2048 + off1);
+                xf[mt][0] = *reinterpret_cast<const ex8*>(base + a_row0 + mt * 2048 + off0);
+                xf[mt][1] = *reinterpret_cast<const ex8*>(base + a_row0 + mt * 2048 + off1);
             }
         };
-        auto read_w = [&](bf16x8(&wf)[2][2], const char* base) {
+        auto read_w = [&](ex8(&wf)[2][2], const char* base) {
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
-                wf[nt][0] = *reinterpret_cast<const bf16x8*>(base + w_row0 + nt * 2048 + off0);
-                wf[nt][1] = *reinterpret_cast<const bf16x8*>(base + w_row0 + nt * 2048 + off1);
+                wf[nt][0] = *reinterpret_cast<const ex8*>(base + w_row0 + nt * 2048 + off0);
+                wf[nt][1] = *reinterpret_cast<const ex8*>(base + w_row0 + nt * 2048 + off1);
             }
         };
-        auto mma = [&](f32x4(&c)[2][4], const bf16x8(&wf)[2][2]) {
+        auto mma = [&](f32x4(&c)[2][4], const ex8(&wf)[2][2]) {
             __builtin_amdgcn_s_setprio(1);
             if constexpr (FP8) {
 #pragma unroll
@@ -1281,7 +1288,7 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_p(GemmParams p, int 
                     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                         for (int mt = 0; mt < 4; ++mt)
-                            c[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt][ss], xf[mt][ss], c[nt][mt], 0, 0, 0);
+                            c[nt][mt] = TT_MFMA_16x16x32(wf[nt][ss], xf[mt][ss], c[nt][mt]);
             }
             __builtin_amdgcn_s_setprio(0);
         };
@@ -1487,7 +1494,7 @@ __global__ __launch_bounds__(64) void gemm_skinny_kernel(GemmParams p) {
     f32x4 acc[1][MT];
 #pragma unroll
     for (int j = 0; j < MT; ++j) acc[0][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    bf16x8 wb[PF], ab[PF][MT];
+    ex8 wb[PF], ab[PF][MT];
     const int nks1 = p.K / 32;
     const int nks = X3 ? 3 * nks1 : nks1;
     auto step_a = [&](int s) { if constexpr (X3) return s < nks1 ? s : s - nks1; else return s; };
@@ -1495,9 +1502,9 @@ __global__ __launch_bounds__(64) void gemm_skinny_kernel(GemmParams p) {
 #pragma unroll
     for (int s = 0; s < PF; ++s)
         if (s < nks) {
-            wb[s] = *reinterpret_cast<const bf16x8*>(wp + step_w(s) * 32);
+            wb[s] = *reinterpret_cast<const ex8*>(wp + step_w(s) * 32);
 #pragma unroll
-            for (int j = 0; j < MT; ++j) ab[s][j] = *reinterpret_cast<const bf16x8*>(ap + j * a16 + step_a(s) * 32);
+            for (int j = 0; j < MT; ++j) ab[s][j] = *reinterpret_cast<const ex8*>(ap + j * a16 + step_a(s) * 32);
         }
     for (int ks = 0; ks < nks; ks += PF) {
 #pragma unroll
@@ -1505,12 +1512,12 @@ __global__ __launch_bounds__(64) void gemm_skinny_kernel(GemmParams p) {
             if (ks + s < nks) {
 #pragma unroll
                 for (int j = 0; j < MT; ++j)
-                    acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[s], ab[s][j], acc[0][j], 0, 0, 0);
+                    acc[0][j] = TT_MFMA_16x16x32(wb[s], ab[s][j], acc[0][j]);
                 const int nx = ks + s + PF;
                 if (nx < nks) {
-                    wb[s] = *reinterpret_cast<const bf16x8*>(wp + step_w(nx) * 32);
+                    wb[s] = *reinterpret_cast<const ex8*>(wp + step_w(nx) * 32);
 #pragma unroll
-                    for (int j = 0; j < MT; ++j) ab[s][j] = *reinterpret_cast<const bf16x8*>(ap + j * a16 + step_a(nx) * 32);
+                    for (int j = 0; j < MT; ++j) ab[s][j] = *reinterpret_cast<const ex8*>(ap + j * a16 + step_a(nx) * 32);
                 }
             }
         }
@@ -1601,7 +1608,7 @@ int launch_skinny(const GemmParams& p, hipStream_t st) {
 
 template <int EPI>
 int launch(const GemmParams& p, hipStream_t st) {
-    if (p.fp8) return launch_fp8<EPI>(p, st);
+    if constexpr (!kF16) if (p.fp8) return launch_fp8<EPI>(p, st);
     static const bool trace = [] { const char* e = getenv("TT_GEMM_TRACE"); return e && e[0] == '1'; }();
     if (trace) fprintf(stderr, "gemm launch<%d> M=%d N=%d K=%d lda=%d ldc=%d ldr=%d\n", EPI, p.M, p.N, p.K, p.lda, p.ldc, p.ldr);
     static const int variant = [] { const char* e = getenv("TT_GEMM_VARIANT"); return e && e[0] ? atoi(e) : 5; }();
@@ -1697,7 +1704,10 @@ bool tt_gemm_skinny_enabled() {
 
 int tt_gemm_launch(const GemmParams& p, int epilogue, hipStream_t st) {
     if (p.M <= 0 || p.N <= 0) return TT_OK;
-    if (p.x3) {
+    if constexpr (kF16) {      // the fp16 instantiation serves the plain 16-bit path only
+        if (p.x3 || p.fp8) { tt_set_error("gemm (fp16 build): split-bf16 / fp8 operands belong to the bf16 instantiation"); return TT_E_UNSUPPORTED; }
+    }
+    if constexpr (!kF16) if (p.x3) {
         switch (epilogue) {
             case TT_EPI_BIAS: return launch_x3<TT_EPI_BIAS>(p, st);
             case TT_EPI_GELU: return launch_x3<TT_EPI_GELU>(p, st);
@@ -1706,7 +1716,7 @@ int tt_gemm_launch(const GemmParams& p, int epilogue, hipStream_t st) {
             default: tt_set_error("gemm x3: epilogue %d has no split-bf16 form", epilogue); return TT_E_UNSUPPORTED;
         }
     }
-    if (p.fp8 && epilogue == TT_EPI_QKV) {
+    if constexpr (!kF16) if (p.fp8 && epilogue == TT_EPI_QKV) {
         // fp8 QKV projection: Q,K columns as a bias GEMM, V columns as un-swapped tiles stored transposed
         if (!p.vt || p.vt_col0 % v3::BN3 || (p.N - p.vt_col0) % v3::BN3 || p.ldvt % 8) {
             tt_set_error("gemm fp8: bad qkv split");
@@ -1785,6 +1795,8 @@ int tt_gemm_launch(const GemmParams& p, int epilogue, hipStream_t st) {
 int tt_scan_gemm_launch(const uint16_t* corpus, int64_t rows, int dim, const uint16_t* queries256, const float* thr256,
                         int32_t* cnt, float* cand_scores, int32_t* cand_idx, int cap, int32_t idx_base, hipStream_t st) {
     if (rows <= 0) return TT_OK;
+    if constexpr (kF16) { tt_set_error("scan gemm: the corpus is bf16 (bf16 instantiation only)"); return TT_E_UNSUPPORTED; }
+    else
     if (rows % v3::BM3 || dim % 128 || dim <= 0 || rows / v3::BM3 > (1 << 24)) {
         tt_set_error("scan gemm: rows=%lld must be a multiple of 256, dim=%d of 128", (long long)rows, dim);
         return TT_E_UNSUPPORTED;

@@ -21,16 +21,16 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 __device__ __forceinline__ void unpack8(const uint4& u, float (&f)[8]) {
-    f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xFFFF0000u);
-    f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xFFFF0000u);
-    f[4] = __uint_as_float(u.z << 16); f[5] = __uint_as_float(u.z & 0xFFFF0000u);
-    f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xFFFF0000u);
+    f[0] = elo(u.x); f[1] = ehi(u.x);
+    f[2] = elo(u.y); f[3] = ehi(u.y);
+    f[4] = elo(u.z); f[5] = ehi(u.z);
+    f[6] = elo(u.w); f[7] = ehi(u.w);
 }
 
 __device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
     uint4 u;
-    u.x = pack_bf16x2(f[0], f[1]); u.y = pack_bf16x2(f[2], f[3]);
-    u.z = pack_bf16x2(f[4], f[5]); u.w = pack_bf16x2(f[6], f[7]);
+    u.x = pack_e2(f[0], f[1]); u.y = pack_e2(f[2], f[3]);
+    u.z = pack_e2(f[4], f[5]); u.w = pack_e2(f[6], f[7]);
     return u;
 }
 

@@ -38,9 +38,9 @@ def _report_unused_kwargs(model_name: str, model_kwargs, tokenizer_kwargs) -> No
     them here instead of dropping them silently."""
     mk = model_kwargs or {}
     td = mk.get("torch_dtype")
-    if td is not None and str(td).replace("torch.", "") not in ("bfloat16", "float32", "fp32"):
+    if td is not None and str(td).replace("torch.", "") not in ("bfloat16", "float16", "float32", "fp32"):
         logger.warning("%s: torch_dtype=%s is not available on the HIP path; computing in bfloat16 "
-                       "(fp32 accumulation). Supported: 'bfloat16' (default), 'float32'.", model_name, td)
+                       "(fp32 accumulation). Supported: 'bfloat16' (default), 'float16', 'float32'.", model_name, td)
     if mk.get("attn_implementation"):
         logger.info("%s: attn_implementation=%s ignored -- attention is always the fused varlen HIP kernel "
                     "(no padding tokens are computed)", model_name, mk["attn_implementation"])

@@ -111,17 +111,21 @@ class EncoderWeights:
     Matrices are stored bf16, biases and LayerNorm parameters fp32.
     """
 
-    def __init__(self, cfg: EncoderConfig, state: Dict[str, torch.Tensor], device: torch.device):
+    def __init__(self, cfg: EncoderConfig, state: Dict[str, torch.Tensor], device: torch.device,
+                 dtype: torch.dtype = torch.bfloat16):
         if device.type != "cuda":
             raise RuntimeError("EncoderWeights need a HIP device; tensor_truth_amd has no CPU path")
+        if dtype not in (torch.bfloat16, torch.float16):
+            raise ValueError("EncoderWeights: the 16-bit path computes in bfloat16 or float16")
         self.cfg = cfg
         self.device = device
+        self.dtype = dtype           # element type of matrices and activations: bf16, or fp16 (libtt_hip's *_f16 entry points)
         sd = _strip_prefix(state)
         self._keep: List[torch.Tensor] = []
         self._named: Dict[str, torch.Tensor] = {}     # HF name -> the resident tensor (state_dict())
 
         def mat(name):
-            t = sd[name].to(device=device, dtype=torch.bfloat16).contiguous()
+            t = sd[name].to(device=device, dtype=dtype).contiguous()
             self._keep.append(t)
             self._named[name] = t
             return t
@@ -152,7 +156,7 @@ class EncoderWeights:
             p = f"encoder.layer.{i}."
             qkv_w = torch.cat([sd[p + f"attention.self.{n}.weight"] for n in ("query", "key", "value")], 0)
             qkv_b = torch.cat([sd[p + f"attention.self.{n}.bias"] for n in ("query", "key", "value")], 0)
-            qkv_w = qkv_w.to(device=device, dtype=torch.bfloat16).contiguous()
+            qkv_w = qkv_w.to(device=device, dtype=dtype).contiguous()
             qkv_b = qkv_b.to(device=device, dtype=torch.float32).contiguous()
             self._keep += [qkv_w, qkv_b]
             for j, nm in enumerate(("query", "key", "value")):
@@ -208,6 +212,8 @@ class EncoderWeights:
         multiples of 256; the bf16 weights stay resident (CLS tail, small batches)."""
         if dtype not in ("bf16", "fp8"):
             raise ValueError(f"gemm dtype {dtype!r} not in ('bf16', 'fp8')")
+        if dtype == "fp8" and self.dtype != torch.bfloat16:
+            raise ValueError("fp8 projections exist for bf16 encoders only")
         n = self.cfg.layers
         if dtype == "fp8":
             if self.cfg.hidden % 256 or self.cfg.ffn % 256:
@@ -497,6 +503,11 @@ class Encoder:
         self.lib = _lib.load_library()
         # one forward (scratch lookup + every launch of it) is enqueued atomically: the workspace is shared per stream
         self._enqueue_lock = _ENQUEUE_LOCKS.setdefault((self.device.type, self.device.index), threading.Lock())
+        self._sfx = "_f16" if weights.dtype == torch.float16 else ""
+
+    def _fn(self, name: str):
+        """The entry point for this encoder's element type: ``name`` (bf16) or its fp16 twin ``name_f16``."""
+        return getattr(self.lib, name + self._sfx)
 
     def _upload(self, batch: PackedBatch):
         """Token arrays of a batch -> device int32 views (ids, pos, types | None, seq_start, seq_len): one pinned
@@ -527,11 +538,11 @@ class Encoder:
         """-> (hidden [n_rows, H] bf16, cls_rows [B] int32 device tensor[, seq_len [B] int32 device tensor])."""
         lib, dev, H = self.lib, self.device, self.cfg.hidden
         ids, pos, types, starts, lens = self._upload(batch)
-        hidden = torch.empty((batch.n_rows, H), dtype=torch.bfloat16, device=dev)
-        need = lib.tt_encoder_workspace_bytes(ctypes.byref(self.w.struct), batch.n_rows)
+        hidden = torch.empty((batch.n_rows, H), dtype=self.w.dtype, device=dev)
+        need = self._fn("tt_encoder_workspace_bytes")(ctypes.byref(self.w.struct), batch.n_rows)
         with self._enqueue_lock, torch.cuda.device(dev):
             ws, base = _scratch.get("enc", dev, need)
-            rc = lib.tt_encoder_forward(ctypes.byref(self.w.struct), ids.data_ptr(), pos.data_ptr(),
+            rc = self._fn("tt_encoder_forward")(ctypes.byref(self.w.struct), ids.data_ptr(), pos.data_ptr(),
                                         types.data_ptr() if types is not None else None, starts.data_ptr(),
                                         lens.data_ptr(), len(batch.seq_len), batch.n_rows, batch.max_len,
                                         hidden.data_ptr(), base, need, torch.cuda.current_stream(dev).cuda_stream)
@@ -566,11 +577,11 @@ class Encoder:
         B = len(batch.seq_len)
         ids, pos, types, starts, lens = self._upload(batch)
         b_pad = (B + 255) // 256 * 256
-        cls = torch.empty((b_pad, H), dtype=torch.bfloat16, device=dev)
-        need = lib.tt_encoder_cls_workspace_bytes(ctypes.byref(self.w.struct), batch.n_rows, B)
+        cls = torch.empty((b_pad, H), dtype=self.w.dtype, device=dev)
+        need = self._fn("tt_encoder_cls_workspace_bytes")(ctypes.byref(self.w.struct), batch.n_rows, B)
         with self._enqueue_lock, torch.cuda.device(dev):
             ws, base = _scratch.get("enc", dev, need)
-            rc = lib.tt_encoder_forward_cls(ctypes.byref(self.w.struct), ids.data_ptr(), pos.data_ptr(),
+            rc = self._fn("tt_encoder_forward_cls")(ctypes.byref(self.w.struct), ids.data_ptr(), pos.data_ptr(),
                                             types.data_ptr() if types is not None else None, starts.data_ptr(),
                                             lens.data_ptr(), B, batch.n_rows, batch.max_len, cls.data_ptr(), base, need,
                                             torch.cuda.current_stream(dev).cuda_stream)
@@ -583,22 +594,26 @@ class Encoder:
         runs for the CLS rows only) or "mean" (sentence-transformers mean pooling over a sequence's tokens: full last layer)."""
         B, H = len(batch.seq_len), self.cfg.hidden
         out = torch.empty((B, H), dtype=torch.float32, device=self.device)
-        out16 = torch.empty((B, H), dtype=torch.bfloat16, device=self.device)
+        # the 16-bit copy of an embedding is a SCAN QUERY, i.e. bf16 like the corpus: the bf16 kernels write it themselves, in
+        # the fp16 mode it is rounded from the fp32 vector here (round to nearest even either way)
+        f16 = self.w.dtype == torch.float16
+        out16 = None if f16 else torch.empty((B, H), dtype=torch.bfloat16, device=self.device)
+        o16 = None if f16 else out16.data_ptr()
         if pooling == "mean":
             hidden, starts, lens = self.forward_packed(batch, want_lens=True)
             with torch.cuda.device(self.device):
-                rc = self.lib.tt_embed_pool_mean(hidden.data_ptr(), H, starts.data_ptr(), lens.data_ptr(), B, H, out.data_ptr(),
-                                                 out16.data_ptr(), torch.cuda.current_stream(self.device).cuda_stream)
+                rc = self._fn("tt_embed_pool_mean")(hidden.data_ptr(), H, starts.data_ptr(), lens.data_ptr(), B, H, out.data_ptr(),
+                                                    o16, torch.cuda.current_stream(self.device).cuda_stream)
             _lib.check(rc, "tt_embed_pool_mean")
-            return out, out16
+            return out, (out.to(torch.bfloat16) if f16 else out16)
         if pooling != "cls":
             raise ValueError(f"pooling '{pooling}' (supported: 'cls', 'mean')")
         hidden, cls_rows = self.cls_hidden_packed(batch)
         with torch.cuda.device(self.device):
-            rc = self.lib.tt_embed_pool(hidden.data_ptr(), H, cls_rows.data_ptr(), B, H, out.data_ptr(), out16.data_ptr(),
-                                        torch.cuda.current_stream(self.device).cuda_stream)
+            rc = self._fn("tt_embed_pool")(hidden.data_ptr(), H, cls_rows.data_ptr(), B, H, out.data_ptr(), o16,
+                                           torch.cuda.current_stream(self.device).cuda_stream)
         _lib.check(rc, "tt_embed_pool")
-        return out, out16
+        return out, (out.to(torch.bfloat16) if f16 else out16)
 
     def rerank_packed(self, batch: PackedBatch, want_logits: bool = False):
         """-> sigmoid scores fp32 [B] (and logits)."""
@@ -612,7 +627,7 @@ class Encoder:
         need = 2 * ((n_pad * H * 2 + 255) // 256 * 256)
         with self._enqueue_lock, torch.cuda.device(self.device):
             ws, base = _scratch.get("head", self.device, need)
-            rc = self.lib.tt_rerank_head(ctypes.byref(self.w.struct), hidden.data_ptr(), cls_rows.data_ptr(), B,
+            rc = self._fn("tt_rerank_head")(ctypes.byref(self.w.struct), hidden.data_ptr(), cls_rows.data_ptr(), B,
                                          scores.data_ptr(), logits.data_ptr() if want_logits else None, base, need,
                                          torch.cuda.current_stream(self.device).cuda_stream)
         _lib.check(rc, "tt_rerank_head")

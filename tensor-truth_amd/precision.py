@@ -10,10 +10,14 @@ package computes by default.  The unchanged reference calls can still get the re
                       the bf16 matrix cores (``encoder_x3``, a third of the bf16 rate) when the model shape allows,
                       else on the fp32 MFMA (``encoder_f32``).  ``TT_REFERENCE_IMPL=fp32`` forces the latter.
     mode "bf16"       bf16 weights / activations, fp32 accumulate (default; BASELINE configs 2-4)
+    mode "fp16"       IEEE fp16 weights / activations, fp32 accumulate: the bf16 mode's rate (v_mfma_*_f16) with three more
+                      mantissa bits at every rounding point -- scores about ten times closer to the reference than bf16;
+                      what the reference's ``torch_dtype: "float16"`` asks for, and FlagEmbedding's own default for the BGE
+                      models.  Values beyond +-65504 saturate at the GEMM / LayerNorm outputs.
     mode "fp8"        the layer projections in OCP e4m3 (BASELINE config 5's "fp8 MFMA reranker")
 
 Resolution order (first that says something): ``model_kwargs["precision"]``; ``model_kwargs["torch_dtype"]`` (float32 ->
-reference; bfloat16 / float16 -> bf16) and ``model_kwargs["gemm_dtype"]``; ``ModelManager.precision`` (a config key the
+reference; float16 -> fp16; bfloat16 -> bf16) and ``model_kwargs["gemm_dtype"]``; ``ModelManager.precision`` (a config key the
 application sets once; ModelManager puts it into the model_kwargs it builds); the process environment ``TT_PRECISION``;
 "bf16".  The active mode is logged when a model is loaded.
 """
@@ -25,9 +29,9 @@ from typing import Any, Dict, Optional, Tuple
 
 logger = logging.getLogger(__name__)
 
-MODES = ("bf16", "fp8", "reference")
-_ALIASES = {"bf16": "bf16", "bfloat16": "bf16", "fp8": "fp8", "e4m3": "fp8", "reference": "reference", "fp32": "reference",
-            "float32": "reference", "float": "reference", "bf16x3": "reference"}
+MODES = ("bf16", "fp16", "fp8", "reference")
+_ALIASES = {"bf16": "bf16", "bfloat16": "bf16", "fp16": "fp16", "float16": "fp16", "half": "fp16", "fp8": "fp8", "e4m3": "fp8",
+            "reference": "reference", "fp32": "reference", "float32": "reference", "float": "reference", "bf16x3": "reference"}
 
 
 def canonical(value) -> str:
@@ -46,8 +50,10 @@ def resolve(model_kwargs: Optional[Dict[str, Any]] = None, environ=None) -> str:
         t = str(td).replace("torch.", "")
         if t in ("float32", "fp32", "float"):
             return "reference"
+        if t in ("float16", "fp16", "half") and mk.get("gemm_dtype") is None:
+            return "fp16"
         if mk.get("gemm_dtype") is None:
-            return "bf16"          # bfloat16, and float16 / anything else the HIP path maps to bf16 (logged by the callers)
+            return "bf16"          # bfloat16, and anything else the HIP path maps to bf16 (logged by the callers)
     if mk.get("gemm_dtype") is not None:
         return canonical(mk["gemm_dtype"])
     env = (os.environ if environ is None else environ).get("TT_PRECISION")
@@ -82,6 +88,11 @@ def build_encoder(cfg, state, device, model_kwargs: Optional[Dict[str, Any]], wh
 
             w = EncoderWeightsF32(cfg, state, device)
             enc, desc = EncoderF32(w), "reference (fp32 weights, activations and MFMA)"
+    elif mode == "fp16":
+        import torch
+
+        w = EncoderWeights(cfg, state, device, dtype=torch.float16)
+        enc, desc = Encoder(w), "fp16 (fp32 accumulate)"
     else:
         w = EncoderWeights(cfg, state, device)
         w.set_gemm_dtype(mode)

@@ -22,6 +22,7 @@ SHAPE = dict(arch="xlmr", vocab_size=8192, hidden=1024, layers=24, heads=16, ffn
 WEIGHT_SEED = 17
 GOLDEN_NAME = "rank_oracle_24L_4x50x292.npz"   # tests/golden/make_rank_golden.py
 BF16_BOUND = 2e-2      # stated absolute bound of the bf16 mode on a sigmoid score after 24 layers
+FP16_BOUND = 3e-3      # ... of the fp16 mode (same rate, three more mantissa bits per rounding point; measured 1.7e-3)
 FP8_BOUND = 0.2        # stated bound of the fp8 throughput mode; its QUALITY gate is rank agreement, below
 
 
@@ -76,7 +77,7 @@ def _product_scores(dev, W, pairs, gemm_dtype):
     from tensor_truth_amd.encoder import Encoder, EncoderConfig, EncoderWeights, pack_token_matrix
 
     cfg = EncoderConfig(**SHAPE)
-    enc = Encoder(EncoderWeights(cfg, W, dev))
+    enc = Encoder(EncoderWeights(cfg, W, dev, dtype=torch.float16 if gemm_dtype == "fp16" else torch.bfloat16))
     flat = pairs.reshape(-1, PAIR_TOKENS).astype(np.int32)
     batch = pack_token_matrix(flat, cfg)
     if gemm_dtype == "fp8":
@@ -126,6 +127,30 @@ def test_bf16_top10_of_50_at_full_depth(dev, built_lib, oracle_scores):
             n_exact2 += int(assert_topn_on_separable(w2[q].numpy(), g2[q].numpy(), TOP_N, 2 * e2, f"scaled head x{a:g}, query {q}")[2])
         print(f"  head scaled x{a:g}: oracle scores span {w2.min().item():.2f}..{w2.max().item():.2f}, bf16 max |err| {e2:.3f}; "
               f"exact top-{TOP_N} set decidable (cut gap > 2 x err) on {n_exact2}/{N_QUERIES} queries")
+
+
+def test_fp16_top10_of_50_at_full_depth(dev, built_lib, oracle_scores):
+    """The fp16 mode (`precision="fp16"`): the bf16 mode's rate, an order of magnitude closer to the oracle -- so the gate that is
+    thin for bf16 (few separable pairs, top-10 membership rarely decidable) has teeth here."""
+    ocfg, W, pairs, want = oracle_scores
+    got = _product_scores(dev, W, pairs, "fp16")
+    err = (got - want).abs().max().item()
+    assert err <= FP16_BOUND, f"fp16 score error after 24 layers: {err}"
+    n_sep = n_in = n_out = n_exact = 0
+    for q in range(N_QUERIES):
+        n_sep += assert_order_on_separable(want[q].numpy(), got[q].numpy(), 2 * FP16_BOUND, f"query {q}")
+        a, b, exact = assert_topn_on_separable(want[q].numpy(), got[q].numpy(), TOP_N, 2 * FP16_BOUND, f"query {q}")
+        n_in, n_out, n_exact = n_in + a, n_out + b, n_exact + int(exact)
+    total = N_QUERIES * N_PAIRS * (N_PAIRS - 1) // 2
+    taus = [kendall_tau(want[q].numpy(), got[q].numpy()) for q in range(N_QUERIES)]
+    over = [topn_overlap(want[q].numpy(), got[q].numpy(), TOP_N) for q in range(N_QUERIES)]
+    print(f"fp16 @24L, {N_QUERIES}x{N_PAIRS} pairs x {PAIR_TOKENS} tok: max |err| {err:.5f}; {n_sep}/{total} pairs separable "
+          f"at gap > {2 * FP16_BOUND} all ordered as the oracle; top-{TOP_N}: {n_in} decisive members in, {n_out} decisive "
+          f"non-members out, exact set required for {n_exact}/{N_QUERIES} queries; Kendall tau {min(taus):.3f}..{max(taus):.3f}; "
+          f"top-{TOP_N} overlap {min(over):.2f}..{max(over):.2f}")
+    assert n_sep >= total * 6 // 10, (n_sep, total)                 # most pairs are separable at this bound (bf16: ~a quarter)
+    assert n_in + n_out >= N_QUERIES * 35                            # and most of the 50 candidates are decisive for the top-10
+    assert min(taus) >= 0.97 and min(over) >= 0.9
 
 
 def test_fp8_rank_quality_at_full_depth(dev, built_lib, oracle_scores):

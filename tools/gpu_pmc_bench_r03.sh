@@ -7,7 +7,7 @@
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-LEGS="--no-cpu-baseline --no-fp8-leg --no-reference-leg --no-surface-leg --no-config5-leg"
+LEGS="--no-cpu-baseline --no-fp8-leg --no-reference-leg --no-fp16-leg --no-surface-leg --no-config5-leg"
 rm -rf gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_mfma gpurun_out/prof_headline
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch -- python3 bench.py --steps 1 --warmup 1 $LEGS > gpurun_out/pmc_fetch.log 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write -- python3 bench.py --steps 1 --warmup 1 $LEGS > gpurun_out/pmc_write.log 2>&1
