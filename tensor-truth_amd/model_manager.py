@@ -81,7 +81,7 @@ class ModelManager:
         self._model_lock = threading.Lock()
         self.embedding_model_configs: Dict[str, Dict] = dict(DEFAULT_EMBEDDING_MODEL_CONFIGS)
         self.model_kwargs_overrides: Dict[str, Dict[str, Any]] = {}  # model name -> extra model_kwargs
-        # Process-level precision of the models this manager loads: None (= TT_PRECISION, else bf16), "bf16", "fp8" or
+        # Process-level precision of the models this manager loads: None (= TT_PRECISION, else bf16), "bf16", "fp16", "fp8" or
         # "reference" -- the reference's own fp32 semantics for its unchanged calls (precision.py).  Set it before the
         # first get_embedder / get_reranker, or call set_precision() (drops the resident models).
         self.precision: Optional[str] = None
