@@ -105,7 +105,10 @@ __device__ __forceinline__ float elo(uint32_t u) { return (float)__builtin_bit_c
 __device__ __forceinline__ float ehi(uint32_t u) { return (float)__builtin_bit_cast(f16x2_t, u).y; }
 __device__ __forceinline__ float ebits_to_f32(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
 // round to nearest even; finite values beyond the format's range saturate at +-65504 instead of becoming infinite
-__device__ __forceinline__ float e_sat(float f) { return __builtin_amdgcn_fmed3f(f, -65504.0f, 65504.0f); }
+#ifndef TT_F16_SAT
+#define TT_F16_SAT 1
+#endif
+__device__ __forceinline__ float e_sat(float f) { return TT_F16_SAT ? __builtin_amdgcn_fmed3f(f, -65504.0f, 65504.0f) : f; }
 __device__ __forceinline__ uint16_t f32_to_ebits(float f) { return __builtin_bit_cast(uint16_t, (_Float16)e_sat(f)); }
 __device__ __forceinline__ uint32_t pack_e2(float lo, float hi) {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{e_sat(lo), e_sat(hi)}, f16x2_t));
