@@ -200,3 +200,23 @@ def test_precision_selector_reaches_the_fp16_mode(dev, built_lib):
         EncoderWeights(cfg, W, torch.device(dev), dtype=torch.float16).set_gemm_dtype("fp8")
     scores = rr.predict([("alpha beta", "gamma delta epsilon"), ("alpha beta", "zeta eta")])
     assert len(scores) == 2 and all(0.0 < s < 1.0 for s in scores)
+    # the embedder through the same selector; the process-level switch (ModelManager) hands the mode to what it loads
+    from tensor_truth_amd.embedding import HipHuggingFaceEmbedding
+    from tensor_truth_amd.model_manager import ModelManager
+
+    cfgb = EncoderConfig(**SMALL_B)
+    Wb = oe.synth_weights(oe.EncoderConfig(**SMALL_B), seed=6)
+    kw = {"encoder_config": cfgb, "state_dict": Wb, "tokenizer": HashTokenizer("bert", 3000)}
+    e16 = HipHuggingFaceEmbedding("test/bge-small-shaped", device="cuda", model_kwargs={**kw, "torch_dtype": torch.float16})
+    ebf = HipHuggingFaceEmbedding("test/bge-small-shaped", device="cuda", model_kwargs=kw)
+    assert e16.precision.startswith("fp16") and ebf.precision.startswith("bf16")
+    a, b = torch.tensor(e16.get_text_embedding("tensor kernel wave matrix")), torch.tensor(ebf.get_text_embedding("tensor kernel wave matrix"))
+    assert abs(a.norm().item() - 1) < 1e-3 and (a * b).sum().item() > 0.9995
+    mm = ModelManager.get_instance()
+    prev = mm.precision
+    try:
+        mm.set_precision("fp16")
+        assert mm._with_precision({"encoder_config": cfgb})["precision"] == "fp16"
+        assert mm._with_precision({"torch_dtype": "float32"}).get("precision") is None      # an explicit per-model dtype wins
+    finally:
+        mm.set_precision(prev)
