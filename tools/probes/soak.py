@@ -25,6 +25,15 @@ for mode in ("bf16", "fp8"):
     torch.cuda.synchronize()
     print(f"{mode}: {n_rep} repeated forwards (6 layers, 800x292), non-identical results: {bad}  ({time.time()-t0:.1f}s)", flush=True)
 rr.w.set_gemm_dtype("bf16")
+# ---- 1b. the fp16 instantiation of the same kernels (tt_*_f16): identical bits across repetitions, too
+rr16 = Encoder(EncoderWeights(cfg, synthetic_state_device(cfg, dev, seed=2), dev, dtype=torch.float16))
+ref = rr16.rerank_packed(batch).clone(); bad = 0
+t0 = time.time()
+for i in range(n_rep):
+    if not torch.equal(rr16.rerank_packed(batch), ref): bad += 1
+torch.cuda.synchronize()
+print(f"fp16: {n_rep} repeated forwards (6 layers, 800x292), non-identical results: {bad}  ({time.time()-t0:.1f}s)", flush=True)
+del rr16
 # ---- 2. GEMM epilogues vs torch on fresh data
 shapes = [(3072, 1024), (1024, 1024), (4096, 1024), (1024, 4096)]
 worst = 0.0
@@ -47,3 +56,22 @@ for rep in range(n_gemm):
             worst = max(worst, err)
             assert err < 1.0, (M, n, k, epi, err)
 print(f"gemm: {n_gemm} x 4 shapes x 3 epilogues on random M, worst error / tolerance = {worst:.3f}")
+worst = 0.0
+for rep in range(n_gemm):
+    M = int(rng.integers(8, 400)) * 256
+    for n, k in shapes:
+        for epi in (0, 1, 2):
+            a = (torch.randn(M, k, device=dev)).to(torch.float16)
+            w = (torch.randn(n, k, device=dev) * 0.03).to(torch.float16)
+            b = torch.randn(n, device=dev)
+            r = torch.randn(M, n, device=dev).to(torch.float16)
+            c = torch.empty(M, n, device=dev, dtype=torch.float16)
+            rc = lib.tt_gemm_f16(a.data_ptr(), w.data_ptr(), b.data_ptr(), r.data_ptr() if epi == 2 else None, c.data_ptr(), M, n, k, epi, st)
+            assert rc == 0
+            want = a.float() @ w.float().T + b
+            if epi == 1: want = torch.nn.functional.gelu(want)
+            if epi == 2: want = want + r.float()
+            err = ((c.float() - want).abs() / (want.abs() * 2.0 ** -10 + 2e-3)).max().item()
+            worst = max(worst, err)
+            assert err < 1.0, (M, n, k, epi, err)
+print(f"gemm fp16: {n_gemm} x 4 shapes x 3 epilogues on random M, worst error / tolerance (2^-10 |ref| + 2e-3) = {worst:.3f}")
