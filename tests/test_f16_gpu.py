@@ -220,3 +220,34 @@ def test_precision_selector_reaches_the_fp16_mode(dev, built_lib):
         assert mm._with_precision({"torch_dtype": "float32"}).get("precision") is None      # an explicit per-model dtype wins
     finally:
         mm.set_precision(prev)
+
+
+def test_forward_f16_with_outlier_features(dev, built_lib):
+    """Real XLM-R / BERT checkpoints carry a few "outlier" hidden features (LayerNorm gains of tens, activations of hundreds).
+    The fp16 mode must take them: a checkpoint-like perturbation -- two features with LayerNorm gain x40 in every layer and an
+    FFN whose intermediate reaches into the thousands -- stays finite and stays closer to the fp32 oracle than bf16 does."""
+    from tensor_truth_amd.encoder import Encoder, EncoderConfig, EncoderWeights
+
+    cfg = EncoderConfig(**SMALL_X)
+    ocfg = oe.EncoderConfig(**SMALL_X)
+    W = oe.synth_weights(ocfg, seed=8)
+    for name in list(W):
+        if name.endswith("LayerNorm.weight"):
+            W[name] = W[name].clone()
+            W[name][[7, 133]] *= 40.0                                   # outlier features in the residual stream
+        if name.endswith("intermediate.dense.weight"):
+            W[name] = W[name] * 6.0                                     # FFN intermediate in the hundreds / thousands
+        if name.endswith("output.dense.weight") and "attention" not in name:
+            W[name] = W[name] / 6.0
+    rng = np.random.default_rng(3)
+    seqs = _ragged(rng, 32, 6, 250, 3000, 0, 2)
+    ids, mask = _padded(seqs, 1)
+    with torch.no_grad():
+        ref = oe.rerank_logits(ids, mask, W, ocfg)
+        hid = oe.encoder_forward(ids, mask, W, ocfg, layers=1)
+    assert hid.abs().max().item() > 30.0                               # the outliers are really there
+    got16 = Encoder(EncoderWeights(cfg, W, dev, dtype=torch.float16)).rerank(seqs, want_logits=True)[1].cpu()
+    got_bf = Encoder(EncoderWeights(cfg, W, dev)).rerank(seqs, want_logits=True)[1].cpu()
+    assert torch.isfinite(got16).all()
+    e16, ebf = (got16 - ref).abs().max().item(), (got_bf - ref).abs().max().item()
+    assert e16 < 5e-3 and e16 < ebf, (e16, ebf)        # measured 2.2e-3 vs 4.8e-3 (logits of magnitude ~1)
