@@ -85,6 +85,10 @@ class ShardedHipVectorIndex:
         self._scan, self._merge = scan_fn, merge_fn
         self._collective_lock = threading.Lock()
         self._tick_fronts = 0                      # live _TickFront threads (they own this index's collectives)
+        self._written = None                       # (HipVectorRetriever._gpu_stream: event behind the last write to the rows)
+        if local_rows.is_cuda:
+            self._written = torch.cuda.Event()
+            self._written.record(torch.cuda.current_stream(local_rows.device))
         n_local = local_rows.shape[0]
         pieces = max(1, min(int(logical_shards), max(n_local, 1)))
         self._shards: List[Tuple[torch.Tensor, int]] = []
@@ -431,6 +435,15 @@ class ShardedHipVectorRetriever(HipVectorRetriever):
         k = min(self.similarity_top_k, idx.n_total)
         if k < 1:
             return [[] for _ in bundles]
-        scores, rows = idx.search(self._query_matrix(bundles), k)
-        scores, rows = scores.cpu().tolist(), rows.cpu().tolist()
+        world, _ = _world(idx.group)
+        stream = self._gpu_stream() if world == 1 and idx.device.type == "cuda" else None    # (collective rounds stay where they are)
+        if stream is None:
+            scores, rows = idx.search(self._query_matrix(bundles), k)
+            scores, rows = scores.cpu().tolist(), rows.cpu().tolist()
+        else:
+            with torch.cuda.stream(stream):
+                if idx._written is not None:
+                    stream.wait_event(idx._written)
+                scores, rows = idx.search(self._query_matrix(bundles), k)
+                scores, rows = scores.cpu().tolist(), rows.cpu().tolist()
         return [self.nodes_from_hits(s, r, idx.leaf_ids) for s, r in zip(scores, rows)]
