@@ -20,6 +20,7 @@ offender sees an exception -- the other callers get exactly their serial results
 """
 from __future__ import annotations
 
+import os
 import threading
 import time
 from typing import Any, Callable, List, Optional, Sequence
@@ -69,7 +70,7 @@ class Coalescer:
         self._finished = 0
         self._finish = finish
         self._retry_lock = threading.Lock()
-        self.depth = max(1, depth)
+        self.depth = max(1, int(os.environ.get("TT_COALESCE_DEPTH", depth)))     # (TT_COALESCE_DEPTH: A/B switch of the pipeline depth)
         self.max_batch = max_batch
         self.max_wait_s = max_wait_s
         self._lock = threading.Lock()

@@ -25,6 +25,7 @@ rerank above it are partitioned over the GPUs (throughput scales with the ranks;
 from __future__ import annotations
 
 import math
+import os
 import threading
 import time
 from typing import Callable, Dict, List, Optional, Sequence, Tuple  # noqa: F401
@@ -343,57 +344,69 @@ class _TickFront:
         world, rank = _world(idx.group)
         dev = idx.device
         batch: List[_TickSlot] = []
+        import contextlib
+
+        ctx = contextlib.nullcontext()
         if dev.type == "cuda":
             torch.cuda.set_device(dev)         # (the current device is per thread)
+            if os.environ.get("TT_RETRIEVE_STREAM", "1") != "0":
+                # the rounds' GPU work (query embedding, the collectives' device side, the shard scan, the merge) on the
+                # front's own high-priority stream: it must not queue behind the rerank batches of this rank's callers
+                # (HipVectorRetriever._gpu_stream: one idle gap per scan batch otherwise)
+                stream = torch.cuda.Stream(device=dev, priority=-1)
+                if idx._written is not None:
+                    stream.wait_event(idx._written)
+                ctx = torch.cuda.stream(stream)
         try:
-            while True:
-                with self._lock:
-                    batch = self._queue[: self.max_batch]
-                    del self._queue[: len(batch)]
-                    closing = self._closing and not self._queue
-                q16, round_error = None, None
-                if batch:
-                    batch, q16 = self._embed_own(batch)
-                nq = len(batch)
-                flags = torch.zeros((world, 2), dtype=torch.int64, device=dev)
-                with idx._collective_lock:
-                    dist.all_gather_into_tensor(flags.view(-1), torch.tensor([nq, 1 if (closing and nq == 0) else 0],
-                                                                             dtype=torch.int64, device=dev), group=idx.group)
-                    flags_h = flags.cpu()
-                    nmax = int(flags_h[:, 0].max().item())
-                    self.ticks += 1
+            with ctx:
+                while True:
+                    with self._lock:
+                        batch = self._queue[: self.max_batch]
+                        del self._queue[: len(batch)]
+                        closing = self._closing and not self._queue
+                    q16, round_error = None, None
+                    if batch:
+                        batch, q16 = self._embed_own(batch)
+                    nq = len(batch)
+                    flags = torch.zeros((world, 2), dtype=torch.int64, device=dev)
+                    with idx._collective_lock:
+                        dist.all_gather_into_tensor(flags.view(-1), torch.tensor([nq, 1 if (closing and nq == 0) else 0],
+                                                                                 dtype=torch.int64, device=dev), group=idx.group)
+                        flags_h = flags.cpu()
+                        nmax = int(flags_h[:, 0].max().item())
+                        self.ticks += 1
+                        if nmax == 0:
+                            if bool(flags_h[:, 1].all().item()):
+                                return                                   # every rank is closing and idle: all leave at this tick
+                            hits = None
+                        else:
+                            k = min(r.similarity_top_k, idx.n_total)
+                            if q16 is None:
+                                q16 = torch.zeros((0, idx.dim), dtype=torch.bfloat16, device=dev)
+                            try:
+                                hits = idx._round_partitioned(q16, k, nmax) if k >= 1 else None
+                            except ShardRoundError as exc:      # raised by EVERY rank in this round: the protocol stays aligned
+                                round_error, hits = exc, None
+                            self.rounds += 1
                     if nmax == 0:
-                        if bool(flags_h[:, 1].all().item()):
-                            return                                   # every rank is closing and idle: all leave at this tick
-                        hits = None
-                    else:
-                        k = min(r.similarity_top_k, idx.n_total)
-                        if q16 is None:
-                            q16 = torch.zeros((0, idx.dim), dtype=torch.bfloat16, device=dev)
-                        try:
-                            hits = idx._round_partitioned(q16, k, nmax) if k >= 1 else None
-                        except ShardRoundError as exc:      # raised by EVERY rank in this round: the protocol stays aligned
-                            round_error, hits = exc, None
-                        self.rounds += 1
-                if nmax == 0:
-                    time.sleep(self.idle_sleep_s)
-                    continue
-                if batch and round_error is not None:           # this round's callers fail, the front lives on
-                    for s_ in batch:
-                        s_.error = round_error
-                        s_.event.set()
-                    batch = []
-                if batch:
-                    if hits is None:
-                        results = [[] for _ in batch]
-                    else:
-                        scores, rows = hits[0].cpu().tolist(), hits[1].cpu().tolist()
-                        results = [r.nodes_from_hits(s_, r_, idx.leaf_ids) for s_, r_ in zip(scores, rows)]
-                    self.items += len(batch)
-                    for s_, res in zip(batch, results):
-                        s_.result = res
-                        s_.event.set()
-                    batch = []
+                        time.sleep(self.idle_sleep_s)
+                        continue
+                    if batch and round_error is not None:           # this round's callers fail, the front lives on
+                        for s_ in batch:
+                            s_.error = round_error
+                            s_.event.set()
+                        batch = []
+                    if batch:
+                        if hits is None:
+                            results = [[] for _ in batch]
+                        else:
+                            scores, rows = hits[0].cpu().tolist(), hits[1].cpu().tolist()
+                            results = [r.nodes_from_hits(s_, r_, idx.leaf_ids) for s_, r_ in zip(scores, rows)]
+                        self.items += len(batch)
+                        for s_, res in zip(batch, results):
+                            s_.result = res
+                            s_.event.set()
+                        batch = []
         except BaseException as exc:  # noqa: BLE001 - a failed collective: nobody may wait forever
             with self._lock:
                 self._dead = exc
