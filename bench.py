@@ -113,6 +113,8 @@ def parse():
     ap.add_argument("--no-fp8-leg", action="store_true", help="skip the extra fp8-reranker timing (BASELINE config 5)")
     ap.add_argument("--no-reference-leg", action="store_true", help="skip the reference-precision (bf16x3) timing")
     ap.add_argument("--no-fp16-leg", action="store_true", help="skip the fp16-mode timing")
+    ap.add_argument("--surface-timeout", type=float, default=300.0,
+                    help="world > 1: deadline of the plugin-surface leg in seconds (the headline is printed regardless)")
     ap.add_argument("--headline-only", action="store_true",
                     help="run only the warm-up and timed steps (no scan-only / fp8 / ingest legs): every kernel of the process then "
                          "belongs to the timed workload, so a rocprofv3 --stats summary of this command can be compared with "
@@ -511,8 +513,36 @@ def main():
     # the reference's executor threads do (rag_engine.py:418-424, api/routes/chat.py:367-374); the coalescing front
     # merges them into shared embed / scan / rerank batches.  Strings in, NodeWithScore out; the SAME resident corpus.
     surface = None
+    hard_exit = False
     if not args.headline_only and not args.no_surface_leg:
-        surface = surface_leg(args, dev, shard_rows, emb_cfg, rr_cfg, world, rank, lo)
+        if world == 1:
+            surface = surface_leg(args, dev, shard_rows, emb_cfg, rr_cfg, world, rank, lo)
+        else:
+            # Several ranks: the leg's collectives run over RCCL, which no box available to this build could exercise (two
+            # ranks cannot share a GPU under RCCL; the gloo runs are the evidence).  The headline above is measured and must
+            # reach the JSON line whatever this leg does: it runs in a worker thread under a deadline, and a leg that does
+            # not come back is reported as such -- the process then leaves with os._exit after printing (a thread stuck in a
+            # collective would otherwise block the interpreter's shutdown).
+            import threading
+
+            box = {}
+
+            def _run_surface():
+                torch.cuda.set_device(dev)
+                try:
+                    box["result"] = surface_leg(args, dev, shard_rows, emb_cfg, rr_cfg, world, rank, lo)
+                except BaseException as exc:  # noqa: BLE001
+                    box["error"] = exc
+
+            th = threading.Thread(target=_run_surface, name="surface-leg", daemon=True)
+            th.start()
+            th.join(args.surface_timeout)
+            if th.is_alive():
+                surface, hard_exit = {"error": f"plugin-surface leg did not finish within {args.surface_timeout:.0f} s on rank {rank}"}, True
+            elif "error" in box:
+                surface, hard_exit = {"error": f"plugin-surface leg failed on rank {rank}: {box['error']!r}"}, True
+            else:
+                surface = box["result"]
     config5 = None
     if world == 1 and not args.headline_only and not args.no_config5_leg:
         config5 = config5_leg(args, dev, emb_cfg, rr_cfg)
@@ -640,6 +670,10 @@ def main():
         out["cpu_baseline"] = cpu_baseline(args, emb_cfg, rr_cfg, embedder, reranker, corpus, queries[0], vocab)
     if rank == 0:
         print(json.dumps(out))
+    if hard_exit:
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)        # (see the plugin-surface leg: a worker thread may still sit in a collective)
     if world > 1:
         dist.destroy_process_group()
 
