@@ -35,9 +35,21 @@ def iter_parsed(documents: Sequence, embed_model, chunking_strategy: str = "hier
     overlap = DEFAULT_CHUNK_OVERLAP if chunk_overlap is None else chunk_overlap
     hier = node_parser or HierarchicalNodeParser.from_defaults(chunk_sizes=sizes, chunk_overlap=overlap)
     step = max(1, sub_batch)
+
+    def pieces(items):
+        # The first pieces are SMALL and double up to ``sub_batch``: while the host splits a piece the GPU has only the
+        # previous piece's leaves to embed, and before the first piece nothing at all -- with full-size pieces from the
+        # start a kernel trace shows the GPU idle for the whole first piece of every window (0.4 s per 2048 inputs,
+        # 20 % of a 512-document window); a 128-input first piece keeps that to a few tens of milliseconds.
+        lo, size = 0, min(step, 128)
+        while lo < len(items):
+            yield items[lo:lo + size]
+            lo += size
+            size = min(step, size * 2)
+
     if chunking_strategy == "hierarchical":
-        for lo in range(0, len(documents), step):
-            yield hier.get_nodes_from_documents(documents[lo:lo + step])
+        for piece in pieces(documents):
+            yield hier.get_nodes_from_documents(piece)
         return
     sem = SemanticSplitter(embed_model, buffer_size=semantic_buffer_size,
                            breakpoint_percentile_threshold=semantic_breakpoint_threshold)
@@ -45,8 +57,8 @@ def iter_parsed(documents: Sequence, embed_model, chunking_strategy: str = "hier
     if chunking_strategy == "semantic":
         yield semantic_nodes
         return
-    for lo in range(0, len(semantic_nodes), step):
-        yield hier.get_nodes_from_documents(semantic_nodes[lo:lo + step])
+    for piece in pieces(semantic_nodes):
+        yield hier.get_nodes_from_documents(piece)
 
 
 def parse_documents(documents: Sequence, embed_model, chunking_strategy: str = "hierarchical",
