@@ -370,6 +370,12 @@ int tt_encoder_forward_x3(const tt_encoder_weights_x3* w, const int32_t* ids, co
                           int n_seq, int n_rows, int max_len, float* hidden_out,
                           void* workspace, size_t workspace_bytes, void* stream);
 /* classification head on the fp32 hidden state (workspace as tt_rerank_head_f32) */
+/* Same forward with the LAST layer evaluated for the first row (CLS) of every sequence only -- the split-bf16 twin of
+ * tt_encoder_forward_cls: cls_out [pad(n_seq)][hidden] fp32, pad = n_seq rounded up to 64 (<= 256 sequences) or to 256. */
+size_t tt_encoder_x3_cls_workspace_bytes(const tt_encoder_weights_x3* w, int n_rows, int n_seq);
+int tt_encoder_forward_x3_cls(const tt_encoder_weights_x3* w, const int32_t* ids, const int32_t* pos, const int32_t* type_ids,
+                              const int32_t* seq_start, const int32_t* seq_len, int n_seq, int n_rows, int max_len,
+                              float* cls_out, void* workspace, size_t workspace_bytes, void* stream);
 int tt_rerank_head_x3(const tt_encoder_weights_x3* w, const float* hidden_f32, const int32_t* rows, int n_seq,
                       float* scores, float* logits, void* workspace, size_t workspace_bytes, void* stream);
 /* building blocks (parity tests).  tt_split_planes: fp32 [rows][cols] -> planes [rows][2 cols], cols % 4 == 0.

@@ -87,7 +87,10 @@ SIGNATURES = {
     "tt_rerank_head_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "tt_gemm_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "tt_encoder_x3_workspace_bytes": (c_size_t, [c_void_p, c_int]),
+    "tt_encoder_x3_cls_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),
     "tt_encoder_forward_x3": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                      c_void_p, c_void_p, c_size_t, c_void_p]),
+    "tt_encoder_forward_x3_cls": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                       c_void_p, c_void_p, c_size_t, c_void_p]),
     "tt_rerank_head_x3": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "tt_split_planes": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p]),

@@ -464,12 +464,112 @@ int attention_x3_launch(const AttnX3Params& p, hipStream_t st) {
     return TT_OK;
 }
 
+// ---- CLS-only tail of the last layer (tt_encoder_forward_x3_cls): one wave per (sequence, head), the single query row --------
+// The bf16 path's attention_cls_kernel with every operand as hi + lo planes: q, k and v are rebuilt in fp32 (hi + lo carries 16
+// mantissa bits), the dot products, the softmax and the value sum are fp32, the context goes out as planes again.
+__global__ __launch_bounds__(64) void attention_cls_x3_kernel(AttnX3Params p) {
+    extern __shared__ __attribute__((aligned(16))) float probs_x[];   // [max_len rounded up to 8]
+    constexpr int DH = 64;
+    const int seq = blockIdx.x, head = blockIdx.y, lane = threadIdx.x;
+    const int len = p.seq_len[seq], t0 = p.seq_start[seq];
+    const int t0a = t0 & ~7, off = t0 - t0a, alen = off + len;
+    auto add8 = [](const uint4& h, const uint4& l, float (&f)[8]) {
+        f[0] = __uint_as_float(h.x << 16) + __uint_as_float(l.x << 16); f[1] = __uint_as_float(h.x & 0xFFFF0000u) + __uint_as_float(l.x & 0xFFFF0000u);
+        f[2] = __uint_as_float(h.y << 16) + __uint_as_float(l.y << 16); f[3] = __uint_as_float(h.y & 0xFFFF0000u) + __uint_as_float(l.y & 0xFFFF0000u);
+        f[4] = __uint_as_float(h.z << 16) + __uint_as_float(l.z << 16); f[5] = __uint_as_float(h.z & 0xFFFF0000u) + __uint_as_float(l.z & 0xFFFF0000u);
+        f[6] = __uint_as_float(h.w << 16) + __uint_as_float(l.w << 16); f[7] = __uint_as_float(h.w & 0xFFFF0000u) + __uint_as_float(l.w & 0xFFFF0000u);
+    };
+    float q[DH];
+    {
+        const uint16_t* qp = p.qk + (size_t)t0 * p.ld_qk + p.q_col0 + head * DH;
+#pragma unroll
+        for (int c = 0; c < DH / 8; ++c) {
+            float f[8];
+            add8(*reinterpret_cast<const uint4*>(qp + c * 8), *reinterpret_cast<const uint4*>(qp + p.lo_off + c * 8), f);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) q[c * 8 + i] = f[i];
+        }
+    }
+    const float sc = p.scale * 1.4426950408889634f;
+    float mx = -__builtin_inff();
+    for (int j = off + lane; j < alen; j += 64) {
+        const uint16_t* kp = p.qk + (size_t)(t0a + j) * p.ld_qk + p.k_col0 + head * DH;
+        float acc = 0.f;
+#pragma unroll
+        for (int c = 0; c < DH / 8; ++c) {
+            float f[8];
+            add8(*reinterpret_cast<const uint4*>(kp + c * 8), *reinterpret_cast<const uint4*>(kp + p.lo_off + c * 8), f);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc = fmaf(q[c * 8 + i], f[i], acc);
+        }
+        acc *= sc;
+        probs_x[j] = acc;
+        mx = fmaxf(mx, acc);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float sum = 0.f;
+    const int len8 = (alen + 7) & ~7;
+    for (int j = lane; j < len8; j += 64) {
+        float e = 0.f;
+        if (j >= off && j < alen) e = __builtin_amdgcn_exp2f(probs_x[j] - mx);
+        probs_x[j] = e;
+        sum += e;
+    }
+    sum = wave_sum_x(sum);
+    __syncthreads();
+    const int d = lane;        // DH = 64: one feature per lane
+    float o = 0.f;
+    for (int g8 = 0; g8 * 8 < alen; ++g8) {
+        const size_t at = (size_t)(t0a / 8 + g8) * p.ldvt + (size_t)(head * DH + d) * 8;
+        float v[8];
+        add8(*reinterpret_cast<const uint4*>(p.vt + at), *reinterpret_cast<const uint4*>(p.vt_lo + at), v);
+        const float4 pa = *reinterpret_cast<const float4*>(probs_x + g8 * 8);
+        const float4 pb = *reinterpret_cast<const float4*>(probs_x + g8 * 8 + 4);
+        o = fmaf(pa.x, v[0], o); o = fmaf(pa.y, v[1], o); o = fmaf(pa.z, v[2], o); o = fmaf(pa.w, v[3], o);
+        o = fmaf(pb.x, v[4], o); o = fmaf(pb.y, v[5], o); o = fmaf(pb.z, v[6], o); o = fmaf(pb.w, v[7], o);
+    }
+    o /= sum;
+    const float hi = rbf(o);
+    uint16_t* op = p.out + (size_t)seq * p.ld_out + head * DH + d;
+    op[0] = (uint16_t)(__float_as_uint(hi) >> 16);
+    op[p.out_lo_off] = (uint16_t)(pack_bf16x2(o - hi, 0.f) & 0xFFFFu);
+}
+
+// rows seq_start[b] of an fp32 [T][H] matrix -> dst [n_pad][H] (rows beyond n: zeros)
+__global__ __launch_bounds__(256) void gather_rows_f32_kernel(const float* src, const int32_t* rows, int n, int n_pad, int H, float* dst) {
+    const int b = blockIdx.x;
+    if (b >= n_pad) return;
+    for (int c = threadIdx.x * 4; c < H; c += 256 * 4) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (b < n) v = *reinterpret_cast<const float4*>(src + (size_t)rows[b] * H + c);
+        *reinterpret_cast<float4*>(dst + (size_t)b * H + c) = v;
+    }
+}
+
+int attention_cls_x3_launch(const AttnX3Params& p, hipStream_t st) {
+    if (p.n_seq <= 0) return TT_OK;
+    const size_t lds = (size_t)((p.max_len + 14) / 8 * 8) * sizeof(float);
+    if (lds > 160 * 1024) {
+        tt_set_error("attention_cls_x3: max_len %d exceeds the LDS score buffer", p.max_len);
+        return TT_E_UNSUPPORTED;
+    }
+    TtProfScope prof(TT_K_ATTENTION, st);
+    TT_SET_MAX_LDS(attention_cls_x3_kernel, 160 * 1024);
+    hipLaunchKernelGGL(attention_cls_x3_kernel, dim3(p.n_seq, p.heads), dim3(64), lds, st, p);
+    TT_CHECK_LAUNCH();
+    return TT_OK;
+}
+
+inline int x3_cls_pad(int n_seq) { return n_seq <= 256 ? (n_seq + 63) / 64 * 64 : (n_seq + 255) / 256 * 256; }
+
 // ---- forward ---------------------------------------------------------------------------------------------------------
 struct X3Ws {
     size_t off_xa, off_xb, off_y, off_xpl, off_qk, off_vt, off_vtlo, off_ctx, off_ffn, total;
+    size_t off_cctx, off_cx, off_cy, off_cx1, off_cxpl, off_cffn;     // CLS tail (n_cls > 0)
 };
 
-X3Ws x3_plan(const tt_encoder_weights_x3* w, int n_rows) {
+X3Ws x3_plan(const tt_encoder_weights_x3* w, int n_rows, int n_cls = 0) {
     X3Ws e{};
     const size_t H = (size_t)w->hidden, F = (size_t)w->ffn, T = ((size_t)n_rows + 255) / 256 * 256;
     size_t off = 0;
@@ -483,6 +583,15 @@ X3Ws x3_plan(const tt_encoder_weights_x3* w, int n_rows) {
     e.off_vtlo = take(T * H * 2);
     e.off_ctx = take(T * 2 * H * 2);
     e.off_ffn = take(T * 2 * F * 2);
+    if (n_cls > 0) {
+        const size_t B = (size_t)x3_cls_pad(n_cls);
+        e.off_cctx = take(B * 2 * H * 2);
+        e.off_cx = take(B * H * 4);
+        e.off_cy = take(B * H * 4);
+        e.off_cx1 = take(B * H * 4);
+        e.off_cxpl = take(B * 2 * H * 2);
+        e.off_cffn = take(B * 2 * F * 2);
+    }
     e.total = off;
     return e;
 }
@@ -508,15 +617,21 @@ size_t tt_encoder_x3_workspace_bytes(const tt_encoder_weights_x3* w, int n_rows)
     return x3_plan(w, n_rows).total;
 }
 
-int tt_encoder_forward_x3(const tt_encoder_weights_x3* w, const int32_t* ids, const int32_t* pos, const int32_t* type_ids,
-                          const int32_t* seq_start, const int32_t* seq_len, int n_seq, int n_rows, int max_len,
-                          float* hidden_out, void* workspace, size_t workspace_bytes, void* stream) {
+}  // extern "C"
+
+namespace {
+// hidden_out: the last hidden state [n_rows][H]; cls_out (instead): the last hidden state of every sequence's FIRST row only,
+// [x3_cls_pad(n_seq)][H] -- the last layer then runs its attention, output projection, LayerNorms and FFN for those rows only
+int forward_x3_impl(const tt_encoder_weights_x3* w, const int32_t* ids, const int32_t* pos, const int32_t* type_ids,
+                    const int32_t* seq_start, const int32_t* seq_len, int n_seq, int n_rows, int max_len,
+                    float* hidden_out, float* cls_out, void* workspace, size_t workspace_bytes, void* stream) {
     if (int rc = check_weights_x3(w)) return rc;
     TT_CHECK_ARG(n_rows > 0 && (n_rows % 256 == 0 || (n_rows < 256 && n_rows % 64 == 0)),
                  "n_rows=%d must be a positive multiple of 256 (or 64 / 128 / 192: skinny GEMMs)", n_rows);
     TT_CHECK_ARG(n_seq > 0 && max_len > 0, "n_seq=%d max_len=%d", n_seq, max_len);
-    TT_CHECK_ARG(ids && pos && seq_start && seq_len && hidden_out, "null pointer");
-    const X3Ws e = x3_plan(w, n_rows);
+    TT_CHECK_ARG(ids && pos && seq_start && seq_len && (hidden_out || cls_out), "null pointer");
+    const bool cls_tail = cls_out != nullptr && w->layers > 0;
+    const X3Ws e = x3_plan(w, n_rows, cls_tail ? n_seq : 0);
     if (!workspace || workspace_bytes < e.total) {
         tt_set_error("tt_encoder_forward_x3: workspace %zu < required %zu bytes", workspace_bytes, e.total);
         return TT_E_WORKSPACE;
@@ -545,7 +660,7 @@ int tt_encoder_forward_x3(const tt_encoder_weights_x3* w, const int32_t* ids, co
     int rmask = 0;
     if (const char* m = getenv("TT_X3_ROUND_MASK"); m && m[0]) rmask = (int)strtol(m, nullptr, 0);
     const int ln_out = (rmask & 32) ? 2 : 0, ln_in = (rmask & 16) ? 1 : 0;
-    float* x = w->layers == 0 ? hidden_out : xa;
+    float* x = (w->layers == 0 && hidden_out) ? hidden_out : xa;
     {
         TtProfScope prof(TT_K_ROWOPS, st);
         hipLaunchKernelGGL(embed_ln_x3_kernel, row_grid_x(T), dim3(kRowThreadsX), 0, st, ids, pos, type_ids, w->word_emb, w->pos_emb,
@@ -568,6 +683,55 @@ int tt_encoder_forward_x3(const tt_encoder_weights_x3* w, const int32_t* ids, co
         gv.bias = lw.qkv_b + 2 * H;
         gv.N = H; gv.vt = vt; gv.vt_lo = vtlo; gv.ldvt = 8 * H; gv.vt_col0 = 0;
         if (int rc = tt_gemm_launch(gv, TT_EPI_VT, st)) return rc;
+        if (cls_tail && l == w->layers - 1) {
+            // ---- last layer, first rows only: one-query attention per (sequence, head), then the output projection, the
+            //      LayerNorms and the FFN on n_seq (padded) rows instead of n_rows
+            const int Bp = x3_cls_pad(n_seq);
+            uint16_t* cctx = (uint16_t*)(ws + e.off_cctx);
+            float* cx = (float*)(ws + e.off_cx);
+            float* cy = (float*)(ws + e.off_cy);
+            float* cx1 = (float*)(ws + e.off_cx1);
+            uint16_t* cxpl = (uint16_t*)(ws + e.off_cxpl);
+            uint16_t* cffn = (uint16_t*)(ws + e.off_cffn);
+            TT_CHECK_HIP(hipMemsetAsync(cctx, 0, (size_t)Bp * 2 * H * 2, st));
+            AttnX3Params ac{};
+            ac.qk = qk; ac.ld_qk = 4 * H; ac.q_col0 = 0; ac.k_col0 = H; ac.lo_off = 2 * H; ac.vt = vt; ac.vt_lo = vtlo; ac.ldvt = 8 * H;
+            ac.out = cctx; ac.ld_out = 2 * H; ac.out_lo_off = H; ac.seq_start = seq_start; ac.seq_len = seq_len;
+            ac.n_seq = n_seq; ac.heads = w->heads; ac.max_len = max_len; ac.scale = 0.125f;
+            if (int rc = attention_cls_x3_launch(ac, st)) return rc;
+            {
+                TtProfScope prof(TT_K_ROWOPS, st);
+                hipLaunchKernelGGL(gather_rows_f32_kernel, dim3(Bp), dim3(256), 0, st, x, seq_start, n_seq, Bp, H, cx);
+                TT_CHECK_LAUNCH();
+            }
+            GemmParams go{};
+            go.x3 = 1;
+            go.A = cctx; go.lda = 2 * H; go.W = (const uint16_t*)lw.o_w; go.ldw = 2 * H; go.bias = lw.o_b;
+            go.res32 = cx; go.ldr = H; go.C32 = cy; go.ldc = H; go.M = Bp; go.N = H; go.K = H;
+            if (int rc = tt_gemm_launch(go, TT_EPI_RESIDUAL, st)) return rc;
+            {
+                TtProfScope prof(TT_K_ROWOPS, st);
+                hipLaunchKernelGGL(layernorm_x3_kernel, row_grid_x(Bp), dim3(kRowThreadsX), 0, st, cy, cx1, cxpl, lw.ln1_g, lw.ln1_b, Bp, H,
+                                   w->ln_eps, ln_in | ln_out);
+                TT_CHECK_LAUNCH();
+            }
+            GemmParams g1{};
+            g1.x3 = 1;
+            g1.A = cxpl; g1.lda = 2 * H; g1.W = (const uint16_t*)lw.ffn1_w; g1.ldw = 2 * H; g1.bias = lw.ffn1_b;
+            g1.C = cffn; g1.ldc = 2 * F; g1.c_lo_off = F; g1.M = Bp; g1.N = F; g1.K = H;
+            g1.x3_zero_lo = (rmask & 64) ? 1 : 0;
+            if (int rc = tt_gemm_launch(g1, TT_EPI_GELU, st)) return rc;
+            GemmParams g2{};
+            g2.x3 = 1;
+            g2.A = cffn; g2.lda = 2 * F; g2.W = (const uint16_t*)lw.ffn2_w; g2.ldw = 2 * F; g2.bias = lw.ffn2_b;
+            g2.res32 = cx1; g2.ldr = H; g2.C32 = cy; g2.ldc = H; g2.M = Bp; g2.N = H; g2.K = F;
+            if (int rc = tt_gemm_launch(g2, TT_EPI_RESIDUAL, st)) return rc;
+            TtProfScope prof(TT_K_ROWOPS, st);
+            hipLaunchKernelGGL(layernorm_x3_kernel, row_grid_x(Bp), dim3(kRowThreadsX), 0, st, cy, cls_out, (uint16_t*)nullptr, lw.ln2_g,
+                               lw.ln2_b, Bp, H, w->ln_eps, ln_in | ln_out);
+            TT_CHECK_LAUNCH();
+            return TT_OK;
+        }
         AttnX3Params a{};
         a.qk = qk; a.ld_qk = 4 * H; a.q_col0 = 0; a.k_col0 = H; a.lo_off = 2 * H; a.vt = vt; a.vt_lo = vtlo; a.ldvt = 8 * H;
         a.out = ctx; a.ld_out = 2 * H; a.out_lo_off = H; a.seq_start = seq_start; a.seq_len = seq_len;
@@ -607,7 +771,37 @@ int tt_encoder_forward_x3(const tt_encoder_weights_x3* w, const int32_t* ids, co
         }
         x = dst;
     }
+    if (cls_out) {     // no layers: the "last hidden state" is the embedding LayerNorm's output -- gather the first rows
+        TtProfScope prof(TT_K_ROWOPS, st);
+        const int Bp = x3_cls_pad(n_seq);
+        hipLaunchKernelGGL(gather_rows_f32_kernel, dim3(Bp), dim3(256), 0, st, x, seq_start, n_seq, Bp, H, cls_out);
+        TT_CHECK_LAUNCH();
+    }
     return TT_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int tt_encoder_forward_x3(const tt_encoder_weights_x3* w, const int32_t* ids, const int32_t* pos, const int32_t* type_ids,
+                          const int32_t* seq_start, const int32_t* seq_len, int n_seq, int n_rows, int max_len,
+                          float* hidden_out, void* workspace, size_t workspace_bytes, void* stream) {
+    TT_CHECK_ARG(hidden_out != nullptr, "null pointer");
+    return forward_x3_impl(w, ids, pos, type_ids, seq_start, seq_len, n_seq, n_rows, max_len, hidden_out, nullptr, workspace,
+                           workspace_bytes, stream);
+}
+
+size_t tt_encoder_x3_cls_workspace_bytes(const tt_encoder_weights_x3* w, int n_rows, int n_seq) {
+    if (!w || n_rows <= 0 || n_seq <= 0) return 0;
+    return x3_plan(w, n_rows, n_seq).total;
+}
+
+int tt_encoder_forward_x3_cls(const tt_encoder_weights_x3* w, const int32_t* ids, const int32_t* pos, const int32_t* type_ids,
+                              const int32_t* seq_start, const int32_t* seq_len, int n_seq, int n_rows, int max_len,
+                              float* cls_out, void* workspace, size_t workspace_bytes, void* stream) {
+    TT_CHECK_ARG(cls_out != nullptr, "null pointer");
+    return forward_x3_impl(w, ids, pos, type_ids, seq_start, seq_len, n_seq, n_rows, max_len, nullptr, cls_out, workspace,
+                           workspace_bytes, stream);
 }
 
 int tt_rerank_head_x3(const tt_encoder_weights_x3* w, const float* hidden_f32, const int32_t* rows, int n_seq, float* scores,

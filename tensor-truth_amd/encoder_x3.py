@@ -174,6 +174,25 @@ class EncoderX3:
         _lib.check(rc, "tt_encoder_forward_x3")
         return (hidden, starts, lens) if want_lens else (hidden, starts)
 
+    def cls_hidden_packed(self, batch: PackedBatch) -> Tuple[torch.Tensor, torch.Tensor]:
+        """-> (final hidden state of every sequence's first row [pad(B), H] fp32, row ids [B] int32): the last layer runs for
+        those rows only (``tt_encoder_forward_x3_cls``), as ``Encoder.cls_hidden_packed`` does in the 16-bit modes."""
+        lib, dev, H = self.lib, self.device, self.cfg.hidden
+        B = len(batch.seq_len)
+        batch = _pad_rows(batch)
+        ids, pos, types, starts, lens = self._upload(batch)
+        b_pad = (B + 63) // 64 * 64 if B <= 256 else (B + 255) // 256 * 256
+        cls = torch.empty((b_pad, H), dtype=torch.float32, device=dev)
+        need = lib.tt_encoder_x3_cls_workspace_bytes(ctypes.byref(self.w.struct), batch.n_rows, B)
+        with self._enqueue_lock, torch.cuda.device(dev):
+            ws, base = _scratch.get("encx3", dev, need)
+            rc = lib.tt_encoder_forward_x3_cls(ctypes.byref(self.w.struct), ids.data_ptr(), pos.data_ptr(),
+                                               types.data_ptr() if types is not None else None, starts.data_ptr(),
+                                               lens.data_ptr(), B, batch.n_rows, batch.max_len, cls.data_ptr(), base, need,
+                                               torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(rc, "tt_encoder_forward_x3_cls")
+        return cls, torch.arange(B, dtype=torch.int32, device=dev)
+
     def embed_packed(self, batch: PackedBatch, pooling: str = "cls") -> Tuple[torch.Tensor, torch.Tensor]:
         B, H = len(batch.seq_len), self.cfg.hidden
         out = torch.empty((B, H), dtype=torch.float32, device=self.device)
@@ -187,7 +206,7 @@ class EncoderX3:
             return out, out16
         if pooling != "cls":
             raise ValueError(f"pooling '{pooling}' (supported: 'cls', 'mean')")
-        hidden, rows = self.forward_packed(batch)
+        hidden, rows = self.cls_hidden_packed(batch)
         with torch.cuda.device(self.device):
             rc = self.lib.tt_embed_pool_f32(hidden.data_ptr(), H, rows.data_ptr(), B, H, out.data_ptr(), out16.data_ptr(),
                                             torch.cuda.current_stream(self.device).cuda_stream)
@@ -197,7 +216,7 @@ class EncoderX3:
     def rerank_packed(self, batch: PackedBatch, want_logits: bool = False):
         if not self.cfg.num_labels:
             raise RuntimeError("these weights carry no classification head")
-        hidden, rows = self.forward_packed(batch)
+        hidden, rows = self.cls_hidden_packed(batch)
         B, H = len(batch.seq_len), self.cfg.hidden
         scores = torch.empty(B, dtype=torch.float32, device=self.device)
         logits = torch.empty(B, dtype=torch.float32, device=self.device) if want_logits else None

@@ -238,3 +238,42 @@ def test_precision_selector_reaches_both_surfaces(dev, built_lib, monkeypatch):
     ids, mask = _pad([emb._tokenizer.encode(t, emb.max_length) for t in texts], cfg.pad_id)
     assert (e - oe.embed(ids, mask, W, cfg_o)).abs().max().item() <= 5e-5
     mm.ModelManager.reset_instance()
+
+
+def test_cls_only_last_layer_equals_the_full_forward_rows(dev, built_lib):
+    """``tt_encoder_forward_x3_cls`` (the last layer for every sequence's first row only) against the first rows of the full
+    forward: the GEMM rows are bit-identical whichever kernel computes them, the one-query attention sums its keys in another
+    order than the tiled kernel -- fp32 rounding noise apart, the same numbers.  Few sequences (skinny tail GEMMs) and many
+    (tiled tail GEMMs); embeddings and rerank scores go through this path."""
+    import numpy as np
+
+    from oracle import encoder as oe
+    from tensor_truth_amd.encoder import EncoderConfig, pack_tokens
+    from tensor_truth_amd.encoder_x3 import EncoderWeightsX3, EncoderX3
+
+    shape = dict(arch="xlmr", vocab_size=2000, hidden=256, layers=3, heads=4, ffn=1024, max_pos=320, type_vocab=1, pad_id=1,
+                 ln_eps=1e-5, num_labels=1)
+    cfg, ocfg = EncoderConfig(**shape), oe.EncoderConfig(**shape)
+    W = oe.synth_weights(ocfg, seed=23)
+    enc = EncoderX3(EncoderWeightsX3(cfg, W, dev))
+    rng = np.random.default_rng(6)
+    for n_seq in (5, 70, 300):
+        seqs = [[0] + rng.integers(5, 2000, size=int(rng.integers(3, 120))).tolist() + [2] for _ in range(n_seq)]
+        batch = pack_tokens(seqs, cfg, None, None)
+        full, starts = enc.forward_packed(batch)
+        cls, rows = enc.cls_hidden_packed(batch)
+        want = full[starts[:n_seq].long()].cpu()
+        got = cls[:n_seq].cpu()
+        assert torch.isfinite(got).all()
+        assert (got - want).abs().max().item() < 2e-5 * max(1.0, want.abs().max().item()), n_seq
+        assert rows.tolist() == list(range(n_seq))
+    # and against the fp32 oracle through the public calls (which use the CLS path)
+    seqs = [[0] + rng.integers(5, 2000, size=int(rng.integers(3, 200))).tolist() + [2] for _ in range(40)]
+    L = max(map(len, seqs))
+    ids = torch.full((40, L), 1, dtype=torch.long); mask = torch.zeros((40, L), dtype=torch.long)
+    for i, sq in enumerate(seqs):
+        ids[i, :len(sq)] = torch.tensor(sq); mask[i, :len(sq)] = 1
+    with torch.no_grad():
+        ref = oe.rerank_scores(ids, mask, W, ocfg)
+    got = enc.rerank(seqs).cpu()
+    assert ((got - ref).abs() / ref.abs()).max().item() < 1e-4
