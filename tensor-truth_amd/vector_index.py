@@ -412,13 +412,16 @@ class HipVectorRetriever:
         self._stream: Optional[torch.cuda.Stream] = None
 
     def _gpu_stream(self):
-        """The query embedding + scan of a batch run on the retriever's OWN high-priority stream.  On the stream the
-        reranker uses they would queue behind whatever rerank batch is running (tens of ms), the callers of this batch
-        would come back late, and the GPU would then idle while THEIR rerank batch is tokenised and packed: 78 gaps of
-        ~8 ms per 78 scan batches, 11 % of the time, in a kernel trace of the plugin-surface leg.  On its own stream the
-        retrieval slips in at the rerank GEMMs' tile boundaries and the next rerank batch is ready while the current one
-        still runs.  ``TT_RETRIEVE_STREAM=0``: the caller's current stream, as before."""
-        if os.environ.get("TT_RETRIEVE_STREAM", "1") == "0":
+        """Opt-in (``TT_RETRIEVE_STREAM=1``): the query embedding + scan of a batch on the retriever's OWN high-priority stream.
+        On the stream the reranker uses a retrieval batch queues behind whatever rerank batch is running (tens of ms), its
+        callers come back late, and the GPU then idles while THEIR rerank batch is tokenised and packed: one ~8 ms gap per
+        scan batch, 11 % of the time, in a kernel trace of the plugin-surface leg -- and 95 -> 104 queries/s with the own
+        stream.  It is OFF by default because the results are then no longer reproducible run to run: a streaming filter
+        scan that runs BESIDE an encoder forward of the other stream disturbs that forward's embedding-LayerNorm kernel
+        (a handful of output elements per few hundred rows come out as their LayerNorm bias alone; reproduced in isolation
+        by ``tools/probes/contention_race.py``; no out-of-bounds write, no other kernel of the library or of torch is
+        affected; root cause not found).  On one stream the two never overlap."""
+        if os.environ.get("TT_RETRIEVE_STREAM", "0") != "1":
             return None
         if self._stream is None:
             dev = self.index.device
