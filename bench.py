@@ -124,14 +124,15 @@ def parse():
 
 
 def csrc_sha256() -> str:
-    """Hash of the kernel sources (csrc/*.hip, *.h + the ABI header): ties a PMC traffic file to the tree it was measured on."""
+    """Hash of the kernel sources (csrc/*.hip, *.h, the Makefile with its per-file flags, + the ABI header): ties a PMC traffic file to
+    the tree it was measured on."""
     import glob
     import hashlib
 
     h = hashlib.sha256()
     files = sorted(glob.glob(os.path.join(ROOT, "tensor-truth_amd", "csrc", "*.hip")) +
                    glob.glob(os.path.join(ROOT, "tensor-truth_amd", "csrc", "*.h")) +
-                   [os.path.join(ROOT, "include", "tt_hip.h")])
+                   [os.path.join(ROOT, "tensor-truth_amd", "csrc", "Makefile"), os.path.join(ROOT, "include", "tt_hip.h")])
     for f in files:
         h.update(os.path.basename(f).encode())
         with open(f, "rb") as fh:

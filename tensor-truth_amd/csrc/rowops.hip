@@ -53,6 +53,15 @@ __device__ __forceinline__ uint2 pack_fp8x8(const float (&f)[8]) {
 // normalise x[kMaxChunks][8] (this lane's share of a row of H values) and store bf16; optionally also the
 // per-row fp8 quantisation of the bf16-rounded result (q8_row, *q8_scale = absmax / 448): the A operand of the
 // fp8 GEMMs, produced while the row is in registers
+// a * b + c with the product ROUNDED before the add, whatever -ffp-contract says: the sums of squares and the head's dot product round
+// like the CPU oracle's (x * x).sum() -- and like this file's earlier builds, in which the SLP vectoriser happened to keep these products
+// apart from their adds (the file is now built without it: Makefile).  The empty asm makes the product opaque to the contraction pass.
+__device__ __forceinline__ float mul_then_add(float a, float b, float c) {
+    float p = a * b;
+    asm("" : "+v"(p));
+    return p + c;
+}
+
 template <bool NTS = false>
 __device__ __forceinline__ void ln_finish(float (&x)[kMaxChunks][8], int nchunk_total, int lane, int H, float eps,
                                           const float* gamma, const float* beta, uint16_t* out_row,
@@ -71,7 +80,7 @@ __device__ __forceinline__ void ln_finish(float (&x)[kMaxChunks][8], int nchunk_
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const float d = x[c][i] - mean;
-                v += d * d;
+                v = mul_then_add(d, d, v);
             }
     const float rstd = rsqrtf(wave_sum(v) / (float)H + eps);
 #pragma unroll
@@ -202,7 +211,7 @@ __global__ __launch_bounds__(kRowThreads) void cls_pool_kernel(const uint16_t* h
         if (ch < nch) {
             unpack8(*reinterpret_cast<const uint4*>(src + ch * 8), x[c]);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) ss += x[c][i] * x[c][i];
+            for (int i = 0; i < 8; ++i) ss = mul_then_add(x[c][i], x[c][i], ss);
         }
     }
     const float nrm = fmaxf(sqrtf(wave_sum(ss)), 1e-12f);
@@ -263,7 +272,7 @@ __global__ __launch_bounds__(kRowThreads) void mean_pool_kernel(const void* hidd
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             acc[c][i] *= inv_len;
-            if (lane + 64 * c < nch) ss += acc[c][i] * acc[c][i];
+            if (lane + 64 * c < nch) ss = mul_then_add(acc[c][i], acc[c][i], ss);
         }
     const float inv = 1.0f / fmaxf(sqrtf(wave_sum(ss)), 1e-12f);
 #pragma unroll
@@ -307,7 +316,7 @@ __global__ __launch_bounds__(kRowThreads) void head_out_kernel(const uint16_t* t
         unpack8(*reinterpret_cast<const uint4*>(t + (size_t)b * ld + ch * 8), a);
         unpack8(*reinterpret_cast<const uint4*>(w + ch * 8), ww);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc += a[i] * ww[i];
+        for (int i = 0; i < 8; ++i) acc = mul_then_add(a[i], ww[i], acc);
     }
     acc = wave_sum(acc) + bias[0];
     if (lane == 0) {

@@ -349,7 +349,7 @@ class _TickFront:
         ctx = contextlib.nullcontext()
         if dev.type == "cuda":
             torch.cuda.set_device(dev)         # (the current device is per thread)
-            if os.environ.get("TT_RETRIEVE_STREAM", "0") == "1":       # opt-in: see HipVectorRetriever._gpu_stream
+            if os.environ.get("TT_RETRIEVE_STREAM", "1") != "0":       # see HipVectorRetriever._gpu_stream
                 # the rounds' GPU work (query embedding, the collectives' device side, the shard scan, the merge) on the
                 # front's own high-priority stream: it must not queue behind the rerank batches of this rank's callers
                 # (HipVectorRetriever._gpu_stream: one idle gap per scan batch otherwise)

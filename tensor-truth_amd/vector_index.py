@@ -412,16 +412,14 @@ class HipVectorRetriever:
         self._stream: Optional[torch.cuda.Stream] = None
 
     def _gpu_stream(self):
-        """Opt-in (``TT_RETRIEVE_STREAM=1``): the query embedding + scan of a batch on the retriever's OWN high-priority stream.
-        On the stream the reranker uses a retrieval batch queues behind whatever rerank batch is running (tens of ms), its
-        callers come back late, and the GPU then idles while THEIR rerank batch is tokenised and packed: one ~8 ms gap per
-        scan batch, 11 % of the time, in a kernel trace of the plugin-surface leg -- and 95 -> 104 queries/s with the own
-        stream.  It is OFF by default because the results are then no longer reproducible run to run: a streaming filter
-        scan that runs BESIDE an encoder forward of the other stream disturbs that forward's embedding-LayerNorm kernel
-        (a handful of output elements per few hundred rows come out as their LayerNorm bias alone; reproduced in isolation
-        by ``tools/probes/contention_race.py``; no out-of-bounds write, no other kernel of the library or of torch is
-        affected; root cause not found).  On one stream the two never overlap."""
-        if os.environ.get("TT_RETRIEVE_STREAM", "0") != "1":
+        """The query embedding + scan of a batch run on the retriever's OWN high-priority stream (``TT_RETRIEVE_STREAM=0`` puts them
+        back on the caller's).  On the stream the reranker uses, a retrieval batch queues behind whatever rerank batch is running
+        (tens of ms), its callers come back late, and the GPU then idles while THEIR rerank batch is tokenised and packed: one
+        ~8 ms gap per scan batch, 11 % of the time, in a kernel trace of the plugin-surface leg -- 95 -> 104 queries/s with the
+        own stream.  Two streams mean scans run BESIDE encoder forwards; the results stay bit-identical to the one-stream ones
+        (tests/test_concurrent_streams_gpu.py) now that no kernel holds the packed-f32 form that misbehaves beside another
+        kernel's MFMAs (profiles/r03_pk_mfma_hazard.log; tests/test_lib_abi.py checks the disassembly)."""
+        if os.environ.get("TT_RETRIEVE_STREAM", "1") == "0":
             return None
         if self._stream is None:
             dev = self.index.device
