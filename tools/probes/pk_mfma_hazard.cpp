@@ -86,6 +86,28 @@ __global__ void victim(unsigned long long* cnt, int iters, float seed) {
     if (threadIdx.x == 0) atomicAdd(&cnt[7], (unsigned long long)((long long)iters * blockDim.x * 2 / 1000));
 }
 
+// The library's only other op_sel user: v_fma_mix_f32 reading an fp16 from the LOW / HIGH half of a dword as src1 (attention_cls_kernel, fp16 build)
+template <int HI>
+__global__ void victim_mix(unsigned long long* cnt, int iters, float seed) {
+    const int lane = threadIdx.x & 63;
+    float a = seed + 0.001f * (float)(threadIdx.x + 1);
+    const float c = 0.125f * (float)(1 + (lane & 7));
+    unsigned bad = 0;
+    for (int it = 0; it < iters; ++it) {
+        const _Float16 h0 = (_Float16)(0.5f + 0.01f * (float)((it + lane) & 31)), h1 = (_Float16)(1.5f + 0.02f * (float)((it + lane) & 15));
+        const unsigned hw = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+        float r;
+        if constexpr (HI) asm volatile("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "=v"(r) : "v"(a), "v"(hw), "v"(c));
+        else asm volatile("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[0,1,0]" : "=v"(r) : "v"(a), "v"(hw), "v"(c));
+        const float e = __builtin_fmaf(a, (float)(HI ? h1 : h0), c);
+        bad += __float_as_uint(r) != __float_as_uint(e);
+        a = a * 1.0001f + 0.003f;
+        if (a > 64.f) a -= 63.f;
+    }
+    if (bad) { atomicAdd(&cnt[0], (unsigned long long)bad); atomicAdd(&cnt[1 + (lane >> 4)], (unsigned long long)bad); atomicAdd(&cnt[5], (unsigned long long)bad); }
+    if (threadIdx.x == 0) atomicAdd(&cnt[7], (unsigned long long)((long long)iters * blockDim.x / 1000));
+}
+
 // aggressors: K = 0 plain FMA loop (control), 1 = 16x16x32 bf16 MFMA (the GEMMs'), 2 = 32x32x16 bf16 MFMA (the scan's, attention's)
 template <int K>
 __global__ void aggressor(float* sink, int iters) {
@@ -118,7 +140,7 @@ __global__ void aggressor(float* sink, int iters) {
     }
 }
 
-template <int V>
+template <int V>   // V < 100: packed form V of FORMS; 100 / 101: v_fma_mix_f32 reading the low / high fp16
 static void run_victim(const char* name, hipStream_t vs, hipStream_t as, int agg, int agg_iters, unsigned long long* dcnt, float* sink) {
     unsigned long long h[8];
     CK(hipMemsetAsync(dcnt, 0, sizeof h, vs));
@@ -128,7 +150,8 @@ static void run_victim(const char* name, hipStream_t vs, hipStream_t as, int agg
     else if (agg == 2) aggressor<2><<<512, 256, 0, as>>>(sink, agg_iters / 2);
     int launches = 0;
     do {                                    // victim launches for as long as the aggressor is resident (at least 4, at most 64)
-        victim<V><<<2048, 256, 0, vs>>>(dcnt, 256, 1.0f + 0.01f * (float)launches);
+        if constexpr (V >= 100) victim_mix<V - 100><<<2048, 256, 0, vs>>>(dcnt, 256, 1.0f + 0.01f * (float)launches);
+        else victim<V><<<2048, 256, 0, vs>>>(dcnt, 256, 1.0f + 0.01f * (float)launches);
         CK(hipStreamSynchronize(vs));
         ++launches;
     } while (launches < 4 || (agg >= 0 && hipStreamQuery(as) == hipErrorNotReady && launches < 64));
@@ -151,6 +174,8 @@ int main(int argc, char** argv) {
 #define X(ID, OP, SEL, SELHI, NEG, TXT) run_victim<ID>(TXT, vs, as, agg, agg_iters, dcnt, sink);
         FORMS(X)
 #undef X
+        run_victim<100>("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[0,1,0]", vs, as, agg, agg_iters, dcnt, sink);
+        run_victim<101>("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,1,0]", vs, as, agg, agg_iters, dcnt, sink);
         fflush(stdout);
     }
     (void)kForms;
