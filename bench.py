@@ -553,11 +553,11 @@ def main():
 
     # ---- roofline of the dominant kernel (GEMM, MFMA-bound) and of the scan (HBM-bound) -------
     H, F, L = emb_cfg.hidden, emb_cfg.ffn, emb_cfg.layers
-    # algorithmic GEMM flops of what is computed (real tokens only): L-1 full layers + the last layer's QKV
-    # projection for every token, the last layer's output projection + FFN for the CLS rows only, the head
+    # algorithmic GEMM flops of what is computed (real tokens only): L-1 full layers + the last layer's K and V
+    # projections for every token; the last layer's query, output projection + FFN for the CLS rows only; the head
     full_layer = 2 * (3 * H * H + H * H + 2 * H * F)
-    gemm_flops_per_token = (L - 1) * full_layer + 2 * 3 * H * H
-    cls_tail_flops = 2 * (H * H + 2 * H * F)
+    gemm_flops_per_token = (L - 1) * full_layer + 2 * 2 * H * H
+    cls_tail_flops = 2 * (H * H + H * H + 2 * H * F)
     n_seq_step = Bq + Bq * K
     head_flops = 2 * H * H * (Bq * K)
     gemm_flops_step = (gemm_flops_per_token * (tokens_step["embed"] + tokens_step["rerank"])

@@ -389,7 +389,7 @@ __global__ __launch_bounds__(64) void attention_cls_kernel(AttnParams p) {
     // query row -> registers (every lane holds the whole q: uniform address)
     float q[DH];
     {
-        const uint16_t* qp = p.qk + (size_t)t0 * p.ld_qk + p.q_col0 + head * DH;
+        const uint16_t* qp = p.q_rows ? p.q_rows + (size_t)seq * p.ld_q_rows + head * DH : p.qk + (size_t)t0 * p.ld_qk + p.q_col0 + head * DH;
 #pragma unroll
         for (int c = 0; c < DH / 8; ++c) {
             const uint4 u = *reinterpret_cast<const uint4*>(qp + c * 8);

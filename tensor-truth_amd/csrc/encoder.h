@@ -72,6 +72,8 @@ struct AttnParams {
     float lazy;               // set by the launcher: log2 slack of the running softmax reference
     int n_qt;                 // set by the launcher: query tiles per sequence (grid decode)
     unsigned long long* dbg;  // diagnostic build only (tools/att_stamps): s_memtime stamps of one workgroup; NULL otherwise
+    const uint16_t* q_rows;   // CLS variant only: the query row of sequence b at q_rows + b * ld_q_rows (+ h*dh); NULL = row seq_start[b] of qk
+    int ld_q_rows;
 };
 int tt_attention_launch(const AttnParams& p, hipStream_t st);
 // CLS-only variant: one query row (seq_start[b]) per sequence; out row index = sequence index

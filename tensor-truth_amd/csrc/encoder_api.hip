@@ -160,6 +160,17 @@ static int forward_impl(const tt_encoder_weights* w, const int32_t* ids, const i
         if (e.fp8 && (f8mask & 1)) {   // x's e4m3 copy and row scales come from the LayerNorm that produced x
             g.A = (const uint16_t*)q8; g.W = (const uint16_t*)lw.qkv_w8; g.a_scale = q8s; g.w_scale = lw.qkv_wscale; g.fp8 = 1;
         }
+        // last layer of the CLS tail: only the first row of every sequence needs a QUERY, so the big projection computes K and V alone
+        // (the weight rows H..3H; K lands in its usual columns H..2H of qk) and the queries come from a small GEMM over the gathered
+        // first rows below.  Same kernels, same K order per output element: bit-identical to the full projection.  Not for the e4m3
+        // projection (byte-sized weights); TT_CLS_KV_ONLY=0 restores the full projection (A/B, tests).
+        bool kv_only = cls_tail && l == w->layers - 1 && !g.fp8;
+        if (kv_only)
+            if (const char* ev = getenv("TT_CLS_KV_ONLY"); ev && ev[0] == '0') kv_only = false;
+        if (kv_only) {
+            g.W = (const uint16_t*)lw.qkv_w + (size_t)H * H; g.bias = lw.qkv_b + H;
+            g.C = qk + H; g.N = 2 * H; g.vt_col0 = H;
+        }
         if (int rc = tt_gemm_launch(g, TT_EPI_QKV, st)) return rc;
         if (cls_tail && l == w->layers - 1) {
             // ---- last layer, CLS rows only: attention of the one query row per sequence, then the
@@ -171,16 +182,23 @@ static int forward_impl(const tt_encoder_weights* w, const int32_t* ids, const i
             uint16_t* cx1 = (uint16_t*)(ws + e.off_cx1);
             uint16_t* cffn = (uint16_t*)(ws + e.off_cffn);
             TT_CHECK_HIP(hipMemsetAsync(cctx, 0, (size_t)Bp * H * 2, st));
+            {
+                TtProfScope prof(TT_K_ROWOPS, st);
+                if (int rc = tt_gather_rows_launch(x, H, seq_start, n_seq, Bp, H, cx, st)) return rc;
+            }
             AttnParams ac{};
+            if (kv_only) {   // the first rows' queries (cy is free until the output projection writes it)
+                GemmParams gq{};
+                gq.A = cx; gq.lda = H; gq.W = (const uint16_t*)lw.qkv_w; gq.bias = lw.qkv_b;
+                gq.C = cy; gq.ldc = H; gq.M = Bp; gq.N = H; gq.K = H;
+                if (int rc = tt_gemm_launch(gq, TT_EPI_BIAS, st)) return rc;
+                ac.q_rows = cy; ac.ld_q_rows = H;
+            }
             ac.qk = qk; ac.ld_qk = 2 * H; ac.q_col0 = 0; ac.k_col0 = H; ac.vt = vt; ac.ldvt = 8 * H;
             ac.out = cctx; ac.ld_out = H; ac.seq_start = seq_start; ac.seq_len = seq_len;
             ac.n_seq = n_seq; ac.heads = w->heads; ac.head_dim = dh; ac.max_len = max_len;
             ac.scale = 1.0f / sqrtf((float)dh);
             if (int rc = tt_attention_cls_launch(ac, st)) return rc;
-            {
-                TtProfScope prof(TT_K_ROWOPS, st);
-                if (int rc = tt_gather_rows_launch(x, H, seq_start, n_seq, Bp, H, cx, st)) return rc;
-            }
             GemmParams go{};
             go.A = cctx; go.lda = H; go.W = (const uint16_t*)lw.o_w; go.bias = lw.o_b;
             go.residual = cx; go.ldr = H; go.C = cy; go.ldc = H; go.M = Bp; go.N = H; go.K = H;

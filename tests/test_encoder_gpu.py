@@ -347,6 +347,42 @@ def test_cls_only_last_layer_matches_full_forward(dev, built_lib, shape):
     assert err.mean().item() < 3e-3
 
 
+@pytest.mark.parametrize("shape,dtype", [("xlmr256", torch.bfloat16), ("bert384", torch.bfloat16), ("xlmr1024", torch.bfloat16),
+                                         ("xlmr1024", torch.float16), ("xlmr1024-one", torch.bfloat16)])
+def test_cls_tail_kv_only_projection_is_bit_identical(dev, built_lib, monkeypatch, shape, dtype):
+    """Last layer of the CLS tail: K and V from the big projection, the first rows' queries from a small GEMM over the gathered
+    rows (encoder_api.hip) -- the same bits as the full Q,K,V projection it replaces (TT_CLS_KV_ONLY=0), on the mixed-epilogue path
+    (small grids), the split path (>= 4096 rows) and the skinny path (one query), bf16 and fp16."""
+    from tensor_truth_amd.encoder import Encoder, EncoderConfig, EncoderWeights, pack_tokens, synthetic_state
+
+    if shape == "xlmr256":
+        cfg = EncoderConfig(arch="xlmr", vocab_size=2000, hidden=256, layers=3, heads=4, ffn=512, max_pos=600, type_vocab=1, pad_id=1,
+                            ln_eps=1e-5, num_labels=1)
+        lens = [300, 1, 64, 65, 129, 7, 513, 40]
+    elif shape == "bert384":
+        cfg = EncoderConfig(arch="bert", vocab_size=2000, hidden=384, layers=2, heads=12, ffn=1536, max_pos=600, type_vocab=2, pad_id=0,
+                            ln_eps=1e-12, num_labels=1)
+        lens = [300, 1, 64, 65, 129, 7, 513, 40]
+    else:
+        cfg = EncoderConfig(arch="xlmr", vocab_size=2000, hidden=1024, layers=2, heads=16, ffn=4096, max_pos=600, type_vocab=1, pad_id=1,
+                            ln_eps=1e-5, num_labels=1)
+        lens = [34] if shape.endswith("one") else [200 + 3 * i for i in range(24)]
+    enc = Encoder(EncoderWeights(cfg, synthetic_state(cfg, seed=7), dev, dtype=dtype))
+    g = torch.Generator().manual_seed(2)
+    seqs = [torch.randint(4, 2000, (n,), generator=g).tolist() for n in lens]
+    batch = pack_tokens(seqs, cfg)
+    cls_new = enc.cls_hidden_packed(batch)[0][: len(seqs)].clone()
+    emb_new = enc.embed_packed(batch)[0].clone()
+    score_new = enc.rerank_packed(batch).clone()
+    monkeypatch.setenv("TT_CLS_KV_ONLY", "0")
+    cls_old = enc.cls_hidden_packed(batch)[0][: len(seqs)]
+    emb_old = enc.embed_packed(batch)[0]
+    score_old = enc.rerank_packed(batch)
+    torch.cuda.synchronize()
+    assert torch.isfinite(cls_new.float()).all()
+    assert torch.equal(cls_new, cls_old) and torch.equal(emb_new, emb_old) and torch.equal(score_new, score_old)
+
+
 def test_forward_is_bit_reproducible(dev, built_lib):
     """The GEMM / attention kernels order their LDS-DMA copies with hand-counted waits: a mis-counted one would show up
     as an occasional different bit.  Same batch, same weights -> the same bits every time (bf16 and fp8 modes);
