@@ -10,6 +10,8 @@ between breakpoints.
 """
 from __future__ import annotations
 
+import os
+
 import re
 from typing import List, Optional, Sequence
 
@@ -130,15 +132,21 @@ class SemanticSplitter:
         docs = list(documents)
         texts = [d.get_content() if hasattr(d, "get_content") else str(d) for d in docs]
         nodes: List[TextNode] = []
-        # documents per embedding call: bounded by the number of sentence groups (host memory for the strings)
-        calls, lo = [], 0
+        # documents per embedding call: bounded by the number of sentence groups (host memory for the strings).  The first calls
+        # are SMALL and double up to that bound: before the first call's groups are enqueued the GPU has nothing to do, and a
+        # call's documents are cut on the host while the GPU embeds the NEXT call's groups -- with one big call per window a
+        # kernel trace shows the GPU idle through all of the window's sentence splitting and all of its cutting
+        # (profiles/r03_ingest_busy.log).  The cuts do not depend on the partition: thresholds are per document, embeddings
+        # do not depend on the batch they travel in.
+        calls, lo, cap = [], 0, min(max_groups_per_call, int(os.environ.get("TT_SEMANTIC_FIRST_CALL", "2048")))
         while lo < len(docs):
-            hi, budget = lo, max_groups_per_call
+            hi, budget = lo, cap
             while hi < len(docs) and (hi == lo or budget > 0):
                 budget -= max(1, texts[hi].count(".") + texts[hi].count("\n"))
                 hi += 1
             calls.append((lo, hi))
             lo = hi
+            cap = min(max_groups_per_call, cap * 2)
         # software pipeline: call i + 1's sentence groups are tokenized and their forward passes enqueued BEFORE call i's
         # distances are fetched, so the GPU embeds them while the host cuts call i's documents and builds its nodes
         pending = self._begin_split(texts[calls[0][0]:calls[0][1]]) if calls else None
