@@ -52,6 +52,27 @@ def breakpoints_from_distances(dist: Sequence[float], percentile: float) -> List
     return [int(i) for i in np.nonzero(d > thr)[0]]
 
 
+
+def embedding_calls(texts: Sequence[str], max_groups_per_call: int = 65536, first_call: Optional[int] = None) -> List[tuple]:
+    """Documents per embedding call of the semantic pass -> [(lo, hi), ...], contiguous, in order, covering every text once.
+    A call is bounded by its (estimated) number of sentence groups -- host memory for the strings.  The first calls are SMALL
+    and double up to that bound: before the first call's groups are enqueued the GPU has nothing to do, and a call's documents
+    are cut on the host while the GPU embeds the NEXT call's groups -- with one big call per window a kernel trace shows the
+    GPU idle through all of the window's sentence splitting and all of its cutting (profiles/r03_ingest_busy.log).  The cuts do
+    not depend on the partition: thresholds are per document, embeddings do not depend on the batch they travel in."""
+    if first_call is None:
+        first_call = int(os.environ.get("TT_SEMANTIC_FIRST_CALL", "2048"))
+    calls, lo, cap = [], 0, max(1, min(max_groups_per_call, first_call))
+    while lo < len(texts):
+        hi, budget = lo, cap
+        while hi < len(texts) and (hi == lo or budget > 0):
+            budget -= max(1, texts[hi].count(".") + texts[hi].count("\n"))
+            hi += 1
+        calls.append((lo, hi))
+        lo = hi
+        cap = min(max_groups_per_call, cap * 2)
+    return calls
+
 class SemanticSplitter:
     def __init__(self, embed_model, buffer_size: int = 1, breakpoint_percentile_threshold: float = 95):
         self.embed_model = embed_model
@@ -132,21 +153,7 @@ class SemanticSplitter:
         docs = list(documents)
         texts = [d.get_content() if hasattr(d, "get_content") else str(d) for d in docs]
         nodes: List[TextNode] = []
-        # documents per embedding call: bounded by the number of sentence groups (host memory for the strings).  The first calls
-        # are SMALL and double up to that bound: before the first call's groups are enqueued the GPU has nothing to do, and a
-        # call's documents are cut on the host while the GPU embeds the NEXT call's groups -- with one big call per window a
-        # kernel trace shows the GPU idle through all of the window's sentence splitting and all of its cutting
-        # (profiles/r03_ingest_busy.log).  The cuts do not depend on the partition: thresholds are per document, embeddings
-        # do not depend on the batch they travel in.
-        calls, lo, cap = [], 0, min(max_groups_per_call, int(os.environ.get("TT_SEMANTIC_FIRST_CALL", "2048")))
-        while lo < len(docs):
-            hi, budget = lo, cap
-            while hi < len(docs) and (hi == lo or budget > 0):
-                budget -= max(1, texts[hi].count(".") + texts[hi].count("\n"))
-                hi += 1
-            calls.append((lo, hi))
-            lo = hi
-            cap = min(max_groups_per_call, cap * 2)
+        calls = embedding_calls(texts, max_groups_per_call)
         # software pipeline: call i + 1's sentence groups are tokenized and their forward passes enqueued BEFORE call i's
         # distances are fetched, so the GPU embeds them while the host cuts call i's documents and builds its nodes
         pending = self._begin_split(texts[calls[0][0]:calls[0][1]]) if calls else None

@@ -1077,3 +1077,45 @@ def test_oracle_mean_pooling_matches_the_formula_on_ragged_masks():
         want = want / want.norm()
         assert torch.allclose(got[b], want, atol=1e-6)
     assert torch.allclose(got[2], oe.cls_pool_normalize(h)[2], atol=1e-6)      # one token: mean pooling = CLS pooling
+
+
+def test_ingest_ramps_cover_every_input_once_in_order():
+    """The two ramps of the ingest pipeline (small first pieces so the GPU starts early): the semantic pass's embedding calls
+    (``semantic.embedding_calls``) and the hierarchical pass's pieces (``index_builder.iter_parsed``) partition their inputs
+    contiguously, in order, without loss, and grow towards their bound."""
+    from tensor_truth_amd.semantic import embedding_calls
+
+    texts = ["a. b. c." * (1 + i % 7) for i in range(1000)]
+    for first, cap in ((64, 4096), (1, 8), (10 ** 9, 10 ** 9), (2048, 65536)):
+        calls = embedding_calls(texts, cap, first)
+        assert calls[0][0] == 0 and calls[-1][1] == len(texts)
+        assert all(a[1] == b[0] for a, b in zip(calls, calls[1:])) and all(lo < hi for lo, hi in calls)
+        sizes = [hi - lo for lo, hi in calls]
+        assert all(a <= b + 7 for a, b in zip(sizes[:-1], sizes[1:-1]))      # growing budget (a text holds up to 7 x 3 groups)
+        if (first, cap) == (64, 4096):
+            assert sizes[0] < sizes[2] < sizes[4]
+    assert embedding_calls([], 100, 10) == []
+    assert embedding_calls(["no sentence end"], 100, 10) == [(0, 1)]
+
+    class _Doc:
+        def __init__(self, i):
+            self.text, self.metadata, self.id_ = f"doc {i}. " * 3, {}, f"d{i}"
+
+        def get_content(self, *a, **k):
+            return self.text
+
+    class _Hier:                                              # records the pieces it is handed
+        def __init__(self):
+            self.seen = []
+
+        def get_nodes_from_documents(self, piece):
+            self.seen.append(len(piece))
+            return list(piece)
+
+    from tensor_truth_amd.index_builder import iter_parsed
+
+    docs = [_Doc(i) for i in range(1000)]
+    h = _Hier()
+    out = [n for nodes in iter_parsed(docs, None, "hierarchical", node_parser=h, sub_batch=512) for n in nodes]
+    assert [d.id_ for d in out] == [d.id_ for d in docs]
+    assert h.seen[:3] == [128, 256, 512] and sum(h.seen) == 1000 and max(h.seen) == 512
