@@ -39,24 +39,25 @@ def launch_plan(argv, environ):
             gpus = int(a.split("=", 1)[1])
     if gpus <= 1 or "WORLD_SIZE" in environ or "RANK" in environ or "LOCAL_RANK" in environ:
         return None
-    port = environ.get("MASTER_PORT")
-    if not port:
-        import socket
-
-        with socket.socket() as s:                  # a free port, decided by the kernel
-            s.bind(("127.0.0.1", 0))
-            port = str(s.getsockname()[1])
+    port = environ.get("MASTER_PORT") or _free_port()
     return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
             "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
 
 
-def self_launch(cmd):
-    """Run the ranks as a CHILD process (never exec: the driver may already hold the GPU, and a process that has touched
-    HIP must not be replaced); the ranks' other output goes to stderr, rank 0's JSON line is the one line on stdout;
-    exit with the child's code."""
+def _free_port() -> str:
+    import socket
+
+    with socket.socket() as s:                      # a free port, decided by the kernel
+        s.bind(("127.0.0.1", 0))
+        return str(s.getsockname()[1])
+
+
+def _run_ranks(cmd, env):
+    """One child process running the ranks -> (exit code, rank 0's JSON line or None); everything else the ranks print
+    goes to stderr."""
     import subprocess
 
-    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=None, text=True, bufsize=1)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=None, text=True, bufsize=1, env=env)
     line_json = None
     for line in proc.stdout:
         s = line.strip()
@@ -64,13 +65,63 @@ def self_launch(cmd):
             line_json = s                             # held back: printed once, as the ONLY line on stdout
         else:
             sys.stderr.write(line)                    # (gloo / launcher chatter of the ranks)
-    rc = proc.wait()
+    return proc.wait(), line_json
+
+
+def self_launch(cmd, environ=None):
+    """Run the ranks as a CHILD process (never exec: the driver may already hold the GPU, and a process that has touched
+    HIP must not be replaced); the ranks' other output goes to stderr, rank 0's JSON line is the one line on stdout;
+    exit with the child's code.
+
+    First-contact safety: the ranks start with a pre-flight of the collectives the step uses
+    (preflight_collectives below); if the child dies before a JSON line -- RCCL init, IPC handles, the pre-flight -- ONE
+    fresh child is started with HSA_ENABLE_IPC_MODE_LEGACY flipped (this pool's driver wants 0 = dmabuf IPC, which is what
+    the environment exports; another host may want the legacy handles) and a new rendezvous port.  This parent never
+    touches the GPU, and nothing is re-exec'ed.  The JSON line reports the setting that worked (config.ipc_mode_legacy)."""
+    env = dict(os.environ if environ is None else environ)
+    rc, line_json = _run_ranks(cmd, env)
+    if line_json is None and rc != 0 and env.get("TT_BENCH_NO_IPC_RETRY") != "1":
+        flipped = dict(env)
+        flipped["HSA_ENABLE_IPC_MODE_LEGACY"] = "1" if env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0") == "0" else "0"
+        flipped["TT_BENCH_IPC_RETRY"] = "1"           # (reported in the JSON line: config.ipc_mode_retry)
+        cmd2 = list(cmd)
+        if "--master-port" in cmd2:
+            cmd2[cmd2.index("--master-port") + 1] = _free_port()
+        sys.stderr.write(f"bench.py: the ranks exited {rc} before a JSON line; one fresh attempt with "
+                         f"HSA_ENABLE_IPC_MODE_LEGACY={flipped['HSA_ENABLE_IPC_MODE_LEGACY']}\n")
+        rc, line_json = _run_ranks(cmd2, flipped)
     if line_json is not None:
         print(line_json, flush=True)
     elif rc == 0:
         sys.stderr.write("bench.py: the ranks exited 0 without a JSON line\n")
         rc = 1
     raise SystemExit(rc)
+
+
+def preflight_collectives(dist, torch, dev, rank, world):
+    """First step of every world > 1 run (tools/nccl_two_rank_smoke.py's checks, in process): the collectives the step uses,
+    checked against what they must return, before any model is loaded -- all-gather of packed partial top-k blocks, barrier,
+    all-reduce MAX (the max-over-ranks timing), ragged all_gather.  A failure raises with the backend's own error text: the
+    rank exits non-zero before any JSON line, and a self-launching parent retries once with the other IPC mode."""
+    Q, K = 64, 50
+    mine = torch.empty((Q, K, 2), dtype=torch.float32, device=dev)
+    mine[..., 0] = torch.arange(Q * K, device=dev, dtype=torch.float32).view(Q, K) + 1000.0 * rank
+    mine[..., 1] = float(rank)
+    out = torch.empty((world, Q, K, 2), dtype=torch.float32, device=dev)
+    dist.all_gather_into_tensor(out.view(-1), mine.view(-1))
+    for r in range(world):
+        want = torch.arange(Q * K, device=dev, dtype=torch.float32).view(Q, K) + 1000.0 * r
+        if not (torch.equal(out[r, ..., 0], want) and bool((out[r, ..., 1] == float(r)).all())):
+            raise RuntimeError(f"pre-flight: rank {rank} received a wrong all-gather block from rank {r}")
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64, device=dev)
+    dist.barrier()
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if t.item() != float(world):
+        raise RuntimeError(f"pre-flight: all-reduce MAX returned {t.item()} on rank {rank}, expected {world}")
+    counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(counts, torch.tensor([rank * 3 + 1], dtype=torch.int64, device=dev))
+    if [int(c.item()) for c in counts] != [r * 3 + 1 for r in range(world)]:
+        raise RuntimeError(f"pre-flight: ragged all_gather wrong on rank {rank}")
 
 
 if __name__ == "__main__":
@@ -106,6 +157,9 @@ def parse():
     ap.add_argument("--embed-chunks", type=int, default=1024, help="chunks per GPU in the ingest (chunks embedded/s) leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-surface-leg", action="store_true", help="skip the plugin-surface leg (32 request threads through retrieve() / postprocess_nodes())")
+    ap.add_argument("--surface-leg", action="store_true",
+                    help="world > 1: run the plugin-surface leg too (off by default there until it has run over RCCL on a real multi-GPU box: "
+                         "its collectives are issued from the retriever's tick thread, under a deadline)")
     ap.add_argument("--no-config5-leg", action="store_true", help="skip the composed BASELINE config 5 leg (semantic-hierarchical ingest + auto-merging retrieval + fp8 reranker)")
     ap.add_argument("--surface-threads", type=int, default=32)
     ap.add_argument("--surface-queries", type=int, default=256, help="queries the surface leg issues in all (N=1 only)")
@@ -195,8 +249,13 @@ def main():
             dist.init_process_group("gloo", timeout=datetime.timedelta(minutes=30))
         else:
             dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(minutes=30))
+        preflight_collectives(dist, torch, dev, rank, world)
+        # control plane: a gloo group beside the data-plane communicator, for agreements the main thread must be able to reach
+        # while a worker thread may sit in a data-plane collective (the plugin-surface leg's outcome, below)
+        ctl_group = dist.new_group(backend="gloo", timeout=datetime.timedelta(minutes=10))
 
     from tensor_truth_amd import _lib
+    from tensor_truth_amd import scan as tscan
     from tensor_truth_amd.encoder import (BGE_M3, BGE_RERANKER_V2_M3, Encoder, EncoderConfig, EncoderWeights,
                                           pack_token_matrix, pack_tokens, synthetic_state_device)
     from tensor_truth_amd.sharded import shard_bounds
@@ -254,9 +313,9 @@ def main():
         tokens_step["rerank"] = rb.n_tokens
         tokens_step["last_pairs"] = pair_ids          # (the rank-quality leg re-scores a few of these in every precision mode)
         scores = reranker.rerank_packed(rb).view(Bq, K)
-        # 6. top-n by rerank score (host-visible result, as the postprocessor returns it)
-        top_s, top_j = torch.topk(scores, topn, dim=1)
-        rows = torch.gather(i.long(), 1, top_j)
+        # 6. top-n by rerank score (host-visible result, as the postprocessor returns it): tt_topk_merge over the K scored
+        #    candidates of every query, ordered (score desc, row asc)
+        top_s, rows = tscan.topk_merge(scores, i, topn)
         return top_s.cpu(), rows.cpu()
 
     def sync_all():
@@ -329,8 +388,6 @@ def main():
     # per-stage device times from HIP events, and the whole batch as a fraction of the HBM roofline on ALGORITHMIC bytes
     scan_shard = None
     if world == 1 and not args.headline_only and (hi - lo) >= args.corpus_rows // 8 >= 262144:
-        from tensor_truth_amd import scan as tscan
-
         rows8 = args.corpus_rows // 8
         shard8 = shard_rows[:rows8]
         q8 = torch.nn.functional.normalize(torch.randn(256, D, device=dev, generator=torch.Generator(device=dev).manual_seed(4322)), dim=1).to(torch.bfloat16)
@@ -518,7 +575,7 @@ def main():
     # merges them into shared embed / scan / rerank batches.  Strings in, NodeWithScore out; the SAME resident corpus.
     surface = None
     hard_exit = False
-    if not args.headline_only and not args.no_surface_leg:
+    if not args.headline_only and not args.no_surface_leg and (world == 1 or args.surface_leg):
         if world == 1:
             surface = surface_leg(args, dev, shard_rows, emb_cfg, rr_cfg, world, rank, lo)
         else:
@@ -547,6 +604,18 @@ def main():
                 surface, hard_exit = {"error": f"plugin-surface leg failed on rank {rank}: {box['error']!r}"}, True
             else:
                 surface = box["result"]
+            # The ranks AGREE on the leg's outcome before anything is printed -- on the main thread, over the gloo control
+            # group (never the data-plane communicator: a worker that has not come back may still sit in one of its
+            # collectives).  One failed or timed-out rank fails the leg everywhere: the JSON line says surface_failed, every
+            # rank then leaves the same way (os._exit after printing), and none goes on to destroy_process_group while a
+            # peer's thread is still inside a collective.
+            flag = torch.tensor([1 if hard_exit else 0], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=ctl_group)
+            if int(flag.item()):
+                if not hard_exit:
+                    surface = {"error": "plugin-surface leg failed or timed out on another rank", "local_result": surface}
+                surface["surface_failed"] = True
+                hard_exit = True
     config5 = None
     if world == 1 and not args.headline_only and not args.no_config5_leg:
         config5 = config5_leg(args, dev, emb_cfg, rr_cfg)
@@ -621,7 +690,8 @@ def main():
         "metric": "queries/sec (embed+top-k+rerank) over 10M x 1024 corpus",
         "value": world * Bq * args.steps / dt,
         "unit": "queries/s",
-        "n_gpus": world,
+        "n_gpus": 1 if one_device else world,       # physical devices (TT_BENCH_ONE_DEVICE=1: all ranks share GPU 0)
+        "ranks": world,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3,
@@ -638,6 +708,14 @@ def main():
             "pair_tokens": args.query_len + args.chunk_len + 4, "encoder_layers": L,
             "parallelism": f"corpus row-sharded x{world}, encoders replicated",
             "ranks_share_one_device": one_device,   # TT_BENCH_ONE_DEVICE=1 (debugging aid): all ranks on GPU 0 over gloo -- not a scaling number
+            # multi-process GPU work on this pool needs dmabuf IPC (0); a self-launched run that died before its JSON line is
+            # retried once with the other setting (self_launch): this is the one the printed numbers were measured under
+            "ipc_mode_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"), "ipc_mode_retry": os.environ.get("TT_BENCH_IPC_RETRY") == "1",
+            # the rate INSIDE north_star's score tolerance (1e-3 relative): the same step with both encoders in the
+            # reference's own precision -- what an unchanged reference call (no dtype) gets; `value` is the bf16 mode
+            # BASELINE's configurations name.  Detail under reference_precision.
+            "at_tolerance_queries_per_s": reference_leg["queries_per_s"] if reference_leg else None,
+            "at_tolerance_mode": reference_leg["dtype"] if reference_leg else None,
             "chunks_reranked_per_s": world * Bq * K * args.steps / dt,
             "chunks_embedded_per_s": chunks_per_s,
             "embed_batch": f"{args.embed_chunks} chunks x {args.chunk_len + 2} tok per GPU (bge-m3 shape)",
@@ -656,9 +734,9 @@ def main():
             "launches": gemm_n, "avg_launch_ms": gemm_ms / max(gemm_n, 1),
             "algorithmic_flops_per_launch": gemm_flops_step * args.steps / max(gemm_n, 1),
             "mfma_busy": mfma_busy, "mfma_busy_note": mfma_note,
-            # what the chip sustains on this data with NO operand traffic: a stream of nothing but v_mfma_f32_16x16x32_bf16
-            # (tools/gemm4w_bench variant 14, profiles/r03_gemm_4wave_ab.log) -- the clock it holds under an MFMA-only load
-            "mfma_only_stream_TFLOPs": 1803.0,
+            # CONSTANT, not measured by this run: what the chip sustained in round 3 on a stream of nothing but
+            # v_mfma_f32_16x16x32_bf16, no operand traffic (tools/gemm4w_bench variant 14, profiles/r03_gemm_4wave_ab.log)
+            "mfma_only_stream_TFLOPs": {"value": 1803.0, "measured_by_this_run": False, "source": "profiles/r03_gemm_4wave_ab.log"},
         },
         "roofline_scan": {
             "kernel": ("gemm_kernel_v3<TT_EPI_SCAN> (tiled MFMA filter pass over the corpus shard)" if tiled
@@ -814,9 +892,9 @@ def surface_leg(args, dev, shard_rows, emb_cfg, rr_cfg, world=1, rank=0, row_lo=
 
     K, topn = args.top_k, args.top_n
     emb = HipHuggingFaceEmbedding("BAAI/bge-m3", device=str(dev), embed_batch_size=128,
-                                  model_kwargs={"encoder_config": emb_cfg, "synthetic_seed": 1})
+                                  model_kwargs={"encoder_config": emb_cfg, "synthetic_seed": 1, "torch_dtype": "bfloat16"})
     rr = HipSentenceTransformerRerank(model="BAAI/bge-reranker-v2-m3", top_n=topn, device=str(dev), batch_pairs=4096,
-                                      model_kwargs={"encoder_config": rr_cfg, "synthetic_seed": 2})
+                                      model_kwargs={"encoder_config": rr_cfg, "synthetic_seed": 2, "torch_dtype": "bfloat16"})
     n = shard_rows.shape[0] if world == 1 else args.corpus_rows
     index = ShardedHipVectorIndex(shard_rows.shape[1], shard_rows, row_lo, n, _RowIds(n), _SynthDocstore(args.chunk_len),
                                   embed_model=emb, score_mode="cosine", queries="partitioned" if world > 1 else "replicated")
@@ -849,6 +927,10 @@ def surface_leg(args, dev, shard_rows, emb_cfg, rr_cfg, world=1, rank=0, row_lo=
         if world > 1:
             retr.close(timeout=600)                # leave the lock-step front whatever happened (every rank does)
     if world > 1:
+        tick = getattr(retr, "_tick", None)
+        if tick is not None and tick._thread.is_alive():
+            # close() came back on its timeout: the tick thread still owns the communicator -- no collective from this thread
+            raise RuntimeError("the retriever's tick thread did not stop within 600 s of close()")
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -886,7 +968,7 @@ def config5_leg(args, dev, emb_cfg, rr_cfg):
         docs.append(TextNode(text=" ".join(sents), metadata={"title": f"doc {d}"}))
     mm.ModelManager.reset_instance()
     mgr = mm.ModelManager.get_instance()
-    mgr.model_kwargs_overrides["BAAI/bge-m3"] = {"encoder_config": emb_cfg, "synthetic_seed": 1}
+    mgr.model_kwargs_overrides["BAAI/bge-m3"] = {"encoder_config": emb_cfg, "synthetic_seed": 1, "torch_dtype": "bfloat16"}
     mgr.model_kwargs_overrides["BAAI/bge-reranker-v2-m3"] = {"encoder_config": rr_cfg, "synthetic_seed": 2, "gemm_dtype": "fp8"}
     emb = mgr.get_embedder("BAAI/bge-m3", "cuda")
     torch.cuda.synchronize()

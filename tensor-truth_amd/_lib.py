@@ -25,6 +25,33 @@ def lib_path() -> str:
     return os.path.join(_HERE, _LIB_NAME)
 
 
+_isa_ok = None
+
+
+def isa_checked() -> bool:
+    """True when csrc/check_isa.py has disassembled THIS build of the library and found no packed-f32 instruction of the form
+    that misbehaves beside another stream's MFMAs (its stamp, ``libtt_hip.so.isa_ok``, holds the library's sha256).  Code that
+    runs kernels on two streams at once (the retriever's own stream, vector_index.py) asks first and stays on one stream
+    otherwise."""
+    global _isa_ok
+    if _isa_ok is None:
+        import hashlib
+
+        ok = False
+        try:
+            with open(lib_path() + ".isa_ok") as fh:
+                want = fh.read().strip()
+            h = hashlib.sha256()
+            with open(lib_path(), "rb") as fh:
+                for blk in iter(lambda: fh.read(1 << 20), b""):
+                    h.update(blk)
+            ok = h.hexdigest() == want
+        except OSError:
+            ok = False
+        _isa_ok = ok
+    return _isa_ok
+
+
 _F32P = ctypes.POINTER(c_float)
 _I32P = ctypes.POINTER(c_int32)
 

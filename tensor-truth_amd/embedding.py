@@ -13,6 +13,7 @@ import logging
 from concurrent.futures import ThreadPoolExecutor
 from typing import Any, Dict, List, Optional, Sequence
 
+import numpy as np
 import torch
 
 from . import weights as _weights
@@ -40,7 +41,7 @@ def _report_unused_kwargs(model_name: str, model_kwargs, tokenizer_kwargs) -> No
     td = mk.get("torch_dtype")
     if td is not None and str(td).replace("torch.", "") not in ("bfloat16", "float16", "float32", "fp32"):
         logger.warning("%s: torch_dtype=%s is not available on the HIP path; computing in bfloat16 "
-                       "(fp32 accumulation). Supported: 'bfloat16' (default), 'float16', 'float32'.", model_name, td)
+                       "(fp32 accumulation). Supported: 'float32' (what no torch_dtype means, as in the reference), 'bfloat16', 'float16'.", model_name, td)
     if mk.get("attn_implementation"):
         logger.info("%s: attn_implementation=%s ignored -- attention is always the fused varlen HIP kernel "
                     "(no padding tokens are computed)", model_name, mk["attn_implementation"])
@@ -80,7 +81,7 @@ class HipHuggingFaceEmbedding:
                                       f"(CLS and mean pooling, both followed by L2 normalisation, are)")
         self.pooling = pooling
         # precision.resolve(): model_kwargs (torch_dtype float32 = the reference's own default, config_schema.py:66-76),
-        # ModelManager.precision, TT_PRECISION; default bf16.  (`_model.parameters()` is read by the memory accounting.)
+        # ModelManager.precision, TT_PRECISION; default: the reference's fp32 semantics.  (`_model.parameters()` is read by the memory accounting.)
         self._model, self._encoder, self.precision = _precision.build_encoder(cfg, state, dev, model_kwargs, f"embedder {model_name}")
         self._tokenizer = (model_kwargs or {}).get("tokenizer") or load_tokenizer(mdir, cfg.arch, cfg.vocab_size)
         self.max_length = min(max_length or cfg.max_seq_len, cfg.max_seq_len)
@@ -174,9 +175,10 @@ class HipHuggingFaceEmbedding:
 
     @staticmethod
     def similarity(a: Sequence[float], b: Sequence[float], mode: str = "cosine") -> float:
-        ta, tb = torch.tensor(a, dtype=torch.float64), torch.tensor(b, dtype=torch.float64)
+        # host arithmetic on two Python vectors, as llama-index's BaseEmbedding.similarity ([UPSTREAM-K]): not the hot path
+        ta, tb = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
         if mode == "dot_product":
-            return float(ta @ tb)
+            return float(np.dot(ta, tb))
         if mode == "euclidean":
-            return float(-(ta - tb).norm())
-        return float((ta @ tb) / (ta.norm() * tb.norm()).clamp_min(1e-30))
+            return float(-np.linalg.norm(ta - tb))
+        return float(np.dot(ta, tb) / max(np.linalg.norm(ta) * np.linalg.norm(tb), 1e-30))

@@ -81,7 +81,7 @@ class ModelManager:
         self._model_lock = threading.Lock()
         self.embedding_model_configs: Dict[str, Dict] = dict(DEFAULT_EMBEDDING_MODEL_CONFIGS)
         self.model_kwargs_overrides: Dict[str, Dict[str, Any]] = {}  # model name -> extra model_kwargs
-        # Process-level precision of the models this manager loads: None (= TT_PRECISION, else bf16), "bf16", "fp16", "fp8" or
+        # Process-level precision of the models this manager loads: None (= TT_PRECISION, else the reference's fp32 semantics), "bf16", "fp16", "fp8" or
         # "reference" -- the reference's own fp32 semantics for its unchanged calls (precision.py).  Set it before the
         # first get_embedder / get_reranker, or call set_precision() (drops the resident models).
         self.precision: Optional[str] = None
@@ -147,7 +147,7 @@ class ModelManager:
                 logger.info("flash_attention requested for %s: the HIP encoder's attention is always a fused varlen "
                             "kernel, nothing to enable", model_name)
             logger.info("Creating embedding model: %s (batch_size=%d, dtype=%s)", model_name, batch,
-                        mc.torch_dtype or "bfloat16 (HIP default)")
+                        mc.torch_dtype or "none named: precision.resolve() decides (default: the reference's fp32 semantics)")
             model_kwargs.update(self.model_kwargs_overrides.get(model_name, {}))
             model_kwargs = self._with_precision(model_kwargs)
             tokenizer_kwargs = {"padding_side": mc.padding_side} if mc.padding_side else None

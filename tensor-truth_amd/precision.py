@@ -3,13 +3,16 @@
 The reference never passes a dtype to its reranker (``SentenceTransformerRerank(model=, top_n=, device=)``,
 ``src/tensortruth/services/model_manager.py:333-337``) and passes one to its embedder only when the per-model config
 holds ``torch_dtype`` (``services/model_manager.py:218-229``; ``app_utils/config_schema.py:66-76``: default None), so the
-reference's own precision is fp32.  BASELINE.json's configurations name bf16 (and fp8 for config 5), which is what this
-package computes by default.  The unchanged reference calls can still get the reference's arithmetic:
+reference's own precision is fp32 -- and so is this package's DEFAULT: an unchanged reference call (no dtype anywhere)
+resolves to mode "reference", whose scores are within north_star's 1e-3 relative of the reference's CPU path.
+BASELINE.json's configurations name bf16 (and fp8 for config 5): those are the modes a caller NAMES (``torch_dtype:
+"bfloat16"`` in the per-model config, as the reference's own config schema allows; ``TT_PRECISION=bf16``;
+``ModelManager.set_precision("bf16")``), and the ones ``bench.py`` names for its headline.
 
     mode "reference"  fp32 semantics: scores within north_star's 1e-3 relative of the CPU path.  Runs as split-bf16 on
                       the bf16 matrix cores (``encoder_x3``, a third of the bf16 rate) when the model shape allows,
                       else on the fp32 MFMA (``encoder_f32``).  ``TT_REFERENCE_IMPL=fp32`` forces the latter.
-    mode "bf16"       bf16 weights / activations, fp32 accumulate (default; BASELINE configs 2-4)
+    mode "bf16"       bf16 weights / activations, fp32 accumulate (BASELINE configs 2-4; the reference's ``torch_dtype: bfloat16``)
     mode "fp16"       IEEE fp16 weights / activations, fp32 accumulate: the bf16 mode's rate (v_mfma_*_f16) with three more
                       mantissa bits at every rounding point -- scores about ten times closer to the reference than bf16;
                       what the reference's ``torch_dtype: "float16"`` asks for, and FlagEmbedding's own default for the BGE
@@ -19,7 +22,8 @@ package computes by default.  The unchanged reference calls can still get the re
 Resolution order (first that says something): ``model_kwargs["precision"]``; ``model_kwargs["torch_dtype"]`` (float32 ->
 reference; float16 -> fp16; bfloat16 -> bf16) and ``model_kwargs["gemm_dtype"]``; ``ModelManager.precision`` (a config key the
 application sets once; ModelManager puts it into the model_kwargs it builds); the process environment ``TT_PRECISION``;
-"bf16".  The active mode is logged when a model is loaded.
+"reference" (round 4; rounds 1-3 defaulted to bf16, which put the unchanged calls 10x outside the tolerance).  The active
+mode is logged when a model is loaded.
 """
 from __future__ import annotations
 
@@ -30,6 +34,9 @@ from typing import Any, Dict, Optional, Tuple
 logger = logging.getLogger(__name__)
 
 MODES = ("bf16", "fp16", "fp8", "reference")
+# what a call that names no dtype gets: the reference's own arithmetic (services/model_manager.py:333-337 passes none;
+# app_utils/config_schema.py:66-76 defaults torch_dtype to None) -- fp32 semantics
+DEFAULT_MODE = "reference"
 _ALIASES = {"bf16": "bf16", "bfloat16": "bf16", "fp16": "fp16", "float16": "fp16", "half": "fp16", "fp8": "fp8", "e4m3": "fp8",
             "reference": "reference", "fp32": "reference", "float32": "reference", "float": "reference", "bf16x3": "reference"}
 
@@ -59,7 +66,7 @@ def resolve(model_kwargs: Optional[Dict[str, Any]] = None, environ=None) -> str:
     env = (os.environ if environ is None else environ).get("TT_PRECISION")
     if env:
         return canonical(env)
-    return "bf16"
+    return DEFAULT_MODE
 
 
 def reference_impl(cfg, environ=None) -> str:

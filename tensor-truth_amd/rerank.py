@@ -48,7 +48,7 @@ class HipSentenceTransformerRerank:
         # pairs are truncated by the tokenizer (longest-first, specials kept): never beyond what the model has positions for
         self.max_length = min(max_length, cfg.max_seq_len)
         # precision.resolve(): model_kwargs, ModelManager.precision, TT_PRECISION -- "reference" gives the unchanged
-        # reference call (no dtype: fp32, model_manager.py:333-337) its fp32 semantics; default bf16 (BASELINE configs 2-4)
+        # reference call (no dtype: fp32, model_manager.py:333-337) its fp32 semantics, and is the default; bf16 / fp16 / fp8 when named
         # (`.model` is what the reference's memory accounting reads)
         self.model, self._encoder, self.precision = _precision.build_encoder(cfg, state, dev, model_kwargs, f"reranker {model}")
         self._tokenizer = (model_kwargs or {}).get("tokenizer") or load_tokenizer(mdir, cfg.arch, cfg.vocab_size)

@@ -10,6 +10,7 @@ the reference's ``indexes/{model_id}/{module}/`` layout: ``corpus.bf16`` (raw ro
 from __future__ import annotations
 
 import json
+import logging
 import math
 import os
 import re
@@ -20,9 +21,12 @@ from typing import Dict, Iterable, List, Optional, Sequence
 import numpy as np
 import torch
 
+from . import _lib
 from . import scan as _scan
 from .coalesce import Coalescer
 from .schema import MetadataMode, NodeWithScore, QueryBundle, TextNode, as_query_bundle
+
+logger = logging.getLogger(__name__)
 
 INDEX_METADATA_FILENAME = "index_metadata.json"   # reference: indexing/metadata.py:17
 INDEX_VERSION = "1.0"
@@ -421,6 +425,13 @@ class HipVectorRetriever:
         kernel's MFMAs (profiles/r03_pk_mfma_hazard.log; tests/test_lib_abi.py checks the disassembly).
         Several PROCESSES sharing one GPU should turn it off: their streams oversubscribe the hardware queues (bench.py, one-device mode)."""
         if os.environ.get("TT_RETRIEVE_STREAM", "1") == "0":
+            return None
+        if not _lib.isa_checked():
+            # the library was not (or not successfully) disassembled by csrc/check_isa.py after its link: two-stream bit
+            # reproducibility is not established for this binary -- stay on the caller's stream
+            if not getattr(HipVectorRetriever, "_warned_isa", False):
+                HipVectorRetriever._warned_isa = True
+                logger.warning("libtt_hip.so carries no valid ISA-check stamp (csrc/check_isa.py): retrieval stays on the caller's stream")
             return None
         if self._stream is None:
             dev = self.index.device

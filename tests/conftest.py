@@ -12,6 +12,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    config.addinivalue_line("markers", "default_precision: runs WITHOUT the suite-wide TT_PRECISION=bf16 (checks what an unchanged reference call gets)")
     # the CPU oracle mostly runs small shapes: on a 256-core GPU host torch's default (one thread per core) makes every
     # small matmul a 256-way barrier (a 3 s test took 260 s); the full-depth oracle raises the count for itself
     try:
@@ -35,6 +36,19 @@ def _restore_torch_threads():
     yield
     if torch.get_num_threads() != before:
         torch.set_num_threads(before)
+
+
+@pytest.fixture(autouse=True)
+def _suite_names_bf16(request, monkeypatch):
+    """The product's default precision is the reference's own (fp32 semantics: ``precision.DEFAULT_MODE``, round 4).  The
+    suites of rounds 1-3 build the plugin surfaces without naming a dtype and hold them to bf16-grade bounds, i.e. they test the
+    bf16 mode: they NAME it here, through the process setting (``TT_PRECISION=bf16``).  Tests marked ``default_precision`` run
+    without the variable and check what the unchanged reference calls get."""
+    if request.node.get_closest_marker("default_precision") is None:
+        monkeypatch.setenv("TT_PRECISION", "bf16")
+    else:
+        monkeypatch.delenv("TT_PRECISION", raising=False)
+    yield
 
 
 @pytest.fixture(scope="session")

@@ -54,3 +54,40 @@ def test_self_launch_relays_json_last_and_exit_code(tmp_path):
         assert r.returncode == rc
         assert r.stdout.strip().splitlines() == ['{"metric": "m", "value": 1.0, "n_gpus": 2}']     # the one line on stdout
         assert r.stderr.strip().splitlines()[-2:] == ["noise before", "noise after"]
+
+
+def test_self_launch_retries_once_with_the_other_ipc_mode(tmp_path):
+    """First-contact safety: ranks that die before a JSON line (RCCL init / IPC handles / the collective pre-flight) get ONE
+    fresh child with HSA_ENABLE_IPC_MODE_LEGACY flipped and a new rendezvous port; the JSON line of the attempt that worked
+    is the one line on stdout; a child that fails both ways passes its exit code on."""
+    child = tmp_path / "child.py"
+    child.write_text(textwrap.dedent("""
+        import json, os, sys
+        want, port = sys.argv[1], sys.argv[sys.argv.index("--master-port") + 1]
+        print("attempt with", os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"), "port", port)
+        if os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") != want:
+            sys.exit(5)                                   # e.g. hipIpcGetMemHandle: invalid argument
+        print(json.dumps({"metric": "m", "value": 2.0, "ipc": os.environ["HSA_ENABLE_IPC_MODE_LEGACY"],
+                          "retry": os.environ.get("TT_BENCH_IPC_RETRY") == "1", "port": port}))
+    """))
+    driver = tmp_path / "driver.py"
+    driver.write_text(textwrap.dedent(f"""
+        import os, sys
+        sys.path.insert(0, {os.path.dirname(os.path.abspath(bench.__file__))!r})
+        import bench
+        env = dict(os.environ); env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"; env.pop("TT_BENCH_IPC_RETRY", None)
+        bench.self_launch([sys.executable, {str(child)!r}, sys.argv[1], "--master-port", "29999"], env)
+    """))
+    import json
+
+    r = subprocess.run([sys.executable, str(driver), "0"], capture_output=True, text=True, timeout=300)      # first setting works
+    got = json.loads(r.stdout.strip())
+    assert r.returncode == 0 and got["ipc"] == "0" and got["retry"] is False and got["port"] == "29999"
+    r = subprocess.run([sys.executable, str(driver), "1"], capture_output=True, text=True, timeout=300)      # only the flipped one does
+    assert r.returncode == 0 and len(r.stdout.strip().splitlines()) == 1
+    got = json.loads(r.stdout.strip())
+    assert got["ipc"] == "1" and got["retry"] is True and got["port"] != "29999"
+    assert "one fresh attempt with HSA_ENABLE_IPC_MODE_LEGACY=1" in r.stderr
+    r = subprocess.run([sys.executable, str(driver), "neither"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 5 and r.stdout.strip() == ""
+    assert r.stderr.count("\nattempt with") + r.stderr.startswith("attempt with") == 2    # exactly one retry

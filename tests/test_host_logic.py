@@ -974,14 +974,14 @@ def test_persist_guard_serialises_writers_of_one_directory(tmp_path):
 
 def test_precision_resolution_order():
     """precision.resolve(): explicit model_kwargs beat the ModelManager key (which arrives as model_kwargs["precision"]
-    only when nothing explicit is there), which beats TT_PRECISION, which beats the bf16 default; torch_dtype float32 is
+    only when nothing explicit is there), which beats TT_PRECISION, which beats the default -- the reference's own fp32 semantics (round 4); torch_dtype float32 is
     the reference's own spelling of "reference" (config_schema.py:66-76)."""
     import torch
 
     from tensor_truth_amd import model_manager as mm
     from tensor_truth_amd import precision as P
 
-    assert P.resolve(None, {}) == "bf16" and P.resolve({}, {"TT_PRECISION": "reference"}) == "reference"
+    assert P.resolve(None, {}) == "reference" == P.DEFAULT_MODE and P.resolve({}, {"TT_PRECISION": "bf16"}) == "bf16"
     assert P.resolve({"torch_dtype": "float32"}, {}) == "reference" and P.resolve({"torch_dtype": torch.float32}, {}) == "reference"
     assert P.resolve({"torch_dtype": "bfloat16"}, {"TT_PRECISION": "reference"}) == "bf16"
     assert P.resolve({"gemm_dtype": "fp8"}, {"TT_PRECISION": "reference"}) == "fp8"

@@ -52,40 +52,44 @@ def test_product_path_refuses_cpu_tensors(built_lib):
         scan.scan_topk(c, c[:2], 2)
 
 
-def _device_disassembly(lib_path, tmp_path):
-    """Disassembly of every gfx950 code object bundled in the shared library (one offload bundle per translation unit)."""
-    import subprocess
+def _check_isa():
+    import importlib.util
 
-    llvm = "/opt/rocm/lib/llvm/bin"
-    fat = str(tmp_path / "fat.bin")
-    subprocess.run([f"{llvm}/llvm-objcopy", "-O", "binary", "--only-section=.hip_fatbin", lib_path, fat], check=True)
-    blob = open(fat, "rb").read()
-    starts = [m.start() for m in re.finditer(b"__CLANG_OFFLOAD_BUNDLE__", blob)]
-    assert starts, "no offload bundle in the library"
-    out = []
-    for i, s in enumerate(starts):
-        chunk, co = str(tmp_path / f"b{i}.bin"), str(tmp_path / f"b{i}.co")
-        with open(chunk, "wb") as fh:
-            fh.write(blob[s:starts[i + 1] if i + 1 < len(starts) else len(blob)])
-        subprocess.run([f"{llvm}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={chunk}",
-                        "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"], check=True)
-        out.append(subprocess.run([f"{llvm}/llvm-objdump", "-d", co], check=True, capture_output=True, text=True).stdout)
-    return "\n".join(out)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("tt_check_isa", os.path.join(root, "tensor-truth_amd", "csrc", "check_isa.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
 
 
 def test_no_packed_f32_form_that_breaks_beside_mfma(built_lib, tmp_path):
     """gfx950, measured (tools/probes/pk_mfma_hazard.cpp, profiles/r03_pk_mfma_hazard.log): a v_pk_mul/add/fma_f32 whose op_sel bit
     for src1 is set (the LOW result reads src1's HIGH dword) returns a wrong low result in lanes 48-63 whenever another kernel's MFMA
     loop shares the SIMD; every other packed form is sound.  The compiler's SLP vectoriser emitted that form in embed_ln_kernel, which
-    made forwards differ when a scan ran on a second stream.  No kernel of the library may hold it."""
-    if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
+    made forwards differ when a scan ran on a second stream.  No kernel of the library may hold it.
+    The same check is a post-link step of the Makefile (csrc/check_isa.py), whose stamp gates the retriever's second stream."""
+    ck = _check_isa()
+    if not os.path.exists(f"{ck.LLVM}/llvm-objdump"):
         pytest.skip("no llvm-objdump")
-    dis = _device_disassembly(built_lib, tmp_path)
-    assert dis.count("v_mfma_") > 1000                         # it is the device code we are looking at
-    packed = re.findall(r"v_pk_(?:mul|add|fma)_f32[^\n]*", dis)
-    assert len(packed) > 1000                                   # (the sound forms are in use: GEMM epilogues, softmax)
-    fragile = [p for p in packed if re.search(r"op_sel:\[[01],1", p)]
+    dis = ck.device_disassembly(built_lib, str(tmp_path))
+    fragile, other, n_packed, n_mfma = ck.fragile_packed(dis)
+    assert n_mfma > 1000                                        # it is the device code we are looking at
+    assert n_packed > 1000                                      # (the sound forms are in use: GEMM epilogues, softmax)
     assert not fragile, f"{len(fragile)} packed-f32 instructions read src1's high dword for the low result, e.g. {fragile[0]}"
     # the other packed families (f16 / bf16 / integer) were not probed: none of them may carry that selector either
-    other = [p for p in re.findall(r"v_pk_\w+[^\n]*", dis) if re.search(r"op_sel:\[[01],1", p)]
     assert not other, f"{len(other)} packed instructions with op_sel set for src1 (unprobed beside MFMAs), e.g. {other[0]}"
+
+
+def test_isa_stamp_matches_the_built_library(built_lib):
+    """The Makefile's post-link check stamped THIS binary (sha256): the retriever may use its own stream.  A stale or missing stamp
+    (a build without llvm-objdump, a library swapped in by hand) turns the second stream off instead of trusting it."""
+    from tensor_truth_amd import _lib
+
+    ck = _check_isa()
+    if not os.path.exists(f"{ck.LLVM}/llvm-objdump") and not os.path.exists(ck.stamp_path(built_lib)):
+        pytest.skip("built without llvm-objdump: no stamp, second stream off")
+    assert open(ck.stamp_path(built_lib)).read().strip() == ck.sha256_of(built_lib)
+    assert _lib.isa_checked()
+    # the fragile form is recognised when it is there
+    assert ck.fragile_packed("v_pk_mul_f32 v[0:1], v[2:3], v[4:5] op_sel:[0,1]\nv_mfma_f32_16x16x32_bf16 a, b, c\n")[0]
+    assert not ck.fragile_packed("v_pk_mul_f32 v[0:1], v[2:3], v[4:5] op_sel_hi:[1,0]\n")[0]

@@ -187,10 +187,13 @@ def test_x3_forward_matches_the_fp32_oracle(dev, built_lib, shape):
     assert torch.equal(two.cpu()[0], emb.cpu()[2]) and torch.equal(two.cpu()[1], emb.cpu()[6])
 
 
+@pytest.mark.default_precision
 def test_precision_selector_reaches_both_surfaces(dev, built_lib, monkeypatch):
-    """TT_PRECISION=reference (process level), ModelManager.set_precision (config key) and model_kwargs each select the
-    reference arithmetic for the UNCHANGED reference calls -- SentenceTransformerRerank(model=, top_n=, device=) carries
-    no dtype (model_manager.py:333-337); TT_REFERENCE_IMPL=fp32 picks the fp32-MFMA implementation of it."""
+    """The UNCHANGED reference calls -- SentenceTransformerRerank(model=, top_n=, device=) carries no dtype
+    (model_manager.py:333-337), the embedder none unless the per-model config names one -- get the reference's own fp32
+    semantics BY DEFAULT (round 4; precision.DEFAULT_MODE), scores within 1e-3 relative of the fp32 oracle; TT_PRECISION
+    (process level), ModelManager.set_precision (config key) and model_kwargs name another mode; TT_REFERENCE_IMPL=fp32
+    picks the fp32-MFMA implementation of the reference mode."""
     from tensor_truth_amd import model_manager as mm
     from tensor_truth_amd.encoder import Encoder, EncoderConfig
     from tensor_truth_amd.encoder_f32 import EncoderF32
@@ -212,7 +215,12 @@ def test_precision_selector_reaches_both_surfaces(dev, built_lib, monkeypatch):
     monkeypatch.delenv("TT_PRECISION", raising=False)
     monkeypatch.delenv("TT_REFERENCE_IMPL", raising=False)
     rr = HipSentenceTransformerRerank(model="test/xenc", top_n=3, device="cuda", model_kwargs=dict(base))
-    assert isinstance(rr._encoder, Encoder) and rr.precision.startswith("bf16")          # default unchanged
+    assert isinstance(rr._encoder, EncoderX3) and rr.precision.startswith("reference") and scores_of(rr) <= 2e-4    # the default
+    monkeypatch.setenv("TT_PRECISION", "bf16")
+    rr = HipSentenceTransformerRerank(model="test/xenc", top_n=3, device="cuda", model_kwargs=dict(base))
+    assert isinstance(rr._encoder, Encoder) and rr.precision.startswith("bf16")          # the process setting names bf16
+    rr = HipSentenceTransformerRerank(model="test/xenc", top_n=3, device="cuda", model_kwargs={**base, "torch_dtype": "bfloat16"})
+    assert isinstance(rr._encoder, Encoder)                                                # the reference's own config spelling
     monkeypatch.setenv("TT_PRECISION", "reference")
     rr = HipSentenceTransformerRerank(model="test/xenc", top_n=3, device="cuda", model_kwargs=dict(base))
     assert isinstance(rr._encoder, EncoderX3) and scores_of(rr) <= 2e-4
@@ -228,12 +236,14 @@ def test_precision_selector_reaches_both_surfaces(dev, built_lib, monkeypatch):
     mgr = mm.ModelManager.get_instance()
     mgr.model_kwargs_overrides["test/xenc"] = dict(base)
     mgr.model_kwargs_overrides["test/emb"] = {"encoder_config": EncoderConfig(**{**XLMR, "num_labels": 0}), "state_dict": W}
-    assert isinstance(mgr.get_reranker("test/xenc", top_n=3, device="cuda")._encoder, Encoder)
-    mgr.set_precision("reference")
-    rr = mgr.get_reranker("test/xenc", top_n=3, device="cuda")
+    rr = mgr.get_reranker("test/xenc", top_n=3, device="cuda")                            # nothing named anywhere: the default
     assert isinstance(rr._encoder, EncoderX3) and scores_of(rr) <= 2e-4
+    mgr.set_precision("bf16")
+    assert isinstance(mgr.get_reranker("test/xenc", top_n=3, device="cuda")._encoder, Encoder)
+    assert isinstance(mgr.get_embedder("test/emb", "cuda")._encoder, Encoder)
+    mgr.set_precision(None)
     emb = mgr.get_embedder("test/emb", "cuda")
-    assert isinstance(emb._encoder, EncoderX3)
+    assert isinstance(emb._encoder, EncoderX3) and emb.precision.startswith("reference")
     e = torch.tensor(emb.get_text_embedding_batch(texts))
     ids, mask = _pad([emb._tokenizer.encode(t, emb.max_length) for t in texts], cfg.pad_id)
     assert (e - oe.embed(ids, mask, W, cfg_o)).abs().max().item() <= 5e-5
