@@ -22,7 +22,8 @@ class TTError(RuntimeError):
 
 
 def lib_path() -> str:
-    return os.path.join(_HERE, _LIB_NAME)
+    # TT_LIB_NAME=libtt_hip_diag.so: the diagnostic build (csrc `make DIAG=1`), for tools/probes only
+    return os.path.join(_HERE, os.environ.get("TT_LIB_NAME") or _LIB_NAME)
 
 
 _isa_ok = None

@@ -474,15 +474,19 @@ int tt_attention_launch(const AttnParams& p, hipStream_t st) {
     static const bool xcd = [] { const char* e = getenv("TT_ATT_XCD"); return e && e[0] == '1'; }();
     q.n_qt = xcd ? n_qt : -n_qt;
     TtProfScope prof(TT_K_ATTENTION, st);
+#if TT_DIAG   // stamped / ablated instantiations: the diagnostic library only (tools/att_stamps, tools/gpu_att_ablate.sh)
     if (p.head_dim == 64 && p.dbg) {
         hipLaunchKernelGGL((attention_kernel<64, true>), grid, dim3(64 * kWaves), 0, st, q);
-    } else if (p.head_dim == 64) {
-        static const int abl = [] { const char* e = getenv("TT_ATT_ABLATE"); return e && e[0] ? atoi(e) : 0; }();
+    } else if (p.head_dim == 64 && TT_DIAG_ENV_INT("TT_ATT_ABLATE", 0) != 0) {
+        static const int abl = TT_DIAG_ENV_INT("TT_ATT_ABLATE", 0);
         if (abl == 1) hipLaunchKernelGGL((attention_kernel<64, false, 1>), grid, dim3(64 * kWaves), 0, st, q);
         else if (abl == 2) hipLaunchKernelGGL((attention_kernel<64, false, 2>), grid, dim3(64 * kWaves), 0, st, q);
         else if (abl == 3) hipLaunchKernelGGL((attention_kernel<64, false, 3>), grid, dim3(64 * kWaves), 0, st, q);
-        else if (abl == 4) hipLaunchKernelGGL((attention_kernel<64, false, 4>), grid, dim3(64 * kWaves), 0, st, q);
-        else hipLaunchKernelGGL(attention_kernel<64>, grid, dim3(64 * kWaves), 0, st, q);
+        else hipLaunchKernelGGL((attention_kernel<64, false, 4>), grid, dim3(64 * kWaves), 0, st, q);
+    } else
+#endif
+    if (p.head_dim == 64) {
+        hipLaunchKernelGGL(attention_kernel<64>, grid, dim3(64 * kWaves), 0, st, q);
     } else if (p.head_dim == 32) {
         hipLaunchKernelGGL(attention_kernel<32>, grid, dim3(64 * kWaves), 0, st, q);
     } else {

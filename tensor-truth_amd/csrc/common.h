@@ -4,6 +4,7 @@
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "../../include/tt_hip.h"
 
@@ -19,6 +20,21 @@
 #endif
 #if TT_F16
 #include "f16_names.h"
+#endif
+
+// ---- diagnostic build -------------------------------------------------------------------------------------------------------
+// Switches that compute WRONG results by design (ablations of the attention loop, rounding masks of the reference-precision
+// forward, the GEMM traffic / stamp experiments) or re-read the environment on every forward exist only in the diagnostic
+// library, `make DIAG=1` -> libtt_hip_diag.so (tools/ and tools/probes/ load that one: TT_LIB_NAME).  In the product library
+// TT_DIAG_ENV_INT is its default: a stray environment variable cannot change a score, and the ablation instantiations are
+// not compiled.  A/B switches whose two sides give the same (or equally valid) results stay, read once into a static.
+#ifndef TT_DIAG
+#define TT_DIAG 0
+#endif
+#if TT_DIAG
+#define TT_DIAG_ENV_INT(name, dflt) ([]() -> int { const char* e_ = getenv(name); return e_ && e_[0] ? (int)strtol(e_, nullptr, 0) : (dflt); }())
+#else
+#define TT_DIAG_ENV_INT(name, dflt) (dflt)
 #endif
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));

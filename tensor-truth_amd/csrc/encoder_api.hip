@@ -136,16 +136,12 @@ static int forward_impl(const tt_encoder_weights* w, const int32_t* ids, const i
     }
 
     const int dh = H / w->heads;
-    // TT_FP8_MASK (diagnostic, default 0xF; read per forward so that one process can sweep it): which projections of an fp8
+    // TT_FP8_MASK (DIAGNOSTIC LIBRARY ONLY, `make DIAG=1`; default 0xF; read per forward there so that one process can sweep it): which projections of an fp8
     // forward run in e4m3 -- bit 0 QKV, 1 attention output, 2 FFN-up, 3 FFN-down (needs bit 2: the intermediate is then
     // written as e4m3); the others stay bf16.  TT_FP8_SKIP_FIRST / TT_FP8_SKIP_LAST: that many layers at either end stay bf16
     // altogether (tools/probes/fp8_sensitivity.py: rank agreement with the fp32 path per setting).
-    int f8mask_all = 0xF, f8first = 0, f8last = 0;
-    if (e.fp8) {
-        if (const char* m = getenv("TT_FP8_MASK"); m && m[0]) f8mask_all = (int)strtol(m, nullptr, 0);
-        if (const char* m = getenv("TT_FP8_SKIP_FIRST"); m && m[0]) f8first = atoi(m);
-        if (const char* m = getenv("TT_FP8_SKIP_LAST"); m && m[0]) f8last = atoi(m);
-    }
+    const int f8mask_all = TT_DIAG_ENV_INT("TT_FP8_MASK", 0xF), f8first = TT_DIAG_ENV_INT("TT_FP8_SKIP_FIRST", 0),
+              f8last = TT_DIAG_ENV_INT("TT_FP8_SKIP_LAST", 0);
     for (int l = 0; l < w->layers; ++l) {
         const tt_layer_weights& lw = w->layer[l];
         TT_CHECK_ARG(lw.qkv_w && lw.qkv_b && lw.o_w && lw.o_b && lw.ln1_g && lw.ln1_b && lw.ffn1_w && lw.ffn1_b &&
@@ -163,10 +159,10 @@ static int forward_impl(const tt_encoder_weights* w, const int32_t* ids, const i
         // last layer of the CLS tail: only the first row of every sequence needs a QUERY, so the big projection computes K and V alone
         // (the weight rows H..3H; K lands in its usual columns H..2H of qk) and the queries come from a small GEMM over the gathered
         // first rows below.  Same kernels, same K order per output element: bit-identical to the full projection.  Not for the e4m3
-        // projection (byte-sized weights); TT_CLS_KV_ONLY=0 restores the full projection (A/B, tests).
-        bool kv_only = cls_tail && l == w->layers - 1 && !g.fp8;
-        if (kv_only)
-            if (const char* ev = getenv("TT_CLS_KV_ONLY"); ev && ev[0] == '0') kv_only = false;
+        // projection (byte-sized weights); TT_CLS_KV_ONLY=0 restores the full projection (A/B; both sides give the same bits,
+        // tests/test_encoder_gpu.py compares them from two processes: the switch is read ONCE).
+        static const bool kv_only_on = [] { const char* ev = getenv("TT_CLS_KV_ONLY"); return !(ev && ev[0] == '0'); }();
+        const bool kv_only = cls_tail && l == w->layers - 1 && !g.fp8 && kv_only_on;
         if (kv_only) {
             g.W = (const uint16_t*)lw.qkv_w + (size_t)H * H; g.bias = lw.qkv_b + H;
             g.C = qk + H; g.N = 2 * H; g.vt_col0 = H;
@@ -383,8 +379,8 @@ int tt_gemm_bf16(const void* a, const void* w, const float* bias, const void* re
     g.A = (const uint16_t*)a; g.lda = k; g.W = (const uint16_t*)w; g.bias = bias;
     g.residual = (const uint16_t*)residual; g.ldr = n; g.C = (uint16_t*)c; g.ldc = n;
     g.M = m; g.N = n; g.K = k;
-    // timing experiment only (wrong results): every output row lands on row 0 / every A row-block reads block 0
-    static const int dbg = [] { const char* e = getenv("TT_GEMM_DEBUG_TRAFFIC"); return e && e[0] ? atoi(e) : 0; }();
+    // timing experiment only (wrong results; diagnostic library only): every output row lands on row 0 / every A row-block reads block 0
+    static const int dbg = TT_DIAG_ENV_INT("TT_GEMM_DEBUG_TRAFFIC", 0);
     if (dbg & 1) g.ldc = 0;
     if (dbg & 2) g.lda = 0;
     return tt_gemm_launch(g, epilogue, (hipStream_t)stream);

@@ -1642,8 +1642,9 @@ int launch(const GemmParams& p, hipStream_t st) {
             }
         }
         auto kern = v3::gemm_kernel_v3<EPI, 4>;
+#if TT_DIAG
         if constexpr (EPI == TT_EPI_BIAS) {   // diagnostic build of the 4-slot loop with s_memtime stamps (tools/gemm_stamps)
-            static const int abl = [] { const char* e = getenv("TT_GEMM_ABLATE"); return e && e[0] ? atoi(e) : 0; }();
+            static const int abl = TT_DIAG_ENV_INT("TT_GEMM_ABLATE", 0);
             if (abl == 8) {   // stamped persistent kernel (tools/gemm_stamps_p)
                 const int cus8 = tt_cu_count_cached() / 8 * 8;
                 TT_SET_MAX_LDS((v3::gemm_kernel_p<EPI, false, true>), v3::kLds3);
@@ -1658,6 +1659,7 @@ int launch(const GemmParams& p, hipStream_t st) {
             if (abl == 7) kern = v3::gemm_kernel_v3<EPI, 47>;   // chunk-major store experiment (output layout differs!)
             if (abl == 6 || abl == 7) TT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, v3::kLds3));
         }
+#endif
         TT_SET_MAX_LDS((v3::gemm_kernel_v3<EPI, 4>), v3::kLds3);
         GemmParams q = p;
         // whole-line stores as streaming stores: +1...3 % on the bias-only shapes, -0.7 ms per bench step (with the old 32-byte
@@ -1665,9 +1667,9 @@ int launch(const GemmParams& p, hipStream_t st) {
         static const int nts = [] { const char* e = getenv("TT_GEMM_NT_STORE"); return e && e[0] ? atoi(e) : 1; }();
         q.nt_store = nts;
         q.sn = SN;
-        static const bool a0 = [] { const char* e = getenv("TT_GEMM_DEBUG_A0"); return e && e[0] == '1'; }();
+        static const bool a0 = TT_DIAG_ENV_INT("TT_GEMM_DEBUG_A0", 0) == 1;      // (wrong results: diagnostic library only)
         if (a0) q.xp |= 0x20000;
-        static const int stamp_block = [] { const char* e = getenv("TT_GEMM_STAMP_BLOCK"); return e && e[0] ? atoi(e) : 0; }();
+        static const int stamp_block = TT_DIAG_ENV_INT("TT_GEMM_STAMP_BLOCK", 0);
         q.xp |= stamp_block << 20;
         {
             TtProfScope prof(TT_K_GEMM, st);

@@ -651,14 +651,13 @@ int forward_x3_impl(const tt_encoder_weights_x3* w, const int32_t* ids, const in
     uint16_t* ffn = (uint16_t*)(ws + e.off_ffn);
     TT_CHECK_HIP(hipMemsetAsync(ctx, 0, (size_t)T * 2 * H * 2, st));    // rows of no sequence are never written by attention
 
-    // TT_X3_ROUND_MASK (diagnostic, default 0; read per forward): re-introduce ONE of the bf16 path's rounding points at a time
+    // TT_X3_ROUND_MASK (DIAGNOSTIC LIBRARY ONLY, `make DIAG=1`; default 0, read per forward there): re-introduce ONE of the bf16 path's rounding points at a time
     // into this fp32-grade forward -- the error budget of the bf16 mode (tools/probes/bf16_error_budget.py).  bit 1: Q / K / V
     // projections' outputs, 2: softmax probabilities, 3: attention context, 4: pre-LayerNorm sums (attention output + residual,
     // FFN output + residual), 5: LayerNorm outputs (incl. the embedding LayerNorm; the residual branch reads the rounded copy, as
     // in the bf16 path), 6: FFN intermediate (GELU output).  (Bit 0, bf16 WEIGHTS, is applied where the planes are made:
     // encoder_x3.EncoderWeightsX3(round_weights=True).)
-    int rmask = 0;
-    if (const char* m = getenv("TT_X3_ROUND_MASK"); m && m[0]) rmask = (int)strtol(m, nullptr, 0);
+    const int rmask = TT_DIAG_ENV_INT("TT_X3_ROUND_MASK", 0);
     const int ln_out = (rmask & 32) ? 2 : 0, ln_in = (rmask & 16) ? 1 : 0;
     float* x = (w->layers == 0 && hidden_out) ? hidden_out : xa;
     {

@@ -33,6 +33,7 @@ from typing import Callable, Dict, List, Optional, Sequence, Tuple  # noqa: F401
 import torch
 import torch.distributed as dist
 
+from . import _lib
 from . import sharded as _sh
 from .schema import NodeWithScore, TextNode
 from .vector_index import (HipVectorIndex, HipVectorRetriever, _read_persisted, _node_from_dict)
@@ -290,10 +291,17 @@ class _TickFront:
     aligned (a rank that simply stopped would leave the others in a collective for the process group's timeout).  ``close()`` raises this rank's closing flag;
     the thread keeps serving the other ranks' rounds (they need this shard) until every rank has raised its own."""
 
-    def __init__(self, retriever: "ShardedHipVectorRetriever", max_batch: int, idle_sleep_s: float = 2e-4):
+    def __init__(self, retriever: "ShardedHipVectorRetriever", max_batch: int, idle_sleep_s: float = 2e-4, idle_sleep_max_s: float = 5e-3):
         self.retriever, self.index = retriever, retriever.index
         self.max_batch = max(1, int(max_batch))
-        self.idle_sleep_s = idle_sleep_s
+        # Idle ticks back off: an idle front used to run a collective + a host sync every 200 us for the life of the retriever
+        # (~5 k collectives/s on every GPU of an idle server).  The pause doubles per idle tick up to idle_sleep_max_s and
+        # snaps back on the first tick that carries a query; the count of idle ticks is a function of what every rank saw in
+        # the same collectives, so all ranks pause alike.  A local submit() cuts this rank's own pause short (its tick then
+        # waits in the collective for the slowest sleeper: at most idle_sleep_max_s of added latency for the first query after
+        # an idle spell).
+        self.idle_sleep_s, self.idle_sleep_max_s = idle_sleep_s, max(idle_sleep_s, idle_sleep_max_s)
+        self._wake = threading.Event()
         self._lock = threading.Lock()
         self._queue: List[_TickSlot] = []
         self._closing = False
@@ -309,6 +317,7 @@ class _TickFront:
             if self._closing or self._dead is not None:
                 raise RuntimeError("the sharded retriever's serving front is closed") from self._dead
             self._queue.append(slot)
+        self._wake.set()
         slot.event.wait()
         if slot.error is not None:
             raise slot.error
@@ -317,6 +326,7 @@ class _TickFront:
     def close(self, timeout: Optional[float] = None) -> None:
         with self._lock:
             self._closing = True
+        self._wake.set()
         self._thread.join(timeout)
 
     def _embed_own(self, batch: List[_TickSlot]):
@@ -344,12 +354,13 @@ class _TickFront:
         world, rank = _world(idx.group)
         dev = idx.device
         batch: List[_TickSlot] = []
+        idle_ticks = 0
         import contextlib
 
         ctx = contextlib.nullcontext()
         if dev.type == "cuda":
             torch.cuda.set_device(dev)         # (the current device is per thread)
-            if os.environ.get("TT_RETRIEVE_STREAM", "1") != "0":       # see HipVectorRetriever._gpu_stream
+            if os.environ.get("TT_RETRIEVE_STREAM", "1") != "0" and _lib.isa_checked():       # see HipVectorRetriever._gpu_stream
                 # the rounds' GPU work (query embedding, the collectives' device side, the shard scan, the merge) on the
                 # front's own high-priority stream: it must not queue behind the rerank batches of this rank's callers
                 # (HipVectorRetriever._gpu_stream: one idle gap per scan batch otherwise)
@@ -389,8 +400,12 @@ class _TickFront:
                                 round_error, hits = exc, None
                             self.rounds += 1
                     if nmax == 0:
-                        time.sleep(self.idle_sleep_s)
+                        idle_ticks += 1
+                        self._wake.wait(min(self.idle_sleep_max_s, self.idle_sleep_s * (1 << min(idle_ticks - 1, 10))))
+                        self._wake.clear()
                         continue
+                    idle_ticks = 0
+                    self._wake.clear()
                     if batch and round_error is not None:           # this round's callers fail, the front lives on
                         for s_ in batch:
                             s_.error = round_error
@@ -439,7 +454,9 @@ class ShardedHipVectorRetriever(HipVectorRetriever):
     _retrieve = retrieve
 
     def close(self, timeout: Optional[float] = None) -> None:
-        """Leave the lock-step serving front (multi-rank ``queries="partitioned"`` only; SPMD: every rank calls it)."""
+        """Leave the lock-step serving front (multi-rank ``queries="partitioned"`` only).  SPMD: EVERY rank must call it -- the
+        front's thread keeps answering the other ranks' rounds (they need this shard) until all ranks have raised their closing
+        flag, and while it lives it owns the process group's collectives (``index.search()`` from another thread raises)."""
         if self._tick is not None:
             self._tick.close(timeout)
 

@@ -349,10 +349,25 @@ def test_cls_only_last_layer_matches_full_forward(dev, built_lib, shape):
 
 @pytest.mark.parametrize("shape,dtype", [("xlmr256", torch.bfloat16), ("bert384", torch.bfloat16), ("xlmr1024", torch.bfloat16),
                                          ("xlmr1024", torch.float16), ("xlmr1024-one", torch.bfloat16)])
-def test_cls_tail_kv_only_projection_is_bit_identical(dev, built_lib, monkeypatch, shape, dtype):
+def test_cls_tail_kv_only_projection_is_bit_identical(dev, built_lib, tmp_path, shape, dtype):
     """Last layer of the CLS tail: K and V from the big projection, the first rows' queries from a small GEMM over the gathered
     rows (encoder_api.hip) -- the same bits as the full Q,K,V projection it replaces (TT_CLS_KV_ONLY=0), on the mixed-epilogue path
-    (small grids), the split path (>= 4096 rows) and the skinny path (one query), bf16 and fp16."""
+    (small grids), the split path (>= 4096 rows) and the skinny path (one query), bf16 and fp16.  The library reads the switch once
+    per process, so the other side runs in a child process (this file as a script) and hands its tensors over in a file."""
+    import subprocess
+    import sys
+
+    cls_new, emb_new, score_new = _kv_only_case(shape, dtype, dev)
+    out = tmp_path / "old.pt"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TT_CLS_KV_ONLY="0", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    subprocess.run([sys.executable, os.path.abspath(__file__), "kv_only_child", shape, str(dtype), str(out)], check=True, env=env, timeout=600)
+    cls_old, emb_old, score_old = torch.load(str(out))
+    assert torch.isfinite(cls_new.float()).all()
+    assert torch.equal(cls_new.cpu(), cls_old) and torch.equal(emb_new.cpu(), emb_old) and torch.equal(score_new.cpu(), score_old)
+
+
+def _kv_only_case(shape, dtype, dev):
     from tensor_truth_amd.encoder import Encoder, EncoderConfig, EncoderWeights, pack_tokens, synthetic_state
 
     if shape == "xlmr256":
@@ -371,16 +386,11 @@ def test_cls_tail_kv_only_projection_is_bit_identical(dev, built_lib, monkeypatc
     g = torch.Generator().manual_seed(2)
     seqs = [torch.randint(4, 2000, (n,), generator=g).tolist() for n in lens]
     batch = pack_tokens(seqs, cfg)
-    cls_new = enc.cls_hidden_packed(batch)[0][: len(seqs)].clone()
-    emb_new = enc.embed_packed(batch)[0].clone()
-    score_new = enc.rerank_packed(batch).clone()
-    monkeypatch.setenv("TT_CLS_KV_ONLY", "0")
-    cls_old = enc.cls_hidden_packed(batch)[0][: len(seqs)]
-    emb_old = enc.embed_packed(batch)[0]
-    score_old = enc.rerank_packed(batch)
+    cls = enc.cls_hidden_packed(batch)[0][: len(seqs)].clone()
+    emb = enc.embed_packed(batch)[0].clone()
+    score = enc.rerank_packed(batch).clone()
     torch.cuda.synchronize()
-    assert torch.isfinite(cls_new.float()).all()
-    assert torch.equal(cls_new, cls_old) and torch.equal(emb_new, emb_old) and torch.equal(score_new, score_old)
+    return cls, emb, score
 
 
 def test_forward_is_bit_reproducible(dev, built_lib):
@@ -544,3 +554,12 @@ def test_bench_sized_attention_sampled_sequences_and_order_equivariance(dev, bui
     valid = torch.cat([torch.arange(i * stride, i * stride + L) for i in range(n_seq)]).to(dev)
     want = torch.cat([torch.arange(starts[p], starts[p] + L) for p in perm]).to(dev)
     assert torch.equal(out_p[valid], out[want])
+
+
+if __name__ == "__main__":          # child of test_cls_tail_kv_only_projection_is_bit_identical (TT_CLS_KV_ONLY=0 in its environment)
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    if len(sys.argv) == 5 and sys.argv[1] == "kv_only_child":
+        dt = {"torch.bfloat16": torch.bfloat16, "torch.float16": torch.float16}[sys.argv[3]]
+        torch.save(tuple(t.cpu() for t in _kv_only_case(sys.argv[2], dt, torch.device("cuda:0"))), sys.argv[4])

@@ -4,11 +4,11 @@
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
 export LD_LIBRARY_PATH=$PWD/tensor-truth_amd:$LD_LIBRARY_PATH
-make -C tools gemm_stamps gemm_bench > /dev/null 2>&1
+make -C tensor-truth_amd/csrc DIAG=1 -j4 > /dev/null 2>&1; make -C tools gemm_stamps gemm_bench_diag > /dev/null 2>&1
 {
 if [ -z "$SKIP_TIME" ]; then for a0 in 0 1 0 1; do
   echo "== TT_GEMM_DEBUG_A0=$a0: gemm_bench 473600 10"
-  TT_GEMM_DEBUG_A0=$a0 timeout 120 tools/gemm_bench 473600 10 | sed -n 2,8p
+  TT_GEMM_DEBUG_A0=$a0 timeout 120 tools/gemm_bench_diag 473600 10 | sed -n 2,8p
 done; fi
 for shape in "118272 3072 1024" "118272 1024 4096"; do for blk in 1000 2000; do for a0 in 0 1; do
   echo "== TT_GEMM_DEBUG_A0=$a0 stamps of workgroup $blk, K-tile 6: M N K = $shape"

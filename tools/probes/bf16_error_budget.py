@@ -2,6 +2,9 @@
 ONE of the bf16 path's rounding points switched back on at a time (TT_X3_ROUND_MASK / EncoderWeightsX3(round_weights=True)),
 at full depth -- 4 queries x 50 pairs x 292 tokens x 24 layers, the inputs and fp32-oracle scores of
 tests/test_rank_agreement_gpu.py (committed fixture) -- reporting each setting's sigmoid-score error and rank agreement."""
+import os as _os
+
+_os.environ.setdefault("TT_LIB_NAME", "libtt_hip_diag.so")   # the switches this probe sweeps exist in the diagnostic library only (csrc: make DIAG=1)
 import os
 import sys
 

@@ -5,6 +5,9 @@
 seed): scores of the fp32 reference-precision path vs the fp8 mode with a subset of the layer projections in e4m3 and the
 rest in bf16 -> max |score error|, Kendall tau, top-10 overlap, and the time of one 1600-pair rerank batch.
 """
+import os as _os
+
+_os.environ.setdefault("TT_LIB_NAME", "libtt_hip_diag.so")   # the switches this probe sweeps exist in the diagnostic library only (csrc: make DIAG=1)
 import os
 import sys
 import time
