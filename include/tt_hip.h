@@ -391,6 +391,78 @@ int tt_attention_x3(const void* qk_planes, int ld_qk, int q_col0, int k_col0, in
                     const void* vt_lo, int ldvt, void* out_planes, int ld_out, int out_lo_off,
                     const int32_t* seq_start, const int32_t* seq_len, int n_seq, int heads, int max_len, void* stream);
 
+/* ---- reference precision on TWO matrix-time units: the "f16c" forward (csrc/f16c_path.hip, round 4) --------------------
+ * What the reference's unchanged calls compute -- fp32 semantics (services/model_manager.py:333-337 passes no dtype;
+ * app_utils/config_schema.py:66-76: torch_dtype None) -- at half the bf16 matrix rate instead of split-bf16's third: every
+ * GEMM operand is carried as "c-planes", hi = fp16(x) plus two OCP e4m3 planes (x and x - hi) with one E8M0 block exponent
+ * per 32 elements, and a product runs as  hi.hi (fp16 MFMA) + e4m3(a).e4m3(w_lo) + e4m3(a_lo).e4m3(w)  (block-scaled MFMA at
+ * twice the rate; the cross terms are 2^-12 of the result).  Attention on single fp16 products, fp32 softmax; residual
+ * stream, LayerNorm, exact-erf GELU and the head in fp32.  Scores within 1e-3 relative of the CPU path (measured 1e-4).
+ * Weights: matrices as c-planes in the weight flavour [out][hi: 2 in | lo8: in | x8: in] bytes + tiled scales, both made by
+ * tt_f16c_quantize(weight = 1) from the fp32 tensor; tables, biases, LayerNorm parameters and the head fp32.
+ * hidden a multiple of 256 (<= 1024) with head_dim 64, ffn a multiple of 256, n_rows a multiple of 256. */
+typedef struct tt_layer_weights_f16c {
+    const void* qkv_w;   /* c-planes [3H][4H bytes] */
+    const void* qkv_s;   /* tiled scales, tt_f16c_scale_bytes(3H, H, 1) bytes */
+    const float* qkv_b;
+    const void* o_w;     /* [H][4H bytes] */
+    const void* o_s;
+    const float* o_b;
+    const float* ln1_g;
+    const float* ln1_b;
+    const void* ffn1_w;  /* [F][4H bytes] */
+    const void* ffn1_s;
+    const float* ffn1_b;
+    const void* ffn2_w;  /* [H][4F bytes] */
+    const void* ffn2_s;
+    const float* ffn2_b;
+    const float* ln2_g;
+    const float* ln2_b;
+} tt_layer_weights_f16c;
+
+typedef struct tt_encoder_weights_f16c {
+    int32_t hidden, layers, heads, ffn, vocab, max_pos, type_vocab;
+    float ln_eps;
+    const float* word_emb;  /* [vocab][H] fp32 */
+    const float* pos_emb;
+    const float* type_emb;
+    const float* emb_ln_g;
+    const float* emb_ln_b;
+    const tt_layer_weights_f16c* layer; /* host array [layers] */
+    const float* cls_dense_w;  /* [H][H] fp32 or NULL */
+    const float* cls_dense_b;
+    const float* cls_out_w;
+    const float* cls_out_b;
+} tt_encoder_weights_f16c;
+
+size_t tt_encoder_f16c_workspace_bytes(const tt_encoder_weights_f16c* w, int n_rows);
+/* hidden_out: [n_rows][H] fp32 last hidden state (pool it with tt_embed_pool_f32 / tt_embed_pool_mean_f32) */
+int tt_encoder_forward_f16c(const tt_encoder_weights_f16c* w, const int32_t* ids, const int32_t* pos,
+                            const int32_t* type_ids, const int32_t* seq_start, const int32_t* seq_len,
+                            int n_seq, int n_rows, int max_len, float* hidden_out,
+                            void* workspace, size_t workspace_bytes, void* stream);
+/* the LAST layer for the first row (CLS) of every sequence only: cls_out [pad(n_seq)][hidden] fp32, pad = n_seq rounded up to 256 */
+size_t tt_encoder_f16c_cls_workspace_bytes(const tt_encoder_weights_f16c* w, int n_rows, int n_seq);
+int tt_encoder_forward_f16c_cls(const tt_encoder_weights_f16c* w, const int32_t* ids, const int32_t* pos, const int32_t* type_ids,
+                                const int32_t* seq_start, const int32_t* seq_len, int n_seq, int n_rows, int max_len,
+                                float* cls_out, void* workspace, size_t workspace_bytes, void* stream);
+int tt_rerank_head_f16c(const tt_encoder_weights_f16c* w, const float* hidden_f32, const int32_t* rows, int n_seq,
+                        float* scores, float* logits, void* workspace, size_t workspace_bytes, void* stream);
+/* building blocks (weight preparation, parity tests).
+ * tt_f16c_quantize: fp32 [rows][k] (k a multiple of 256) -> c-planes [rows][4 k bytes] + tiled scales
+ *   (tt_f16c_scale_bytes(rows, k, weight) bytes); weight = 0: activation flavour [hi | x8 | lo8], 1: weight flavour
+ *   [hi | lo8 | x8] with two scale parts.  Rows are padded to 256 in the scale array only.
+ * tt_gemm_f16c: a c-planes [m][4k], w c-planes [n][4k]; m, n multiples of 256, k of 128; epilogue 0: fp16 c_out [m][n] =
+ *   a.w^T + bias; 1: exact-erf GELU -> c-planes c_out [m][4n] + c_scales; 2: fp32 c_out [m][n] = a.w^T + bias + residual_f32.
+ * tt_attention_f16c: tt_attention_varlen_f16's inputs (fp16 Q / K, V in the V8 layout, head_dim 64), context as c-planes. */
+size_t tt_f16c_scale_bytes(int64_t rows, int k, int weight);
+int tt_f16c_quantize(const float* in_f32, int64_t rows, int k, int weight, void* out_planes, void* out_scales, void* stream);
+int tt_gemm_f16c(const void* a_planes, const void* a_scales, const void* w_planes, const void* w_scales, const float* bias,
+                 const float* residual_f32, void* c_out, void* c_scales, int m, int n, int k, int epilogue, void* stream);
+int tt_attention_f16c(const void* qk_f16, int ld_qk, int q_col0, int k_col0, const void* vt_f16, int ldvt, void* out_planes,
+                      void* out_scales, const int32_t* seq_start, const int32_t* seq_len, int n_seq, int heads, int max_len,
+                      void* stream);
+
 /* Per-kernel device timing (HIP events on the launch stream), for bench.py's roofline leg.
  * tt_prof_enable(1) (or a mask of 1 << id, to time only some kernels) starts recording one event pair per launch of the tracked kernels on the
  * calling thread; tt_prof_read() synchronises those events and returns total milliseconds

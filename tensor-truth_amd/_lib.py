@@ -125,6 +125,20 @@ SIGNATURES = {
     "tt_gemm_x3": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "tt_attention_x3": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int,
                                 c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    # reference precision on two matrix-time units (csrc/f16c_path.hip)
+    "tt_encoder_f16c_workspace_bytes": (c_size_t, [c_void_p, c_int]),
+    "tt_encoder_f16c_cls_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),
+    "tt_encoder_forward_f16c": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                        c_void_p, c_void_p, c_size_t, c_void_p]),
+    "tt_encoder_forward_f16c_cls": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                            c_void_p, c_void_p, c_size_t, c_void_p]),
+    "tt_rerank_head_f16c": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "tt_f16c_scale_bytes": (c_size_t, [c_int64, c_int, c_int]),
+    "tt_f16c_quantize": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "tt_gemm_f16c": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                             c_int, c_void_p]),
+    "tt_attention_f16c": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                  c_int, c_int, c_void_p]),
     "tt_prof_enable": (c_int, [c_int]),
     "tt_prof_read": (c_int, [c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int)]),
 }

@@ -21,6 +21,7 @@
 // therefore goes global -> LDS -> MFMA operand without any transposition or padding.
 #include "common.h"
 #include "encoder.h"
+#include "f16c.h"
 
 namespace {
 
@@ -361,6 +362,39 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attention_kernel(AttnParams p)
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
     if (q_row < len) {
+        if (p.out_scales) {
+            // f16c: c-planes.  A scale block = 32 consecutive columns = one d tile of this head: this lane's 16 values and those
+            // of the lane holding the row's other column quads (hh ^ 1: same q_row, so both are inside this branch).
+            char* orow = reinterpret_cast<char*>(p.out) + (size_t)(t0 + q_row) * p.ld_out * 2;
+            const int W = p.out_width, nks = W >> 7;
+#pragma unroll
+            for (int d = 0; d < DT; ++d) {
+                float y[16];
+                float amax = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    y[r] = acc_o[d][r] * inv;
+                    asm("" : "+v"(y[r]));            // opaque: no fusing of "* inv" into the "y - hi" of the split
+                    amax = fmaxf(amax, fabsf(y[r]));
+                }
+                amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+                int sbyte, sh;
+                xc_block_scale(amax, sbyte, sh);
+                const int col0 = head * DH + 32 * d;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    uint2 hi;
+                    uint32_t x8, l8;
+                    xc_split4(y[4 * g + 0], y[4 * g + 1], y[4 * g + 2], y[4 * g + 3], sh, sh + 11, hi, x8, l8);
+                    const int col = col0 + 8 * g + 4 * hh;
+                    *reinterpret_cast<uint2*>(orow + (size_t)col * 2) = hi;
+                    *reinterpret_cast<uint32_t*>(orow + (size_t)2 * W + col) = x8;
+                    *reinterpret_cast<uint32_t*>(orow + (size_t)3 * W + col) = l8;
+                }
+                if (hh == 0) p.out_scales[xc_a_scale_at(t0 + q_row, col0 >> 5, nks)] = (uint8_t)sbyte;
+            }
+            return;
+        }
         uint16_t* op = p.out + (size_t)(t0 + q_row) * p.ld_out + head * DH;
 #pragma unroll
         for (int d = 0; d < DT; ++d)
@@ -447,6 +481,26 @@ __global__ __launch_bounds__(64) void attention_cls_kernel(AttnParams p) {
         o = fmaf(pb.z, elo(u.w), o); o = fmaf(pb.w, ehi(u.w), o);
     }
     if constexpr (PARTS == 2) o += __shfl_xor(o, 32, 64);
+    if (p.out_scales) {
+        // f16c: c-planes (row = sequence index).  DH = 64: lanes 0-31 / 32-63 are the two scale blocks of this head.
+        float y = o / sum;
+        asm("" : "+v"(y));
+        float amax = fabsf(y);
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
+        int sbyte, sh;
+        xc_block_scale(amax, sbyte, sh);
+        if (part == 0) {
+            const int W = p.out_width, col = head * DH + d;
+            char* orow = reinterpret_cast<char*>(p.out) + (size_t)seq * p.ld_out * 2;
+            const uint16_t hb = f32_to_ebits(y);
+            *reinterpret_cast<uint16_t*>(orow + (size_t)col * 2) = hb;
+            orow[(size_t)2 * W + col] = (char)(xc_pack4(xc_sat(ldexpf(y, sh)), 0.f, 0.f, 0.f) & 0xFFu);
+            orow[(size_t)3 * W + col] = (char)(xc_pack4(xc_sat(ldexpf(y - ebits_to_f32(hb), sh + 11)), 0.f, 0.f, 0.f) & 0xFFu);
+            if ((d & 31) == 0) p.out_scales[xc_a_scale_at(seq, col >> 5, W >> 7)] = (uint8_t)sbyte;
+        }
+        return;
+    }
     if (part == 0) p.out[(size_t)seq * p.ld_out + head * DH + d] = f32_to_ebits(o / sum);
 }
 

@@ -49,6 +49,20 @@ struct GemmParams {
     const float* res32;       // fp32 residual [M][ldr]
     uint16_t* vt_lo;          // lo plane of the V8 output
     int x3_zero_lo;           // diagnostic (TT_X3_ROUND_MASK): planes outputs are written with lo = 0, i.e. rounded to bf16
+    // ---- f16c operands: reference precision on TWO matrix-time units (f16c_path.hip; fp16 instantiation only) ---------------
+    // A value x is carried as "c-planes": hi = fp16(x), x8 = e4m3(x 2^-s), lo8 = e4m3((x - hi) 2^-(s - 11)), with one E8M0 block
+    // exponent s per 32 consecutive K elements (s = exponent of the block's absmax - 7).  A row of an operand is ONE byte stream
+    //     A[m]: [ hi: 2K bytes | x8: K | lo8: K ]        W[n]: [ hi: 2K | lo8: K | x8: K ]        (lda = ldw = 2K uint16 = 4K bytes)
+    // and the product runs as ONE contraction over 2 K / 64 K-tiles of 128 bytes: K / 64 tiles of v_mfma_f32_16x16x32_f16
+    // (hi.hi), then K / 64 tiles of v_mfma_scale_f32_16x16x128_f8f6f4 with the block scales (x8.w_lo8, then lo8.w_x8): the cross
+    // terms are 2^-12 of the result and need 2^-4, the dropped lo.lo term is 2^-24.  Scales are stored TILED, 1 KiB per (256-row
+    // block, 128-element K-tile), in the order the kernel reads them (f16c_path.hip: a_scale_at / w_scale_at).
+    // Epilogues: BIAS -> plain fp16 C (Q, K), VT -> fp16 V8, GELU -> c-planes (C = hi plane base, ldc = 2N uint16, c_scales),
+    // RESIDUAL -> fp32 C32 = acc + bias + res32.
+    int xc;
+    const uint8_t* a_scales;  // [M / 256][K / 128][1024]
+    const uint8_t* w_scales;  // [N / 256][2 K / 128][1024]: the w_lo8 part's K / 128 chunks, then the w_x8 part's (exponents - 11)
+    uint8_t* c_scales;        // GELU epilogue: the output's scales, tiled for a consumer with K = N
 };
 // Filter pass of the similarity scan for 65..256 queries per pass as a 256x256x64-tiled MFMA contraction (gemm.hip):
 // corpus [rows][dim] bf16 with rows a multiple of 256, queries256 [256][dim] bf16 (rows beyond the batch zero),
@@ -74,6 +88,10 @@ struct AttnParams {
     unsigned long long* dbg;  // diagnostic build only (tools/att_stamps): s_memtime stamps of one workgroup; NULL otherwise
     const uint16_t* q_rows;   // CLS variant only: the query row of sequence b at q_rows + b * ld_q_rows (+ h*dh); NULL = row seq_start[b] of qk
     int ld_q_rows;
+    // f16c (fp16 instantiation): the context goes out as c-planes (f16c.h) -- `out` = the hi plane of rows of 4 * out_width bytes
+    // (ld_out = 2 * out_width), x8 / lo8 planes behind it, block scales tiled for a consumer with K = out_width.  NULL = fp16 out.
+    uint8_t* out_scales;
+    int out_width;            // heads * head_dim
 };
 int tt_attention_launch(const AttnParams& p, hipStream_t st);
 // CLS-only variant: one query row (seq_start[b]) per sequence; out row index = sequence index

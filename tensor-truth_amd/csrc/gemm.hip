@@ -20,6 +20,7 @@
 #include <type_traits>
 
 #include "encoder.h"
+#include "f16c.h"
 
 namespace {
 
@@ -715,6 +716,89 @@ __device__ __forceinline__ void epilogue_x3(const GemmParams& p, f32x4 (&acc)[2]
         }
 }
 
+// ---- f16c epilogue (GemmParams.xc, GELU): the output as c-planes, i.e. as the NEXT GEMM's A operand ---------------------------
+// Same accumulator layout as epilogue_x3: after the permlane16 swap a lane owns 8 consecutive columns of one row; the 32
+// columns of a scale block (n0 + wn 64 + qn 32 + [0, 32)) are this lane's two chunks (nt = 0, 1) and those of the lane 32
+// further on (the other 8-column half): the block's absmax is one cross-lane exchange.  Per block: E = exponent of the absmax,
+// scale byte s = E - 7 (biased); hi = fp16(v); x8 = e4m3(v 2^(7 - E)); lo8 = e4m3((v - hi) 2^(18 - E)) -- |v - hi| <= 2^(E - 11).
+// One byte per (row, block) goes to the tiled scale array of a consumer with K = p.N.
+template <int EPI>
+__device__ __forceinline__ void epilogue_xc(const GemmParams& p, f32x4 (&acc)[2][2][2][4], const char* smem, int bias_off, int m0,
+                                            int n0, int wm, int wn, int lane) {
+    static_assert(EPI == TT_EPI_GELU || EPI == TT_EPI_BIAS, "c-planes come out of the bias / GELU epilogues");
+    const int g = lane >> 4;
+    const bool odd = (g & 1) != 0;
+    const int ncol = wn * 64 + (g & ~1) * 4;
+    const int mrow = wm * 64 + (lane & 15);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)smem;
+    float4 bias[2][2][2];
+    {
+        const uint32_t baddr = lds0 + bias_off + ncol * 4;
+        u32x4 b[8];
+        b[0] = lds_read128_async<0>(baddr);        b[1] = lds_read128_async<16>(baddr);
+        b[2] = lds_read128_async<64>(baddr);       b[3] = lds_read128_async<80>(baddr);
+        b[4] = lds_read128_async<128>(baddr);      b[5] = lds_read128_async<144>(baddr);
+        b[6] = lds_read128_async<192>(baddr);      b[7] = lds_read128_async<208>(baddr);
+        lds_wait(b[0], b[1], b[2], b[3]);
+        lds_wait(b[4], b[5], b[6], b[7]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            bias[i >> 2][(i >> 1) & 1][i & 1] = float4{__uint_as_float(b[i].x), __uint_as_float(b[i].y), __uint_as_float(b[i].z),
+                                                       __uint_as_float(b[i].w)};
+    }
+    char* cb = reinterpret_cast<char*>(p.C);
+    const size_t row_bytes = (size_t)p.ldc * 2;          // = 4 N
+    const int nks_out = p.N >> 7;                        // 128-element K-tiles of the consumer
+#pragma unroll
+    for (int qm = 0; qm < 2; ++qm)
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+            const int m = m0 + qm * 128 + mrow + (pr * 2 + (odd ? 1 : 0)) * 16;
+            char* crow = cb + (size_t)m * row_bytes;
+#pragma unroll
+            for (int qn = 0; qn < 2; ++qn) {
+                float v[2][8];
+                float amax = 0.f;
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[qm][qn][nt][2 * pr][k]),
+                                                                        __float_as_uint(acc[qm][qn][nt][2 * pr + 1][k]),
+                                                                        false, false);
+                        v[nt][k] = __uint_as_float(r[0]);
+                        v[nt][4 + k] = __uint_as_float(r[1]);
+                    }
+                    const float4 b0 = bias[qn][nt][0], b1 = bias[qn][nt][1];
+                    v[nt][0] += b0.x; v[nt][1] += b0.y; v[nt][2] += b0.z; v[nt][3] += b0.w;
+                    v[nt][4] += b1.x; v[nt][5] += b1.y; v[nt][6] += b1.z; v[nt][7] += b1.w;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        if constexpr (EPI == TT_EPI_GELU) v[nt][k] = gelu_exact(v[nt][k]);
+                        asm("" : "+v"(v[nt][k]));        // opaque before it is split (see epilogue_x3)
+                        amax = fmaxf(amax, fabsf(v[nt][k]));
+                    }
+                }
+                amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+                int sbyte, sh;
+                xc_block_scale(amax, sbyte, sh);
+                const int n_blk = n0 + wn * 64 + qn * 32;
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const int n = n_blk + nt * 16 + (g & ~1) * 4;
+                    uint2 h0, h1;
+                    uint32_t xa, xb, la, lb;
+                    xc_split4(v[nt][0], v[nt][1], v[nt][2], v[nt][3], sh, sh + 11, h0, xa, la);
+                    xc_split4(v[nt][4], v[nt][5], v[nt][6], v[nt][7], sh, sh + 11, h1, xb, lb);
+                    *reinterpret_cast<uint4*>(crow + (size_t)n * 2) = uint4{h0.x, h0.y, h1.x, h1.y};
+                    *reinterpret_cast<uint2*>(crow + (size_t)2 * p.N + n) = make_uint2(xa, xb);
+                    *reinterpret_cast<uint2*>(crow + (size_t)3 * p.N + n) = make_uint2(la, lb);
+                }
+                if ((lane & 32) == 0) p.c_scales[xc_a_scale_at(m, n_blk >> 5, nks_out)] = (uint8_t)sbyte;
+            }
+        }
+}
+
 // TT_EPI_SCAN: nothing is stored.  In the swapped accumulator layout a lane holds ONE corpus row (m-tile row l & 15)
 // and four consecutive queries per 16x16 tile, so the per-query threshold filter is four compares against a float4
 // of the tile's threshold strip (LDS, staged like a bias strip).  Survivors are rare (about k * rows / sample rows
@@ -827,9 +911,39 @@ __device__ __forceinline__ f32x4 mfma_fp8(const ex8& a0, const ex8& a1, const ex
     return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
 }
 
-template <int EPI, int SLOTS, bool FP8 = false, bool X3 = false>
+// ---- f16c operands (GemmParams.xc): fp16 tiles, then block-scaled e4m3 tiles, in one K stream ------------------------------
+// The e4m3 tiles' E8M0 block scales ride the operand pipeline: one 256-byte LDS-DMA per wave and tile (waves 0-3 the tile's
+// 1-KiB strip of A scales, waves 4-7 the W strip) into one of four 2-KiB buffers behind the operand slots, two tiles ahead.
+constexpr int kXcScaleOff = kLds3;            // 4 x {A strip 1 KiB, W strip 1 KiB}
+constexpr int kLdsXc = kLds3 + 4 * 2048;      // 142 KiB
+// a strip is stored in the order its readers want it (one ds_read_b32 = the four scales of a lane's MFMAs):
+//   A: byte ((qm 2 + wm) 16 + frow) 16 + g 4 + mt  = scale of tile row qm 128 + wm 64 + mt 16 + frow, block g
+//   W: byte ((wn 16 + frow) 4 + g) 4 + qn 2 + nt    = scale of tile column wn 64 + qn 32 + nt 16 + frow, block g
+__device__ __forceinline__ void glds4(const void* base, uint32_t voff, uint32_t lds_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1"
+                 :: "v"(voff), "s"(base), "s"(lds_addr) : "memory", "m0");
+}
+// one K = 128 step of e4m3 products with block scales: byte OA of lane (row, g)'s scale_a is the E8M0 scale of block g (k in
+// [32 g, 32 g + 32)) of that row of operand a, byte OB of scale_b likewise for operand b (tools/probes/mfma_scale_probe.cpp)
+template <int OA, int OB>
+__device__ __forceinline__ f32x4 mfma_fp8_scaled(const ex8& a0, const ex8& a1, const ex8& b0, const ex8& b1, f32x4 c, uint32_t scale_a,
+                                                 uint32_t scale_b) {
+    const v8i a = __builtin_bit_cast(v8i, Frag2{a0, a1});
+    const v8i b = __builtin_bit_cast(v8i, Frag2{b0, b1});
+    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, OA, (int)scale_a, OB, (int)scale_b);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (N > 0) {
+        static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+
+template <int EPI, int SLOTS, bool FP8 = false, bool X3 = false, bool XC = false>
 __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
     static_assert(!(FP8 && X3), "split-bf16 operands are bf16");
+    static_assert(!XC || (!FP8 && !X3 && kF16), "f16c operands: the fp16 instantiation, no other operand mode");
     constexpr int ES = FP8 ? 1 : 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -853,8 +967,9 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
     if (tm >= mt_n || tn >= nt_n) return;
     const int m0 = tm * BM3, n0 = tn * BN3;
     // split-bf16 (X3): three passes over K -- hi.hi, hi.lo, lo.hi -- as ONE K stream of 3 nk1 tiles (GemmParams.x3)
+    // f16c (XC): K / 64 fp16 tiles, then K / 64 e4m3 tiles (x8.w_lo8: K / 128, lo8.w_x8: K / 128) -- the rows ARE that stream
     const int nk1 = p.K * ES / 128;
-    const int nk = X3 ? 3 * nk1 : nk1;
+    const int nk = X3 ? 3 * nk1 : (XC ? 2 * nk1 : nk1);
     auto tile_a = [&](int t) { if constexpr (X3) return t < nk1 ? t : t - nk1; else return t; };
     auto tile_w = [&](int t) { if constexpr (X3) return t < 2 * nk1 ? t : t - 2 * nk1; else return t; };
 
@@ -901,7 +1016,7 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
         }
     };
     // residual tile -> LDS, four parts of (2 pieces x 2 copies) per wave; layout: see epilogue_all
-    constexpr bool kResLds = (EPI == TT_EPI_RESIDUAL) && !X3;   // (split-bf16: the residual is fp32, read by the epilogue)
+    constexpr bool kResLds = (EPI == TT_EPI_RESIDUAL) && !X3 && !XC;   // (split-bf16 / f16c: the residual is fp32, read by the epilogue)
     uint32_t voffR[2] = {0u, 0u};
     if constexpr (kResLds) {
 #pragma unroll
@@ -964,6 +1079,11 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
 
     ex8 xf[4][2], wf0[2][2], wf1[2][2];
 
+    // f16c: an e4m3 tile is read exactly like an fp16 tile -- lane (row, g) takes bytes [16 g, 16 g + 16) and [64 + 16 g,
+    // 64 + 16 g + 16) of its row.  That IS the instruction's K order (registers 0-3 of lane group g: k = 16 g ..., registers
+    // 4-7: k = 64 + 16 g ...), and the E8M0 scale of the tile's 32-element block b = k / 32 is taken from lane group b's scale
+    // register, whatever lanes hold the block's data (measured: tools/probes/mfma_scale_map2.cpp) -- so lane (row, g) supplies
+    // the scale of block g of its row, which is how the scale strips are laid out.
     auto read_a = [&](const char* base) {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
@@ -976,6 +1096,23 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
         for (int nt = 0; nt < 2; ++nt) {
             wf[nt][0] = *reinterpret_cast<const ex8*>(base + w_row0 + nt * 2048 + off0);
             wf[nt][1] = *reinterpret_cast<const ex8*>(base + w_row0 + nt * 2048 + off1);
+        }
+    };
+    // f16c: scale strips of e4m3 K-tile t (>= nk1) -> scale buffer t & 3: one 256-byte copy per wave
+    uint32_t sa_reg[2] = {0u, 0u}, sw_reg = 0u;
+    const int sa_off = (wm * 16 + frow) * 16 + fchk * 4;                 // + qm * 512
+    const int sw_off = 1024 + (wn * 16 + frow) * 16 + fchk * 4;
+    auto stage_scales = [&](int t) {
+        if constexpr (XC) {
+            const int u = t - nk1, nks = nk1 >> 1;                        // nks = K / 128 e4m3 tiles per part
+            const uint8_t* src = wave < 4 ? p.a_scales + ((size_t)(m0 >> 8) * nks + (u >= nks ? u - nks : u)) * 1024 + wave * 256
+                                          : p.w_scales + ((size_t)(n0 >> 8) * nk1 + u) * 1024 + (wave - 4) * 256;
+            const unsigned long long b64 = reinterpret_cast<unsigned long long>(src);
+            const unsigned int blo = __builtin_amdgcn_readfirstlane((unsigned int)b64);
+            const unsigned int bhi = __builtin_amdgcn_readfirstlane((unsigned int)(b64 >> 32));
+            const uint32_t dst = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem + kXcScaleOff + (t & 3) * 2048 +
+                                 (wave < 4 ? wave * 256 : 1024 + (wave - 4) * 256);
+            glds4(reinterpret_cast<const void*>(((unsigned long long)bhi << 32) | blo), (uint32_t)lane * 4u, dst);
         }
     };
     // Tiles of the V third of a QKV projection are produced un-swapped (a = X, b = W): a lane then holds 4
@@ -1010,6 +1147,22 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
         }
         __builtin_amdgcn_s_setprio(0);
     };
+    // f16c, e4m3 tiles: one scaled MFMA per 16 x 16 output tile and K-tile; the A rows' scales are the four bytes of sa (byte
+    // mt), the W columns' of sw (byte qn 2 + nt)
+    auto mma8 = [&](f32x4(&c)[2][4], const ex8(&wf)[2][2], uint32_t sa, uint32_t sw, auto qnc) {
+        if constexpr (XC) {
+            constexpr int QN = decltype(qnc)::value;
+            __builtin_amdgcn_s_setprio(1);
+            static_for<2>([&](auto ntc) {
+                static_for<4>([&](auto mtc) {
+                    constexpr int nt = decltype(ntc)::value, mt = decltype(mtc)::value;
+                    if constexpr (vblk) c[nt][mt] = mfma_fp8_scaled<mt, QN * 2 + nt>(xf[mt][0], xf[mt][1], wf[nt][0], wf[nt][1], c[nt][mt], sa, sw);
+                    else c[nt][mt] = mfma_fp8_scaled<QN * 2 + nt, mt>(wf[nt][0], wf[nt][1], xf[mt][0], xf[mt][1], c[nt][mt], sw, sa);
+                });
+            });
+            __builtin_amdgcn_s_setprio(0);
+        }
+    };
     // 4-slot variant: La (A-lo, W-lo, W-hi fragments) | Ca (quadrants 00, 01) | Lb (A-hi) | Cb (11, 10):
     // half as many barriers per MFMA.
     unsigned long long* dbg = reinterpret_cast<unsigned long long*>(p.vt);
@@ -1027,15 +1180,23 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
     auto wait_n = [&](int n) {
         if (n == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
         else if (n == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+        else if (n == 9) asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory");
+        else if (n == 7) asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         TT_SLOT_END();
     };
-    // Copy schedule:  La(t): W-hi(t+1), A-hi(t+1)   Lb(t): A-lo(t+2), W-lo(t+2).
+    // Copy schedule:  La(t): W-hi(t+1), A-hi(t+1)   Lb(t): A-lo(t+2), W-lo(t+2) [f16c: + the scale strips of e4m3 tile t+2].
     // (Moving half of the copies into the C slots was measured neutral-to-worse: an LDS-DMA issue
     // costs ~100 cycles wherever it sits, and the C slot is then as long as the L slot.)
-    auto tile4 = [&](int t, auto bufc) {
+    // (f8c: the tile's flavour in the f16c stream -- false: fp16 MFMAs, true: scaled e4m3 MFMAs; always false otherwise)
+    auto tile4 = [&](int t, auto bufc, auto f8c) {
         constexpr int B = decltype(bufc)::value;
+        constexpr bool F8T = XC && decltype(f8c)::value;
         const bool more1 = t + 1 < nk, more2 = t + 2 < nk;
+        // f16c: vector-memory operations that may still be in flight at the two counted waits -- the copies of Lb(t - 1)
+        // resp. Lb(t) include one scale strip when the tile they prefetch (t + 1 resp. t + 2) is an e4m3 tile
+        const int sc_la = (XC && t + 1 >= nk1 && t + 1 < nk) ? 1 : 0, sc_lb = (XC && t + 2 >= nk1 && t + 2 < nk) ? 1 : 0;
+        const char* sbuf = smem + kXcScaleOff + (t & 3) * 2048;
         // La
         stamp(t);                                  // 0: La start
         if (more1) {
@@ -1048,13 +1209,22 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
         read_a(smem + slot_off(0, 0, B));
         read_w(wf0, smem + slot_off(1, 0, B));
         read_w(wf1, smem + slot_off(1, 1, B));
+        if constexpr (F8T) {
+            sa_reg[0] = *reinterpret_cast<const uint32_t*>(sbuf + sa_off);
+            sw_reg = *reinterpret_cast<const uint32_t*>(sbuf + sw_off);
+        }
         stamp(t);                                  // 2: reads issued
         if (SLOTS == 46) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         stamp(t);                                  // 3: reads returned
-        wait_n((t + 1 < nk || kResLds) ? 8 : 0);
+        wait_n((t + 1 < nk || kResLds) ? 8 + sc_la : 0);
         stamp(t);                                  // 4: past barrier (Ca start)
-        mma(acc[0][0], wf0);                       // Ca
-        mma(acc[0][1], wf1);
+        if constexpr (F8T) {
+            mma8(acc[0][0], wf0, sa_reg[0], sw_reg, std::integral_constant<int, 0>{});
+            mma8(acc[0][1], wf1, sa_reg[0], sw_reg, std::integral_constant<int, 1>{});
+        } else {
+            mma(acc[0][0], wf0);                   // Ca
+            mma(acc[0][1], wf1);
+        }
         stamp(t);                                  // 5: MFMAs issued
         TT_SLOT_END();
         // Lb
@@ -1062,26 +1232,44 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
         if (more2) {
             stage_half<0, ES>(p, smem, 0, B, tile_a(t + 2), wave, voffA, m0, n0);
             stage_half<1, ES>(p, smem, 0, B, tile_w(t + 2), wave, voffW, m0, n0);
+            if (sc_lb) stage_scales(t + 2);
         } else if (kResLds) {
             stage_res(B == 0 ? 0 : 2);             // tile nk-2 (B = 0): lo slots of buffer 0; tile nk-1: of buffer 1
         }
         stamp(t);                                  // 7
         read_a(smem + slot_off(0, 1, B));
+        if constexpr (F8T) sa_reg[1] = *reinterpret_cast<const uint32_t*>(sbuf + 512 + sa_off);
         stamp(t);                                  // 8
         if (SLOTS == 46) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         stamp(t);                                  // 9
-        wait_n((t + 2 < nk || kResLds) ? 6 : 0);
+        wait_n((t + 2 < nk || kResLds) ? 6 + sc_lb : 0);
         stamp(t);                                  // 10: Cb start
-        mma(acc[1][1], wf1);                       // Cb
-        mma(acc[1][0], wf0);
+        if constexpr (F8T) {
+            mma8(acc[1][1], wf1, sa_reg[1], sw_reg, std::integral_constant<int, 1>{});
+            mma8(acc[1][0], wf0, sa_reg[1], sw_reg, std::integral_constant<int, 0>{});
+        } else {
+            mma(acc[1][1], wf1);                   // Cb
+            mma(acc[1][0], wf0);
+        }
         stamp(t);                                  // 11
         TT_SLOT_END();
         stamp(t);                                  // 12
     };
 
-    for (int t = 0; t < nk; t += 2) {
-        tile4(t, std::integral_constant<int, 0>{});
-        if (t + 1 < nk) tile4(t + 1, std::integral_constant<int, 1>{});
+    if constexpr (XC) {
+        for (int t = 0; t < nk1; t += 2) {          // nk1 = K / 64 is even (K a multiple of 128)
+            tile4(t, std::integral_constant<int, 0>{}, std::false_type{});
+            tile4(t + 1, std::integral_constant<int, 1>{}, std::false_type{});
+        }
+        for (int t = nk1; t < nk; t += 2) {
+            tile4(t, std::integral_constant<int, 0>{}, std::true_type{});
+            tile4(t + 1, std::integral_constant<int, 1>{}, std::true_type{});
+        }
+    } else {
+        for (int t = 0; t < nk; t += 2) {
+            tile4(t, std::integral_constant<int, 0>{}, std::false_type{});
+            if (t + 1 < nk) tile4(t + 1, std::integral_constant<int, 1>{}, std::false_type{});
+        }
     }
     cstamp(2);
     if (!late) TT_SLOT_END();   // match the extra barrier the late group took up front
@@ -1096,6 +1284,10 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
                 gemm_epilogue_vt<2, 4, FP8, X3>(p, acc[qm][qn], m0 + qm * 128 + wm * 64, n0 + wn * 64 + qn * 32, lane);
     } else if constexpr (X3) {
         epilogue_x3<EPI>(p, acc, smem, kBiasOff, m0, n0, wm, wn, lane);
+    } else if constexpr (XC && EPI == TT_EPI_RESIDUAL) {
+        epilogue_x3<EPI>(p, acc, smem, kBiasOff, m0, n0, wm, wn, lane);          // fp32 out = acc + bias + fp32 residual
+    } else if constexpr (XC && EPI == TT_EPI_GELU) {
+        epilogue_xc<EPI>(p, acc, smem, kBiasOff, m0, n0, wm, wn, lane);          // c-planes out
     } else if constexpr (EPI == TT_EPI_QKV) {
 #pragma unroll
         for (int qm = 0; qm < 2; ++qm)
@@ -1591,6 +1783,49 @@ int launch_x3(const GemmParams& p, hipStream_t st) {
     }
 }
 
+// f16c operands (GemmParams.xc): the 256x256 one-tile kernel on the fp16 + scaled-e4m3 K stream; bias (fp16 out), GELU
+// (c-planes out), residual (fp32 out), V^T (fp16 V8 out).  fp16 instantiation only.
+template <int EPI>
+int launch_xc(const GemmParams& p, hipStream_t st) {
+    if constexpr (kF16 && (EPI == TT_EPI_BIAS || EPI == TT_EPI_GELU || EPI == TT_EPI_VT || EPI == TT_EPI_RESIDUAL)) {
+        const int ldw = p.ldw ? p.ldw : 2 * p.K;
+        if (p.M % v3::BM3 || p.N % v3::BN3 || p.K % 128 || p.K < 128 || p.lda < 2 * p.K || ldw < 2 * p.K || p.lda % 8 || ldw % 8 || !p.A ||
+            !p.W || !p.bias || !p.a_scales || !p.w_scales) {
+            tt_set_error("gemm f16c: M=%d N=%d K=%d lda=%d ldw=%d: M, N multiples of 256, K of 128, c-planes [.][>= 2K uint16] with tiled scales",
+                         p.M, p.N, p.K, p.lda, ldw);
+            return TT_E_UNSUPPORTED;
+        }
+        if constexpr (EPI == TT_EPI_RESIDUAL) {
+            if (!p.C32 || !p.res32 || p.ldc % 4 || p.ldr % 4) { tt_set_error("gemm f16c: residual epilogue needs fp32 C32 / res32"); return TT_E_INVALID; }
+        } else if constexpr (EPI == TT_EPI_VT) {
+            if (!p.vt || p.ldvt % 8) { tt_set_error("gemm f16c: V^T epilogue needs vt"); return TT_E_INVALID; }
+        } else if constexpr (EPI == TT_EPI_GELU) {
+            if (!p.C || !p.c_scales || p.ldc != 2 * p.N) { tt_set_error("gemm f16c: c-planes output needs C, c_scales, ldc = 2 N"); return TT_E_INVALID; }
+        } else {
+            if (!p.C || p.ldc % 8) { tt_set_error("gemm f16c: fp16 output needs C, ldc %% 8 == 0"); return TT_E_INVALID; }
+        }
+        const int mt_n = p.M / v3::BM3, nt_n = p.N / v3::BN3;
+        const int SN = super_sn(nt_n), SM = 32 / SN;
+        const int supers = ((mt_n + SM - 1) / SM) * ((nt_n + SN - 1) / SN);
+        int blocks = supers * SM * SN;
+        blocks = (blocks + 7) / 8 * 8;
+        TT_SET_MAX_LDS((v3::gemm_kernel_v3<EPI, 4, false, false, true>), v3::kLdsXc);
+        {
+            TtProfScope prof(TT_K_GEMM, st);
+            GemmParams q = p;
+            q.sn = SN;
+            q.ldw = ldw;
+            q.nt_store = 1;
+            hipLaunchKernelGGL((v3::gemm_kernel_v3<EPI, 4, false, false, true>), dim3(blocks), dim3(v3::kThreads3), v3::kLdsXc, st, q);
+        }
+        TT_CHECK_LAUNCH();
+        return TT_OK;
+    } else {
+        tt_set_error("gemm f16c: epilogue %d has no f16c form (fp16 instantiation: bias, GELU, residual, V^T)", EPI);
+        return TT_E_UNSUPPORTED;
+    }
+}
+
 bool skinny_shape(const GemmParams& p) {
     return !p.fp8 && tt_gemm_skinny_enabled() && p.M > 0 && p.M <= 256 && p.M % 64 == 0 && p.N % 16 == 0 && p.K % 32 == 0 && p.K > 0;
 }
@@ -1708,6 +1943,18 @@ int tt_gemm_launch(const GemmParams& p, int epilogue, hipStream_t st) {
     if (p.M <= 0 || p.N <= 0) return TT_OK;
     if constexpr (kF16) {      // the fp16 instantiation serves the plain 16-bit path only
         if (p.x3 || p.fp8) { tt_set_error("gemm (fp16 build): split-bf16 / fp8 operands belong to the bf16 instantiation"); return TT_E_UNSUPPORTED; }
+        if (p.xc) {
+            switch (epilogue) {
+                case TT_EPI_BIAS: return launch_xc<TT_EPI_BIAS>(p, st);
+                case TT_EPI_GELU: return launch_xc<TT_EPI_GELU>(p, st);
+                case TT_EPI_RESIDUAL: return launch_xc<TT_EPI_RESIDUAL>(p, st);
+                case TT_EPI_VT: return launch_xc<TT_EPI_VT>(p, st);
+                default: tt_set_error("gemm f16c: epilogue %d has no f16c form", epilogue); return TT_E_UNSUPPORTED;
+            }
+        }
+    } else if (p.xc) {
+        tt_set_error("gemm (bf16 build): f16c operands belong to the fp16 instantiation");
+        return TT_E_UNSUPPORTED;
     }
     if constexpr (!kF16) if (p.x3) {
         switch (epilogue) {

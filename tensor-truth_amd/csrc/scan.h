@@ -61,6 +61,10 @@ struct SelectParams {
     int32_t* cnt_out;         // optional [Q]: number of valid outputs (<= k)
     int32_t* overflow_flag;   // optional
     int min_valid;            // > 0: fewer than min_valid valid outputs for a query also raise *overflow_flag
+    // k <= 64 kernel only -- the small launches around the threshold selection of a tiled filter batch, folded into it:
+    int thr_relax;            // thr_out is lowered by 2^-13 |thr| + 2e-6 (see scan_api.hip: two summation orders of one dot product)
+    int32_t* zero_cnt;        // optional [grid.x]: zero_cnt[q] = 0 (the filter pass's candidate counters)
+    int n_real;               // 0 = every block has a list; else blocks q >= n_real only write thr_out[q] = +inf, zero_cnt[q] = 0
     // optional segmentation of each query's list (tt_scan_topk_segmented): block (q, s) selects over
     // positions [seg_off[s], seg_off[s+1]) of query q's scores (and idx, when given), writes output row
     // q * n_seg + s; implicit indices are emitted as (position in the segment) + seg_add[s].
@@ -71,3 +75,5 @@ struct SelectParams {
 };
 
 int tt_select_launch(const SelectParams& p, int n_queries, hipStream_t stream);
+// true when a selection with this k runs on the k <= 64 kernel, i.e. thr_relax / zero_cnt / n_real are available
+bool tt_select_fused_outputs(int k);

@@ -325,13 +325,25 @@ int tt_scan_topk(const void* corpus_bf16, int64_t n_rows, int dim, const void* q
     s1.out_stride = pl.cap;
     s1.thr_out = thr;
     s1.cnt_out = nullptr;
-    if (pl.gemm) {   // thresholds of the padding queries: +inf (nothing passes)
-        hipLaunchKernelGGL(fill_f32_kernel, dim3((pl.q256 + 255) / 256), dim3(256), 0, st, thr, __builtin_inff(), pl.q256);
-        TT_CHECK_LAUNCH();
+    // k <= 64: the launches around this selection are folded into it (one launch instead of four): it runs a block for every
+    // slot of the padded query batch -- padding slots write thr = +inf (nothing passes) --, every block zeroes its candidate
+    // counter, and the tiled path's threshold relaxation (below) is applied where thr is written
+    const bool fused = tt_select_fused_outputs(k);
+    if (fused) {
+        s1.n_real = n_queries;
+        s1.zero_cnt = cnt;
+        s1.thr_relax = pl.gemm ? 1 : 0;
+        rc = tt_select_launch(s1, pl.qpad, st);
+        if (rc) return rc;
+    } else {
+        if (pl.gemm) {   // thresholds of the padding queries: +inf (nothing passes)
+            hipLaunchKernelGGL(fill_f32_kernel, dim3((pl.q256 + 255) / 256), dim3(256), 0, st, thr, __builtin_inff(), pl.q256);
+            TT_CHECK_LAUNCH();
+        }
+        rc = tt_select_launch(s1, n_queries, st);
+        if (rc) return rc;
     }
-    rc = tt_select_launch(s1, n_queries, st);
-    if (rc) return rc;
-    if (pl.gemm) {
+    if (pl.gemm && !fused) {
         // The thresholds come from the streaming sample kernel (v_mfma_f32_32x32x16_bf16), the tiled filter pass recomputes the
         // scores on v_mfma_f32_16x16x32_bf16 with another K grouping and summation order: the two fp32 sums of one row are not
         // guaranteed to agree in the last bits, so the row that DEFINES thr could miss it by an ulp (k = 1 with the best row
@@ -342,14 +354,18 @@ int tt_scan_topk(const void* corpus_bf16, int64_t n_rows, int dim, const void* q
         hipLaunchKernelGGL(relax_thr_kernel, dim3((n_queries + 255) / 256), dim3(256), 0, st, thr, n_queries);
         TT_CHECK_LAUNCH();
     }
-    TT_CHECK_HIP(hipMemsetAsync(cnt, 0, (size_t)pl.qpad * sizeof(int32_t), st));
+    if (!fused) TT_CHECK_HIP(hipMemsetAsync(cnt, 0, (size_t)pl.qpad * sizeof(int32_t), st));
 
     if (pl.gemm) {
         // 3'. filter pass as a tiled contraction: rows [0, rows256) x 256 queries per launch, ONE pass over the corpus per
         //     256 queries; the < 256 tail rows through the streaming kernel (private lists of one block)
-        uint16_t* q256 = (uint16_t*)(ws + pl.off_q256);
-        TT_CHECK_HIP(hipMemsetAsync(q256, 0, (size_t)pl.q256 * dim * sizeof(uint16_t), st));
-        TT_CHECK_HIP(hipMemcpyAsync(q256, queries_bf16, (size_t)n_queries * dim * sizeof(uint16_t), hipMemcpyDeviceToDevice, st));
+        const uint16_t* q256 = (const uint16_t*)queries_bf16;
+        if (n_queries != pl.q256) {     // a ragged batch: zero-padded copy (a full 256-query batch is read where it lies)
+            uint16_t* qpad256 = (uint16_t*)(ws + pl.off_q256);
+            TT_CHECK_HIP(hipMemsetAsync(qpad256 + (size_t)n_queries * dim, 0, (size_t)(pl.q256 - n_queries) * dim * sizeof(uint16_t), st));
+            TT_CHECK_HIP(hipMemcpyAsync(qpad256, queries_bf16, (size_t)n_queries * dim * sizeof(uint16_t), hipMemcpyDeviceToDevice, st));
+            q256 = qpad256;
+        }
         const int64_t rows256 = n_rows / 256 * 256;
         for (int b = 0; b < pl.q256 / 256; ++b) {
             rc = tt_scan_gemm_launch((const uint16_t*)corpus_bf16, rows256, dim, q256 + (size_t)b * 256 * dim, thr + b * 256,

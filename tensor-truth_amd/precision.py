@@ -9,9 +9,11 @@ BASELINE.json's configurations name bf16 (and fp8 for config 5): those are the m
 "bfloat16"`` in the per-model config, as the reference's own config schema allows; ``TT_PRECISION=bf16``;
 ``ModelManager.set_precision("bf16")``), and the ones ``bench.py`` names for its headline.
 
-    mode "reference"  fp32 semantics: scores within north_star's 1e-3 relative of the CPU path.  Runs as split-bf16 on
-                      the bf16 matrix cores (``encoder_x3``, a third of the bf16 rate) when the model shape allows,
-                      else on the fp32 MFMA (``encoder_f32``).  ``TT_REFERENCE_IMPL=fp32`` forces the latter.
+    mode "reference"  fp32 semantics: scores within north_star's 1e-3 relative of the CPU path.  Runs as "f16c" -- fp16
+                      main products + block-scaled e4m3 correction terms, HALF the bf16 matrix rate (``encoder_f16c``,
+                      round 4) -- when the model shape allows (hidden a multiple of 256, 64-wide heads), else on the fp32
+                      MFMA (``encoder_f32``, 1/16).  ``TT_REFERENCE_IMPL=bf16x3`` selects round 3's split-bf16
+                      implementation (``encoder_x3``, a third of the bf16 rate), ``TT_REFERENCE_IMPL=fp32`` the fp32 MFMA.
     mode "bf16"       bf16 weights / activations, fp32 accumulate (BASELINE configs 2-4; the reference's ``torch_dtype: bfloat16``)
     mode "fp16"       IEEE fp16 weights / activations, fp32 accumulate: the bf16 mode's rate (v_mfma_*_f16) with three more
                       mantissa bits at every rounding point -- scores about ten times closer to the reference than bf16;
@@ -70,13 +72,16 @@ def resolve(model_kwargs: Optional[Dict[str, Any]] = None, environ=None) -> str:
 
 
 def reference_impl(cfg, environ=None) -> str:
-    """"bf16x3" (split-bf16 on the bf16 matrix cores) where the model shape fits, else "fp32" (fp32 MFMA)."""
-    from . import encoder_x3
+    """"f16c" (fp16 + e4m3 corrections: two matrix-time units) where the model shape fits, else "fp32" (fp32 MFMA);
+    ``TT_REFERENCE_IMPL`` = "bf16x3" / "fp32" forces one of the older implementations."""
+    from . import encoder_f16c, encoder_x3
 
     forced = (os.environ if environ is None else environ).get("TT_REFERENCE_IMPL", "").strip().lower()
     if forced in ("fp32", "float32", "f32"):
         return "fp32"
-    return "bf16x3" if encoder_x3.supports(cfg) else "fp32"
+    if forced in ("bf16x3", "x3", "split-bf16"):
+        return "bf16x3" if encoder_x3.supports(cfg) else "fp32"
+    return "f16c" if encoder_f16c.supports(cfg) else "fp32"
 
 
 def build_encoder(cfg, state, device, model_kwargs: Optional[Dict[str, Any]], what: str) -> Tuple[Any, Any, str]:
@@ -85,7 +90,14 @@ def build_encoder(cfg, state, device, model_kwargs: Optional[Dict[str, Any]], wh
 
     mode = resolve(model_kwargs)
     if mode == "reference":
-        if reference_impl(cfg) == "bf16x3":
+        impl = reference_impl(cfg)
+        if impl == "f16c":
+            from .encoder_f16c import EncoderF16C, EncoderWeightsF16C
+
+            w = EncoderWeightsF16C(cfg, state, device)
+            enc, desc = EncoderF16C(w), ("reference (fp32 semantics as fp16 products + block-scaled e4m3 correction terms on the "
+                                         "matrix cores, fp32 residual stream)")
+        elif impl == "bf16x3":
             from .encoder_x3 import EncoderWeightsX3, EncoderX3
 
             w = EncoderWeightsX3(cfg, state, device)

@@ -85,3 +85,71 @@ def test_adjacent_cosine_random(dev, built_lib, n, h):
     got = adjacent_distances(e.to(dev)).cpu()
     assert got.shape == want.shape
     assert (got - want).abs().max().item() < 2e-6
+
+
+@pytest.mark.parametrize("m", [1, 2, 63, 64, 65, 127, 128, 129, 1000, 1024, 1025, 4096, 5000, 16385, 70001])
+@pytest.mark.parametrize("k", [1, 10, 50, 64])
+def test_wave_register_select_list_lengths(dev, built_lib, m, k):
+    """The k <= 64 selection kernel (select.hip select_wave_kernel: per-wave bitonic sort in registers, DPP / v_permlane swaps,
+    chunk skipping, one LDS merge) on list lengths around every chunk (64) and wave-count (128, 1024) boundary, with NaN scores,
+    -0.0 / +0.0, exact ties (index ascending), padding entries and ascending input (no chunk can be skipped): indices and scores
+    bit-exact against the oracle's stable merge."""
+    from tensor_truth_amd import scan as tscan
+
+    g = torch.Generator().manual_seed(31 * m + k)
+    q = 7
+    vals = torch.randn(q, m, generator=g)
+    vals[0] = torch.sort(vals[0]).values                               # ascending: every chunk beats the running list
+    vals[1] = torch.sort(vals[1], descending=True).values             # descending: only the first chunk(s) matter
+    if m >= 4:
+        vals[2, :: 3] = 0.25                                           # exact ties
+        vals[3, 0], vals[3, m // 2] = 0.0, -0.0                        # the two zeros compare equal: index decides
+        vals[3, 1::2] = -1.0
+        vals[4, ::5] = float("nan")                                    # never selected
+    idx = torch.stack([torch.randperm(m, generator=g) for _ in range(q)]).to(torch.int32) * 7 + 3
+    pad = torch.rand(q, m, generator=g) < 0.1
+    pad[5] = True                                                      # a query with no live candidate at all
+    vals[pad] = float("-inf")
+    idx[pad] = -1
+    live = vals.clone()
+    live[torch.isnan(live)] = float("-inf")                            # the oracle's view of "never selected"
+    li = idx.clone()
+    li[torch.isnan(vals)] = -1
+    want_v, want_i = osc.merge_topk(live, li.to(torch.int64), k)
+    got_v, got_i = tscan.topk_merge(vals.to(dev), idx.to(dev), k)
+    torch.cuda.synchronize()
+    assert torch.equal(got_i.cpu().to(torch.int64), want_i), (m, k)
+    gv, wv = got_v.cpu(), want_v
+    assert torch.equal(gv == 0, wv == 0) and torch.equal(torch.where(gv == 0, torch.zeros_like(gv), gv), torch.where(wv == 0, torch.zeros_like(wv), wv))
+
+
+def test_wave_select_equals_lds_network_in_a_child_process(dev, built_lib, tmp_path):
+    """A/B: TT_SELECT_WAVE=0 (the LDS network of rounds 1-3, still the kernel for k > 64) returns the same bits as the
+    wave-register kernel on a sampled-threshold scan (sample select with the fused threshold outputs + final select over private
+    and shared candidate lists) and on a tiled 256-query batch."""
+    import os
+    import subprocess
+    import sys
+
+    from tensor_truth_amd import scan as tscan
+
+    def run():
+        out = []
+        for n, nq, k in ((200_000, 16, 50), (300_007, 256, 50), (300_007, 100, 7)):
+            corpus = osc.synth_corpus(n, 1024, seed=5)
+            queries, _ = osc.synth_queries(corpus, nq, seed=6)
+            s, i = tscan.scan_topk(corpus.to(dev), queries.to(dev), k)
+            out += [s.cpu(), i.cpu()]
+        return out
+
+    mine = run()
+    if os.environ.get("TT_SELECT_AB_CHILD"):
+        torch.save(mine, os.environ["TT_SELECT_AB_CHILD"])
+        return
+    other = tmp_path / "lds.pt"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TT_SELECT_WAVE="0", TT_SELECT_AB_CHILD=str(other))
+    subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.abspath(__file__) + "::test_wave_select_equals_lds_network_in_a_child_process"],
+                   check=True, env=env, cwd=root, timeout=900, capture_output=True)
+    theirs = torch.load(str(other))
+    assert len(mine) == len(theirs) and all(torch.equal(a, b) for a, b in zip(mine, theirs))

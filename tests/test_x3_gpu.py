@@ -213,7 +213,7 @@ def test_precision_selector_reaches_both_surfaces(dev, built_lib, monkeypatch):
         return ((got - want).abs() / want.abs()).max().item()
 
     monkeypatch.delenv("TT_PRECISION", raising=False)
-    monkeypatch.delenv("TT_REFERENCE_IMPL", raising=False)
+    monkeypatch.setenv("TT_REFERENCE_IMPL", "bf16x3")      # this file tests the split-bf16 implementation (the default one: test_f16c_gpu.py)
     rr = HipSentenceTransformerRerank(model="test/xenc", top_n=3, device="cuda", model_kwargs=dict(base))
     assert isinstance(rr._encoder, EncoderX3) and rr.precision.startswith("reference") and scores_of(rr) <= 2e-4    # the default
     monkeypatch.setenv("TT_PRECISION", "bf16")
@@ -227,7 +227,7 @@ def test_precision_selector_reaches_both_surfaces(dev, built_lib, monkeypatch):
     monkeypatch.setenv("TT_REFERENCE_IMPL", "fp32")
     rr = HipSentenceTransformerRerank(model="test/xenc", top_n=3, device="cuda", model_kwargs=dict(base))
     assert isinstance(rr._encoder, EncoderF32) and scores_of(rr) <= 1e-4
-    monkeypatch.delenv("TT_REFERENCE_IMPL")
+    monkeypatch.setenv("TT_REFERENCE_IMPL", "bf16x3")
     rr = HipSentenceTransformerRerank(model="test/xenc", top_n=3, device="cuda", model_kwargs={**base, "precision": "bf16"})
     assert isinstance(rr._encoder, Encoder)                                                # an explicit kwarg beats the environment
     monkeypatch.delenv("TT_PRECISION")
