@@ -452,7 +452,7 @@ int tt_rerank_head_f16c(const tt_encoder_weights_f16c* w, const float* hidden_f3
  * tt_f16c_quantize: fp32 [rows][k] (k a multiple of 256) -> c-planes [rows][4 k bytes] + tiled scales
  *   (tt_f16c_scale_bytes(rows, k, weight) bytes); weight = 0: activation flavour [hi | x8 | lo8], 1: weight flavour
  *   [hi | lo8 | x8] with two scale parts.  Rows are padded to 256 in the scale array only.
- * tt_gemm_f16c: a c-planes [m][4k], w c-planes [n][4k]; m, n multiples of 256, k of 128; epilogue 0: fp16 c_out [m][n] =
+ * tt_gemm_f16c: a c-planes [m][4k], w c-planes [n][4k]; m, n, k multiples of 256; epilogue 0: fp16 c_out [m][n] =
  *   a.w^T + bias; 1: exact-erf GELU -> c-planes c_out [m][4n] + c_scales; 2: fp32 c_out [m][n] = a.w^T + bias + residual_f32.
  * tt_attention_f16c: tt_attention_varlen_f16's inputs (fp16 Q / K, V in the V8 layout, head_dim 64), context as c-planes. */
 size_t tt_f16c_scale_bytes(int64_t rows, int k, int weight);

@@ -34,6 +34,8 @@ struct GemmParams {
     int32_t* scan_idx;        // [N][scan_cap]
     int scan_cap;
     int32_t scan_idx_base;    // emitted index = scan_idx_base + A row
+    int scan_rows;            // rows of the shard (0 = M).  Not a multiple of 256: M = rows rounded up, and the LAST tile is the
+                              // shard's last 256 rows (it overlaps its predecessor; the rows scored twice are reported once)
     // ---- split-bf16 ("bf16x3") operands: reference precision on the bf16 matrix cores (x3_path.hip) -------------------
     // A value x is carried as TWO bf16 planes, hi = bf16(x) and lo = bf16(x - hi) (x = hi + lo to 2^-17 relative), stored
     // side by side in a row: A[m][0..K) = hi, A[m][K..2K) = lo (lda >= 2K), W[n][0..K) = hi, W[n][K..2K) = lo (ldw = 2K).
@@ -53,7 +55,7 @@ struct GemmParams {
     // A value x is carried as "c-planes": hi = fp16(x), x8 = e4m3(x 2^-s), lo8 = e4m3((x - hi) 2^-(s - 11)), with one E8M0 block
     // exponent s per 32 consecutive K elements (s = exponent of the block's absmax - 7).  A row of an operand is ONE byte stream
     //     A[m]: [ hi: 2K bytes | x8: K | lo8: K ]        W[n]: [ hi: 2K | lo8: K | x8: K ]        (lda = ldw = 2K uint16 = 4K bytes)
-    // and the product runs as ONE contraction over 2 K / 64 K-tiles of 128 bytes: K / 64 tiles of v_mfma_f32_16x16x32_f16
+    // and the product runs as ONE contraction over 2 K / 64 K-tiles of 128 bytes (K a multiple of 256): K / 64 tiles of v_mfma_f32_16x16x32_f16
     // (hi.hi), then K / 64 tiles of v_mfma_scale_f32_16x16x128_f8f6f4 with the block scales (x8.w_lo8, then lo8.w_x8): the cross
     // terms are 2^-12 of the result and need 2^-4, the dropped lo.lo term is 2^-24.  Scales are stored TILED, 1 KiB per (256-row
     // block, 128-element K-tile), in the order the kernel reads them (f16c_path.hip: a_scale_at / w_scale_at).

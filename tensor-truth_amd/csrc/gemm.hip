@@ -722,6 +722,29 @@ __device__ __forceinline__ void epilogue_x3(const GemmParams& p, f32x4 (&acc)[2]
 // further on (the other 8-column half): the block's absmax is one cross-lane exchange.  Per block: E = exponent of the absmax,
 // scale byte s = E - 7 (biased); hi = fp16(v); x8 = e4m3(v 2^(7 - E)); lo8 = e4m3((v - hi) 2^(18 - E)) -- |v - hi| <= 2^(E - 11).
 // One byte per (row, block) goes to the tiled scale array of a consumer with K = p.N.
+// exact-erf GELU to fp32 grade without libm: gelu(x) = max(x, 0) - |x| / 2 * erfc(|x| / sqrt 2), erfc by the Chebyshev fit
+// t exp(-z^2 + P(t)), t = 1 / (1 + z / 2) (fractional error < 1.2e-7 for every z >= 0: the error of the GELU is below
+// 1.2e-7 of the CORRECTION term, i.e. relatively accurate on both tails).  One v_rcp_f32, ten FMAs, one v_exp_f32: the libm
+// erff of epilogue_x3 made this GEMM's epilogue a quarter of its time (2.48 matrix-time units against the 1.95 of the same K
+// with a bias epilogue, profiles/r04_f16c_gemm_shapes.log).
+__device__ __forceinline__ float gelu_erfc(float x) {
+    const float ax = fabsf(x);
+    const float z = ax * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.5f, z, 1.0f));
+    float p = 0.17087277f;
+    p = fmaf(p, t, -0.82215223f);
+    p = fmaf(p, t, 1.48851587f);
+    p = fmaf(p, t, -1.13520398f);
+    p = fmaf(p, t, 0.27886807f);
+    p = fmaf(p, t, -0.18628806f);
+    p = fmaf(p, t, 0.09678418f);
+    p = fmaf(p, t, 0.37409196f);
+    p = fmaf(p, t, 1.00002368f);
+    p = fmaf(p, t, -1.26551223f);
+    const float e = t * __builtin_amdgcn_exp2f((p - z * z) * 1.4426950408889634f);      // erfc(z)
+    return fmaxf(x, 0.f) - 0.5f * ax * e;
+}
+
 template <int EPI>
 __device__ __forceinline__ void epilogue_xc(const GemmParams& p, f32x4 (&acc)[2][2][2][4], const char* smem, int bias_off, int m0,
                                             int n0, int wm, int wn, int lane) {
@@ -774,7 +797,7 @@ __device__ __forceinline__ void epilogue_xc(const GemmParams& p, f32x4 (&acc)[2]
                     v[nt][4] += b1.x; v[nt][5] += b1.y; v[nt][6] += b1.z; v[nt][7] += b1.w;
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
-                        if constexpr (EPI == TT_EPI_GELU) v[nt][k] = gelu_exact(v[nt][k]);
+                        if constexpr (EPI == TT_EPI_GELU) v[nt][k] = gelu_erfc(v[nt][k]);
                         asm("" : "+v"(v[nt][k]));        // opaque before it is split (see epilogue_x3)
                         amax = fmaxf(amax, fabsf(v[nt][k]));
                     }
@@ -832,6 +855,8 @@ __device__ __forceinline__ void scan_append(const GemmParams& p, int q, int32_t 
 template <int MODE>
 __device__ __forceinline__ void scan_filter_epilogue(const GemmParams& p, f32x4 (&acc)[2][2][2][4], char* smem, int thr_off,
                                                      int m0, int wm, int wn, int lane) {
+    // first row this tile reports: m0, except for the shifted last tile of a shard whose rows are not a multiple of 256
+    const int row_min = (p.scan_rows && (p.scan_rows & 255) && m0 == p.scan_rows - 256) ? (p.scan_rows & ~255) : m0;
     const int g = lane >> 4, l15 = lane & 15;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)smem;
     const int wave_id = wm * 4 + wn;
@@ -852,9 +877,11 @@ __device__ __forceinline__ void scan_filter_epilogue(const GemmParams& p, f32x4 
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) {
                     const f32x4 v = acc[qm][qn][nt][mt];
-                    const bool hit = (v[0] >= t[0]) | (v[1] >= t[1]) | (v[2] >= t[2]) | (v[3] >= t[3]);
+                    const int rt = qm * 128 + wm * 64 + mt * 16 + l15;          // row inside the tile
+                    // (the shard's last tile when its rows are not a multiple of 256: it starts 256 rows before the end, the rows
+                    // it shares with its predecessor were reported by that one)
+                    const bool hit = ((v[0] >= t[0]) | (v[1] >= t[1]) | (v[2] >= t[2]) | (v[3] >= t[3])) & (m0 + rt >= row_min);
                     if (hit) {
-                        const int rt = qm * 128 + wm * 64 + mt * 16 + l15;      // row inside the tile
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
                             if (v[r] >= t[r]) {
@@ -912,10 +939,12 @@ __device__ __forceinline__ f32x4 mfma_fp8(const ex8& a0, const ex8& a1, const ex
 }
 
 // ---- f16c operands (GemmParams.xc): fp16 tiles, then block-scaled e4m3 tiles, in one K stream ------------------------------
-// The e4m3 tiles' E8M0 block scales ride the operand pipeline: one 256-byte LDS-DMA per wave and tile (waves 0-3 the tile's
-// 1-KiB strip of A scales, waves 4-7 the W strip) into one of four 2-KiB buffers behind the operand slots, two tiles ahead.
-constexpr int kXcScaleOff = kLds3;            // 4 x {A strip 1 KiB, W strip 1 KiB}
-constexpr int kLdsXc = kLds3 + 4 * 2048;      // 142 KiB
+// The e4m3 tiles' E8M0 block scales ride the operand pipeline in GROUPS OF FOUR K-tiles: one 1-KiB LDS-DMA per wave and group
+// (wave w: the A strip (w even) or W strip (w odd) of the group's tile w / 2) into one of two 8-KiB group buffers behind the
+// operand slots, issued two tiles ahead of the group's first tile.  (A copy per wave and TILE -- 256 bytes each -- made an
+// e4m3 tile 1.18x as long as an fp16 tile: an LDS-DMA issue costs ~100 cycles whatever its size.)
+constexpr int kXcScaleOff = kLds3;            // 2 groups x 4 tiles x {A strip 1 KiB, W strip 1 KiB}
+constexpr int kLdsXc = kLds3 + 2 * 8192;      // 150 KiB
 // a strip is stored in the order its readers want it (one ds_read_b32 = the four scales of a lane's MFMAs):
 //   A: byte ((qm 2 + wm) 16 + frow) 16 + g 4 + mt  = scale of tile row qm 128 + wm 64 + mt 16 + frow, block g
 //   W: byte ((wn 16 + frow) 4 + g) 4 + qn 2 + nt    = scale of tile column wn 64 + qn 32 + nt 16 + frow, block g
@@ -965,7 +994,11 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
     const int tm = (sidx / supers_n) * SM + widx / SN;
     const int tn = (sidx % supers_n) * SN + widx % SN;
     if (tm >= mt_n || tn >= nt_n) return;
-    const int m0 = tm * BM3, n0 = tn * BN3;
+    int m0_nominal = tm * BM3;
+    if constexpr (EPI == TT_EPI_SCAN) {
+        if (p.scan_rows && m0_nominal + BM3 > p.scan_rows) m0_nominal = p.scan_rows - BM3;      // the shard's last 256 rows
+    }
+    const int m0 = m0_nominal, n0 = tn * BN3;
     // split-bf16 (X3): three passes over K -- hi.hi, hi.lo, lo.hi -- as ONE K stream of 3 nk1 tiles (GemmParams.x3)
     // f16c (XC): K / 64 fp16 tiles, then K / 64 e4m3 tiles (x8.w_lo8: K / 128, lo8.w_x8: K / 128) -- the rows ARE that stream
     const int nk1 = p.K * ES / 128;
@@ -1098,21 +1131,22 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
             wf[nt][1] = *reinterpret_cast<const ex8*>(base + w_row0 + nt * 2048 + off1);
         }
     };
-    // f16c: scale strips of e4m3 K-tile t (>= nk1) -> scale buffer t & 3: one 256-byte copy per wave
+    // f16c: scale strips of the four e4m3 K-tiles t .. t + 3 (t - nk1 a multiple of 4; nk1 is one: K % 256 == 0) -> group
+    // buffer ((t - nk1) >> 2) & 1: wave w copies tile t + w / 2's A strip (w even) or W strip (w odd), 1 KiB
     uint32_t sa_reg[2] = {0u, 0u}, sw_reg = 0u;
     const int sa_off = (wm * 16 + frow) * 16 + fchk * 4;                 // + qm * 512
     const int sw_off = 1024 + (wn * 16 + frow) * 16 + fchk * 4;
     auto stage_scales = [&](int t) {
         if constexpr (XC) {
-            const int u = t - nk1, nks = nk1 >> 1;                        // nks = K / 128 e4m3 tiles per part
-            const uint8_t* src = wave < 4 ? p.a_scales + ((size_t)(m0 >> 8) * nks + (u >= nks ? u - nks : u)) * 1024 + wave * 256
-                                          : p.w_scales + ((size_t)(n0 >> 8) * nk1 + u) * 1024 + (wave - 4) * 256;
+            const int u = t - nk1 + (wave >> 1), nks = nk1 >> 1;          // nks = K / 128 e4m3 tiles per part
+            const uint8_t* src = (wave & 1) ? p.w_scales + ((size_t)(n0 >> 8) * nk1 + u) * 1024
+                                            : p.a_scales + ((size_t)(m0 >> 8) * nks + (u >= nks ? u - nks : u)) * 1024;
             const unsigned long long b64 = reinterpret_cast<unsigned long long>(src);
             const unsigned int blo = __builtin_amdgcn_readfirstlane((unsigned int)b64);
             const unsigned int bhi = __builtin_amdgcn_readfirstlane((unsigned int)(b64 >> 32));
-            const uint32_t dst = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem + kXcScaleOff + (t & 3) * 2048 +
-                                 (wave < 4 ? wave * 256 : 1024 + (wave - 4) * 256);
-            glds4(reinterpret_cast<const void*>(((unsigned long long)bhi << 32) | blo), (uint32_t)lane * 4u, dst);
+            const uint32_t dst = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem + kXcScaleOff +
+                                 (((t - nk1) >> 2) & 1) * 8192 + wave * 1024;
+            glds16(reinterpret_cast<const void*>(((unsigned long long)bhi << 32) | blo), (uint32_t)lane * 16u, dst);
         }
     };
     // Tiles of the V third of a QKV projection are produced un-swapped (a = X, b = W): a lane then holds 4
@@ -1195,8 +1229,10 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
         const bool more1 = t + 1 < nk, more2 = t + 2 < nk;
         // f16c: vector-memory operations that may still be in flight at the two counted waits -- the copies of Lb(t - 1)
         // resp. Lb(t) include one scale strip when the tile they prefetch (t + 1 resp. t + 2) is an e4m3 tile
-        const int sc_la = (XC && t + 1 >= nk1 && t + 1 < nk) ? 1 : 0, sc_lb = (XC && t + 2 >= nk1 && t + 2 < nk) ? 1 : 0;
-        const char* sbuf = smem + kXcScaleOff + (t & 3) * 2048;
+        // (a group of four e4m3 tiles, when the tile prefetched there opens one)
+        const int sc_la = (XC && t + 1 >= nk1 && t + 1 < nk && ((t + 1 - nk1) & 3) == 0) ? 1 : 0;
+        const int sc_lb = (XC && t + 2 >= nk1 && t + 2 < nk && ((t + 2 - nk1) & 3) == 0) ? 1 : 0;
+        const char* sbuf = smem + kXcScaleOff + (((t - nk1) >> 2) & 1) * 8192 + ((t - nk1) & 3) * 2048;
         // La
         stamp(t);                                  // 0: La start
         if (more1) {
@@ -1344,7 +1380,11 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_p(GemmParams p, int 
         const int sidx = L / per_super, widx = L % per_super;
         const int tm = (sidx / supers_n) * SM + widx / SN;
         const int tn = (sidx % supers_n) * SN + widx % SN;
-        m0 = __builtin_amdgcn_readfirstlane(tm * BM3);
+        int mm = tm * BM3;
+        if constexpr (EPI == TT_EPI_SCAN) {
+            if (p.scan_rows && mm + BM3 > p.scan_rows) mm = p.scan_rows - BM3;                    // the shard's last 256 rows
+        }
+        m0 = __builtin_amdgcn_readfirstlane(mm);
         n0 = __builtin_amdgcn_readfirstlane(tn * BN3);
         return tm < mt_n && tn < nt_n;
     };
@@ -1789,9 +1829,9 @@ template <int EPI>
 int launch_xc(const GemmParams& p, hipStream_t st) {
     if constexpr (kF16 && (EPI == TT_EPI_BIAS || EPI == TT_EPI_GELU || EPI == TT_EPI_VT || EPI == TT_EPI_RESIDUAL)) {
         const int ldw = p.ldw ? p.ldw : 2 * p.K;
-        if (p.M % v3::BM3 || p.N % v3::BN3 || p.K % 128 || p.K < 128 || p.lda < 2 * p.K || ldw < 2 * p.K || p.lda % 8 || ldw % 8 || !p.A ||
+        if (p.M % v3::BM3 || p.N % v3::BN3 || p.K % 256 || p.K < 256 || p.lda < 2 * p.K || ldw < 2 * p.K || p.lda % 8 || ldw % 8 || !p.A ||
             !p.W || !p.bias || !p.a_scales || !p.w_scales) {
-            tt_set_error("gemm f16c: M=%d N=%d K=%d lda=%d ldw=%d: M, N multiples of 256, K of 128, c-planes [.][>= 2K uint16] with tiled scales",
+            tt_set_error("gemm f16c: M=%d N=%d K=%d lda=%d ldw=%d: M, N, K multiples of 256, c-planes [.][>= 2K uint16] with tiled scales",
                          p.M, p.N, p.K, p.lda, ldw);
             return TT_E_UNSUPPORTED;
         }
@@ -2046,15 +2086,16 @@ int tt_scan_gemm_launch(const uint16_t* corpus, int64_t rows, int dim, const uin
     if (rows <= 0) return TT_OK;
     if constexpr (kF16) { tt_set_error("scan gemm: the corpus is bf16 (bf16 instantiation only)"); return TT_E_UNSUPPORTED; }
     else
-    if (rows % v3::BM3 || dim % 128 || dim <= 0 || rows / v3::BM3 > (1 << 24)) {
-        tt_set_error("scan gemm: rows=%lld must be a multiple of 256, dim=%d of 128", (long long)rows, dim);
+    if (rows < v3::BM3 || dim % 128 || dim <= 0 || rows / v3::BM3 > (1 << 24)) {
+        tt_set_error("scan gemm: rows=%lld must be at least 256, dim=%d a multiple of 128", (long long)rows, dim);
         return TT_E_UNSUPPORTED;
     }
     GemmParams p{};
     p.A = corpus;
     p.W = queries256;
     p.bias = thr256;
-    p.M = (int)rows;
+    p.M = (int)((rows + v3::BM3 - 1) / v3::BM3 * v3::BM3);
+    p.scan_rows = (int)rows;
     p.N = v3::BN3;
     p.K = dim;
     p.lda = dim;

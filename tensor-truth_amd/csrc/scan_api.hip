@@ -3,6 +3,8 @@
 // Pipeline of tt_scan_topk for a shard of N rows (all launches on one stream):
 //   1. sample : one max per (32-row group, query) over n0 / 32 groups spread evenly over the shard
 //               (every (N / n0)-th group: ingest order clusters topics)   (scan_kernel OUT=2)
+//               [65+ queries over a large shard: step 3 is ONE tiled MFMA contraction per 256 queries instead (gemm.hip,
+//                TT_EPI_SCAN), its last tile shifted to the shard's last 256 rows when the row count is ragged]
 //   2. select : thr[q] = k-th best group maximum                        (select_kernel)
 //   3. filter : all N rows, scores >= thr[q] go to atomic-free private lists
 //               (overflowing lanes: shared per-query list)               (scan_kernel OUT=0)
@@ -366,7 +368,10 @@ int tt_scan_topk(const void* corpus_bf16, int64_t n_rows, int dim, const void* q
             TT_CHECK_HIP(hipMemcpyAsync(qpad256, queries_bf16, (size_t)n_queries * dim * sizeof(uint16_t), hipMemcpyDeviceToDevice, st));
             q256 = qpad256;
         }
-        const int64_t rows256 = n_rows / 256 * 256;
+        // (rows not a multiple of 256: the contraction's last tile is the shard's last 256 rows -- no separate pass over the tail;
+        //  TT_SCAN_GEMM_TAIL=1: rounds 2-3's form, the < 256 tail rows through the streaming kernel, the A/B switch)
+        static const bool tail_pass = [] { const char* e = getenv("TT_SCAN_GEMM_TAIL"); return e && e[0] == '1'; }();
+        const int64_t rows256 = tail_pass ? n_rows / 256 * 256 : n_rows;
         for (int b = 0; b < pl.q256 / 256; ++b) {
             rc = tt_scan_gemm_launch((const uint16_t*)corpus_bf16, rows256, dim, q256 + (size_t)b * 256 * dim, thr + b * 256,
                                      cnt + b * 256, cs + (size_t)b * 256 * pl.cap, ci + (size_t)b * 256 * pl.cap, pl.cap, idx_base, st);

@@ -77,8 +77,14 @@ def build_index(documents: Sequence, embed_model, persist_dir: Optional[str] = N
                 chunk_overlap: Optional[int] = None, semantic_buffer_size: int = 1,
                 semantic_breakpoint_threshold: float = 95, embedding_model: Optional[str] = None, node_parser=None,
                 progress_callback: Optional[Callable[[str, int, int], None]] = None,
-                window_docs: int = 8192) -> HipVectorIndex:
+                window_docs: int = 8192, workers: Optional[int] = None) -> HipVectorIndex:
     """-> the module's HipVectorIndex (persisted under ``persist_dir`` when given).
+
+    ``workers`` (default: ``TT_INGEST_WORKERS``, else up to 8 of the host's cores; 0 = everything in this process): sentence
+    splitting, hierarchical parsing and tokenization run in that many worker PROCESSES (``ingest_workers.py``) while this one
+    only feeds the GPU -- round 3's single-process pipeline kept the GPU 0.75 busy from strings, its idle gaps the host-only
+    stretches of one Python thread.  Same nodes, same rows, same order (node ids are uuid4 either way).  Used for the
+    ``hierarchical`` and ``semantic_hierarchical`` strategies with the package's own parser and tokenizers.
 
     Documents are processed in windows of ``window_docs`` (parse -> docstore -> embed the leaves -> append the rows), so a
     100k-document build (BASELINE config 5) holds one window's sentence groups and strings at a time, not all of them.
@@ -95,8 +101,11 @@ def build_index(documents: Sequence, embed_model, persist_dir: Optional[str] = N
         progress_callback("parsing", 0, n_docs)
     index = HipVectorIndex(embed_model.config.hidden if hasattr(embed_model, "config") else len(embed_model.get_text_embedding("x")),
                            embed_model=embed_model)
+    if _build_with_workers(index, documents, embed_model, chunking_strategy, chunk_sizes, chunk_overlap, semantic_buffer_size,
+                           semantic_breakpoint_threshold, node_parser, workers):
+        n_docs = 0        # (done: skip the in-process loop below)
     step = max(n_docs, 1) if window_docs <= 0 else window_docs
-    for lo in range(0, max(n_docs, 1), step):
+    for lo in range(0, n_docs, step):
         # the leaf forward passes of one piece are only ENQUEUED by index.add (nothing below waits for the GPU except the
         # staging ring's back-pressure), so the GPU embeds piece i while this thread splits piece i + 1
         for nodes in iter_parsed(documents[lo:lo + step], embed_model, chunking_strategy, chunk_sizes, chunk_overlap,
@@ -113,6 +122,56 @@ def build_index(documents: Sequence, embed_model, persist_dir: Optional[str] = N
                       chunk_sizes=sizes, chunking_strategy=chunking_strategy,
                       chunk_overlap=DEFAULT_CHUNK_OVERLAP if chunk_overlap is None else chunk_overlap)
     return index
+
+
+def _build_with_workers(index, documents, embed_model, chunking_strategy, chunk_sizes, chunk_overlap, buffer_size, percentile,
+                        node_parser, workers) -> bool:
+    """The worker-process form of the build loop (``ingest_workers.IngestWorkers.run``).  -> False when it does not apply."""
+    import torch
+
+    from . import ingest_workers as iw
+    from .semantic import adjacent_distances
+
+    W = iw.default_workers() if workers is None else int(workers)
+    min_docs = int(os.environ.get("TT_INGEST_WORKERS_MIN_DOCS", "64"))
+    if (W <= 0 or node_parser is not None or chunking_strategy not in ("hierarchical", "semantic_hierarchical")
+            or not hasattr(embed_model, "embed_token_batches") or len(documents) < min_docs):
+        return False
+    try:
+        tk_spec = iw.tokenizer_spec(embed_model._tokenizer)
+    except TypeError:
+        return False
+    spec = {"tokenizer": tk_spec, "max_length": embed_model.max_length, "text_instruction": getattr(embed_model, "text_instruction", "") or "",
+            "buffer_size": buffer_size, "percentile": percentile,
+            "chunk_sizes": list(chunk_sizes) if chunk_sizes is not None else list(DEFAULT_CHUNK_SIZES),
+            "chunk_overlap": DEFAULT_CHUNK_OVERLAP if chunk_overlap is None else chunk_overlap}
+    pool = iw.get_workers(spec, W)
+
+    def distances(emb):
+        # the copy back is enqueued behind this chunk's own forward passes, with an event of its own: waiting for it waits for
+        # this chunk only, not for what was enqueued after it
+        d = adjacent_distances(emb)
+        host = torch.empty(d.shape, dtype=d.dtype, pin_memory=True)
+        host.copy_(d, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(d.device))
+
+        def ready(block: bool = False) -> bool:
+            if block:
+                ev.synchronize()
+                return True
+            return ev.query()
+
+        return host.numpy(), ready
+
+    def on_nodes(nodes, leaf_pos, emb):
+        index.add_to_docstore(nodes)                       # storage_context.docstore.add_documents(nodes), builder.py:430
+        if emb is not None:
+            index.add([nodes[i] for i in leaf_pos], embeddings=emb)      # VectorStoreIndex(leaf_nodes, ...), builder.py:437-442
+
+    pool.run(documents, chunking_strategy == "semantic_hierarchical", embed_model.embed_token_batches, distances, on_nodes,
+             chunk_docs=int(os.environ.get("TT_INGEST_CHUNK_DOCS", "48")))
+    return True
 
 
 def build_index_sharded(documents: Sequence, embed_model, group=None, queries: str = "replicated", **build_kw):

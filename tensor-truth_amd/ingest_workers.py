@@ -1,0 +1,400 @@
+"""Host side of the ingest in WORKER PROCESSES: sentence splitting, hierarchical parsing and tokenization leave the
+process that feeds the GPU.
+
+The composed ingest (``index_builder.build_index``: the reference's ``build_module``, ``indexing/builder.py:376-453``)
+is host-bound from strings: a kernel trace of round 3's single-process pipeline shows the GPU 0.75 busy, its 45 idle gaps
+the stretches where ONE Python thread splits sentences, walks the chunk hierarchy and tokenizes (a second parsing thread
+lost to the GIL, ``profiles/r03_ingest_busy.log``).  Here that work runs in ``W`` spawned processes; the feeding process
+only moves arrays:
+
+    worker, phase "split"   texts of a document chunk -> sentences, sentence groups, their token ids            (flat int32 + lengths)
+    feeder                  group tokens -> embeddings -> adjacent distances (GPU, enqueued) -> host, one event per chunk
+    worker, phase "cut"     distances -> per-document percentile cuts -> semantic chunks -> hierarchical nodes,
+                            leaf token ids                                                                      (nodes + flat int32)
+    feeder                  docstore, leaf tokens -> embeddings (GPU, enqueued) -> index rows
+
+A chunk's two phases run on the SAME worker (its sentences stay there: only distances travel back), chunks are dealt
+round-robin and consumed in document order, so the index is the one the in-process path builds (node ids apart: uuid4
+either way) -- embeddings do not depend on the batch they travel in.  A worker is a FRESH interpreter (``python -c``, pickled
+messages over its stdin / stdout): it imports numpy and this package's host modules only -- no torch, never the GPU -- it does
+not re-import the parent's main module (as ``multiprocessing``'s spawn would), and it may be started after the parent has
+touched the GPU (nothing is forked).  Workers are kept for the life of the process and reused by later builds.
+"""
+from __future__ import annotations
+
+import atexit
+import os
+import pickle
+import select
+import struct
+import subprocess
+import sys
+from collections import deque
+from typing import Callable, Dict, List, Optional, Sequence
+
+import numpy as np
+
+
+class _PipeConn:
+    """Length-prefixed pickles over a pair of raw file descriptors: send / recv / poll."""
+
+    def __init__(self, rfd: int, wfd: int, duplex_safe: bool = False):
+        self.rfd, self.wfd, self.buf = rfd, wfd, bytearray()
+        # duplex_safe (the FEEDER's end): a send never blocks on a full pipe without draining the other direction -- the worker
+        # at the far end may itself be blocked writing a large answer (800 KB of token ids against a 64 KB pipe) that nobody reads
+        # while the feeder sits in write(): both would wait forever.  The write end is non-blocking and the send loop reads
+        # whatever arrives in between.
+        self.duplex_safe = duplex_safe
+        if duplex_safe:
+            os.set_blocking(wfd, False)
+
+    def send(self, obj) -> None:
+        data = pickle.dumps(obj, protocol=pickle.HIGHEST_PROTOCOL)
+        view = memoryview(struct.pack("<Q", len(data)) + data)
+        while len(view):
+            if not self.duplex_safe:
+                view = view[os.write(self.wfd, view):]
+                continue
+            readable, writable, _ = select.select([self.rfd], [self.wfd], [])
+            if readable:
+                chunk = os.read(self.rfd, 1 << 20)
+                if not chunk:
+                    raise EOFError("ingest worker closed its pipe")
+                self.buf += chunk
+            if writable:
+                try:
+                    view = view[os.write(self.wfd, view[: 1 << 16]):]
+                except BlockingIOError:
+                    pass
+
+    def _fill(self, block: bool) -> bool:
+        """Read what is there (block: wait for at least one byte).  -> False at end of file."""
+        if not block and not select.select([self.rfd], [], [], 0)[0]:
+            return True
+        chunk = os.read(self.rfd, 1 << 20)
+        if not chunk:
+            return False
+        self.buf += chunk
+        return True
+
+    def _complete(self) -> bool:
+        return len(self.buf) >= 8 and len(self.buf) >= 8 + struct.unpack_from("<Q", self.buf)[0]
+
+    def poll(self) -> bool:
+        while not self._complete():
+            before = len(self.buf)
+            if not self._fill(False) or len(self.buf) == before:
+                break
+        return self._complete()
+
+    def recv(self):
+        while not self._complete():
+            if not self._fill(True):
+                raise EOFError("ingest worker closed its pipe")
+        n = struct.unpack_from("<Q", self.buf)[0]
+        obj = pickle.loads(bytes(self.buf[8:8 + n]))
+        del self.buf[:8 + n]
+        return obj
+
+
+def tokenizer_spec(tk):
+    """What a worker needs to rebuild the feeder's tokenizer."""
+    from .tokenization import HFTokenizer, HashTokenizer
+
+    if isinstance(tk, HashTokenizer):
+        return ("hash", tk.arch, tk.vocab_size)
+    if isinstance(tk, HFTokenizer):
+        return ("hf", tk._json, tk.arch)
+    raise TypeError(f"ingest workers cannot rebuild a {type(tk).__name__}: pass workers=0 to stay in process")
+
+
+def _tokenizer_from_spec(spec):
+    from .tokenization import HFTokenizer, HashTokenizer
+
+    if spec[0] == "hash":
+        return HashTokenizer(spec[1], spec[2])
+    return HFTokenizer(None, spec[2], json_str=spec[1])
+
+
+def _flatten(seqs: Sequence[Sequence[int]]):
+    lens = np.fromiter((len(s) for s in seqs), dtype=np.int32, count=len(seqs))
+    flat = np.empty(int(lens.sum()), dtype=np.int32)
+    pos = 0
+    for s, n in zip(seqs, lens):
+        flat[pos:pos + n] = s
+        pos += n
+    return flat, lens
+
+
+def unflatten(flat: np.ndarray, lens: np.ndarray) -> List[np.ndarray]:
+    ends = np.cumsum(lens)
+    return [flat[e - n:e] for e, n in zip(ends, lens)]
+
+
+def _doc_record(doc):
+    return (doc.get_content() if hasattr(doc, "get_content") else str(doc), dict(getattr(doc, "metadata", {}) or {}),
+            list(getattr(doc, "excluded_embed_metadata_keys", None) or []), list(getattr(doc, "excluded_llm_metadata_keys", None) or []))
+
+
+class _Host:
+    """The host-only steps, shared by the workers and by the in-process reference run of the tests."""
+
+    def __init__(self, spec: Dict):
+        from .node_parser import HierarchicalNodeParser
+
+        self.tk = _tokenizer_from_spec(spec["tokenizer"])
+        self.max_length = spec["max_length"]
+        self.prefix = spec["text_instruction"] or ""
+        self.buffer_size = spec["buffer_size"]
+        self.percentile = spec["percentile"]
+        self.hier = HierarchicalNodeParser.from_defaults(chunk_sizes=spec["chunk_sizes"], chunk_overlap=spec["chunk_overlap"])
+        self.state: Dict[int, tuple] = {}
+
+    def _tokens(self, texts: List[str]):
+        full = [self.prefix + t for t in texts] if self.prefix else texts
+        seqs = self.tk.encode_batch(full, self.max_length) if hasattr(self.tk, "encode_batch") else [self.tk.encode(t, self.max_length) for t in full]
+        return _flatten(seqs)
+
+    def split(self, chunk_id: int, docs: List[tuple]):
+        """-> (spans [(first group, sentences) or (-1, 0) per document], flat group tokens, lengths)"""
+        from .semantic_host import split_sentences
+
+        b = self.buffer_size
+        sents = [split_sentences(d[0]) for d in docs]
+        spans, groups = [], []
+        for ss in sents:
+            if len(ss) > 1:
+                spans.append((len(groups), len(ss)))
+                groups.extend("".join(ss[max(0, i - b): i + b + 1]) for i in range(len(ss)))
+            else:
+                spans.append((-1, 0))
+        self.state[chunk_id] = (docs, sents, spans)
+        flat, lens = self._tokens(groups) if groups else (np.zeros(0, np.int32), np.zeros(0, np.int32))
+        return np.asarray(spans, dtype=np.int64).reshape(-1, 2), flat, lens
+
+    def cut(self, chunk_id: int, dist: np.ndarray):
+        """distances of the chunk's concatenated groups -> (all hierarchy nodes, leaf positions, flat leaf tokens, lengths)"""
+        from .schema import TextNode
+        from .semantic_host import breakpoints_from_distances, join_chunks
+
+        docs, sents, spans = self.state.pop(chunk_id)
+        sem_nodes = []
+        for (text, meta, ex_embed, ex_llm), ss, (lo, n) in zip(docs, sents, spans):
+            if lo < 0:
+                chunks = [text] if text.strip() else []
+            else:
+                chunks = join_chunks(ss, breakpoints_from_distances(dist[lo:lo + n - 1], self.percentile))
+            for c in chunks:
+                nd = TextNode(text=c, metadata=dict(meta))
+                for key, val in (("excluded_embed_metadata_keys", ex_embed), ("excluded_llm_metadata_keys", ex_llm)):
+                    if val:
+                        try:
+                            setattr(nd, key, list(val))
+                        except Exception:  # noqa: BLE001
+                            pass
+                sem_nodes.append(nd)
+        return self._hierarchy(sem_nodes)
+
+    def parse(self, docs: List[tuple]):
+        """hierarchical strategy: documents -> nodes (no semantic pass)"""
+        from .schema import TextNode
+
+        srcs = []
+        for text, meta, ex_embed, ex_llm in docs:
+            nd = TextNode(text=text, metadata=dict(meta))
+            for key, val in (("excluded_embed_metadata_keys", ex_embed), ("excluded_llm_metadata_keys", ex_llm)):
+                if val:
+                    try:
+                        setattr(nd, key, list(val))
+                    except Exception:  # noqa: BLE001
+                        pass
+            srcs.append(nd)
+        return self._hierarchy(srcs)
+
+    def _hierarchy(self, sources):
+        from .node_parser import get_leaf_nodes
+        from .schema import MetadataMode
+
+        nodes = self.hier.get_nodes_from_documents(sources)
+        leaf_pos = np.asarray([i for i, n in enumerate(nodes) if not getattr(n, "child_ids", None)], dtype=np.int64)
+        texts = [nodes[i].get_content(metadata_mode=MetadataMode.EMBED) for i in leaf_pos]
+        flat, lens = self._tokens(texts) if texts else (np.zeros(0, np.int32), np.zeros(0, np.int32))
+        return nodes, leaf_pos, flat, lens
+
+
+def _stdio_worker():
+    """Entry point of a worker process: messages on stdin, answers on stdout (anything the host code prints goes to stderr)."""
+    conn = _PipeConn(os.dup(0), os.dup(1))
+    os.dup2(2, 1)                       # stray prints must not corrupt the message stream
+    _worker_main(conn, conn.recv())
+
+
+def _worker_main(conn, spec):
+    host = _Host(spec)
+    conn.send(("ready",))
+    while True:
+        msg = conn.recv()
+        op = msg[0]
+        if op == "stop":
+            break
+        try:
+            if op == "split":
+                conn.send(("split", msg[1]) + tuple(host.split(msg[1], msg[2])))
+            elif op == "cut":
+                conn.send(("cut", msg[1]) + tuple(host.cut(msg[1], msg[2])))
+            elif op == "parse":
+                conn.send(("cut", msg[1]) + tuple(host.parse(msg[2])))
+        except Exception as exc:  # noqa: BLE001 - reported to the feeder, which raises
+            import traceback
+
+            conn.send(("error", msg[1], f"{exc!r}\n{traceback.format_exc()}"))
+
+
+def default_workers() -> int:
+    env = os.environ.get("TT_INGEST_WORKERS")
+    if env is not None and env != "":
+        return max(0, int(env))
+    try:
+        cpus = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cpus = os.cpu_count() or 1
+    return max(0, min(8, cpus - 2))
+
+
+_POOLS: Dict[bytes, "IngestWorkers"] = {}
+
+
+def get_workers(spec: Dict, workers: int) -> "IngestWorkers":
+    """The process's worker pool for this host configuration (started on first use, reused by later builds, closed at exit)."""
+    key = pickle.dumps((sorted(spec.items(), key=lambda kv: kv[0]), workers))
+    pool = _POOLS.get(key)
+    if pool is None or not pool.alive():
+        pool = _POOLS[key] = IngestWorkers(spec, workers)
+    return pool
+
+
+@atexit.register
+def _close_pools() -> None:
+    for pool in list(_POOLS.values()):
+        pool.close()
+    _POOLS.clear()
+
+
+class IngestWorkers:
+    """W host workers behind pipes.  ``run`` drives one build's chunks through them in document order."""
+
+    def __init__(self, spec: Dict, workers: int):
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))          # where the tensor_truth_amd import shim lives
+        code = f"import sys; sys.path.insert(0, {root!r}); from tensor_truth_amd.ingest_workers import _stdio_worker; _stdio_worker()"
+        self.conns, self.procs = [], []
+        for _ in range(workers):
+            p = subprocess.Popen([sys.executable, "-c", code], stdin=subprocess.PIPE, stdout=subprocess.PIPE, bufsize=0)
+            self.procs.append(p)
+            self.conns.append(_PipeConn(p.stdout.fileno(), p.stdin.fileno(), duplex_safe=True))
+        self.buffers: List[Dict] = [dict() for _ in range(workers)]
+        for c in self.conns:
+            c.send(spec)
+        for c in self.conns:                      # (interpreter start + imports: a few tenths of a second, paid once per process)
+            msg = c.recv()
+            if msg[0] != "ready":
+                raise RuntimeError(f"ingest worker failed to start: {msg}")
+
+    def alive(self) -> bool:
+        return bool(self.procs) and all(p.poll() is None for p in self.procs)
+
+    def close(self) -> None:
+        for c, p in zip(self.conns, self.procs):
+            try:
+                c.send(("stop",))
+                p.stdin.close()
+            except Exception:  # noqa: BLE001
+                pass
+        for p in self.procs:
+            try:
+                p.wait(timeout=5)
+            except Exception:  # noqa: BLE001
+                p.kill()
+        self.conns, self.procs = [], []
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _store(self, w: int, msg) -> None:
+        if msg[0] == "error":
+            raise RuntimeError(f"ingest worker {w} failed on chunk {msg[1]}: {msg[2]}")
+        self.buffers[w][(msg[0], msg[1])] = msg[2:]
+
+    def poll(self, w: int, key) -> Optional[tuple]:
+        while key not in self.buffers[w] and self.conns[w].poll():
+            self._store(w, self.conns[w].recv())
+        return self.buffers[w].pop(key, None)
+
+    def wait(self, w: int, key) -> tuple:
+        while key not in self.buffers[w]:
+            self._store(w, self.conns[w].recv())
+        return self.buffers[w].pop(key)
+
+    def run(self, documents: Sequence, semantic: bool, embed_tokens: Callable, distances: Callable, on_nodes: Callable,
+            chunk_docs: int = 48, inflight_per_worker: int = 3) -> None:
+        """``embed_tokens(list of int32 arrays) -> embeddings`` (enqueues GPU work), ``distances(embeddings) -> (host array,
+        ready())`` (adjacent distances copied back asynchronously; ``ready(block)`` tells / waits), ``on_nodes(nodes,
+        leaf positions, leaf embeddings)`` (docstore + index rows), called in document order."""
+        W = len(self.conns)
+        docs = [_doc_record(d) for d in documents]
+        # small first chunks put the GPU to work early; then chunk_docs
+        bounds, size = [0], max(4, chunk_docs // 8)
+        while bounds[-1] < len(docs):
+            bounds.append(min(len(docs), bounds[-1] + size))
+            size = min(chunk_docs, size * 2)
+        chunks = list(zip(bounds[:-1], bounds[1:]))
+        n = len(chunks)
+        sent = n_split = n_cut_sent = done = 0
+        dist_q: deque = deque()                       # (chunk, host array, ready)
+        max_ahead = W * inflight_per_worker
+        while done < n:
+            progressed = False
+            while sent < n and sent - done < max_ahead:                                   # a) hand out chunks
+                lo, hi = chunks[sent]
+                self.conns[sent % W].send(("split" if semantic else "parse", sent, docs[lo:hi]))
+                sent += 1
+                progressed = True
+            if semantic:
+                while n_split < sent:                                                     # b) groups -> GPU
+                    r = self.poll(n_split % W, ("split", n_split))
+                    if r is None:
+                        break
+                    spans, flat, lens = r
+                    if len(lens):
+                        host, ready = distances(embed_tokens(unflatten(flat, lens)))
+                    else:
+                        host, ready = np.zeros(0, np.float32), (lambda block=False: True)
+                    dist_q.append((n_split, host, ready))
+                    n_split += 1
+                    progressed = True
+                while dist_q and dist_q[0][2](False):                                     # c) distances -> worker
+                    c, host, _ = dist_q.popleft()
+                    self.conns[c % W].send(("cut", c, np.array(host, copy=True)))
+                    n_cut_sent += 1
+                    progressed = True
+            else:
+                n_split = n_cut_sent = sent
+            while done < n_cut_sent:                                                      # d) nodes + leaf tokens -> GPU, index
+                r = self.poll(done % W, ("cut", done))
+                if r is None:
+                    break
+                nodes, leaf_pos, flat, lens = r
+                on_nodes(nodes, leaf_pos, embed_tokens(unflatten(flat, lens)) if len(lens) else None)
+                done += 1
+                progressed = True
+            if progressed:
+                continue
+            # nothing could move: wait for the most urgent thing
+            if done < n_cut_sent:
+                self.buffers[done % W][("cut", done)] = self.wait(done % W, ("cut", done))
+            elif dist_q:
+                dist_q[0][2](True)
+            elif n_split < sent:
+                self.buffers[n_split % W][("split", n_split)] = self.wait(n_split % W, ("split", n_split))

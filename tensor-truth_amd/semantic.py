@@ -20,12 +20,7 @@ import torch
 
 from . import _lib
 from .schema import TextNode
-
-_SENT = re.compile(r"[^.!?\n]+[.!?]*[\n]*|[\n]+")
-
-
-def split_sentences(text: str) -> List[str]:
-    return [s for s in (m.group(0) for m in _SENT.finditer(text)) if s.strip()]
+from .semantic_host import breakpoints_from_distances, join_chunks, split_sentences  # noqa: F401  (host-only steps, torch-free)
 
 
 def adjacent_distances(emb: torch.Tensor) -> torch.Tensor:
@@ -42,14 +37,6 @@ def adjacent_distances(emb: torch.Tensor) -> torch.Tensor:
         _lib.check(rc, "tt_adjacent_cosine")
     return out
 
-
-def breakpoints_from_distances(dist: Sequence[float], percentile: float) -> List[int]:
-    """Indices i such that a cut falls after sentence i (host logic, known-answer tested)."""
-    d = np.asarray(dist, dtype=np.float64)
-    if d.size == 0:
-        return []
-    thr = np.percentile(d, percentile)
-    return [int(i) for i in np.nonzero(d > thr)[0]]
 
 
 
@@ -88,15 +75,7 @@ class SemanticSplitter:
             return self.embed_model._embed_texts(groups, getattr(self.embed_model, "text_instruction", ""))
         return torch.tensor(self.embed_model.get_text_embedding_batch(groups), device="cuda")
 
-    @staticmethod
-    def _join(sentences: List[str], cuts: Sequence[int]) -> List[str]:
-        chunks, start = [], 0
-        for c in cuts:
-            chunks.append("".join(sentences[start:c + 1]).strip())
-            start = c + 1
-        if start < len(sentences):
-            chunks.append("".join(sentences[start:]).strip())
-        return [c for c in chunks if c]
+    _join = staticmethod(join_chunks)
 
     def split_texts(self, texts: Sequence[str]) -> List[List[str]]:
         """Chunks of every text.  The sentence groups of ALL texts are embedded in one pipelined call (batches of

@@ -309,3 +309,35 @@ def test_config5_retrieval_stage_is_decidable_in_the_reference_precision(dev, bu
           f"{n_identical}/{len(queries)} queries")
     assert n_identical >= len(queries) * 17 // 20, n_identical
     mm.ModelManager.reset_instance()
+
+
+@pytest.mark.parametrize("strategy", ["semantic_hierarchical", "hierarchical"])
+def test_worker_process_ingest_builds_the_same_index(dev, built_lib, strategy):
+    """build_index with the host work in worker processes (ingest_workers.py: sentence splitting, hierarchy, tokenization off the
+    feeding process) against the single-process pipeline: the same leaf texts in the same order and the SAME BITS in the index
+    matrix -- cuts come from the same distances (embeddings do not depend on the batch they travel in), leaves from the same
+    token ids."""
+    from tensor_truth_amd import model_manager as mm
+    from tensor_truth_amd.encoder import EncoderConfig
+    from tensor_truth_amd.index_builder import build_index
+
+    cfg = EncoderConfig(**SMALL)
+    mm.ModelManager.reset_instance()
+    mgr = mm.ModelManager.get_instance()
+    mgr.model_kwargs_overrides["test/emb"] = {"encoder_config": cfg, "synthetic_seed": 5}
+    emb = mgr.get_embedder("test/emb", "cuda")
+    docs = _docs(n_docs=150, seed=4)
+    kw = dict(chunking_strategy=strategy, chunk_sizes=[64, 32, 16], chunk_overlap=4)
+    a = build_index(docs, emb, workers=0, **kw)
+    b = build_index(docs, emb, workers=3, **kw)
+    torch.cuda.synchronize()
+    ta = [a.docstore[i].text for i in a.leaf_ids]
+    tb = [b.docstore[i].text for i in b.leaf_ids]
+    assert a.n == b.n > 400 and ta == tb
+    assert torch.equal(a._mat[: a.n], b._mat[: b.n])
+    # every hierarchy level reached the docstore, with the same parent / child structure
+    assert len(a.docstore) == len(b.docstore)
+    pa = sorted((n.text, len(n.child_ids), n.parent_id is None) for n in a.docstore.values())
+    pb = sorted((n.text, len(n.child_ids), n.parent_id is None) for n in b.docstore.values())
+    assert pa == pb
+    mm.ModelManager.reset_instance()

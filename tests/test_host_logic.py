@@ -1119,3 +1119,61 @@ def test_ingest_ramps_cover_every_input_once_in_order():
     out = [n for nodes in iter_parsed(docs, None, "hierarchical", node_parser=h, sub_batch=512) for n in nodes]
     assert [d.id_ for d in out] == [d.id_ for d in docs]
     assert h.seen[:3] == [128, 256, 512] and sum(h.seen) == 1000 and max(h.seen) == 512
+
+
+def test_ingest_worker_processes_build_the_same_nodes_in_order(tmp_path):
+    """ingest_workers.IngestWorkers (the host side of build_index in worker processes): document chunks go through the two
+    phases on their own worker and come back in document order -- same node texts, same hierarchy links, same leaf token ids
+    as the in-process host steps (the GPU steps are replaced by deterministic numpy stand-ins: no GPU here)."""
+    import numpy as np
+
+    from tensor_truth_amd import ingest_workers as iw
+    from tensor_truth_amd.schema import TextNode
+
+    spec = {"tokenizer": ("hash", "xlmr", 250002), "max_length": 64, "text_instruction": "passage: ", "buffer_size": 1, "percentile": 90,
+            "chunk_sizes": [128, 32, 16], "chunk_overlap": 4}
+    rng = np.random.default_rng(3)
+    docs = []
+    for i in range(70):
+        n_sent = 1 if i % 17 == 0 else int(rng.integers(20, 50))          # single-sentence documents take the no-split branch
+        text = " ".join(" ".join(f"w{rng.integers(0, 400)}" for _ in range(rng.integers(6, 18))) + "." for _ in range(n_sent))
+        d = TextNode(text="" if i == 33 else text, metadata={"title": f"doc {i}", "secret": "x"})
+        d.excluded_embed_metadata_keys = ["secret"]
+        docs.append(d)
+
+    def embed_tokens(seqs):
+        return np.stack([np.array([np.sum(s) % 97 + 1, len(s), (int(s[0]) * 7 + int(s[-1])) % 31 + 1, np.sum(s[::2]) % 13 + 1], dtype=np.float64) for s in seqs])
+
+    def distances(e):
+        e = e / np.linalg.norm(e, axis=1, keepdims=True)
+        return (1 - (e[:-1] * e[1:]).sum(1)).astype(np.float32), (lambda block=False: True)
+
+    for semantic in (True, False):
+        got = []
+        pool = iw.get_workers(spec, 3)
+        pool.run(docs, semantic, embed_tokens, distances, lambda nodes, pos, emb: got.append((nodes, pos, emb)), chunk_docs=16)
+        host = iw._Host(spec)
+        recs = [iw._doc_record(d) for d in docs]
+        if semantic:
+            _, flat, lens = host.split(0, recs)
+            nodes, leaf_pos, lf, ll = host.cut(0, distances(embed_tokens(iw.unflatten(flat, lens)))[0])
+        else:
+            nodes, leaf_pos, lf, ll = host.parse(recs)
+        mine = [n for g in got for n in g[0]]
+        assert [n.text for n in mine] == [n.text for n in nodes] and len(mine) > 300
+        assert [n.metadata for n in mine] == [n.metadata for n in nodes]
+        # links: same shape (ids differ: uuid4), expressed as positions
+        def links(ns):
+            pos = {n.id_: i for i, n in enumerate(ns)}
+            return [(pos.get(n.parent_id), [pos[c] for c in n.child_ids], pos.get(n.prev_id), pos.get(n.next_id)) for n in ns]
+        assert links(mine) == links(nodes)
+        # leaf embeddings arrive with their chunk, computed from the same token ids (EMBED content: "secret" excluded, prefix added)
+        want = embed_tokens(iw.unflatten(lf, ll))
+        assert np.array_equal(np.concatenate([g[2] for g in got if g[2] is not None]), want)
+        off = 0
+        for g_nodes, g_pos, _ in got:
+            assert all(not g_nodes[i].child_ids for i in g_pos)
+            off += len(g_nodes)
+    # a worker that cannot even start (an invalid hierarchy) is an error of the caller's, not a hang
+    with pytest.raises((EOFError, RuntimeError)):
+        iw.IngestWorkers({**spec, "chunk_sizes": [16, 32]}, 1)

@@ -21,6 +21,7 @@ SHAPE = dict(arch="xlmr", vocab_size=8192, hidden=1024, layers=24, heads=16, ffn
              pad_id=1, ln_eps=1e-5, num_labels=1)
 WEIGHT_SEED = 17
 GOLDEN_NAME = "rank_oracle_24L_4x50x292.npz"   # tests/golden/make_rank_golden.py
+STRESS_GOLDEN_NAME = "rank_oracle_stress_24L_4x50x292.npz"   # ... --stress: trained-model statistics (tests/stress_weights.py)
 BF16_BOUND = 2e-2      # stated absolute bound of the bf16 mode on a sigmoid score after 24 layers
 FP16_BOUND = 3e-3      # ... of the fp16 mode (same rate, three more mantissa bits per rounding point; measured 2.4e-3)
 FP8_BOUND = 0.2        # stated bound of the fp8 throughput mode; its QUALITY gate is rank agreement, below

@@ -4,7 +4,7 @@
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out; export TMPDIR=/tmp
 rm -rf gpurun_out/ingest_trace
-timeout 600 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/ingest_trace -- python3 tools/probes/ingest_profile.py ${DOCS:-2048} > gpurun_out/ingest_busy_run.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/ingest_trace -- python3 tools/probes/ingest_profile.py ${DOCS:-2048} > gpurun_out/ingest_busy_run.log 2>&1
 grep -i "docs/s\|ingest\|leaves" gpurun_out/ingest_busy_run.log | head -5 | cut -c1-240
 python3 - <<'PY'
 import csv, glob

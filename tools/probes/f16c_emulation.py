@@ -105,6 +105,14 @@ def forward(ids, mask, W, cfg, variant, wcache):
         lin = lambda x, wn, bn: lin_f16c(x, wsplit(wn), f(bn), variant.split("+")[0])  # noqa: E731
     att16 = variant not in ("fp32", "bf16x3") and "+att32" not in variant
     ra = f16 if att16 else (lambda t: t)
+    # "+respl": the residual branch reads hi + lo8 of the LayerNorm output's c-planes instead of an fp32 copy (saves 8 of the
+    # ~40 bytes per element and layer the row kernels and residual epilogues move): what does it cost?
+    if "+respl" in variant:
+        def rs(t):
+            s = Split(t)
+            return s.hi + s.lo8
+    else:
+        rs = lambda t: t  # noqa: E731
 
     ids = ids.to(torch.int64)
     B, L = ids.shape
@@ -114,6 +122,7 @@ def forward(ids, mask, W, cfg, variant, wcache):
         f("embeddings.token_type_embeddings.weight")[torch.zeros_like(ids)]
     x = oe.layer_norm(x, f("embeddings.LayerNorm.weight"), f("embeddings.LayerNorm.bias"), cfg.ln_eps)
     neg = torch.zeros(B, 1, 1, L, dtype=torch.float32)
+    xr = rs(x)
     neg.masked_fill_(mask.to(torch.bool).logical_not().view(B, 1, 1, L), float("-inf"))
     scale = 1.0 / math.sqrt(dh)
     for i in range(cfg.layers):
@@ -131,10 +140,12 @@ def forward(ids, mask, W, cfg, variant, wcache):
         ctx = (ra(e) @ v) / denom
         ctx = ctx.transpose(1, 2).reshape(B, L, H)
         a = lin(ctx, p + "attention.output.dense.weight", p + "attention.output.dense.bias")
-        x = oe.layer_norm(a + x, f(p + "attention.output.LayerNorm.weight"), f(p + "attention.output.LayerNorm.bias"), cfg.ln_eps)
+        x = oe.layer_norm(a + xr, f(p + "attention.output.LayerNorm.weight"), f(p + "attention.output.LayerNorm.bias"), cfg.ln_eps)
+        xr = rs(x)
         h = oe.gelu_erf(lin(x, p + "intermediate.dense.weight", p + "intermediate.dense.bias"))
         o = lin(h, p + "output.dense.weight", p + "output.dense.bias")
-        x = oe.layer_norm(o + x, f(p + "output.LayerNorm.weight"), f(p + "output.LayerNorm.bias"), cfg.ln_eps)
+        x = oe.layer_norm(o + xr, f(p + "output.LayerNorm.weight"), f(p + "output.LayerNorm.bias"), cfg.ln_eps)
+        xr = rs(x)
     h = x[:, 0, :]
     t = torch.tanh(h @ f("classifier.dense.weight").T + f("classifier.dense.bias"))
     return torch.sigmoid((t @ f("classifier.out_proj.weight").T + f("classifier.out_proj.bias"))[:, 0])

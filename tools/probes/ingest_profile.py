@@ -34,7 +34,7 @@ def main():
                 sents.append(" ".join(w[band + int(j)] for j in rng.integers(0, 1000, size=k)) + ".")
         docs.append(TextNode(text=" ".join(sents), metadata={"title": f"doc {d}"}))
     mgr = mm.ModelManager.get_instance()
-    mgr.model_kwargs_overrides["BAAI/bge-m3"] = {"encoder_config": BGE_M3, "synthetic_seed": 1}
+    mgr.model_kwargs_overrides["BAAI/bge-m3"] = {"encoder_config": BGE_M3, "synthetic_seed": 1, "torch_dtype": "bfloat16"}
     emb = mgr.get_embedder("BAAI/bge-m3", "cuda")
     build_index(docs[:64], emb, chunking_strategy="semantic_hierarchical", chunk_sizes=[512, 128, 64], chunk_overlap=8)   # warm-up
     if os.environ.get("SWITCH_INTERVAL"):
@@ -47,7 +47,10 @@ def main():
                             window_docs=win)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        print(f"{n_docs} docs -> {index.n} leaves in {dt:.2f} s = {n_docs / dt:.1f} docs/s (unprofiled, window_docs={win})")
+        from tensor_truth_amd.ingest_workers import default_workers
+
+        print(f"{n_docs} docs -> {index.n} leaves in {dt:.2f} s = {n_docs / dt:.1f} docs/s (unprofiled, window_docs={win}, "
+              f"host workers {default_workers()})")
     if os.environ.get("NO_PROFILE") == "1":
         return
     pr = cProfile.Profile()
