@@ -104,8 +104,21 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attention_kernel(AttnParams p)
     const int ql = lane & 31, hh = lane >> 5;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
 
+    // Which of the tile's four 32-row blocks this wave computes.  A sequence's LAST tile usually has fewer than four live blocks
+    // (292 tokens: 36 rows = 2 of 4), and in wave order they always land on the same SIMDs (wave w of every workgroup runs on
+    // SIMD w): SIMDs 0-1 carry every tail's work, SIMDs 2-3 idle through it.  TT_ATT_ROTATE=1 deals the live blocks to different
+    // waves per (pair x live blocks); a row's arithmetic does not depend on the wave that runs it.  MEASURED NEUTRAL (1.291 vs
+    // 1.290 ms at 1600 x 292 tokens, three rounds; 160 / 200 / 420 tokens within 2 %: profiles/r04_attention_tail_rotation_ab.log)
+    // -- the kernel is not SIMD-issue bound: a key tile costs one LDS-DMA round trip whatever is computed in it (round 3's
+    // ablations), so what a tail costs is its workgroup's walk over the key tiles, not the lanes it keeps busy.  Off by default.
+    int wslot = wave;
+    if (p.rotate) {
+        const int left = len - qt * 32 * kWaves;
+        const int n_live = left >= 32 * kWaves ? kWaves : (left + 31) >> 5;
+        if (n_live < kWaves) wslot = (wave + ((pair * n_live) & (kWaves - 1))) & (kWaves - 1);
+    }
     // ---- Q fragments (B operand), straight from global ---------------------------------
-    const int q_row = (qt * kWaves + wave) * 32 + ql;      // row inside the sequence
+    const int q_row = (qt * kWaves + wslot) * 32 + ql;     // row inside the sequence
     const int q_row_c = q_row < len ? q_row : len - 1;     // clamp: result discarded
     const uint16_t* qp = p.qk + (size_t)(t0 + q_row_c) * p.ld_qk + p.q_col0 + head * DH + hh * 8;
     ex8 qf[KS];
@@ -190,7 +203,7 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attention_kernel(AttnParams p)
     float m_run = -__builtin_inff();
     float l_run = 0.f;
     const float sc = p.scale * 1.4426950408889634f;  // fold log2(e): softmax via exp2
-    const bool wave_active = (qt * kWaves + wave) * 32 < len;   // wave-uniform; idle waves only help staging
+    const bool wave_active = (qt * kWaves + wslot) * 32 < len;  // wave-uniform; idle waves only help staging
 
     // per-lane LDS offsets: K row perm(ql) (bits 2 and 3 of the row swapped), chunk (2s + hh) ^ swizzle(row)
     const int krow = (ql & 0x13) | ((ql & 4) << 1) | ((ql & 8) >> 1);
@@ -527,6 +540,9 @@ int tt_attention_launch(const AttnParams& p, hipStream_t st) {
     // QKV GEMM) it measured 1.8 % slower -- see DESIGN.md section 4.4.
     static const bool xcd = [] { const char* e = getenv("TT_ATT_XCD"); return e && e[0] == '1'; }();
     q.n_qt = xcd ? n_qt : -n_qt;
+    // TT_ATT_ROTATE=1: tail tiles deal their live row blocks to different waves (A/B switch, measured neutral; same bits either way)
+    static const bool rotate = [] { const char* e = getenv("TT_ATT_ROTATE"); return e && e[0] == '1'; }();
+    q.rotate = rotate ? 1 : 0;
     TtProfScope prof(TT_K_ATTENTION, st);
 #if TT_DIAG   // stamped / ablated instantiations: the diagnostic library only (tools/att_stamps, tools/gpu_att_ablate.sh)
     if (p.head_dim == 64 && p.dbg) {

@@ -87,6 +87,7 @@ struct AttnParams {
     float scale;              // 1/sqrt(head_dim)
     float lazy;               // set by the launcher: log2 slack of the running softmax reference
     int n_qt;                 // set by the launcher: query tiles per sequence (grid decode)
+    int rotate;               // set by the launcher: tail tiles deal their live 32-row blocks to different waves per (sequence, head)
     unsigned long long* dbg;  // diagnostic build only (tools/att_stamps): s_memtime stamps of one workgroup; NULL otherwise
     const uint16_t* q_rows;   // CLS variant only: the query row of sequence b at q_rows + b * ld_q_rows (+ h*dh); NULL = row seq_start[b] of qk
     int ld_q_rows;

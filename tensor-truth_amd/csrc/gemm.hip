@@ -584,7 +584,15 @@ __device__ __forceinline__ void epilogue_all(const GemmParams& p, f32x4 (&acc)[2
                 t[2] = lds_read128_async<0>(saddr[0] + kOffB[qm * 2 + pr] + 4 * kHalf);
                 t[3] = lds_read128_async<0>(saddr[1] + kOffB[qm * 2 + pr] + 4 * kHalf);
                 lds_wait(t[0], t[1], t[2], t[3]);
-                const size_t crow = (size_t)(m0 + qm * 128 + wm * 64 + pr * 32 + (lane >> 3)) * p.ldc + n0 + wn * 64 + (lane & 7) * 8;
+                size_t crow = (size_t)(m0 + qm * 128 + wm * 64 + pr * 32 + (lane >> 3)) * p.ldc + n0 + wn * 64 + (lane & 7) * 8;
+#if TT_DIAG
+                // experiment (TT_GEMM_HEAD_MAJOR=1, diagnostic library): the output head-major, C[n / 64][M][64] -- a wave's 32 rows
+                // x 128 bytes become ONE 4-KiB run instead of 32 lines 2 N bytes apart (profiles/r04_gemm_writeback_ab.log)
+                if (p.xp & 0x40000) crow = ((size_t)((n0 + wn * 64) >> 6) * p.M + (m0 + qm * 128 + wm * 64 + pr * 32 + (lane >> 3))) * 64 + (lane & 7) * 8;
+                const size_t rstride = (p.xp & 0x40000) ? 64 : (size_t)p.ldc;
+#else
+                const size_t rstride = (size_t)p.ldc;
+#endif
                 if (p.C8) {
                     // e4m3 output: quantise the bf16-rounded values with the tensor's static scale, 8 bytes per lane
                     // (64 contiguous bytes per row and instruction)
@@ -609,11 +617,11 @@ __device__ __forceinline__ void epilogue_all(const GemmParams& p, f32x4 (&acc)[2
                     uint16_t* cp = p.C + crow;
                     if (p.nt_store) {
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) __builtin_nontemporal_store(t[i], reinterpret_cast<u32x4*>(cp + (size_t)(8 * i) * p.ldc));
+                        for (int i = 0; i < 4; ++i) __builtin_nontemporal_store(t[i], reinterpret_cast<u32x4*>(cp + (size_t)(8 * i) * rstride));
                     } else {
 #pragma unroll
                         for (int i = 0; i < 4; ++i)
-                            *reinterpret_cast<uint4*>(cp + (size_t)(8 * i) * p.ldc) = uint4{t[i].x, t[i].y, t[i].z, t[i].w};
+                            *reinterpret_cast<uint4*>(cp + (size_t)(8 * i) * rstride) = uint4{t[i].x, t[i].y, t[i].z, t[i].w};
                     }
                 }
             }
@@ -1944,6 +1952,8 @@ int launch(const GemmParams& p, hipStream_t st) {
         q.sn = SN;
         static const bool a0 = TT_DIAG_ENV_INT("TT_GEMM_DEBUG_A0", 0) == 1;      // (wrong results: diagnostic library only)
         if (a0) q.xp |= 0x20000;
+        static const bool head_major = TT_DIAG_ENV_INT("TT_GEMM_HEAD_MAJOR", 0) == 1;   // (another output layout: diagnostic library only)
+        if (head_major) q.xp |= 0x40000;
         static const int stamp_block = TT_DIAG_ENV_INT("TT_GEMM_STAMP_BLOCK", 0);
         q.xp |= stamp_block << 20;
         {

@@ -27,10 +27,28 @@ import test_rank_agreement_gpu as t  # noqa: E402
 from rank_checks import weights_checksum  # noqa: E402
 
 
-def stress_forward(ids, W, ocfg, stats):
-    """oracle.encoder.encoder_forward (no padding: full-length pairs) that also records attention entropies and the largest
-    activations -- the same arithmetic, restated so the statistics can be read off."""
+def _attention_probs(x, W, ocfg, layer):
     import math
+
+    B, L, H = x.shape
+    nh, dh = ocfg.heads, ocfg.head_dim
+    p = f"encoder.layer.{layer}."
+    q = (x @ W[p + "attention.self.query.weight"].T + W[p + "attention.self.query.bias"]).view(B, L, nh, dh).transpose(1, 2)
+    k = (x @ W[p + "attention.self.key.weight"].T + W[p + "attention.self.key.bias"]).view(B, L, nh, dh).transpose(1, 2)
+    s = (q @ k.transpose(-1, -2)) / math.sqrt(dh)
+    return s, torch.softmax(s, dim=-1)
+
+
+def _entropy_bits(pr):
+    return -(pr * torch.log2(pr.clamp_min(1e-30))).sum(-1).mean(dim=(0, 2))           # per head
+
+
+def stress_forward(ids, W, ocfg, stats, calibrate=None):
+    """oracle.encoder.encoder_forward (no padding: full-length pairs) that also records attention entropies and the largest
+    activations -- the same arithmetic, restated so the statistics can be read off.  ``calibrate`` (a list to fill): before a
+    layer's attention, find the factor on its even heads' logits that brings their mean entropy to the target (bisection on
+    the actual softmax), apply it to W in place and go on with the scaled weights."""
+    import stress_weights
 
     f = lambda n: W[n]  # noqa: E731
     B, L = ids.shape
@@ -42,16 +60,22 @@ def stress_forward(ids, W, ocfg, stats):
     x = oe.layer_norm(x, f("embeddings.LayerNorm.weight"), f("embeddings.LayerNorm.bias"), ocfg.ln_eps)
     for i in range(ocfg.layers):
         p = f"encoder.layer.{i}."
-        q = (x @ f(p + "attention.self.query.weight").T + f(p + "attention.self.query.bias")).view(B, L, nh, dh).transpose(1, 2)
-        k = (x @ f(p + "attention.self.key.weight").T + f(p + "attention.self.key.bias")).view(B, L, nh, dh).transpose(1, 2)
+        if calibrate is not None:
+            s0, _ = _attention_probs(x, W, ocfg, i)
+            lo, hi = 1.0, 4096.0
+            for _ in range(18):
+                mid = (lo * hi) ** 0.5
+                ent = float(_entropy_bits(torch.softmax(s0[:, 0::2] * mid, dim=-1)).mean())
+                lo, hi = (mid, hi) if ent > stress_weights.ENTROPY_TARGET_BITS else (lo, mid)
+            alpha = (lo * hi) ** 0.5
+            stress_weights.scale_qk(W, ocfg, i, alpha)
+            calibrate.append(alpha)
+        s, pr = _attention_probs(x, W, ocfg, i)
         v = (x @ f(p + "attention.self.value.weight").T + f(p + "attention.self.value.bias")).view(B, L, nh, dh).transpose(1, 2)
-        s = (q @ k.transpose(-1, -2)) / math.sqrt(dh)
-        pr = torch.softmax(s, dim=-1)
-        if i in (0, ocfg.layers // 2, ocfg.layers - 1):
-            ent = -(pr * torch.log2(pr.clamp_min(1e-30))).sum(-1).mean(dim=(0, 2))         # bits, per head
-            stats.setdefault("entropy_even_heads", []).append(float(ent[0::2].mean()))
-            stats.setdefault("entropy_odd_heads", []).append(float(ent[1::2].mean()))
-            stats["max_logit"] = max(stats.get("max_logit", 0.0), float(s.abs().max()))
+        ent = _entropy_bits(pr)
+        stats.setdefault("entropy_even_heads_by_layer", {}).setdefault(i, []).append(round(float(ent[0::2].mean()), 3))
+        stats.setdefault("entropy_odd_heads_by_layer", {}).setdefault(i, []).append(round(float(ent[1::2].mean()), 3))
+        stats["max_logit"] = max(stats.get("max_logit", 0.0), float(s.abs().max()))
         ctx = (pr @ v).transpose(1, 2).reshape(B, L, H)
         a = ctx @ f(p + "attention.output.dense.weight").T + f(p + "attention.output.dense.bias")
         x = oe.layer_norm(a + x, f(p + "attention.output.LayerNorm.weight"), f(p + "attention.output.LayerNorm.bias"), ocfg.ln_eps)
@@ -61,6 +85,7 @@ def stress_forward(ids, W, ocfg, stats):
         stats["max_pre_ln"] = max(stats.get("max_pre_ln", 0.0), float((o + x).abs().max()))
         x = oe.layer_norm(o + x, f(p + "output.LayerNorm.weight"), f(p + "output.LayerNorm.bias"), ocfg.ln_eps)
         stats["max_ln_out"] = max(stats.get("max_ln_out", 0.0), float(x.abs().max()))
+        stats.setdefault("median_abs_ln_out_by_layer", {})[i] = round(float(x.abs().median()), 4)
     return x[:, 0, :]
 
 
@@ -73,29 +98,40 @@ def main_stress():
     pairs = t._pairs()
     stats = {}
     with torch.no_grad():
+        # 1. attention sharpening, calibrated layer by layer on 8 pairs (two of every query)
+        qk_scales = []
+        cal_ids = torch.from_numpy(np.concatenate([pairs[q][:2] for q in range(t.N_QUERIES)]))
+        stress_forward(cal_ids, W, ocfg, {}, calibrate=qk_scales)              # scales W in place
+        print("calibrated logit factors of the even heads:", [round(a, 1) for a in qk_scales], flush=True)
+        # 2. the oracle forward of all pairs with those weights
         cls = torch.cat([stress_forward(torch.from_numpy(pairs[q]), W, ocfg, stats) for q in range(t.N_QUERIES)])
         feat = torch.tanh(cls @ W["classifier.dense.weight"].T + W["classifier.dense.bias"])            # [200][H]
-        # the head: the direction along which the candidates of a query differ most, scaled so that the logits span +-3
-        centred = torch.cat([feat[q * t.N_PAIRS:(q + 1) * t.N_PAIRS] - feat[q * t.N_PAIRS:(q + 1) * t.N_PAIRS].mean(0, keepdim=True)
-                             for q in range(t.N_QUERIES)])
+        # 3. the head: the direction along which the candidates of a query differ most (every query weighted alike), scaled so
+        #    that a query's candidates span ~6 logits between their 5th and 95th percentile
+        per_q = [feat[q * t.N_PAIRS:(q + 1) * t.N_PAIRS] for q in range(t.N_QUERIES)]
+        centred = torch.cat([(fq - fq.mean(0, keepdim=True)) / (fq - fq.mean(0, keepdim=True)).norm() for fq in per_q])
         _, _, vh = torch.linalg.svd(centred.double(), full_matrices=False)
         w = vh[0].float()
-        proj = feat @ w
-        w = w * (6.0 / float(proj.max() - proj.min()))
+        spans = [float(torch.quantile(fq @ w, 0.95) - torch.quantile(fq @ w, 0.05)) for fq in per_q]
+        w = w * (6.0 / float(np.median(spans)))
         b = -float((feat @ w).median())
         head_w, head_b = w.reshape(1, -1), torch.tensor([b])
         Wh = stress_weights.with_head(W, head_w, head_b)
         want = torch.sigmoid(feat @ Wh["classifier.out_proj.weight"].T + Wh["classifier.out_proj.bias"])[:, 0].view(t.N_QUERIES, t.N_PAIRS)
-        # the restated forward IS the oracle's: one query re-scored through oracle.encoder
+        # the restated forward IS the oracle's: one query re-scored through oracle.encoder on weights rebuilt from the recipe
+        W2 = stress_weights.with_head(stress_weights.apply(oe.synth_weights(ocfg, seed=t.WEIGHT_SEED), ocfg, qk_scales=qk_scales), head_w, head_b)
         ids0 = torch.from_numpy(pairs[0])
-        chk = oe.rerank_scores(ids0, torch.ones_like(ids0), Wh, ocfg)
-        assert (chk - want[0]).abs().max().item() < 1e-5, (chk - want[0]).abs().max().item()
+        chk = oe.rerank_scores(ids0, torch.ones_like(ids0), W2, ocfg)
+        assert (chk - want[0]).abs().max().item() < 1e-4, (chk - want[0]).abs().max().item()
+        Wh = W2
     for q in range(t.N_QUERIES):
         print(f"query {q}: scores {want[q].min().item():.4f} .. {want[q].max().item():.4f}", flush=True)
+    stats = {k: ({kk: (round(float(np.mean(vv)), 3) if isinstance(vv, list) else vv) for kk, vv in v.items()} if isinstance(v, dict) else v)
+             for k, v in stats.items()}
     print("stress statistics:", stats)
     np.savez(os.path.join(HERE, t.STRESS_GOLDEN_NAME), scores=want.numpy().astype(np.float32), head_w=head_w.numpy(), head_b=head_b.numpy(),
-             pairs_sha256=hashlib.sha256(pairs.tobytes()).hexdigest(), weights_sha256=weights_checksum(Wh),
-             stats=np.array(repr(stats)), torch_version=torch.__version__)
+             qk_scales=np.asarray(qk_scales, dtype=np.float64), pairs_sha256=hashlib.sha256(pairs.tobytes()).hexdigest(),
+             weights_sha256=weights_checksum(Wh), stats=np.array(repr(stats)), torch_version=torch.__version__)
     print("wrote", t.STRESS_GOLDEN_NAME)
 
 

@@ -283,3 +283,97 @@ def test_f16c_scores_within_1e3_relative_at_full_depth(dev, built_lib, oracle_sc
           f"Kendall tau min {min(taus):.4f}; top-{TOP_N} overlap min {min(over):.2f}; {dt * 1e3:.1f} ms per query of {N_PAIRS} "
           f"pairs x {PAIR_TOKENS} tok alone ({1.0 / dt:.1f} q/s), {dt_b * 1e3:.1f} ms per query in a batch of {N_QUERIES} ({1.0 / dt_b:.1f} q/s)")
     assert min(taus) >= 0.999 and min(over) == 1.0
+
+
+# ---- the same gate on weights with TRAINED-MODEL STATISTICS (tests/stress_weights.py) ----------------------
+# Six hidden dimensions carry massive activations (20-60x the ordinary features) through every layer, half the heads attend with
+# an entropy of 1.5 bits (logits of tens), and the calibrated head spreads a query's candidates over ~6 logits.  There is no
+# network for real checkpoints: this is the offline stand-in for them.  Bounds below are MEASURED on this fixture and asserted
+# with a margin; DESIGN.md section 2 carries them as the "stress" column of the tolerance table.
+STRESS_REFERENCE_REL = 1e-3    # north_star's bar, for the reference-precision implementations
+STRESS_FP16_BOUND = 2e-2       # absolute, fp16 mode (measured below)
+STRESS_BF16_BOUND = 1.5e-1     # absolute, bf16 mode (measured below)
+
+
+@pytest.fixture(scope="module")
+def stress_oracle_scores():
+    import hashlib
+    import os
+
+    import stress_weights
+    from rank_checks import weights_checksum
+
+    ocfg = oe.EncoderConfig(**SHAPE)
+    pairs = _pairs()
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", STRESS_GOLDEN_NAME)
+    assert os.path.exists(path), f"{STRESS_GOLDEN_NAME} missing: python tests/golden/make_rank_golden.py --stress"
+    z = np.load(path)
+    W = stress_weights.with_head(stress_weights.apply(oe.synth_weights(ocfg, seed=WEIGHT_SEED), ocfg, qk_scales=z["qk_scales"]),
+                                 z["head_w"], z["head_b"])
+    assert str(z["pairs_sha256"]) == hashlib.sha256(pairs.tobytes()).hexdigest() and str(z["weights_sha256"]) == weights_checksum(W), \
+        "the stress fixture belongs to other weights / token ids: regenerate it"
+    return ocfg, W, pairs, torch.from_numpy(z["scores"].astype(np.float32))
+
+
+def _mode_scores(dev, W, pairs, mode):
+    from tensor_truth_amd.encoder import Encoder, EncoderConfig, EncoderWeights, pack_token_matrix
+
+    cfg = EncoderConfig(**SHAPE)
+    flat = pairs.reshape(-1, PAIR_TOKENS).astype(np.int32)
+    if mode == "f16c":
+        from tensor_truth_amd.encoder_f16c import EncoderF16C, EncoderWeightsF16C
+
+        enc = EncoderF16C(EncoderWeightsF16C(cfg, W, dev))
+    elif mode == "bf16x3":
+        from tensor_truth_amd.encoder_x3 import EncoderWeightsX3, EncoderX3
+
+        enc = EncoderX3(EncoderWeightsX3(cfg, W, dev))
+    else:
+        enc = Encoder(EncoderWeights(cfg, W, dev, dtype=torch.float16 if mode == "fp16" else torch.bfloat16))
+        if mode == "fp8":
+            enc.calibrate_fp8(pack_token_matrix(flat[:64], cfg))
+            enc.w.set_gemm_dtype("fp8")
+    got = enc.rerank_packed(pack_token_matrix(flat, cfg)).cpu().view(N_QUERIES, N_PAIRS)
+    torch.cuda.synchronize()
+    return got
+
+
+def _report(name, want, got):
+    err = (got - want).abs()
+    rel = (err / want.abs()).max().item()
+    taus = [kendall_tau(want[q].numpy(), got[q].numpy()) for q in range(N_QUERIES)]
+    over = [topn_overlap(want[q].numpy(), got[q].numpy(), TOP_N) for q in range(N_QUERIES)]
+    print(f"stress @24L {name}: scores {want.min().item():.3f}..{want.max().item():.3f}; max |err| {err.max().item():.2e}, max relative {rel:.2e}; "
+          f"Kendall tau {min(taus):.4f}..{max(taus):.4f}; top-{TOP_N} overlap {min(over):.2f}..{max(over):.2f}; finite {bool(torch.isfinite(got).all())}")
+    return err.max().item(), rel, min(taus), min(over)
+
+
+@pytest.mark.parametrize("mode", ["f16c", "bf16x3"])
+def test_stress_weights_reference_precision_within_1e3_relative(dev, built_lib, stress_oracle_scores, mode):
+    """Both implementations of the reference mode on the stress weights: still inside north_star's 1e-3 relative, the oracle's
+    ranking reproduced -- massive activations sharing a 32-element scale block with ordinary features (the e4m3 correction
+    planes' worst case) and attention logits of tens included."""
+    ocfg, W, pairs, want = stress_oracle_scores
+    got = _mode_scores(dev, W, pairs, mode)
+    err, rel, tau, over = _report(mode, want, got)
+    assert torch.isfinite(got).all()
+    assert rel <= STRESS_REFERENCE_REL, f"{mode} on stress weights: relative score error {rel}"
+    assert tau >= 0.995 and over >= 0.9
+    for q in range(N_QUERIES):
+        assert_order_on_separable(want[q].numpy(), got[q].numpy(), 2 * err + 1e-6, f"{mode} stress query {q}")
+
+
+@pytest.mark.parametrize("mode", ["fp16", "bf16", "fp8"])
+def test_stress_weights_16bit_modes_stay_finite_and_bounded(dev, built_lib, stress_oracle_scores, mode):
+    """The named 16-bit modes (and the fp8 throughput mode) on the stress weights: finite -- fp16 saturates instead of overflowing
+    -- and inside their MEASURED bounds, which are what DESIGN.md states for weights with trained-model statistics."""
+    ocfg, W, pairs, want = stress_oracle_scores
+    got = _mode_scores(dev, W, pairs, mode)
+    err, rel, tau, over = _report(mode, want, got)
+    assert torch.isfinite(got).all()
+    if mode == "fp16":
+        assert err <= STRESS_FP16_BOUND
+    elif mode == "bf16":
+        assert err <= STRESS_BF16_BOUND
+    else:
+        assert tau >= 0.2            # (a throughput mode: its gate is that it still ranks better than chance, stated as measured)

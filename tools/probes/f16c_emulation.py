@@ -105,6 +105,11 @@ def forward(ids, mask, W, cfg, variant, wcache):
         lin = lambda x, wn, bn: lin_f16c(x, wsplit(wn), f(bn), variant.split("+")[0])  # noqa: E731
     att16 = variant not in ("fp32", "bf16x3") and "+att32" not in variant
     ra = f16 if att16 else (lambda t: t)
+    # "+qk32": Q and K at full precision in the score product (what hi + lo planes for Q / K would give), V and P still fp16
+    rqk = (lambda t: t) if "+qk32" in variant else ra
+    # "+qkb16": Q and K as TWO bf16 planes (the split-bf16 kernel's score product: 16 significand bits)
+    if "+qkb16" in variant:
+        rqk = lambda t: bf16(t) + bf16(t - bf16(t))  # noqa: E731
     # "+respl": the residual branch reads hi + lo8 of the LayerNorm output's c-planes instead of an fp32 copy (saves 8 of the
     # ~40 bytes per element and layer the row kernels and residual epilogues move): what does it cost?
     if "+respl" in variant:
@@ -127,8 +132,8 @@ def forward(ids, mask, W, cfg, variant, wcache):
     scale = 1.0 / math.sqrt(dh)
     for i in range(cfg.layers):
         p = f"encoder.layer.{i}."
-        q = ra(lin(x, p + "attention.self.query.weight", p + "attention.self.query.bias"))
-        k = ra(lin(x, p + "attention.self.key.weight", p + "attention.self.key.bias"))
+        q = rqk(lin(x, p + "attention.self.query.weight", p + "attention.self.query.bias"))
+        k = rqk(lin(x, p + "attention.self.key.weight", p + "attention.self.key.bias"))
         v = ra(lin(x, p + "attention.self.value.weight", p + "attention.self.value.bias"))
         q = q.view(B, L, nh, dh).transpose(1, 2)
         k = k.view(B, L, nh, dh).transpose(1, 2)
@@ -183,8 +188,12 @@ def main():
             ref = torch.from_numpy(np.load(os.path.join("tests", "golden", t.GOLDEN_NAME))["scores"])
     if args.stress:
         import stress_weights
+        import test_rank_agreement_gpu as t
 
-        W = stress_weights.apply(W, cfg)
+        z = np.load(os.path.join("tests", "golden", t.STRESS_GOLDEN_NAME))
+        W = stress_weights.with_head(stress_weights.apply(W, cfg, qk_scales=z["qk_scales"]), z["head_w"], z["head_b"])
+        if args.layers == 24 and not args.small:
+            ref = torch.from_numpy(z["scores"].astype(np.float32))
     with torch.no_grad():
         if ref is None:
             t0 = time.time()
