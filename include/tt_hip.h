@@ -454,14 +454,39 @@ int tt_rerank_head_f16c(const tt_encoder_weights_f16c* w, const float* hidden_f3
  *   [hi | lo8 | x8] with two scale parts.  Rows are padded to 256 in the scale array only.
  * tt_gemm_f16c: a c-planes [m][4k], w c-planes [n][4k]; m, n, k multiples of 256; epilogue 0: fp16 c_out [m][n] =
  *   a.w^T + bias; 1: exact-erf GELU -> c-planes c_out [m][4n] + c_scales; 2: fp32 c_out [m][n] = a.w^T + bias + residual_f32.
- * tt_attention_f16c: tt_attention_varlen_f16's inputs (fp16 Q / K, V in the V8 layout, head_dim 64), context as c-planes. */
+ * tt_attention_f16c: Q / K as two fp16 planes in one buffer (hi at q_col0 / k_col0 + head * 64, lo lo_off columns further:
+ *   the score product runs on three fp16 products), V fp16 in the V8 layout of tt_attention_varlen, head_dim 64; context as c-planes. */
 size_t tt_f16c_scale_bytes(int64_t rows, int k, int weight);
 int tt_f16c_quantize(const float* in_f32, int64_t rows, int k, int weight, void* out_planes, void* out_scales, void* stream);
 int tt_gemm_f16c(const void* a_planes, const void* a_scales, const void* w_planes, const void* w_scales, const float* bias,
                  const float* residual_f32, void* c_out, void* c_scales, int m, int n, int k, int epilogue, void* stream);
-int tt_attention_f16c(const void* qk_f16, int ld_qk, int q_col0, int k_col0, const void* vt_f16, int ldvt, void* out_planes,
+int tt_attention_f16c(const void* qk_f16, int ld_qk, int q_col0, int k_col0, int lo_off, const void* vt_f16, int ldvt, void* out_planes,
                       void* out_scales, const int32_t* seq_start, const int32_t* seq_len, int n_seq, int heads, int max_len,
                       void* stream);
+
+/* ---- "f16x3": the split-plane forward above with fp16 planes (csrc/x3_path.hip compiled a second time, round 4) -------
+ * Same entry points, same layouts, `_f16` suffix: a value is carried as hi = fp16(x), lo = fp16(x - hi) -- 22 significand
+ * bits per operand instead of the two bf16 planes' 16 -- and a product as three v_mfma_*_f16 products.  It is the DEFAULT
+ * implementation of the reference precision: on weights with trained-model statistics (attention logits of ~100, scores
+ * down to 0.005: tests/stress_weights.py) it holds 1e-3 relative with a margin where bf16x3 sits AT the bar and the
+ * two-unit f16c path is 7x outside.  Values beyond +-65504 saturate in the hi plane (the lo plane takes what is left). */
+size_t tt_encoder_x3_workspace_bytes_f16(const tt_encoder_weights_x3* w, int n_rows);
+int tt_encoder_forward_x3_f16(const tt_encoder_weights_x3* w, const int32_t* ids, const int32_t* pos,
+                              const int32_t* type_ids, const int32_t* seq_start, const int32_t* seq_len,
+                              int n_seq, int n_rows, int max_len, float* hidden_out,
+                              void* workspace, size_t workspace_bytes, void* stream);
+size_t tt_encoder_x3_cls_workspace_bytes_f16(const tt_encoder_weights_x3* w, int n_rows, int n_seq);
+int tt_encoder_forward_x3_cls_f16(const tt_encoder_weights_x3* w, const int32_t* ids, const int32_t* pos, const int32_t* type_ids,
+                                  const int32_t* seq_start, const int32_t* seq_len, int n_seq, int n_rows, int max_len,
+                                  float* cls_out, void* workspace, size_t workspace_bytes, void* stream);
+int tt_rerank_head_x3_f16(const tt_encoder_weights_x3* w, const float* hidden_f32, const int32_t* rows, int n_seq,
+                          float* scores, float* logits, void* workspace, size_t workspace_bytes, void* stream);
+int tt_split_planes_f16(const float* in_f32, int64_t rows, int cols, void* out_planes, void* stream);
+int tt_gemm_x3_f16(const void* a_planes, const void* w_planes, const float* bias, const float* residual_f32, void* c_planes,
+                   float* c_f32, int m, int n, int k, int epilogue, void* stream);
+int tt_attention_x3_f16(const void* qk_planes, int ld_qk, int q_col0, int k_col0, int lo_off, const void* vt_hi,
+                        const void* vt_lo, int ldvt, void* out_planes, int ld_out, int out_lo_off,
+                        const int32_t* seq_start, const int32_t* seq_len, int n_seq, int heads, int max_len, void* stream);
 
 /* Per-kernel device timing (HIP events on the launch stream), for bench.py's roofline leg.
  * tt_prof_enable(1) (or a mask of 1 << id, to time only some kernels) starts recording one event pair per launch of the tracked kernels on the

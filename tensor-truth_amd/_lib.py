@@ -125,6 +125,18 @@ SIGNATURES = {
     "tt_gemm_x3": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "tt_attention_x3": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int,
                                 c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    # the split-plane forward with fp16 planes ("f16x3": x3_path.hip's second instantiation)
+    "tt_encoder_x3_workspace_bytes_f16": (c_size_t, [c_void_p, c_int]),
+    "tt_encoder_x3_cls_workspace_bytes_f16": (c_size_t, [c_void_p, c_int, c_int]),
+    "tt_encoder_forward_x3_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                          c_void_p, c_void_p, c_size_t, c_void_p]),
+    "tt_encoder_forward_x3_cls_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                              c_void_p, c_void_p, c_size_t, c_void_p]),
+    "tt_rerank_head_x3_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "tt_split_planes_f16": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p]),
+    "tt_gemm_x3_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "tt_attention_x3_f16": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int,
+                                    c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     # reference precision on two matrix-time units (csrc/f16c_path.hip)
     "tt_encoder_f16c_workspace_bytes": (c_size_t, [c_void_p, c_int]),
     "tt_encoder_f16c_cls_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),
@@ -137,7 +149,7 @@ SIGNATURES = {
     "tt_f16c_quantize": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "tt_gemm_f16c": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                              c_int, c_void_p]),
-    "tt_attention_f16c": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+    "tt_attention_f16c": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                   c_int, c_int, c_void_p]),
     "tt_prof_enable": (c_int, [c_int]),
     "tt_prof_read": (c_int, [c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int)]),

@@ -444,6 +444,13 @@ __global__ __launch_bounds__(64) void attention_cls_kernel(AttnParams p) {
             q[c * 8 + 2] = elo(u.y); q[c * 8 + 3] = ehi(u.y);
             q[c * 8 + 4] = elo(u.z); q[c * 8 + 5] = ehi(u.z);
             q[c * 8 + 6] = elo(u.w); q[c * 8 + 7] = ehi(u.w);
+            if (p.qk_lo_off) {          // f16c: hi + lo planes
+                const uint4 l = *reinterpret_cast<const uint4*>(qp + p.qk_lo_off + c * 8);
+                q[c * 8 + 0] += elo(l.x); q[c * 8 + 1] += ehi(l.x);
+                q[c * 8 + 2] += elo(l.y); q[c * 8 + 3] += ehi(l.y);
+                q[c * 8 + 4] += elo(l.z); q[c * 8 + 5] += ehi(l.z);
+                q[c * 8 + 6] += elo(l.w); q[c * 8 + 7] += ehi(l.w);
+            }
         }
     }
     const float sc = p.scale * 1.4426950408889634f;
@@ -454,14 +461,14 @@ __global__ __launch_bounds__(64) void attention_cls_kernel(AttnParams p) {
 #pragma unroll
         for (int c = 0; c < DH / 8; ++c) {
             const uint4 u = *reinterpret_cast<const uint4*>(kp + c * 8);
-            acc = fmaf(q[c * 8 + 0], elo(u.x), acc);
-            acc = fmaf(q[c * 8 + 1], ehi(u.x), acc);
-            acc = fmaf(q[c * 8 + 2], elo(u.y), acc);
-            acc = fmaf(q[c * 8 + 3], ehi(u.y), acc);
-            acc = fmaf(q[c * 8 + 4], elo(u.z), acc);
-            acc = fmaf(q[c * 8 + 5], ehi(u.z), acc);
-            acc = fmaf(q[c * 8 + 6], elo(u.w), acc);
-            acc = fmaf(q[c * 8 + 7], ehi(u.w), acc);
+            float kf[8] = {elo(u.x), ehi(u.x), elo(u.y), ehi(u.y), elo(u.z), ehi(u.z), elo(u.w), ehi(u.w)};
+            if (p.qk_lo_off) {
+                const uint4 l = *reinterpret_cast<const uint4*>(kp + p.qk_lo_off + c * 8);
+                kf[0] += elo(l.x); kf[1] += ehi(l.x); kf[2] += elo(l.y); kf[3] += ehi(l.y);
+                kf[4] += elo(l.z); kf[5] += ehi(l.z); kf[6] += elo(l.w); kf[7] += ehi(l.w);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc = fmaf(q[c * 8 + i], kf[i], acc);
         }
         acc *= sc;
         probs[j] = acc;

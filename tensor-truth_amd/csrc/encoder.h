@@ -95,6 +95,7 @@ struct AttnParams {
     // (ld_out = 2 * out_width), x8 / lo8 planes behind it, block scales tiled for a consumer with K = out_width.  NULL = fp16 out.
     uint8_t* out_scales;
     int out_width;            // heads * head_dim
+    int qk_lo_off;            // CLS variant, f16c: Q / K are TWO fp16 planes, the lo plane qk_lo_off columns behind the hi one (0 = one plane)
 };
 int tt_attention_launch(const AttnParams& p, hipStream_t st);
 // CLS-only variant: one query row (seq_start[b]) per sequence; out row index = sequence index

@@ -26,3 +26,12 @@
 #define tt_gemm_bf16 tt_gemm_f16
 #define tt_layernorm_bf16 tt_layernorm_f16
 #define tt_attention_varlen tt_attention_varlen_f16
+// x3_path.hip a second time: the split planes are fp16 there ("f16x3": 22 significand bits per operand instead of bf16x3's 16)
+#define tt_encoder_x3_workspace_bytes tt_encoder_x3_workspace_bytes_f16
+#define tt_encoder_x3_cls_workspace_bytes tt_encoder_x3_cls_workspace_bytes_f16
+#define tt_encoder_forward_x3 tt_encoder_forward_x3_f16
+#define tt_encoder_forward_x3_cls tt_encoder_forward_x3_cls_f16
+#define tt_rerank_head_x3 tt_rerank_head_x3_f16
+#define tt_split_planes tt_split_planes_f16
+#define tt_gemm_x3 tt_gemm_x3_f16
+#define tt_attention_x3 tt_attention_x3_f16

@@ -7,16 +7,17 @@
 //       a.w ~= a_hi.w_hi                                             v_mfma_f32_16x16x32_f16, exact products, fp32 accumulate: 1 unit
 //            + e4m3(a).e4m3(w_lo) + e4m3(a_lo).e4m3(w)               v_mfma_scale_f32_16x16x128_f8f6f4 with E8M0 block scales per
 //                                                                    32 elements: twice the bf16 rate -> 1/2 unit each
-// The two cross terms are 2^-12 of the result and only need e4m3's 2^-4; the dropped lo.lo term is 2^-24.  Attention runs on
-// single fp16 products (Q, K, V, P rounded to fp16; fp32 scores, softmax and accumulators: attention.hip's fp16 instantiation).
+// The two cross terms are 2^-12 of the result and only need e4m3's 2^-4; the dropped lo.lo term is 2^-24.  Attention: the score
+// product on THREE fp16 products (Q and K as two fp16 planes: logits of tens need more than 2^-11), values on one (V and P
+// rounded to fp16); fp32 scores, softmax and accumulators (attention_qk2_kernel below).
 // Everything that is not a product stays fp32, as in x3_path.hip: the residual stream, LayerNorm, exact-erf GELU, the head.
 // CPU emulation of exactly this scheme before any kernel was written (tools/probes/f16c_emulation.py, full depth, the committed
 // fp32 fixture): scores within 8.3e-5 relative of the fp32 oracle, Kendall tau 1.000.
 //
-// Tensors: GEMM A operands and weights are "c-planes" (f16c.h: [hi | x8 | lo8] rows of 4 K bytes + tiled E8M0 scales); Q / K /
-// V are plain fp16 (V in the V8 layout); the residual stream is fp32.  Layer schedule (post-LN block):
-//   qk (fp16), V8 (fp16)  = GEMMc(x_c, Wqkv)              two launches: bias epilogue, V^T epilogue
-//   ctx_c                 = attention_f16(qk, V8)          c-planes written by the attention epilogue
+// Tensors: GEMM A operands and weights are "c-planes" (f16c.h: [hi | x8 | lo8] rows of 4 K bytes + tiled E8M0 scales); Q / K are
+// two fp16 planes, V plain fp16 in the V8 layout; the residual stream is fp32.  Layer schedule (post-LN block):
+//   qk (2 x fp16), V8     = GEMMc(x_c, Wqkv)              two launches: planes epilogue, V^T epilogue
+//   ctx_c                 = attention_qk2(qk, V8)          c-planes written by the attention epilogue
 //   y (fp32)              = GEMMc(ctx_c, Wo) + bo + x      fp32 residual read by the epilogue
 //   x1 (fp32), x1_c       = LayerNorm(y)
 //   f_c                   = GELU_erf(GEMMc(x1_c, W1) + b1) c-planes written by the GEMM epilogue
@@ -179,6 +180,325 @@ __global__ __launch_bounds__(256) void gather_rows_f32c_kernel(const float* src,
     }
 }
 
+
+// ---- attention: scores on THREE fp16 products, values on one -------------------------------------------------------------------
+// The score product is the one place of the path where fp16's 2^-11 is not enough by itself: a trained model's peaked heads carry
+// logits of tens to a hundred, and an operand rounding of 2^-11 on q and k moves such a logit by 0.05 -- percents of a
+// probability, 3e-2 relative on the scores of the stress fixture (tests/stress_weights.py: 1.5-bit attention on half the heads;
+// the split-bf16 path, whose two bf16 planes carry 16 bits, sits exactly AT 1e-3 there).  So Q and K come out of their
+// projection as two fp16 planes, hi = fp16(x), lo = fp16(x - hi) (22 significand bits), and
+//       S^T = K_lo.Q_hi + K_hi.Q_lo + K_hi.Q_hi          fp32 scores and softmax
+//       O^T += V.P                                        V and P single fp16 (a probability's 2^-11 averages out over the keys)
+// x3_path.hip's kernel structure (one workgroup = 4 waves = 128 query rows of one (sequence, head); keys in tiles of 64 through two
+// LDS-DMA buffers, one barrier per tile; both products swapped so the query stays on the lane) with three planes per tile
+// (K hi, K lo, V: 24 KiB) and the c-planes epilogue of attention.hip.
+struct AttnQ2Params {
+    const uint16_t* qk;       // fp16 planes [T][ld_qk]: Q hi at q_col0 + h*64, K hi at k_col0 + h*64; lo planes lo_off columns further
+    const uint16_t* vt;       // V8 fp16 [T/8][heads*64][8]
+    char* out;                // context c-planes [T][4 W bytes]
+    uint8_t* out_scales;
+    const int32_t* seq_start;
+    const int32_t* seq_len;
+    int n_seq, heads, max_len;
+    int ld_qk, q_col0, k_col0, lo_off, ldvt, out_width;
+    float scale, lazy;
+    int n_qt;
+};
+
+typedef unsigned int u32x4q __attribute__((ext_vector_type(4)));
+template <int OFF>
+__device__ __forceinline__ u32x4q ldsq_read128(uint32_t addr) {
+    u32x4q r;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+    return r;
+}
+template <int N>
+__device__ __forceinline__ void ldsq_wait8(u32x4q& a, u32x4q& b, u32x4q& c, u32x4q& d, u32x4q& e, u32x4q& f, u32x4q& g, u32x4q& h) {
+    asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "n"(N));
+}
+template <int N>
+__device__ __forceinline__ void ldsq_wait4(u32x4q& a, u32x4q& b, u32x4q& c, u32x4q& d) {
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
+}
+
+constexpr int kQKTile = 64, kQWaves = 4, kQDH = 64;
+constexpr int kQPlane = kQKTile * kQDH * 2;          // 8 KiB: one plane of a K tile (64 rows x 128 B) or the V tile
+constexpr int kQBuf = 3 * kQPlane;                   // K hi | K lo | V
+constexpr int kQLds = 2 * kQBuf;                     // 48 KiB
+
+__global__ __launch_bounds__(64 * kQWaves, 3) void attention_qk2_kernel(AttnQ2Params p) {
+    constexpr int DH = kQDH, RB = DH * 2, CH = RB / 16, RPB = 256 / RB, KS = DH / 16, DT = DH / 32;
+    constexpr int NP = kQPlane / 1024;               // 8 one-KiB copy pieces per plane and tile
+    constexpr int PPW = NP / kQWaves;                // 2 pieces of every plane per wave
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+
+    const int nqt = p.n_qt;
+    const int L = blockIdx.x;
+    const int qt = L % nqt, pair = L / nqt;
+    if (pair >= p.heads * p.n_seq) return;
+    const int head = pair % p.heads, seq = pair / p.heads;
+    const int len = p.seq_len[seq];
+    if (qt * 32 * kQWaves >= len) return;
+    const int t0 = p.seq_start[seq];
+    const int t0a = t0 & ~7, off = t0 - t0a, alen = off + len;       // aligned key frame of the V8 token groups
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ql = lane & 31, hh = lane >> 5;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+
+    // ---- Q fragments (B operand), both planes, straight from global
+    const int q_row = (qt * kQWaves + wave) * 32 + ql;
+    const int q_row_c = q_row < len ? q_row : len - 1;
+    const uint16_t* qp = p.qk + (size_t)(t0 + q_row_c) * p.ld_qk + p.q_col0 + head * DH + hh * 8;
+    ex8 qh[KS], qlo[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        qh[s] = *reinterpret_cast<const ex8*>(qp + s * 16);
+        qlo[s] = *reinterpret_cast<const ex8*>(qp + p.lo_off + s * 16);
+    }
+
+    const int n_kt = (alen + kQKTile - 1) / kQKTile;
+    const int n_g8 = (alen + 7) >> 3;
+    const uint16_t* kbase = p.qk + (size_t)t0a * p.ld_qk + p.k_col0 + head * DH;
+    const uint16_t* vbase = p.vt + (size_t)(t0a >> 3) * p.ldvt + (size_t)head * DH * 8;
+    constexpr int kRowsPerPiece = 64 / CH;           // 8 K rows per piece
+    uint32_t kvoff0, vvoff0;
+    {
+        const int e = wave * PPW * 64 + lane, r = e / CH, pos = e % CH;
+        kvoff0 = ((uint32_t)r * (uint32_t)p.ld_qk + (uint32_t)((pos ^ ((r / RPB) & (CH - 1))) << 3)) * 2u;
+        const int ev = wave * PPW * 64 + lane;
+        vvoff0 = ((uint32_t)(ev / DH) * (uint32_t)p.ldvt + (uint32_t)((ev % DH) * 8)) * 2u;
+    }
+    auto sbase = [](const void* ptr) {
+        const unsigned long long b = reinterpret_cast<unsigned long long>(ptr);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+        return reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
+    };
+    auto glds16 = [](const char* base, uint32_t voff, uint32_t lds_addr) {
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(lds_addr) : "memory", "m0");
+    };
+    auto issue_tile = [&](int kt) {
+        const uint32_t buf = lds0 + (uint32_t)(kt & 1) * kQBuf;
+        const bool clamp = (kt + 1) * kQKTile > alen || (kt == 0 && off != 0);   // wave-uniform
+        if (!clamp) {
+#pragma unroll
+            for (int i = 0; i < PPW; ++i) {
+                const uint16_t* kb = kbase + ((size_t)kt * kQKTile + (size_t)i * kRowsPerPiece) * p.ld_qk;
+                const uint32_t vo = (i & 1) ? (kvoff0 ^ 64u) : kvoff0;
+                glds16(sbase(kb), vo, buf + (uint32_t)(wave * PPW + i) * 1024u);
+                glds16(sbase(kb + p.lo_off), vo, buf + kQPlane + (uint32_t)(wave * PPW + i) * 1024u);
+            }
+#pragma unroll
+            for (int i = 0; i < PPW; ++i)
+                glds16(sbase(vbase + ((size_t)kt * 8 + i) * p.ldvt), vvoff0, buf + 2 * kQPlane + (uint32_t)(wave * PPW + i) * 1024u);
+            return;
+        }
+        // first / last tile: rows / token groups outside the sequence are clamped to its nearest one (finite values, probability 0)
+        const char* kb = sbase(kbase);
+        const char* kbl = sbase(kbase + p.lo_off);
+        const char* vb = sbase(vbase);
+        int lane_c = lane;
+        asm volatile("" : "+v"(lane_c));
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int e = (wave * PPW + i) * 64 + lane_c, r = e / CH, pos = e % CH;
+            int row = kt * kQKTile + r;
+            row = row < off ? off : (row < alen ? row : alen - 1);
+            const uint32_t vo = ((uint32_t)row * (uint32_t)p.ld_qk + (uint32_t)((pos ^ ((r / RPB) & (CH - 1))) << 3)) * 2u;
+            glds16(kb, vo, buf + (uint32_t)(wave * PPW + i) * 1024u);
+            glds16(kbl, vo, buf + kQPlane + (uint32_t)(wave * PPW + i) * 1024u);
+        }
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int e = (wave * PPW + i) * 64 + lane_c;
+            int g8 = kt * 8 + e / DH;
+            g8 = g8 < n_g8 ? g8 : n_g8 - 1;
+            glds16(vb, ((uint32_t)g8 * (uint32_t)p.ldvt + (uint32_t)((e % DH) * 8)) * 2u, buf + 2 * kQPlane + (uint32_t)(wave * PPW + i) * 1024u);
+        }
+    };
+
+    f32x16 acc_o[DT];
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc_o[d][r] = 0.f;
+    float m_run = -__builtin_inff();
+    float l_run = 0.f;
+    const float sc = p.scale * 1.4426950408889634f;
+    const bool wave_active = (qt * kQWaves + wave) * 32 < len;
+
+    const int krow = (ql & 0x13) | ((ql & 4) << 1) | ((ql & 8) >> 1);     // K row permutation: bits 2 and 3 swapped
+    uint32_t koff[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) koff[s] = lds0 + krow * RB + (((2 * s + hh) ^ ((krow / RPB) & (CH - 1))) << 4);
+    const uint32_t voff = lds0 + 2 * kQPlane + (hh * DH + ql) * 16;         // + (4 j + 2 s2) * DH*16 + 512 dt
+
+    issue_tile(0);
+    for (int kt = 0; kt < n_kt; ++kt) {
+        const int k0 = kt * kQKTile;
+        __builtin_amdgcn_s_waitcnt(0x0F70);          // this wave's pieces of tile kt have landed (builtin: see attention.hip)
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();                // ... everyone's; and tile kt - 1 is no longer read
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 1 < n_kt) issue_tile(kt + 1);
+        if (!wave_active) continue;
+        const uint32_t bufo = (kt & 1) * kQBuf;
+
+        // ---- S^T = K . Q^T, three products, two 32-key sub-tiles
+        f32x16 acc_s[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            u32x4q kh[KS], kl[KS];
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                if (j == 0) { kh[s] = ldsq_read128<0>(koff[s] + bufo); kl[s] = ldsq_read128<kQPlane>(koff[s] + bufo); }
+                else { kh[s] = ldsq_read128<32 * RB>(koff[s] + bufo); kl[s] = ldsq_read128<kQPlane + 32 * RB>(koff[s] + bufo); }
+            }
+            ldsq_wait8<0>(kh[0], kh[1], kh[2], kh[3], kl[0], kl[1], kl[2], kl[3]);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc_s[j][r] = 0.f;
+            // small terms first
+#pragma unroll
+            for (int s = 0; s < KS; ++s) acc_s[j] = TT_MFMA_32x32x16(__builtin_bit_cast(ex8, kl[s]), qh[s], acc_s[j]);
+#pragma unroll
+            for (int s = 0; s < KS; ++s) acc_s[j] = TT_MFMA_32x32x16(__builtin_bit_cast(ex8, kh[s]), qlo[s], acc_s[j]);
+#pragma unroll
+            for (int s = 0; s < KS; ++s) acc_s[j] = TT_MFMA_32x32x16(__builtin_bit_cast(ex8, kh[s]), qh[s], acc_s[j]);
+        }
+        // V fragments of the first 32 keys: in flight during the softmax
+        u32x4q vf[2][2];
+        const uint32_t vaddr = voff + bufo;
+        vf[0][0] = ldsq_read128<0>(vaddr); vf[0][1] = ldsq_read128<512>(vaddr);
+        vf[1][0] = ldsq_read128<2 * DH * 16>(vaddr); vf[1][1] = ldsq_read128<2 * DH * 16 + 512>(vaddr);
+
+        // ---- mask, running reference, exponentials (fp32).  Register r of sub-tile j is key k0 + 32 j + 16 (r>>3) + 8 hh + (r&7)
+        if (kt == 0 && off != 0) {
+            if (hh == 0) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+                    if (r < off) acc_s[0][r] = -__builtin_inff();
+            }
+        }
+        if (k0 + kQKTile > alen) {
+            const int lim = alen - k0 - 8 * hh;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (32 * j + 16 * (r >> 3) + (r & 7) >= lim) acc_s[j][r] = -__builtin_inff();
+        }
+        float mx = -__builtin_inff();
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, acc_s[j][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mt = mx * sc;
+        const float m_new = (mt > m_run + p.lazy) ? mt : m_run;
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+        float psum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e = __builtin_amdgcn_exp2f(fmaf(acc_s[j][r], sc, -m_new));
+                acc_s[j][r] = e;
+                psum += e;
+            }
+        l_run = l_run * alpha + psum;
+        if (kt > 0 && !__all(alpha == 1.0f)) {
+#pragma unroll
+            for (int d = 0; d < DT; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc_o[d][r] *= alpha;
+        }
+
+        // ---- O^T += V^T . P^T, one product
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            ldsq_wait4<0>(vf[0][0], vf[0][1], vf[1][0], vf[1][1]);
+            ex8 va[2][2];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int d = 0; d < DT; ++d) va[s2][d] = __builtin_bit_cast(ex8, vf[s2][d]);
+            if (j == 0) {   // next 32 keys' fragments, in flight during these MFMAs
+                vf[0][0] = ldsq_read128<4 * DH * 16>(vaddr); vf[0][1] = ldsq_read128<4 * DH * 16 + 512>(vaddr);
+                vf[1][0] = ldsq_read128<6 * DH * 16>(vaddr); vf[1][1] = ldsq_read128<6 * DH * 16 + 512>(vaddr);
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                uint4 pb;
+                pb.x = pack_e2_inrange(acc_s[j][8 * s2 + 0], acc_s[j][8 * s2 + 1]);
+                pb.y = pack_e2_inrange(acc_s[j][8 * s2 + 2], acc_s[j][8 * s2 + 3]);
+                pb.z = pack_e2_inrange(acc_s[j][8 * s2 + 4], acc_s[j][8 * s2 + 5]);
+                pb.w = pack_e2_inrange(acc_s[j][8 * s2 + 6], acc_s[j][8 * s2 + 7]);
+                const ex8 pf = __builtin_bit_cast(ex8, pb);
+#pragma unroll
+                for (int d = 0; d < DT; ++d) acc_o[d] = TT_MFMA_32x32x16(va[s2][d], pf, acc_o[d]);
+            }
+        }
+    }
+
+    // ---- normalise and store as c-planes: lane = query row, registers = 4 consecutive d (attention.hip's epilogue)
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    if (q_row < len) {
+        char* orow = p.out + (size_t)(t0 + q_row) * 4 * p.out_width;
+        const int W = p.out_width, nks = W >> 7;
+#pragma unroll
+        for (int d = 0; d < DT; ++d) {
+            float y[16];
+            float amax = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                y[r] = acc_o[d][r] * inv;
+                asm("" : "+v"(y[r]));
+                amax = fmaxf(amax, fabsf(y[r]));
+            }
+            amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+            int sbyte, sh;
+            xc_block_scale(amax, sbyte, sh);
+            const int col0 = head * DH + 32 * d;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                uint2 hi;
+                uint32_t x8, l8;
+                xc_split4(y[4 * g + 0], y[4 * g + 1], y[4 * g + 2], y[4 * g + 3], sh, sh + 11, hi, x8, l8);
+                const int col = col0 + 8 * g + 4 * hh;
+                *reinterpret_cast<uint2*>(orow + (size_t)col * 2) = hi;
+                *reinterpret_cast<uint32_t*>(orow + (size_t)2 * W + col) = x8;
+                *reinterpret_cast<uint32_t*>(orow + (size_t)3 * W + col) = l8;
+            }
+            if (hh == 0) p.out_scales[xc_a_scale_at(t0 + q_row, col0 >> 5, nks)] = (uint8_t)sbyte;
+        }
+    }
+}
+
+int attention_qk2_launch(const AttnQ2Params& p, hipStream_t st) {
+    if (p.n_seq <= 0 || p.max_len <= 0) return TT_OK;
+    if ((p.ld_qk % 8) || (p.q_col0 % 8) || (p.k_col0 % 8) || (p.lo_off % 8) || (p.ldvt % 8) || (p.out_width % 128)) {
+        tt_set_error("attention f16c: leading dimensions / column offsets must keep 16-byte alignment, out_width a multiple of 128");
+        return TT_E_INVALID;
+    }
+    const int n_qt = (p.max_len + 32 * kQWaves - 1) / (32 * kQWaves);
+    const long long pairs = (long long)p.heads * p.n_seq;
+    if (pairs * n_qt > 0x7FFFFFFFLL) {
+        tt_set_error("attention f16c: %lld workgroups exceed the grid limit", pairs * n_qt);
+        return TT_E_UNSUPPORTED;
+    }
+    AttnQ2Params q = p;
+    q.lazy = 8.0f;
+    q.n_qt = n_qt;
+    TT_SET_MAX_LDS(attention_qk2_kernel, kQLds);
+    TtProfScope prof(TT_K_ATTENTION, st);
+    hipLaunchKernelGGL(attention_qk2_kernel, dim3((unsigned)(pairs * n_qt)), dim3(64 * kQWaves), kQLds, st, q);
+    TT_CHECK_LAUNCH();
+    return TT_OK;
+}
+
 inline dim3 row_grid_c(int rows) { return dim3((unsigned)((rows + 3) / 4)); }
 inline size_t scale_bytes(size_t rows256, size_t K) { return rows256 / 256 * (K / 128) * 1024; }      // activation scales
 inline int cls_pad_c(int n_seq) { return (n_seq + 255) / 256 * 256; }
@@ -199,7 +519,7 @@ XcWs xc_plan(const tt_encoder_weights_f16c* w, int n_rows, int n_cls = 0) {
     e.off_y = take(T * H * 4);
     e.off_xc = take(T * 4 * H);
     e.off_xs = take(scale_bytes(T, H));
-    e.off_qk = take(T * 2 * H * 2);
+    e.off_qk = take(T * 4 * H * 2);               // Q hi | K hi | Q lo | K lo
     e.off_vt = take(T * H * 2);
     e.off_ctx = take(T * 4 * H);
     e.off_cs = take(scale_bytes(T, H));
@@ -288,16 +608,16 @@ int forward_c_impl(const tt_encoder_weights_f16c* w, const int32_t* ids, const i
         const tt_layer_weights_f16c& lw = w->layer[l];
         TT_CHECK_ARG(lw.qkv_w && lw.qkv_s && lw.qkv_b && lw.o_w && lw.o_s && lw.o_b && lw.ln1_g && lw.ln1_b && lw.ffn1_w && lw.ffn1_s &&
                          lw.ffn1_b && lw.ffn2_w && lw.ffn2_s && lw.ffn2_b && lw.ln2_g && lw.ln2_b, "layer %d has a null weight pointer", l);
-        // Q, K columns -> fp16 [T][2H]; V columns -> V8 fp16
+        // Q, K columns -> two fp16 planes [T][4H] (hi at [0, 2H), lo at [2H, 4H)); V columns -> V8 fp16
         GemmParams g = gemm_c(xc, xs, lw.qkv_w, (const uint8_t*)lw.qkv_s, lw.qkv_b, T, 2 * H, H);
-        g.C = qk; g.ldc = 2 * H;
+        g.C = qk; g.ldc = 4 * H; g.c_lo_off = 2 * H;
         if (int rc = tt_gemm_launch(g, TT_EPI_BIAS, st)) return rc;
         GemmParams gv = gemm_c(xc, xs, (const char*)lw.qkv_w + (size_t)2 * H * 4 * H, (const uint8_t*)lw.qkv_s + (size_t)(2 * H / 256) * 2 * (H / 128) * 1024,
                                lw.qkv_b + 2 * H, T, H, H);
         gv.vt = vt; gv.ldvt = 8 * H; gv.vt_col0 = 0;
         if (int rc = tt_gemm_launch(gv, TT_EPI_VT, st)) return rc;
-        AttnParams a{};
-        a.qk = qk; a.ld_qk = 2 * H; a.q_col0 = 0; a.k_col0 = H; a.vt = vt; a.ldvt = 8 * H;
+        AttnParams a{};                 // (the CLS tail's one-query kernel: attention.hip, Q / K as hi + lo planes)
+        a.qk = qk; a.ld_qk = 4 * H; a.q_col0 = 0; a.k_col0 = H; a.qk_lo_off = 2 * H; a.vt = vt; a.ldvt = 8 * H;
         a.seq_start = seq_start; a.seq_len = seq_len; a.n_seq = n_seq; a.heads = w->heads; a.head_dim = 64; a.max_len = max_len;
         a.scale = 0.125f; a.out_width = H; a.ld_out = 2 * H;
         if (cls_tail && l == w->layers - 1) {
@@ -343,8 +663,11 @@ int forward_c_impl(const tt_encoder_weights_f16c* w, const int32_t* ids, const i
             TT_CHECK_LAUNCH();
             return TT_OK;
         }
-        a.out = (uint16_t*)ctx; a.out_scales = cs;
-        if (int rc = tt_attention_launch(a, st)) return rc;
+        AttnQ2Params a2{};
+        a2.qk = qk; a2.ld_qk = 4 * H; a2.q_col0 = 0; a2.k_col0 = H; a2.lo_off = 2 * H; a2.vt = vt; a2.ldvt = 8 * H;
+        a2.out = ctx; a2.out_scales = cs; a2.out_width = H; a2.seq_start = seq_start; a2.seq_len = seq_len;
+        a2.n_seq = n_seq; a2.heads = w->heads; a2.max_len = max_len; a2.scale = 0.125f;
+        if (int rc = attention_qk2_launch(a2, st)) return rc;
         GemmParams go = gemm_c(ctx, cs, lw.o_w, (const uint8_t*)lw.o_s, lw.o_b, T, H, H);
         go.res32 = x; go.ldr = H; go.C32 = y; go.ldc = H;
         if (int rc = tt_gemm_launch(go, TT_EPI_RESIDUAL, st)) return rc;
@@ -415,14 +738,14 @@ int tt_gemm_f16c(const void* a_planes, const void* a_scales, const void* w_plane
     return tt_gemm_launch(g, epilogue, (hipStream_t)stream);
 }
 
-int tt_attention_f16c(const void* qk_f16, int ld_qk, int q_col0, int k_col0, const void* vt_f16, int ldvt, void* out_planes,
+int tt_attention_f16c(const void* qk_f16, int ld_qk, int q_col0, int k_col0, int lo_off, const void* vt_f16, int ldvt, void* out_planes,
                       void* out_scales, const int32_t* seq_start, const int32_t* seq_len, int n_seq, int heads, int max_len, void* stream) {
     TT_CHECK_ARG(qk_f16 && vt_f16 && out_planes && out_scales && seq_start && seq_len, "null pointer");
-    AttnParams a{};
-    a.qk = (const uint16_t*)qk_f16; a.ld_qk = ld_qk; a.q_col0 = q_col0; a.k_col0 = k_col0; a.vt = (const uint16_t*)vt_f16; a.ldvt = ldvt;
-    a.out = (uint16_t*)out_planes; a.out_scales = (uint8_t*)out_scales; a.out_width = heads * 64; a.ld_out = 2 * heads * 64;
-    a.seq_start = seq_start; a.seq_len = seq_len; a.n_seq = n_seq; a.heads = heads; a.head_dim = 64; a.max_len = max_len; a.scale = 0.125f;
-    return tt_attention_launch(a, (hipStream_t)stream);
+    AttnQ2Params a{};
+    a.qk = (const uint16_t*)qk_f16; a.ld_qk = ld_qk; a.q_col0 = q_col0; a.k_col0 = k_col0; a.lo_off = lo_off; a.vt = (const uint16_t*)vt_f16;
+    a.ldvt = ldvt; a.out = (char*)out_planes; a.out_scales = (uint8_t*)out_scales; a.out_width = heads * 64;
+    a.seq_start = seq_start; a.seq_len = seq_len; a.n_seq = n_seq; a.heads = heads; a.max_len = max_len; a.scale = 0.125f;
+    return attention_qk2_launch(a, (hipStream_t)stream);
 }
 
 size_t tt_encoder_f16c_workspace_bytes(const tt_encoder_weights_f16c* w, int n_rows) {

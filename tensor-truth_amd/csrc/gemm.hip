@@ -96,11 +96,11 @@ __device__ __forceinline__ void gemm_epilogue_tile(const GemmParams& p, f32x4 (&
     }
 }
 
-// split-bf16 planes are bf16 whatever the element type of this build is
+// (split planes carry the element type of the build: two bf16 planes in the bf16 instantiation -- "bf16x3" --, two fp16 planes
+// in the fp16 one -- "f16x3")
 template <bool X3>
 __device__ __forceinline__ uint32_t pack_sel(float lo, float hi) {
-    if constexpr (X3) return pack_bf16x2(lo, hi);
-    else return pack_e2(lo, hi);
+    return pack_e2(lo, hi);
 }
 
 template <int EPI>
@@ -219,10 +219,10 @@ __device__ __forceinline__ void gemm_epilogue_vt(const GemmParams& p, f32x4 (&ac
             *reinterpret_cast<uint4*>(col + (size_t)(m >> 3) * p.ldvt) = o;
             if constexpr (X3) {   // lo plane: what the bf16 rounding of the hi plane left behind
                 uint4 l;
-                l.x = pack_bf16x2(v[0] - __uint_as_float(o.x << 16), v[1] - __uint_as_float(o.x & 0xFFFF0000u));
-                l.y = pack_bf16x2(v[2] - __uint_as_float(o.y << 16), v[3] - __uint_as_float(o.y & 0xFFFF0000u));
-                l.z = pack_bf16x2(v[4] - __uint_as_float(o.z << 16), v[5] - __uint_as_float(o.z & 0xFFFF0000u));
-                l.w = pack_bf16x2(v[6] - __uint_as_float(o.w << 16), v[7] - __uint_as_float(o.w & 0xFFFF0000u));
+                l.x = pack_e2(v[0] - elo(o.x), v[1] - ehi(o.x));
+                l.y = pack_e2(v[2] - elo(o.y), v[3] - ehi(o.y));
+                l.z = pack_e2(v[4] - elo(o.z), v[5] - ehi(o.z));
+                l.w = pack_e2(v[6] - elo(o.w), v[7] - ehi(o.w));
                 if (p.x3_zero_lo) l = uint4{0u, 0u, 0u, 0u};
                 *reinterpret_cast<uint4*>(p.vt_lo + (size_t)(n - p.vt_col0) * 8 + (size_t)(m >> 3) * p.ldvt) = l;
             }
@@ -709,12 +709,12 @@ __device__ __forceinline__ void epilogue_x3(const GemmParams& p, f32x4 (&acc)[2]
                             }
                         }
                         uint4 o, l;
-                        o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
-                        o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
-                        l.x = pack_bf16x2(v[0] - __uint_as_float(o.x << 16), v[1] - __uint_as_float(o.x & 0xFFFF0000u));
-                        l.y = pack_bf16x2(v[2] - __uint_as_float(o.y << 16), v[3] - __uint_as_float(o.y & 0xFFFF0000u));
-                        l.z = pack_bf16x2(v[4] - __uint_as_float(o.z << 16), v[5] - __uint_as_float(o.z & 0xFFFF0000u));
-                        l.w = pack_bf16x2(v[6] - __uint_as_float(o.w << 16), v[7] - __uint_as_float(o.w & 0xFFFF0000u));
+                        o.x = pack_e2(v[0], v[1]); o.y = pack_e2(v[2], v[3]);
+                        o.z = pack_e2(v[4], v[5]); o.w = pack_e2(v[6], v[7]);
+                        l.x = pack_e2(v[0] - elo(o.x), v[1] - ehi(o.x));
+                        l.y = pack_e2(v[2] - elo(o.y), v[3] - ehi(o.y));
+                        l.z = pack_e2(v[4] - elo(o.z), v[5] - ehi(o.z));
+                        l.w = pack_e2(v[6] - elo(o.w), v[7] - ehi(o.w));
                         if (p.x3_zero_lo) l = uint4{0u, 0u, 0u, 0u};
                         uint16_t* cp = p.C + (size_t)m * p.ldc + n;
                         *reinterpret_cast<uint4*>(cp) = o;
@@ -730,6 +730,65 @@ __device__ __forceinline__ void epilogue_x3(const GemmParams& p, f32x4 (&acc)[2]
 // further on (the other 8-column half): the block's absmax is one cross-lane exchange.  Per block: E = exponent of the absmax,
 // scale byte s = E - 7 (biased); hi = fp16(v); x8 = e4m3(v 2^(7 - E)); lo8 = e4m3((v - hi) 2^(18 - E)) -- |v - hi| <= 2^(E - 11).
 // One byte per (row, block) goes to the tiled scale array of a consumer with K = p.N.
+// f16c, Q / K projection: the output as TWO fp16 planes, hi = fp16(v) at C[m][n], lo = fp16(v - hi) at C[m][c_lo_off + n] (22
+// significand bits for the attention's score product: f16c_path.hip attention_qk2_kernel).  epilogue_x3's structure.
+__device__ __forceinline__ void epilogue_h2(const GemmParams& p, f32x4 (&acc)[2][2][2][4], const char* smem, int bias_off, int m0, int n0,
+                                            int wm, int wn, int lane) {
+    const int g = lane >> 4;
+    const bool odd = (g & 1) != 0;
+    const int ncol = wn * 64 + (g & ~1) * 4;
+    const int mrow = wm * 64 + (lane & 15);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)smem;
+    float4 bias[2][2][2];
+    {
+        const uint32_t baddr = lds0 + bias_off + ncol * 4;
+        u32x4 b[8];
+        b[0] = lds_read128_async<0>(baddr);        b[1] = lds_read128_async<16>(baddr);
+        b[2] = lds_read128_async<64>(baddr);       b[3] = lds_read128_async<80>(baddr);
+        b[4] = lds_read128_async<128>(baddr);      b[5] = lds_read128_async<144>(baddr);
+        b[6] = lds_read128_async<192>(baddr);      b[7] = lds_read128_async<208>(baddr);
+        lds_wait(b[0], b[1], b[2], b[3]);
+        lds_wait(b[4], b[5], b[6], b[7]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            bias[i >> 2][(i >> 1) & 1][i & 1] = float4{__uint_as_float(b[i].x), __uint_as_float(b[i].y), __uint_as_float(b[i].z),
+                                                       __uint_as_float(b[i].w)};
+    }
+#pragma unroll
+    for (int qm = 0; qm < 2; ++qm)
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+            const int m = m0 + qm * 128 + mrow + (pr * 2 + (odd ? 1 : 0)) * 16;
+#pragma unroll
+            for (int qn = 0; qn < 2; ++qn)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    float v[8];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[qm][qn][nt][2 * pr][k]),
+                                                                        __float_as_uint(acc[qm][qn][nt][2 * pr + 1][k]),
+                                                                        false, false);
+                        v[k] = __uint_as_float(r[0]);
+                        v[4 + k] = __uint_as_float(r[1]);
+                    }
+                    const float4 b0 = bias[qn][nt][0], b1 = bias[qn][nt][1];
+                    v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+                    v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) asm("" : "+v"(v[k]));      // opaque before the split (see epilogue_x3)
+                    uint4 o, l;
+                    o.x = pack_e2(v[0], v[1]); o.y = pack_e2(v[2], v[3]);
+                    o.z = pack_e2(v[4], v[5]); o.w = pack_e2(v[6], v[7]);
+                    l.x = pack_e2(v[0] - elo(o.x), v[1] - ehi(o.x)); l.y = pack_e2(v[2] - elo(o.y), v[3] - ehi(o.y));
+                    l.z = pack_e2(v[4] - elo(o.z), v[5] - ehi(o.z)); l.w = pack_e2(v[6] - elo(o.w), v[7] - ehi(o.w));
+                    uint16_t* cp = p.C + (size_t)m * p.ldc + n0 + qn * 32 + nt * 16 + ncol;
+                    *reinterpret_cast<uint4*>(cp) = o;
+                    *reinterpret_cast<uint4*>(cp + p.c_lo_off) = l;
+                }
+        }
+}
+
 // exact-erf GELU to fp32 grade without libm: gelu(x) = max(x, 0) - |x| / 2 * erfc(|x| / sqrt 2), erfc by the Chebyshev fit
 // t exp(-z^2 + P(t)), t = 1 / (1 + z / 2) (fractional error < 1.2e-7 for every z >= 0: the error of the GELU is below
 // 1.2e-7 of the CORRECTION term, i.e. relatively accurate on both tails).  One v_rcp_f32, ten FMAs, one v_exp_f32: the libm
@@ -1332,6 +1391,9 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
         epilogue_x3<EPI>(p, acc, smem, kBiasOff, m0, n0, wm, wn, lane);          // fp32 out = acc + bias + fp32 residual
     } else if constexpr (XC && EPI == TT_EPI_GELU) {
         epilogue_xc<EPI>(p, acc, smem, kBiasOff, m0, n0, wm, wn, lane);          // c-planes out
+    } else if constexpr (XC && EPI == TT_EPI_BIAS) {
+        if (p.c_lo_off) epilogue_h2(p, acc, smem, kBiasOff, m0, n0, wm, wn, lane);                  // two fp16 planes (Q, K)
+        else epilogue_all<EPI, true, false>(p, acc, smem, kBiasOff, kScaleOff, m0, n0, wm, wn, wave, lane, false, NoNext{});
     } else if constexpr (EPI == TT_EPI_QKV) {
 #pragma unroll
         for (int qm = 0; qm < 2; ++qm)
@@ -1698,9 +1760,9 @@ __device__ __forceinline__ void gemm_epilogue_tile_x3(const GemmParams& p, f32x4
                     }
                 }
                 uint2 o, l;
-                o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
-                l.x = pack_bf16x2(v[0] - __uint_as_float(o.x << 16), v[1] - __uint_as_float(o.x & 0xFFFF0000u));
-                l.y = pack_bf16x2(v[2] - __uint_as_float(o.y << 16), v[3] - __uint_as_float(o.y & 0xFFFF0000u));
+                o.x = pack_e2(v[0], v[1]); o.y = pack_e2(v[2], v[3]);
+                l.x = pack_e2(v[0] - elo(o.x), v[1] - ehi(o.x));
+                l.y = pack_e2(v[2] - elo(o.y), v[3] - ehi(o.y));
                 if (p.x3_zero_lo) l = uint2{0u, 0u};
                 if constexpr (EPI == TT_EPI_VT) {      // every column is a V feature: V8 layout, hi and lo planes
                     const size_t at = (size_t)(m >> 3) * p.ldvt + (size_t)(n - p.vt_col0) * 8 + (m & 7);
@@ -1850,7 +1912,10 @@ int launch_xc(const GemmParams& p, hipStream_t st) {
         } else if constexpr (EPI == TT_EPI_GELU) {
             if (!p.C || !p.c_scales || p.ldc != 2 * p.N) { tt_set_error("gemm f16c: c-planes output needs C, c_scales, ldc = 2 N"); return TT_E_INVALID; }
         } else {
-            if (!p.C || p.ldc % 8) { tt_set_error("gemm f16c: fp16 output needs C, ldc %% 8 == 0"); return TT_E_INVALID; }
+            if (!p.C || p.ldc % 8 || p.c_lo_off % 8 || (p.c_lo_off && p.c_lo_off < p.N)) {
+                tt_set_error("gemm f16c: fp16 output needs C, ldc %% 8 == 0 (two planes: c_lo_off >= N, a multiple of 8)");
+                return TT_E_INVALID;
+            }
         }
         const int mt_n = p.M / v3::BM3, nt_n = p.N / v3::BN3;
         const int SN = super_sn(nt_n), SM = 32 / SN;
@@ -1991,8 +2056,8 @@ bool tt_gemm_skinny_enabled() {
 
 int tt_gemm_launch(const GemmParams& p, int epilogue, hipStream_t st) {
     if (p.M <= 0 || p.N <= 0) return TT_OK;
-    if constexpr (kF16) {      // the fp16 instantiation serves the plain 16-bit path only
-        if (p.x3 || p.fp8) { tt_set_error("gemm (fp16 build): split-bf16 / fp8 operands belong to the bf16 instantiation"); return TT_E_UNSUPPORTED; }
+    if constexpr (kF16) {      // the fp16 instantiation: the 16-bit path, split-fp16 planes (x3) and f16c; e4m3-only GEMMs are bf16-side
+        if (p.fp8) { tt_set_error("gemm (fp16 build): fp8 operands belong to the bf16 instantiation"); return TT_E_UNSUPPORTED; }
         if (p.xc) {
             switch (epilogue) {
                 case TT_EPI_BIAS: return launch_xc<TT_EPI_BIAS>(p, st);
@@ -2006,7 +2071,7 @@ int tt_gemm_launch(const GemmParams& p, int epilogue, hipStream_t st) {
         tt_set_error("gemm (bf16 build): f16c operands belong to the fp16 instantiation");
         return TT_E_UNSUPPORTED;
     }
-    if constexpr (!kF16) if (p.x3) {
+    if (p.x3) {
         switch (epilogue) {
             case TT_EPI_BIAS: return launch_x3<TT_EPI_BIAS>(p, st);
             case TT_EPI_GELU: return launch_x3<TT_EPI_GELU>(p, st);

@@ -24,6 +24,8 @@
 #include "common.h"
 #include "encoder.h"
 
+#define TT_MFMA_32x32x16Z(a, b, c, x, y, z) TT_MFMA_32x32x16((a), (b), (c))
+
 extern "C" int tt_rerank_head_f32(const tt_encoder_weights_f32* w, const float* hidden_f32, const int32_t* rows, int n_seq,
                                   float* scores, float* logits, void* workspace, size_t workspace_bytes, void* stream);
 
@@ -41,7 +43,7 @@ __device__ __forceinline__ float wave_sum_x(float v) {
 
 // LayerNorm of a row held as x[c] (float4 = elements 256 c + 4 lane ...), two-pass fp32 statistics; writes the fp32 row
 // (out32, may be NULL) and its two bf16 planes (planes[0..H) = hi, planes[H..2H) = lo; may be NULL)
-__device__ __forceinline__ float rbf(float v) { return __uint_as_float(pack_bf16x2(v, 0.f) << 16); }   // round to bf16, kept as fp32
+__device__ __forceinline__ float rbf(float v) { return elo(pack_e2(v, 0.f)); }   // round to the planes' element type, kept as fp32
 
 // flags (diagnostic, TT_X3_ROUND_MASK): 1 = the input row is rounded to bf16 first, 2 = the output is rounded to bf16
 __device__ __forceinline__ void ln_row_x3(float4 (&x)[kMaxC4], int nc, int H, const float* gamma, const float* beta, float eps,
@@ -76,10 +78,10 @@ __device__ __forceinline__ void ln_row_x3(float4 (&x)[kMaxC4], int nc, int H, co
             if (out32) *reinterpret_cast<float4*>(out32 + e0) = y;
             if (planes) {
                 uint2 hi, lo;
-                hi.x = pack_bf16x2(y.x, y.y);
-                hi.y = pack_bf16x2(y.z, y.w);
-                lo.x = pack_bf16x2(y.x - __uint_as_float(hi.x << 16), y.y - __uint_as_float(hi.x & 0xFFFF0000u));
-                lo.y = pack_bf16x2(y.z - __uint_as_float(hi.y << 16), y.w - __uint_as_float(hi.y & 0xFFFF0000u));
+                hi.x = pack_e2(y.x, y.y);
+                hi.y = pack_e2(y.z, y.w);
+                lo.x = pack_e2(y.x - elo(hi.x), y.y - ehi(hi.x));
+                lo.y = pack_e2(y.z - elo(hi.y), y.w - ehi(hi.y));
                 *reinterpret_cast<uint2*>(planes + e0) = hi;
                 *reinterpret_cast<uint2*>(planes + H + e0) = lo;
             }
@@ -133,10 +135,10 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* in, uint
     const int c = (int)(i % c4) * 4;
     const float4 y = *reinterpret_cast<const float4*>(in + r * cols + c);
     uint2 hi, lo;
-    hi.x = pack_bf16x2(y.x, y.y);
-    hi.y = pack_bf16x2(y.z, y.w);
-    lo.x = pack_bf16x2(y.x - __uint_as_float(hi.x << 16), y.y - __uint_as_float(hi.x & 0xFFFF0000u));
-    lo.y = pack_bf16x2(y.z - __uint_as_float(hi.y << 16), y.w - __uint_as_float(hi.y & 0xFFFF0000u));
+    hi.x = pack_e2(y.x, y.y);
+    hi.y = pack_e2(y.z, y.w);
+    lo.x = pack_e2(y.x - elo(hi.x), y.y - ehi(hi.x));
+    lo.y = pack_e2(y.z - elo(hi.y), y.w - ehi(hi.y));
     *reinterpret_cast<uint2*>(planes + r * 2 * cols + c) = hi;
     *reinterpret_cast<uint2*>(planes + r * 2 * cols + cols + c) = lo;
 }
@@ -204,11 +206,11 @@ __global__ __launch_bounds__(64 * kXWaves, 2) void attention_x3_kernel(AttnX3Par
     const int q_row = (qt * kXWaves + wave) * 32 + ql;
     const int q_row_c = q_row < len ? q_row : len - 1;
     const uint16_t* qp = p.qk + (size_t)(t0 + q_row_c) * p.ld_qk + p.q_col0 + head * DH + hh * 8;
-    bf16x8 qh[KS], qlo[KS];
+    ex8 qh[KS], qlo[KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-        qh[s] = *reinterpret_cast<const bf16x8*>(qp + s * 16);
-        qlo[s] = *reinterpret_cast<const bf16x8*>(qp + p.lo_off + s * 16);
+        qh[s] = *reinterpret_cast<const ex8*>(qp + s * 16);
+        qlo[s] = *reinterpret_cast<const ex8*>(qp + p.lo_off + s * 16);
     }
 
     const int n_kt = (alen + kXKTile - 1) / kXKTile;
@@ -322,13 +324,13 @@ __global__ __launch_bounds__(64 * kXWaves, 2) void attention_x3_kernel(AttnX3Par
             // small terms first
 #pragma unroll
             for (int s = 0; s < KS; ++s)
-                acc_s[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kl[s]), qh[s], acc_s[j], 0, 0, 0);
+                acc_s[j] = TT_MFMA_32x32x16Z(__builtin_bit_cast(ex8, kl[s]), qh[s], acc_s[j], 0, 0, 0);
 #pragma unroll
             for (int s = 0; s < KS; ++s)
-                acc_s[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kh[s]), qlo[s], acc_s[j], 0, 0, 0);
+                acc_s[j] = TT_MFMA_32x32x16Z(__builtin_bit_cast(ex8, kh[s]), qlo[s], acc_s[j], 0, 0, 0);
 #pragma unroll
             for (int s = 0; s < KS; ++s)
-                acc_s[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kh[s]), qh[s], acc_s[j], 0, 0, 0);
+                acc_s[j] = TT_MFMA_32x32x16Z(__builtin_bit_cast(ex8, kh[s]), qh[s], acc_s[j], 0, 0, 0);
         }
 
         // ---- mask, running reference, exponentials (fp32).  Register r of sub-tile j is key k0 + 32 j + 16 (r>>3) + 8 hh + (r&7)
@@ -400,19 +402,19 @@ __global__ __launch_bounds__(64 * kXWaves, 2) void attention_x3_kernel(AttnX3Par
             for (int s2 = 0; s2 < 2; ++s2) {
                 uint4 ph, pl;
                 const float* e = reinterpret_cast<const float*>(&acc_s[j]) + 8 * s2;
-                ph.x = pack_bf16x2(e[0], e[1]); ph.y = pack_bf16x2(e[2], e[3]);
-                ph.z = pack_bf16x2(e[4], e[5]); ph.w = pack_bf16x2(e[6], e[7]);
-                pl.x = pack_bf16x2(e[0] - __uint_as_float(ph.x << 16), e[1] - __uint_as_float(ph.x & 0xFFFF0000u));
-                pl.y = pack_bf16x2(e[2] - __uint_as_float(ph.y << 16), e[3] - __uint_as_float(ph.y & 0xFFFF0000u));
-                pl.z = pack_bf16x2(e[4] - __uint_as_float(ph.z << 16), e[5] - __uint_as_float(ph.z & 0xFFFF0000u));
-                pl.w = pack_bf16x2(e[6] - __uint_as_float(ph.w << 16), e[7] - __uint_as_float(ph.w & 0xFFFF0000u));
+                ph.x = pack_e2(e[0], e[1]); ph.y = pack_e2(e[2], e[3]);
+                ph.z = pack_e2(e[4], e[5]); ph.w = pack_e2(e[6], e[7]);
+                pl.x = pack_e2(e[0] - elo(ph.x), e[1] - ehi(ph.x));
+                pl.y = pack_e2(e[2] - elo(ph.y), e[3] - ehi(ph.y));
+                pl.z = pack_e2(e[4] - elo(ph.z), e[5] - ehi(ph.z));
+                pl.w = pack_e2(e[6] - elo(ph.w), e[7] - ehi(ph.w));
                 if (p.round_flags & 1) pl = uint4{0u, 0u, 0u, 0u};
-                const bf16x8 pfh = __builtin_bit_cast(bf16x8, ph), pfl = __builtin_bit_cast(bf16x8, pl);
+                const ex8 pfh = __builtin_bit_cast(ex8, ph), pfl = __builtin_bit_cast(ex8, pl);
 #pragma unroll
                 for (int d = 0; d < DT; ++d) {
-                    acc_o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vl[s2][d]), pfh, acc_o[d], 0, 0, 0);
-                    acc_o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vh[s2][d]), pfl, acc_o[d], 0, 0, 0);
-                    acc_o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vh[s2][d]), pfh, acc_o[d], 0, 0, 0);
+                    acc_o[d] = TT_MFMA_32x32x16Z(__builtin_bit_cast(ex8, vl[s2][d]), pfh, acc_o[d], 0, 0, 0);
+                    acc_o[d] = TT_MFMA_32x32x16Z(__builtin_bit_cast(ex8, vh[s2][d]), pfl, acc_o[d], 0, 0, 0);
+                    acc_o[d] = TT_MFMA_32x32x16Z(__builtin_bit_cast(ex8, vh[s2][d]), pfh, acc_o[d], 0, 0, 0);
                 }
             }
         }
@@ -431,10 +433,10 @@ __global__ __launch_bounds__(64 * kXWaves, 2) void attention_x3_kernel(AttnX3Par
                       y3 = acc_o[d][4 * g + 3] * inv;
                 asm("" : "+v"(y0), "+v"(y1), "+v"(y2), "+v"(y3));   // opaque: no fusing of "* inv" into the "y - hi" below (see epilogue_x3)
                 uint2 hi, lo;
-                hi.x = pack_bf16x2(y0, y1);
-                hi.y = pack_bf16x2(y2, y3);
-                lo.x = pack_bf16x2(y0 - __uint_as_float(hi.x << 16), y1 - __uint_as_float(hi.x & 0xFFFF0000u));
-                lo.y = pack_bf16x2(y2 - __uint_as_float(hi.y << 16), y3 - __uint_as_float(hi.y & 0xFFFF0000u));
+                hi.x = pack_e2(y0, y1);
+                hi.y = pack_e2(y2, y3);
+                lo.x = pack_e2(y0 - elo(hi.x), y1 - ehi(hi.x));
+                lo.y = pack_e2(y2 - elo(hi.y), y3 - ehi(hi.y));
                 if (p.round_flags & 2) lo = uint2{0u, 0u};
                 *reinterpret_cast<uint2*>(op + 32 * d + 8 * g + 4 * hh) = hi;
                 *reinterpret_cast<uint2*>(op + p.out_lo_off + 32 * d + 8 * g + 4 * hh) = lo;
@@ -474,10 +476,10 @@ __global__ __launch_bounds__(64) void attention_cls_x3_kernel(AttnX3Params p) {
     const int len = p.seq_len[seq], t0 = p.seq_start[seq];
     const int t0a = t0 & ~7, off = t0 - t0a, alen = off + len;
     auto add8 = [](const uint4& h, const uint4& l, float (&f)[8]) {
-        f[0] = __uint_as_float(h.x << 16) + __uint_as_float(l.x << 16); f[1] = __uint_as_float(h.x & 0xFFFF0000u) + __uint_as_float(l.x & 0xFFFF0000u);
-        f[2] = __uint_as_float(h.y << 16) + __uint_as_float(l.y << 16); f[3] = __uint_as_float(h.y & 0xFFFF0000u) + __uint_as_float(l.y & 0xFFFF0000u);
-        f[4] = __uint_as_float(h.z << 16) + __uint_as_float(l.z << 16); f[5] = __uint_as_float(h.z & 0xFFFF0000u) + __uint_as_float(l.z & 0xFFFF0000u);
-        f[6] = __uint_as_float(h.w << 16) + __uint_as_float(l.w << 16); f[7] = __uint_as_float(h.w & 0xFFFF0000u) + __uint_as_float(l.w & 0xFFFF0000u);
+        f[0] = elo(h.x) + elo(l.x); f[1] = ehi(h.x) + ehi(l.x);
+        f[2] = elo(h.y) + elo(l.y); f[3] = ehi(h.y) + ehi(l.y);
+        f[4] = elo(h.z) + elo(l.z); f[5] = ehi(h.z) + ehi(l.z);
+        f[6] = elo(h.w) + elo(l.w); f[7] = ehi(h.w) + ehi(l.w);
     };
     float q[DH];
     {
@@ -532,8 +534,8 @@ __global__ __launch_bounds__(64) void attention_cls_x3_kernel(AttnX3Params p) {
     o /= sum;
     const float hi = rbf(o);
     uint16_t* op = p.out + (size_t)seq * p.ld_out + head * DH + d;
-    op[0] = (uint16_t)(__float_as_uint(hi) >> 16);
-    op[p.out_lo_off] = (uint16_t)(pack_bf16x2(o - hi, 0.f) & 0xFFFFu);
+    op[0] = (uint16_t)(pack_e2(hi, 0.f) & 0xFFFFu);
+    op[p.out_lo_off] = (uint16_t)(pack_e2(o - hi, 0.f) & 0xFFFFu);
 }
 
 // rows seq_start[b] of an fp32 [T][H] matrix -> dst [n_pad][H] (rows beyond n: zeros)

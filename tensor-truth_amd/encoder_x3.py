@@ -46,11 +46,16 @@ def supports(cfg: EncoderConfig) -> bool:
             and cfg.layers > 0)
 
 
-def split_planes(w: torch.Tensor) -> torch.Tensor:
-    """fp32 [out][in] -> bf16 planes [out][2 in]: hi = bf16(w), lo = bf16(w - hi) side by side (``GemmParams.x3``)."""
+def split_planes(w: torch.Tensor, dtype: torch.dtype = torch.bfloat16) -> torch.Tensor:
+    """fp32 [out][in] -> planes [out][2 in] of ``dtype``: hi = dtype(w), lo = dtype(w - hi) side by side (``GemmParams.x3``).
+    bfloat16: "bf16x3" (16 significand bits per operand); float16: "f16x3" (22; values beyond +-65504 saturate in hi)."""
     w = w.to(torch.float32)
-    hi = w.to(torch.bfloat16)
-    lo = (w - hi.to(torch.float32)).to(torch.bfloat16)
+    if dtype == torch.float16:
+        hi = w.clamp(-65504.0, 65504.0).to(torch.float16)
+        lo = (w - hi.to(torch.float32)).clamp(-65504.0, 65504.0).to(torch.float16)
+    else:
+        hi = w.to(torch.bfloat16)
+        lo = (w - hi.to(torch.float32)).to(torch.bfloat16)
     return torch.cat([hi, lo], dim=1).contiguous()
 
 
@@ -60,9 +65,16 @@ class EncoderWeightsX3:
 
     gemm_dtype = "bf16x3"
 
-    def __init__(self, cfg: EncoderConfig, state: Dict[str, torch.Tensor], device: torch.device, round_weights: bool = False):
-        """``round_weights`` (diagnostic, tools/probes/bf16_error_budget.py): every tensor the bf16 path keeps in bf16 -- the
+    def __init__(self, cfg: EncoderConfig, state: Dict[str, torch.Tensor], device: torch.device, round_weights: bool = False,
+                 dtype: torch.dtype = torch.bfloat16):
+        """``dtype``: the planes' element type -- bfloat16 ("bf16x3", round 3) or float16 ("f16x3", round 4: the default
+        implementation of the reference precision; ``EncoderX3`` then calls the library's ``*_f16`` entry points).
+        ``round_weights`` (diagnostic, tools/probes/bf16_error_budget.py): every tensor the bf16 path keeps in bf16 -- the
         matrices and the embedding tables -- is rounded to bf16 first, i.e. the weights' share of the bf16 mode's error."""
+        if dtype not in (torch.bfloat16, torch.float16):
+            raise ValueError("split planes are bfloat16 or float16")
+        self.dtype = dtype
+        self.gemm_dtype = "f16x3" if dtype == torch.float16 else "bf16x3"
         if device.type != "cuda":
             raise RuntimeError("EncoderWeightsX3 need a HIP device; tensor_truth_amd has no CPU path")
         if not supports(cfg):
@@ -79,7 +91,7 @@ class EncoderWeightsX3:
         def planes(x):
             if round_weights:
                 x = x.to(torch.bfloat16)
-            x = split_planes(x.to(device=device))
+            x = split_planes(x.to(device=device), dtype)
             self._keep.append(x)
             return x
 
@@ -115,7 +127,7 @@ class EncoderWeightsX3:
         self.struct = w
 
     def set_gemm_dtype(self, dtype: str) -> None:
-        if dtype not in ("bf16x3", "reference", "float32", "fp32"):
+        if dtype not in ("bf16x3", "f16x3", "reference", "float32", "fp32"):
             raise ValueError(f"split-bf16 weights run in reference precision only (asked for {dtype!r})")
 
     def parameters(self) -> Iterable[torch.Tensor]:
@@ -151,6 +163,7 @@ class EncoderX3:
     def __init__(self, weights: EncoderWeightsX3):
         self.w, self.cfg, self.device = weights, weights.cfg, weights.device
         self.lib = _lib.load_library()
+        self._sfx = "_f16" if getattr(weights, "dtype", torch.bfloat16) == torch.float16 else ""      # fp16 planes: the second instantiation
         self._enqueue_lock = _ENQUEUE_LOCKS.setdefault((self.device.type, self.device.index), threading.Lock())
 
     def _upload(self, batch: PackedBatch):
@@ -164,10 +177,10 @@ class EncoderX3:
         batch = _pad_rows(batch)
         ids, pos, types, starts, lens = self._upload(batch)
         hidden = torch.empty((batch.n_rows, H), dtype=torch.float32, device=dev)
-        need = lib.tt_encoder_x3_workspace_bytes(ctypes.byref(self.w.struct), batch.n_rows)
+        need = getattr(lib, "tt_encoder_x3_workspace_bytes" + self._sfx)(ctypes.byref(self.w.struct), batch.n_rows)
         with self._enqueue_lock, torch.cuda.device(dev):
             ws, base = _scratch.get("encx3", dev, need)
-            rc = lib.tt_encoder_forward_x3(ctypes.byref(self.w.struct), ids.data_ptr(), pos.data_ptr(),
+            rc = getattr(lib, "tt_encoder_forward_x3" + self._sfx)(ctypes.byref(self.w.struct), ids.data_ptr(), pos.data_ptr(),
                                            types.data_ptr() if types is not None else None, starts.data_ptr(),
                                            lens.data_ptr(), len(batch.seq_len), batch.n_rows, batch.max_len,
                                            hidden.data_ptr(), base, need, torch.cuda.current_stream(dev).cuda_stream)
@@ -183,10 +196,10 @@ class EncoderX3:
         ids, pos, types, starts, lens = self._upload(batch)
         b_pad = (B + 63) // 64 * 64 if B <= 256 else (B + 255) // 256 * 256
         cls = torch.empty((b_pad, H), dtype=torch.float32, device=dev)
-        need = lib.tt_encoder_x3_cls_workspace_bytes(ctypes.byref(self.w.struct), batch.n_rows, B)
+        need = getattr(lib, "tt_encoder_x3_cls_workspace_bytes" + self._sfx)(ctypes.byref(self.w.struct), batch.n_rows, B)
         with self._enqueue_lock, torch.cuda.device(dev):
             ws, base = _scratch.get("encx3", dev, need)
-            rc = lib.tt_encoder_forward_x3_cls(ctypes.byref(self.w.struct), ids.data_ptr(), pos.data_ptr(),
+            rc = getattr(lib, "tt_encoder_forward_x3_cls" + self._sfx)(ctypes.byref(self.w.struct), ids.data_ptr(), pos.data_ptr(),
                                                types.data_ptr() if types is not None else None, starts.data_ptr(),
                                                lens.data_ptr(), B, batch.n_rows, batch.max_len, cls.data_ptr(), base, need,
                                                torch.cuda.current_stream(dev).cuda_stream)
@@ -224,7 +237,7 @@ class EncoderX3:
         need = 2 * ((n_pad * H * 4 + 255) // 256 * 256)
         with self._enqueue_lock, torch.cuda.device(self.device):
             ws, base = _scratch.get("headx3", self.device, need)
-            rc = self.lib.tt_rerank_head_x3(ctypes.byref(self.w.struct), hidden.data_ptr(), rows.data_ptr(), B,
+            rc = getattr(self.lib, "tt_rerank_head_x3" + self._sfx)(ctypes.byref(self.w.struct), hidden.data_ptr(), rows.data_ptr(), B,
                                             scores.data_ptr(), logits.data_ptr() if want_logits else None, base, need,
                                             torch.cuda.current_stream(self.device).cuda_stream)
         _lib.check(rc, "tt_rerank_head_x3")

@@ -9,11 +9,16 @@ BASELINE.json's configurations name bf16 (and fp8 for config 5): those are the m
 "bfloat16"`` in the per-model config, as the reference's own config schema allows; ``TT_PRECISION=bf16``;
 ``ModelManager.set_precision("bf16")``), and the ones ``bench.py`` names for its headline.
 
-    mode "reference"  fp32 semantics: scores within north_star's 1e-3 relative of the CPU path.  Runs as "f16c" -- fp16
-                      main products + block-scaled e4m3 correction terms, HALF the bf16 matrix rate (``encoder_f16c``,
-                      round 4) -- when the model shape allows (hidden a multiple of 256, 64-wide heads), else on the fp32
-                      MFMA (``encoder_f32``, 1/16).  ``TT_REFERENCE_IMPL=bf16x3`` selects round 3's split-bf16
-                      implementation (``encoder_x3``, a third of the bf16 rate), ``TT_REFERENCE_IMPL=fp32`` the fp32 MFMA.
+    mode "reference"  fp32 semantics: scores within north_star's 1e-3 relative of the CPU path.  Implementations
+                      (``TT_REFERENCE_IMPL``), all for hidden a multiple of 256 with 64-wide heads, else "fp32":
+                        "f16x3"  (default, round 4) every operand as two fp16 planes, three fp16 MFMA products per product
+                                 (``encoder_x3`` on fp16 planes): a third of the bf16 matrix rate, 22 significand bits -- holds
+                                 1e-3 with a margin even on weights with trained-model statistics (tests/stress_weights.py)
+                        "f16c"   fp16 main products + block-scaled e4m3 correction terms (``encoder_f16c``): HALF the bf16
+                                 rate, 1e-4 on the standard fixture, but 7e-3 relative on the stress fixture's smallest scores
+                                 (ranking intact): the fast variant, for callers who accept that
+                        "bf16x3" round 3's two bf16 planes (16 bits): 2e-5 / 1.0e-3 (standard / stress)
+                        "fp32"   the fp32 MFMA (``encoder_f32``, 1/16 of the bf16 rate)
     mode "bf16"       bf16 weights / activations, fp32 accumulate (BASELINE configs 2-4; the reference's ``torch_dtype: bfloat16``)
     mode "fp16"       IEEE fp16 weights / activations, fp32 accumulate: the bf16 mode's rate (v_mfma_*_f16) with three more
                       mantissa bits at every rounding point -- scores about ten times closer to the reference than bf16;
@@ -72,8 +77,8 @@ def resolve(model_kwargs: Optional[Dict[str, Any]] = None, environ=None) -> str:
 
 
 def reference_impl(cfg, environ=None) -> str:
-    """"f16c" (fp16 + e4m3 corrections: two matrix-time units) where the model shape fits, else "fp32" (fp32 MFMA);
-    ``TT_REFERENCE_IMPL`` = "bf16x3" / "fp32" forces one of the older implementations."""
+    """"f16x3" (two fp16 planes per operand: three matrix-time units) where the model shape fits, else "fp32" (fp32 MFMA);
+    ``TT_REFERENCE_IMPL`` = "f16c" / "bf16x3" / "fp32" selects another implementation."""
     from . import encoder_f16c, encoder_x3
 
     forced = (os.environ if environ is None else environ).get("TT_REFERENCE_IMPL", "").strip().lower()
@@ -81,7 +86,9 @@ def reference_impl(cfg, environ=None) -> str:
         return "fp32"
     if forced in ("bf16x3", "x3", "split-bf16"):
         return "bf16x3" if encoder_x3.supports(cfg) else "fp32"
-    return "f16c" if encoder_f16c.supports(cfg) else "fp32"
+    if forced in ("f16c", "fast"):
+        return "f16c" if encoder_f16c.supports(cfg) else "fp32"
+    return "f16x3" if encoder_x3.supports(cfg) else "fp32"
 
 
 def build_encoder(cfg, state, device, model_kwargs: Optional[Dict[str, Any]], what: str) -> Tuple[Any, Any, str]:
@@ -97,6 +104,13 @@ def build_encoder(cfg, state, device, model_kwargs: Optional[Dict[str, Any]], wh
             w = EncoderWeightsF16C(cfg, state, device)
             enc, desc = EncoderF16C(w), ("reference (fp32 semantics as fp16 products + block-scaled e4m3 correction terms on the "
                                          "matrix cores, fp32 residual stream)")
+        elif impl == "f16x3":
+            import torch
+
+            from .encoder_x3 import EncoderWeightsX3, EncoderX3
+
+            w = EncoderWeightsX3(cfg, state, device, dtype=torch.float16)
+            enc, desc = EncoderX3(w), "reference (fp32 semantics as split-fp16 on the fp16 matrix cores, fp32 residual stream)"
         elif impl == "bf16x3":
             from .encoder_x3 import EncoderWeightsX3, EncoderX3
 

@@ -226,10 +226,11 @@ def test_embedding_does_not_depend_on_the_batch(dev, built_lib):
 
 
 @pytest.mark.default_precision
-def test_the_unchanged_reference_calls_run_f16c(dev, built_lib, monkeypatch):
+def test_the_unchanged_reference_calls_and_their_implementations(dev, built_lib, monkeypatch):
     """SentenceTransformerRerank(model=, top_n=, device=) and the embedder, with no dtype anywhere (services/model_manager.py:
-    333-337, 218-229): the default mode is the reference's own precision and its implementation is this path -- scores within
-    1e-3 relative of the fp32 oracle (measured ~1e-5); TT_REFERENCE_IMPL picks the older implementations."""
+    333-337, 218-229): the default mode is the reference's own precision, implemented on split-fp16 planes ("f16x3": the one that
+    holds 1e-3 on the stress weights too); TT_REFERENCE_IMPL=f16c selects this file's faster path, bf16x3 / fp32 the older ones --
+    all within 1e-3 relative of the fp32 oracle here."""
     from tensor_truth_amd.encoder import EncoderConfig
     from tensor_truth_amd.encoder_f16c import EncoderF16C
     from tensor_truth_amd.encoder_f32 import EncoderF32
@@ -244,6 +245,10 @@ def test_the_unchanged_reference_calls_run_f16c(dev, built_lib, monkeypatch):
     texts = [" ".join(f"w{(7 * i + j) % 50}" for j in range(5 + 3 * i)) for i in range(9)]
     query = "w1 w2 w3 which one"
     rr = HipSentenceTransformerRerank(model="test/xenc", top_n=3, device="cuda", model_kwargs=dict(base))
+    assert isinstance(rr._encoder, EncoderX3) and rr._encoder.w.dtype == torch.float16 and rr.precision.startswith("reference")
+    got_default = torch.tensor(rr.predict([(query, t) for t in texts]))
+    monkeypatch.setenv("TT_REFERENCE_IMPL", "f16c")
+    rr = HipSentenceTransformerRerank(model="test/xenc", top_n=3, device="cuda", model_kwargs=dict(base))
     assert isinstance(rr._encoder, EncoderF16C) and rr.precision.startswith("reference")
     got = torch.tensor(rr.predict([(query, t) for t in texts]))
     toks = [rr._tokenizer.encode_pair(query, t, rr.max_length)[0] for t in texts]
@@ -255,10 +260,12 @@ def test_the_unchanged_reference_calls_run_f16c(dev, built_lib, monkeypatch):
         mask[i, : len(t)] = 1
     want = oe.rerank_scores(ids, mask, W, cfg_o)
     assert ((got - want).abs() / want.abs()).max().item() < 1e-4
+    assert ((got_default - want).abs() / want.abs()).max().item() < 1e-4
     emb = HipHuggingFaceEmbedding("test/emb", device="cuda",
                                   model_kwargs={"encoder_config": EncoderConfig(**{**XLMR, "num_labels": 0}), "state_dict": W})
     assert isinstance(emb._encoder, EncoderF16C)
     monkeypatch.setenv("TT_REFERENCE_IMPL", "bf16x3")
-    assert isinstance(HipSentenceTransformerRerank(model="test/xenc", top_n=3, device="cuda", model_kwargs=dict(base))._encoder, EncoderX3)
+    rr3 = HipSentenceTransformerRerank(model="test/xenc", top_n=3, device="cuda", model_kwargs=dict(base))
+    assert isinstance(rr3._encoder, EncoderX3) and rr3._encoder.w.dtype == torch.bfloat16
     monkeypatch.setenv("TT_REFERENCE_IMPL", "fp32")
     assert isinstance(HipSentenceTransformerRerank(model="test/xenc", top_n=3, device="cuda", model_kwargs=dict(base))._encoder, EncoderF32)

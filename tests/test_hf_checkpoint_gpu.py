@@ -320,6 +320,6 @@ def test_xlmr_base_reranker_shape_vs_oracle(dev, built_lib):
                                           model_kwargs={"encoder_config": cfg, "state_dict": W, "precision": precision,
                                                         "tokenizer": HashTokenizer("xlmr", 4000)})
         assert rr.activation == "sigmoid" and rr.precision.startswith(precision)
-        assert precision != "reference" or "fp16 products" in rr.precision       # 768 = 12 heads x 64: the f16c kernels take it
+        assert precision != "reference" or "split-fp16" in rr.precision          # 768 = 12 heads x 64: the split-plane kernels take it
         got = rr.score_token_pairs(seqs).cpu()
         assert (got - want).abs().max().item() < bound, precision

@@ -290,9 +290,12 @@ def test_f16c_scores_within_1e3_relative_at_full_depth(dev, built_lib, oracle_sc
 # an entropy of 1.5 bits (logits of tens), and the calibrated head spreads a query's candidates over ~6 logits.  There is no
 # network for real checkpoints: this is the offline stand-in for them.  Bounds below are MEASURED on this fixture and asserted
 # with a margin; DESIGN.md section 2 carries them as the "stress" column of the tolerance table.
-STRESS_REFERENCE_REL = 1e-3    # north_star's bar, for the reference-precision implementations
-STRESS_FP16_BOUND = 2e-2       # absolute, fp16 mode (measured below)
-STRESS_BF16_BOUND = 1.5e-1     # absolute, bf16 mode (measured below)
+STRESS_REFERENCE_REL = 1e-3    # north_star's bar: the DEFAULT implementation of the reference precision (f16x3) holds it here too
+STRESS_REL = {"f16x3": 1e-3,   # measured 1.7e-4 (CPU emulation: profiles/r04_f16c_emulation_stress.log)
+              "bf16x3": 1.5e-3,  # measured 1.0017e-3: two bf16 planes carry 16 bits -- AT the bar when logits reach ~100
+              "f16c": 1.2e-2}    # measured 7.2e-3 (on scores of ~0.005: 2e-3 absolute): the fast variant's stated bound
+STRESS_FP16_BOUND = 3e-2       # absolute, fp16 mode (measured 2.0e-2)
+STRESS_BF16_BOUND = 2e-1       # absolute, bf16 mode (measured 1.4e-1)
 
 
 @pytest.fixture(scope="module")
@@ -324,10 +327,10 @@ def _mode_scores(dev, W, pairs, mode):
         from tensor_truth_amd.encoder_f16c import EncoderF16C, EncoderWeightsF16C
 
         enc = EncoderF16C(EncoderWeightsF16C(cfg, W, dev))
-    elif mode == "bf16x3":
+    elif mode in ("bf16x3", "f16x3"):
         from tensor_truth_amd.encoder_x3 import EncoderWeightsX3, EncoderX3
 
-        enc = EncoderX3(EncoderWeightsX3(cfg, W, dev))
+        enc = EncoderX3(EncoderWeightsX3(cfg, W, dev, dtype=torch.float16 if mode == "f16x3" else torch.bfloat16))
     else:
         enc = Encoder(EncoderWeights(cfg, W, dev, dtype=torch.float16 if mode == "fp16" else torch.bfloat16))
         if mode == "fp8":
@@ -348,16 +351,19 @@ def _report(name, want, got):
     return err.max().item(), rel, min(taus), min(over)
 
 
-@pytest.mark.parametrize("mode", ["f16c", "bf16x3"])
-def test_stress_weights_reference_precision_within_1e3_relative(dev, built_lib, stress_oracle_scores, mode):
-    """Both implementations of the reference mode on the stress weights: still inside north_star's 1e-3 relative, the oracle's
-    ranking reproduced -- massive activations sharing a 32-element scale block with ordinary features (the e4m3 correction
-    planes' worst case) and attention logits of tens included."""
+@pytest.mark.parametrize("mode", ["f16x3", "f16c", "bf16x3"])
+def test_stress_weights_reference_precision_implementations(dev, built_lib, stress_oracle_scores, mode):
+    """The implementations of the reference mode on the stress weights.  f16x3 -- the default -- is still inside north_star's
+    1e-3 relative with the oracle's ranking reproduced; bf16x3 sits at the bar (16-bit operands against logits of ~100) and the
+    two-unit f16c path is outside it on the smallest scores (its e4m3 correction terms and single-fp16 P.V leave ~2e-3
+    absolute; ranking intact): each is held to its MEASURED, stated bound, which is why f16x3 is the default."""
     ocfg, W, pairs, want = stress_oracle_scores
     got = _mode_scores(dev, W, pairs, mode)
     err, rel, tau, over = _report(mode, want, got)
     assert torch.isfinite(got).all()
-    assert rel <= STRESS_REFERENCE_REL, f"{mode} on stress weights: relative score error {rel}"
+    assert rel <= STRESS_REL[mode], f"{mode} on stress weights: relative score error {rel}"
+    if mode == "f16x3":
+        assert rel <= STRESS_REFERENCE_REL
     assert tau >= 0.995 and over >= 0.9
     for q in range(N_QUERIES):
         assert_order_on_separable(want[q].numpy(), got[q].numpy(), 2 * err + 1e-6, f"{mode} stress query {q}")
@@ -377,3 +383,34 @@ def test_stress_weights_16bit_modes_stay_finite_and_bounded(dev, built_lib, stre
         assert err <= STRESS_BF16_BOUND
     else:
         assert tau >= 0.2            # (a throughput mode: its gate is that it still ranks better than chance, stated as measured)
+
+
+def test_f16x3_scores_within_1e3_relative_at_full_depth(dev, built_lib, oracle_scores):
+    """The DEFAULT implementation of the reference precision (round 4): split-fp16 planes, three fp16 MFMA products per product --
+    north_star's "fp scores within 1e-3 relative" for all 200 pairs, Kendall tau = 1.000, top-10 identical (and, unlike the
+    other implementations, on the stress fixture too: test_stress_weights_reference_precision_implementations)."""
+    import time
+
+    from tensor_truth_amd.encoder import EncoderConfig, pack_token_matrix
+    from tensor_truth_amd.encoder_x3 import EncoderWeightsX3, EncoderX3
+
+    ocfg, W, pairs, want = oracle_scores
+    cfg = EncoderConfig(**SHAPE)
+    enc = EncoderX3(EncoderWeightsX3(cfg, W, dev, dtype=torch.float16))
+    flat = pairs.reshape(-1, PAIR_TOKENS).astype(np.int32)
+    enc.rerank_packed(pack_token_matrix(flat, cfg))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    got = enc.rerank_packed(pack_token_matrix(flat, cfg)).cpu().view(N_QUERIES, N_PAIRS)
+    dt_b = (time.perf_counter() - t0) / N_QUERIES
+    rel = ((got - want).abs() / want.abs()).max().item()
+    assert rel <= 1e-3, f"f16x3 path: relative score error {rel}"
+    n_sep = 0
+    for q in range(N_QUERIES):
+        n_sep += assert_order_on_separable(want[q].numpy(), got[q].numpy(), 2e-4, f"f16x3 query {q}")
+        assert_topn_on_separable(want[q].numpy(), got[q].numpy(), TOP_N, 2e-4, f"f16x3 query {q}")
+    taus = [kendall_tau(want[q].numpy(), got[q].numpy()) for q in range(N_QUERIES)]
+    over = [topn_overlap(want[q].numpy(), got[q].numpy(), TOP_N) for q in range(N_QUERIES)]
+    print(f"f16x3 @24L: max relative score error {rel:.2e}; {n_sep} pairs separable at 2e-4 all ordered as the oracle; Kendall tau min "
+          f"{min(taus):.4f}; top-{TOP_N} overlap min {min(over):.2f}; {dt_b * 1e3:.1f} ms per query in a batch of {N_QUERIES} ({1.0 / dt_b:.1f} q/s)")
+    assert min(taus) >= 0.999 and min(over) == 1.0

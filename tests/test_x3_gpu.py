@@ -149,8 +149,12 @@ def test_attention_x3_against_fp64(dev, built_lib, lens):
     assert not out.cpu()[~used].any()                   # rows of no sequence are not written
 
 
+@pytest.mark.parametrize("planes", [torch.bfloat16, torch.float16], ids=["bf16x3", "f16x3"])
 @pytest.mark.parametrize("shape", [XLMR, WIDE], ids=["xlmr256", "wide1024"])
-def test_x3_forward_matches_the_fp32_oracle(dev, built_lib, shape):
+def test_x3_forward_matches_the_fp32_oracle(dev, built_lib, shape, planes):
+    """Both instantiations of the split-plane forward: two bf16 planes per operand ("bf16x3", round 3) and two fp16 planes
+    ("f16x3", round 4: x3_path.hip / gemm.hip compiled a second time with the fp16 element helpers; the default implementation
+    of the reference precision)."""
     from tensor_truth_amd.encoder import EncoderConfig, pack_tokens
     from tensor_truth_amd.encoder_x3 import EncoderWeightsX3, EncoderX3
 
@@ -159,7 +163,7 @@ def test_x3_forward_matches_the_fp32_oracle(dev, built_lib, shape):
     g = torch.Generator().manual_seed(4)
     lens = [n for n in (cfg.max_seq_len, 65, 129, 33, 7, 200, 100, 17)]
     seqs = [[0] + torch.randint(4, cfg.vocab_size, (n - 2,), generator=g).tolist() + [2] for n in lens]
-    enc = EncoderX3(EncoderWeightsX3(cfg, W, dev))
+    enc = EncoderX3(EncoderWeightsX3(cfg, W, dev, dtype=planes))
     batch = pack_tokens(seqs, cfg)
     hidden, _ = enc.forward_packed(batch)
     emb, emb16 = enc.embed_packed(batch)

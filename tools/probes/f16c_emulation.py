@@ -101,10 +101,31 @@ def forward(ids, mask, W, cfg, variant, wcache):
             wh, wl = wcache[wn]
             xh = bf16(x); xl = bf16(x - xh)
             return xh @ wh.T + xh @ wl.T + xl @ wh.T + f(bn)
+    elif variant.startswith("f16x3"):
+        # fp16 hi + fp16 lo planes, three fp16 products per product (split-bf16's scheme on fp16 planes: 22 significand bits)
+        def lin(x, wn, bn):
+            if wn not in wcache:
+                w = f(wn); wh = f16(w); wcache[wn] = (wh, f16(w - wh))
+            wh, wl = wcache[wn]
+            xh = f16(x); xl = f16(x - xh)
+            return xh @ wh.T + xh @ wl.T + xl @ wh.T + f(bn)
     else:
-        lin = lambda x, wn, bn: lin_f16c(x, wsplit(wn), f(bn), variant.split("+")[0])  # noqa: E731
+        def lin_h3(x, wn, bn):
+            if ("h3", wn) not in wcache:
+                w = f(wn); wh = f16(w); wcache[("h3", wn)] = (wh, f16(w - wh))
+            wh, wl = wcache[("h3", wn)]
+            xh = f16(x); xl = f16(x - xh)
+            return xh @ wh.T + xh @ wl.T + xl @ wh.T + f(bn)
+
+        def lin(x, wn, bn):
+            # "+qkh3": the query / key projections on three fp16 products (their outputs ARE the logits' operands), the rest f16c
+            if "+qkh3" in variant and (".query." in wn or ".key." in wn):
+                return lin_h3(x, wn, bn)
+            return lin_f16c(x, wsplit(wn), f(bn), variant.split("+")[0])
     att16 = variant not in ("fp32", "bf16x3") and "+att32" not in variant
     ra = f16 if att16 else (lambda t: t)
+    if variant.startswith("f16x3"):
+        ra = lambda t: f16(t) + f16(t - f16(t))  # noqa: E731   (hi + lo planes everywhere in the attention)
     # "+qk32": Q and K at full precision in the score product (what hi + lo planes for Q / K would give), V and P still fp16
     rqk = (lambda t: t) if "+qk32" in variant else ra
     # "+qkb16": Q and K as TWO bf16 planes (the split-bf16 kernel's score product: 16 significand bits)
