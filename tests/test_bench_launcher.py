@@ -91,3 +91,40 @@ def test_self_launch_retries_once_with_the_other_ipc_mode(tmp_path):
     r = subprocess.run([sys.executable, str(driver), "neither"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 5 and r.stdout.strip() == ""
     assert r.stderr.count("\nattempt with") + r.stderr.startswith("attempt with") == 2    # exactly one retry
+
+
+def _preflight_rank(rank, world, port, ret):
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        bench.preflight_collectives(dist, torch, torch.device("cpu"), rank, world)
+        ret.put((rank, "ok"))
+        # a rank that lies about its identity must be caught by its peers' value checks, not pass silently
+        try:
+            bench.preflight_collectives(dist, torch, torch.device("cpu"), rank if rank == 0 else rank + 5, world)
+            ret.put((rank, "undetected"))
+        except RuntimeError as e:
+            ret.put((rank, "caught: " + str(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_preflight_collectives_on_two_gloo_ranks():
+    """The collective pre-flight every world > 1 bench run starts with: passes on a healthy group and raises, naming the rank
+    and the collective, when a block arrives with another rank's values."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = bench._free_port()
+    procs = [ctx.Process(target=_preflight_rank, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [ret.get(timeout=120) for _ in range(4)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(g for g in got if g[1] == "ok") == [(0, "ok"), (1, "ok")]
+    rest = [g for g in got if g[1] != "ok"]
+    assert len(rest) == 2 and all(g[1].startswith("caught: pre-flight:") for g in rest), rest

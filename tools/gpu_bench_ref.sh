@@ -12,5 +12,7 @@ c = j["config"]
 print("headline", j["value"], "ms/step", j["ms_per_step"], "stage", j["stage_ms_per_step"])
 r = c["reference_precision"]
 print("reference", r["queries_per_s"], "ms/step", r["ms_per_step"], "stage", r["stage_ms_per_step"], "gemm launches", r["gemm_launches_per_step"])
+f = r["fast_variant_f16c"]
+print("reference fast (f16c)", f["queries_per_s"], "ms/step", f["ms_per_step"], "stage", f["stage_ms_per_step"])
 print("quality", r["score_quality_vs_fp32_path"])
 PY
