@@ -218,6 +218,63 @@ def passage_tokens(idx: np.ndarray, length: int, vocab: int) -> np.ndarray:
     return (h % np.uint64(vocab - 4) + np.uint64(4)).astype(np.int32)
 
 
+class ClockSampler:
+    """Shader clock and socket power of this rank's GPU, sampled by a thread while the timed steps run (amdsmi; absent or failing
+    -> every field null).  The encoder GEMMs run the chip INTO ITS POWER CAP: with random operands the 1400 W limit holds the
+    shader clock at 1.85-1.95 GHz of the 2.4 GHz the 2.5 PFLOP/s peak is quoted at (profiles/r04_power_cap.log), so the JSON
+    line carries what the clock was while `roofline.achieved` was measured."""
+
+    def __init__(self, index, period_s=0.1):
+        self.samples, self.err, self._stop, self._thread, self._h, self._smi = [], None, False, None, None, None
+        self.period_s = period_s
+        try:
+            import amdsmi
+            amdsmi.amdsmi_init()
+            hs = amdsmi.amdsmi_get_processor_handles()
+            self._h, self._smi = hs[index if index < len(hs) else 0], amdsmi
+        except Exception as e:  # noqa: BLE001
+            self.err = f"{type(e).__name__}: {e}"[:200]
+
+    def _read(self):
+        smi = self._smi
+        clk = smi.amdsmi_get_clock_info(self._h, smi.AmdSmiClkType.GFX)
+        pw = smi.amdsmi_get_power_info(self._h)
+        return clk.get("clk"), clk.get("max_clk"), pw.get("socket_power", pw.get("current_socket_power")), pw.get("power_limit")
+
+    def start(self):
+        if self._h is None:
+            return self
+        import threading
+
+        def loop():
+            while not self._stop:
+                try:
+                    self.samples.append(self._read())
+                except Exception as e:  # noqa: BLE001
+                    self.err = f"{type(e).__name__}: {e}"[:200]
+                    return
+                time.sleep(self.period_s)
+        self._stop = False
+        self._thread = threading.Thread(target=loop, daemon=True)
+        self._thread.start()
+        return self
+
+    def stop(self):
+        self._stop = True
+        if self._thread is not None:
+            self._thread.join(timeout=2.0)
+        num = lambda v: isinstance(v, (int, float))  # noqa: E731
+        clk = sorted(c for c, _, _, _ in self.samples if num(c))
+        pw = [p for _, _, p, _ in self.samples if num(p)]
+        mx = next((m for _, m, _, _ in self.samples if num(m)), None)
+        cap = next((c for _, _, _, c in self.samples if num(c)), None)
+        return {"sclk_mhz_median": clk[len(clk) // 2] if clk else None, "sclk_mhz_min": clk[0] if clk else None,
+                "sclk_mhz_max": clk[-1] if clk else None, "sclk_mhz_spec": mx,
+                "socket_power_w_mean": (sum(pw) / len(pw)) if pw else None,
+                "power_cap_w": (cap / 1e6 if cap and cap > 1e5 else cap), "samples": len(self.samples), "error": self.err,
+                "what": "amdsmi GFX clock / socket power of this rank's GPU, sampled every 0.1 s during the timed steps"}
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -341,11 +398,13 @@ def main():
     # timed region: HIP events (on the launch stream, inside the library) around the two roofline kernels only --
     # an event pair per launch of all ~700 kernels of a step costs ~2 % of the step
     lib.tt_prof_enable((1 << 1) | (1 << 4))
+    sampler = ClockSampler(local_rank if not os.environ.get("TT_BENCH_ONE_DEVICE") else 0).start()
     t0 = time.perf_counter()
     for q in queries:
         step(q)
     sync_all()
     dt = time.perf_counter() - t0
+    clock = sampler.stop()
     prof = read_prof()
     lib.tt_prof_enable(0)
     # one more, untimed, step with every kernel family instrumented: the per-stage table
@@ -779,6 +838,11 @@ def main():
             "launches": gemm_n, "avg_launch_ms": gemm_ms / max(gemm_n, 1),
             "algorithmic_flops_per_launch": gemm_flops_step * args.steps / max(gemm_n, 1),
             "mfma_busy": mfma_busy, "mfma_busy_note": mfma_note,
+            # the chip runs these GEMMs into its power cap (profiles/r04_power_cap.log): the clock while `achieved`
+            # was measured, and the same fraction against the MFMA peak AT THAT CLOCK (peak scales with the shader clock)
+            "clock": clock,
+            "frac_at_sampled_clock": (gemm_tf / (MFMA_BF16_PEAK_TF * clock["sclk_mhz_median"] / clock["sclk_mhz_spec"])
+                                      if clock.get("sclk_mhz_median") and clock.get("sclk_mhz_spec") else None),
             # CONSTANT, not measured by this run: what the chip sustained in round 3 on a stream of nothing but
             # v_mfma_f32_16x16x32_bf16, no operand traffic (tools/gemm4w_bench variant 14, profiles/r03_gemm_4wave_ab.log)
             "mfma_only_stream_TFLOPs": {"value": 1803.0, "measured_by_this_run": False, "source": "profiles/r03_gemm_4wave_ab.log"},

@@ -370,13 +370,14 @@ __device__ __forceinline__ void glds16(const void* base, uint32_t voff, uint32_t
 // constant for the whole kernel (voff[j]), so a copy costs no vector address arithmetic.
 template <int OPERAND, int ES = 2>
 __device__ __forceinline__ void stage_half(const GemmParams& p, char* smem, int half, int buf, int tile, int wave,
-                                           const uint32_t (&voff)[2], int m0, int n0) {
+                                           const uint32_t (&voff)[2], int m0, int n0, int tile_bytes = 128) {
     char* dst = smem + slot_off(OPERAND, half, buf);
-    // ES = bytes per element (2 bf16, 1 fp8); a K-tile is 128 bytes of every row either way
+    // ES = bytes per element (2 bf16, 1 fp8); a K-tile is 128 bytes of every row either way (split planes: 64 bytes of the
+    // hi plane + 64 of the lo plane, tile_bytes = 64; the plane offset is part of the per-lane voff)
     const char* base;
     // (p.xp bit 17, TT_GEMM_DEBUG_A0: every tile reads the A rows of row-block 0 -- wrong results, all A reads L2 hits: what the A misses cost)
-    if constexpr (OPERAND == 0) base = reinterpret_cast<const char*>(p.A) + ((size_t)(((p.xp & 0x20000) ? 0 : m0) + half * 128) * p.lda) * ES + tile * 128;
-    else base = reinterpret_cast<const char*>(p.W) + ((size_t)(n0 + half * 32) * (p.ldw ? p.ldw : p.K)) * ES + tile * 128;   // see w_row_of()
+    if constexpr (OPERAND == 0) base = reinterpret_cast<const char*>(p.A) + ((size_t)(((p.xp & 0x20000) ? 0 : m0) + half * 128) * p.lda) * ES + tile * tile_bytes;
+    else base = reinterpret_cast<const char*>(p.W) + ((size_t)(n0 + half * 32) * (p.ldw ? p.ldw : p.K)) * ES + tile * tile_bytes;   // see w_row_of()
     // keep the base in SGPRs (otherwise hipcc folds it into per-lane 64-bit VGPR addresses and
     // pays two 64-bit vector adds per copy)
     const unsigned long long b64 = reinterpret_cast<unsigned long long>(base);
@@ -1066,12 +1067,15 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
         if (p.scan_rows && m0_nominal + BM3 > p.scan_rows) m0_nominal = p.scan_rows - BM3;      // the shard's last 256 rows
     }
     const int m0 = m0_nominal, n0 = tn * BN3;
-    // split-bf16 (X3): three passes over K -- hi.hi, hi.lo, lo.hi -- as ONE K stream of 3 nk1 tiles (GemmParams.x3)
+    // split planes (X3; round 4): a K-tile is 32 elements of BOTH planes -- a row of the tile in LDS is [hi: 64 bytes | lo: 64
+    // bytes] -- and its three products hi.hi, hi.lo, lo.hi are three MFMAs on the SAME four fragments: a third less LDS-DMA,
+    // a third fewer LDS reads and barriers per MFMA than round 3's three passes over K (one virtual stream of 3 K / 64 tiles)
     // f16c (XC): K / 64 fp16 tiles, then K / 64 e4m3 tiles (x8.w_lo8: K / 128, lo8.w_x8: K / 128) -- the rows ARE that stream
     const int nk1 = p.K * ES / 128;
-    const int nk = X3 ? 3 * nk1 : (XC ? 2 * nk1 : nk1);
-    auto tile_a = [&](int t) { if constexpr (X3) return t < nk1 ? t : t - nk1; else return t; };
-    auto tile_w = [&](int t) { if constexpr (X3) return t < 2 * nk1 ? t : t - 2 * nk1; else return t; };
+    constexpr int TB = X3 ? 64 : 128;                 // bytes a K-tile advances in a plane
+    const int nk = X3 ? 2 * nk1 : (XC ? 2 * nk1 : nk1);
+    auto tile_a = [&](int t) { return t; };
+    auto tile_w = [&](int t) { return t; };
 
     f32x4 acc[2][2][2][4];  // [qm][qn][n-tile][m-tile]
 #pragma unroll
@@ -1097,8 +1101,10 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
     for (int j = 0; j < 2; ++j) {
         const int r = 16 * wave + 8 * j + (lane >> 3);
         const int chunk = (lane & 7) ^ ((r >> 1) & 7);
-        voffA[j] = (uint32_t)r * (uint32_t)p.lda * (uint32_t)ES + (uint32_t)chunk * 16u;
-        voffW[j] = (uint32_t)w_row_of(r) * (uint32_t)(p.ldw ? p.ldw : p.K) * (uint32_t)ES + (uint32_t)chunk * 16u;
+        // (split planes: source chunks 0-3 of a tile row are the hi plane's 64 bytes, 4-7 the lo plane's, K elements further)
+        const uint32_t coff = X3 ? (chunk < 4 ? (uint32_t)chunk * 16u : (uint32_t)p.K * 2u + (uint32_t)(chunk - 4) * 16u) : (uint32_t)chunk * 16u;
+        voffA[j] = (uint32_t)r * (uint32_t)p.lda * (uint32_t)ES + coff;
+        voffW[j] = (uint32_t)w_row_of(r) * (uint32_t)(p.ldw ? p.ldw : p.K) * (uint32_t)ES + coff;
     }
 
     unsigned long long* dbg0 = reinterpret_cast<unsigned long long*>(p.vt);
@@ -1159,13 +1165,13 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
         if (wave == 2) glds16(p.w_scale + n0, lane * 16, (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem + kScaleOff + 1024);
     }
     // ---- prologue: tile 0 complete, tile 1 without its A-hi (issued in L1(0)); same order as steady state
-    stage_half<0, ES>(p, smem, 0, 0, 0, wave, voffA, m0, n0);
-    stage_half<1, ES>(p, smem, 0, 0, 0, wave, voffW, m0, n0);
-    stage_half<1, ES>(p, smem, 1, 0, 0, wave, voffW, m0, n0);
-    stage_half<0, ES>(p, smem, 1, 0, 0, wave, voffA, m0, n0);
+    stage_half<0, ES>(p, smem, 0, 0, 0, wave, voffA, m0, n0, TB);
+    stage_half<1, ES>(p, smem, 0, 0, 0, wave, voffW, m0, n0, TB);
+    stage_half<1, ES>(p, smem, 1, 0, 0, wave, voffW, m0, n0, TB);
+    stage_half<0, ES>(p, smem, 1, 0, 0, wave, voffA, m0, n0, TB);
     if (nk > 1) {
-        stage_half<0, ES>(p, smem, 0, 1, tile_a(1), wave, voffA, m0, n0);
-        stage_half<1, ES>(p, smem, 0, 1, tile_w(1), wave, voffW, m0, n0);
+        stage_half<0, ES>(p, smem, 0, 1, tile_a(1), wave, voffA, m0, n0, TB);
+        stage_half<1, ES>(p, smem, 0, 1, tile_w(1), wave, voffW, m0, n0, TB);
     }
     if (nk > 1) {
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // A-hi(0), A-lo(1), W-lo(1) may be in flight
@@ -1229,6 +1235,19 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
                     if constexpr (vblk) c[nt][mt] = mfma_fp8(xf[mt][0], xf[mt][1], wf[nt][0], wf[nt][1], c[nt][mt]);
                     else c[nt][mt] = mfma_fp8(wf[nt][0], wf[nt][1], xf[mt][0], xf[mt][1], c[nt][mt]);
                 }
+        } else if constexpr (X3) {
+            // fragment [.][0] = the tile's 32 hi-plane elements, [.][1] = its 32 lo-plane elements
+#pragma unroll
+            for (int term = 0; term < 3; ++term) {
+                const int sa = term == 2 ? 1 : 0, sw = term == 1 ? 1 : 0;       // hi.hi, x_hi.w_lo, x_lo.w_hi
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) {
+                        if constexpr (vblk) c[nt][mt] = TT_MFMA_16x16x32(xf[mt][sa], wf[nt][sw], c[nt][mt]);
+                        else c[nt][mt] = TT_MFMA_16x16x32(wf[nt][sw], xf[mt][sa], c[nt][mt]);
+                    }
+            }
         } else if constexpr (vblk) {
 #pragma unroll
             for (int ss = 0; ss < 2; ++ss)
@@ -1303,8 +1322,8 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
         // La
         stamp(t);                                  // 0: La start
         if (more1) {
-            stage_half<1, ES>(p, smem, 1, B ^ 1, tile_w(t + 1), wave, voffW, m0, n0);
-            stage_half<0, ES>(p, smem, 1, B ^ 1, tile_a(t + 1), wave, voffA, m0, n0);
+            stage_half<1, ES>(p, smem, 1, B ^ 1, tile_w(t + 1), wave, voffW, m0, n0, TB);
+            stage_half<0, ES>(p, smem, 1, B ^ 1, tile_a(t + 1), wave, voffA, m0, n0, TB);
         } else if (kResLds) {
             stage_res(1);                          // last tile (B = 1): hi slots of buffer 0
         }
@@ -1333,8 +1352,8 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
         // Lb
         stamp(t);                                  // 6: Lb start
         if (more2) {
-            stage_half<0, ES>(p, smem, 0, B, tile_a(t + 2), wave, voffA, m0, n0);
-            stage_half<1, ES>(p, smem, 0, B, tile_w(t + 2), wave, voffW, m0, n0);
+            stage_half<0, ES>(p, smem, 0, B, tile_a(t + 2), wave, voffA, m0, n0, TB);
+            stage_half<1, ES>(p, smem, 0, B, tile_w(t + 2), wave, voffW, m0, n0, TB);
             if (sc_lb) stage_scales(t + 2);
         } else if (kResLds) {
             stage_res(B == 0 ? 0 : 2);             // tile nk-2 (B = 0): lo slots of buffer 0; tile nk-1: of buffer 1
@@ -1780,8 +1799,8 @@ __device__ __forceinline__ void gemm_epilogue_tile_x3(const GemmParams& p, f32x4
     }
 }
 
-// X3: split-bf16 operands (GemmParams.x3) -- the same loop over the virtual K stream of 3 K (hi.hi, hi.lo, lo.hi), in the
-// tiled kernel's order, so a row's result does not depend on which kernel computed it
+// X3: split-plane operands (GemmParams.x3) -- the same loop over a virtual K stream of 3 K / 32 steps: per 32 K elements the
+// three products hi.hi, x_hi.w_lo, x_lo.w_hi, in the tiled kernel's order, so a row's result does not depend on which kernel computed it
 // MT row tiles of 16 per wave, PF K-steps of loads in flight.  Round 3: one row tile per wave and 24 steps in flight (a
 // query's 64 padded rows on 4 x N/16 waves instead of N/16: the N = 1024 GEMMs had 64 waves on 256 CUs, each waiting for its
 // own 8 loads, 0.44 TB/s of weights); the MFMA chain of a 16 x 16 output tile is the same either way, so the bits are too.
@@ -1799,8 +1818,9 @@ __global__ __launch_bounds__(64) void gemm_skinny_kernel(GemmParams p) {
     ex8 wb[PF], ab[PF][MT];
     const int nks1 = p.K / 32;
     const int nks = X3 ? 3 * nks1 : nks1;
-    auto step_a = [&](int s) { if constexpr (X3) return s < nks1 ? s : s - nks1; else return s; };
-    auto step_w = [&](int s) { if constexpr (X3) return s < 2 * nks1 ? s : s - 2 * nks1; else return s; };
+    // (virtual step s = 3 * (K step) + term; term 0: hi.hi, 1: x_hi.w_lo, 2: x_lo.w_hi -- the tiled kernel's MFMA order per 32 K elements)
+    auto step_a = [&](int s) { if constexpr (X3) return s / 3 + (s % 3 == 2 ? nks1 : 0); else return s; };
+    auto step_w = [&](int s) { if constexpr (X3) return s / 3 + (s % 3 == 1 ? nks1 : 0); else return s; };
 #pragma unroll
     for (int s = 0; s < PF; ++s)
         if (s < nks) {
