@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Matrix-core utilisation of the bench step's kernels from one rocprofv3 --pmc pass (tools/gpu_pmc_bench_r03.sh):
+"""Matrix-core utilisation of the bench step's kernels from one rocprofv3 --pmc pass (tools/gpu_pmc_bench_r04.sh):
 
     mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (kernel cycles x 1024 SIMDs),   kernel cycles = GRBM_GUI_ACTIVE / 8
                 (the counter sums cycles over all SIMDs -- 16 per v_mfma_f32_16x16x32_bf16, 32 per 32x32x16 -- and
@@ -69,7 +69,7 @@ def main(pmc_dir, out):
         res["gemm (all shapes of the rerank forward)"] = {"mfma_busy": tot_m / (tot_c * 1024.0)}
     res["source"] = ("rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY "
                      "GRBM_GUI_ACTIVE --kernel-trace of `python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-fp8-leg "
-                     "--no-reference-leg --no-surface-leg --no-config5-leg` (tools/gpu_pmc_bench_r03.sh); mfma_busy = MFMA busy cycles / "
+                     "--no-reference-leg --no-surface-leg --no-config5-leg` (tools/gpu_pmc_bench_r04.sh); mfma_busy = MFMA busy cycles / "
                      "(GRBM_GUI_ACTIVE / 8 x 1024 SIMDs); profiled passes clock ~3 % lower than un-profiled ones")
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench

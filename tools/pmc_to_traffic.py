@@ -49,7 +49,7 @@ def main(fetch_dir, write_dir, out):
             write = float(wr[i]["Counter_Value"]) * 1024
             res[name] = {"launches": 1, "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write,
                          "hbm_bytes_per_launch": fetch + write}
-    res["source"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/gpu_pmc_bench_r03.sh) of `python3 bench.py --steps 1 "
+    res["source"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/gpu_pmc_bench_r04.sh) of `python3 bench.py --steps 1 "
                      "--warmup 1 --no-cpu-baseline --no-fp8-leg --no-reference-leg --no-surface-leg --no-config5-leg`; FETCH_SIZE doubled (gfx950: the "
                      "counter tallies 128-B requests at 64 B), counters in KiB")
     # ties the file to the kernel sources it was measured on: bench.py refuses it when they differ
