@@ -98,7 +98,7 @@ def self_launch(cmd, environ=None):
     raise SystemExit(rc)
 
 
-def preflight_collectives(dist, torch, dev, rank, world):
+def preflight_collectives(dist, torch, dev, rank, world, group=None):
     """First step of every world > 1 run (tools/nccl_two_rank_smoke.py's checks, in process): the collectives the step uses,
     checked against what they must return, before any model is loaded -- all-gather of packed partial top-k blocks, barrier,
     all-reduce MAX (the max-over-ranks timing), ragged all_gather.  A failure raises with the backend's own error text: the
@@ -108,20 +108,62 @@ def preflight_collectives(dist, torch, dev, rank, world):
     mine[..., 0] = torch.arange(Q * K, device=dev, dtype=torch.float32).view(Q, K) + 1000.0 * rank
     mine[..., 1] = float(rank)
     out = torch.empty((world, Q, K, 2), dtype=torch.float32, device=dev)
-    dist.all_gather_into_tensor(out.view(-1), mine.view(-1))
+    dist.all_gather_into_tensor(out.view(-1), mine.view(-1), group=group)
     for r in range(world):
         want = torch.arange(Q * K, device=dev, dtype=torch.float32).view(Q, K) + 1000.0 * r
         if not (torch.equal(out[r, ..., 0], want) and bool((out[r, ..., 1] == float(r)).all())):
             raise RuntimeError(f"pre-flight: rank {rank} received a wrong all-gather block from rank {r}")
-    t = torch.tensor([float(rank + 1)], dtype=torch.float64, device=dev)
-    dist.barrier()
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    dist.barrier(group=group)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     if t.item() != float(world):
         raise RuntimeError(f"pre-flight: all-reduce MAX returned {t.item()} on rank {rank}, expected {world}")
     counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(counts, torch.tensor([rank * 3 + 1], dtype=torch.int64, device=dev))
+    dist.all_gather(counts, torch.tensor([rank * 3 + 1], dtype=torch.int64, device=dev), group=group)
     if [int(c.item()) for c in counts] != [r * 3 + 1 for r in range(world)]:
         raise RuntimeError(f"pre-flight: ragged all_gather wrong on rank {rank}")
+
+
+def open_data_plane(dist, torch, dev, rank, world, backend="nccl", deadline_s=180.0):
+    """-> (process group for the step's collectives, label).  The default group is gloo (rendezvous, barriers, max-over-ranks
+    timing: host tensors over TCP, nothing a GPU driver can break); the step's own exchange -- the all-gathers of query blocks and
+    packed partial top-k -- gets a group of `backend` ("nccl" = RCCL over xGMI) IF that backend passes the pre-flight on every
+    rank.  Round 3's driver runs at N = 2, 4, 8 died inside RCCL's IPC set-up (hipIpcGetMemHandle: invalid argument) before a step
+    ran; the exchange is ~100 KiB per step and latency-bound, so when RCCL cannot be brought up on a node the same collectives
+    run over the default gloo group (device tensors staged through the host: +~1 ms on a 280 ms step), the JSON line says so
+    (`collective_backend`), and a scaling number exists instead of a dead run.  The attempt runs in a thread under a deadline: a
+    rank whose peers failed fast would otherwise wait in its first collective for the communicator's whole timeout.  The ranks
+    AGREE on the outcome over gloo (MIN of the ok flags), so either all use the RCCL group or none does.
+    -> (None, "gloo (...)") means: use the default group."""
+    import datetime
+    import threading
+
+    box = {"group": None, "err": None}
+
+    def attempt():
+        try:
+            g = dist.new_group(backend=backend, timeout=datetime.timedelta(minutes=30),
+                               **({"device_id": dev} if backend == "nccl" else {}))
+            preflight_collectives(dist, torch, dev, rank, world, group=g)
+            if dev.type == "cuda":
+                torch.cuda.synchronize(dev)
+            box["group"] = g
+        except BaseException as e:  # noqa: BLE001 -- whatever the backend raises, the rank must reach the agreement below
+            box["err"] = f"{type(e).__name__}: {e}".replace("\n", " ")[:300]
+
+    th = threading.Thread(target=attempt, daemon=True)
+    th.start()
+    th.join(timeout=deadline_s)
+    hung = th.is_alive()
+    if hung:
+        box["err"] = f"pre-flight on {backend} did not return within {deadline_s:.0f} s"
+    ok = torch.tensor([1 if (box["group"] is not None and not hung) else 0], dtype=torch.int32)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok.item()) == 1:
+        return box["group"], backend, False
+    mine = box["err"] or f"another rank's {backend} pre-flight failed"
+    sys.stderr.write(f"[bench rank {rank}] {backend} data plane unusable ({mine}); the step's collectives run over gloo\n")
+    return None, f"gloo ({backend} pre-flight failed on at least one rank; rank {rank}: {mine})", hung
 
 
 if __name__ == "__main__":
@@ -297,16 +339,19 @@ def main():
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
 
+    data_group, collective_backend, comm_hung = None, None, False
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         import datetime
 
         # (rank 0 alone runs the accuracy / CPU legs while the others wait at a barrier: keep the collective watchdog well above that)
-        if one_device:
-            dist.init_process_group("gloo", timeout=datetime.timedelta(minutes=30))
+        dist.init_process_group("gloo", timeout=datetime.timedelta(minutes=30))
+        preflight_collectives(dist, torch, torch.device("cpu"), rank, world)
+        if one_device and os.environ.get("TT_BENCH_TRY_NCCL") != "1":
+            # (TT_BENCH_TRY_NCCL=1: attempt RCCL anyway -- it refuses two ranks on one device, which exercises the fallback on real hardware)
+            data_group, collective_backend, comm_hung = None, "gloo (TT_BENCH_ONE_DEVICE: the ranks share one GPU)", False
         else:
-            dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(minutes=30))
-        preflight_collectives(dist, torch, dev, rank, world)
+            data_group, collective_backend, comm_hung = open_data_plane(dist, torch, dev, rank, world)
         # control plane: a gloo group beside the data-plane communicator, for agreements the main thread must be able to reach
         # while a worker thread may sit in a data-plane collective (the plugin-surface leg's outcome, below)
         ctl_group = dist.new_group(backend="gloo", timeout=datetime.timedelta(minutes=10))
@@ -331,7 +376,7 @@ def main():
     # search() = all-gather of the ranks' query embeddings -> local exact scan -> ONE all-gather of the packed
     # partial top-k -> tt_topk_merge.  Node tables are lazy (ids derived from the row), see the surface leg.
     shard_rows = synth_corpus_shard(hi - lo, D, 1234 + rank, dev)
-    corpus = ShardedHipVectorIndex(D, shard_rows, lo, args.corpus_rows, None, None, score_mode="cosine",
+    corpus = ShardedHipVectorIndex(D, shard_rows, lo, args.corpus_rows, None, None, score_mode="cosine", group=data_group,
                                    queries="partitioned", ragged_queries=False)    # every rank brings Bq queries
     embedder = Encoder(EncoderWeights(emb_cfg, synthetic_state_device(emb_cfg, dev, seed=1), dev))
     reranker = Encoder(EncoderWeights(rr_cfg, synthetic_state_device(rr_cfg, dev, seed=2), dev))
@@ -431,7 +476,7 @@ def main():
         lib.tt_prof_enable(0)
         dt_scan = (time.perf_counter() - t3) / 3
         if world > 1:
-            t = torch.tensor([dt_scan], dtype=torch.float64, device=dev)
+            t = torch.tensor([dt_scan], dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt_scan = float(t.item())
         so_ms, so_n = scan_only_prof
@@ -510,7 +555,7 @@ def main():
             quality = rank_quality(reranker, rr_cfg, tokens_step["last_pairs"][: 4 * K], K, topn, dev)
         reranker.w.set_gemm_dtype("bf16")
         if world > 1:
-            t = torch.tensor([dt8], dtype=torch.float64, device=dev)
+            t = torch.tensor([dt8], dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt8 = float(t.item())
         fp8_leg = {"queries_per_s": world * Bq * args.steps / dt8, "ms_per_step": dt8 / args.steps * 1e3,
@@ -519,7 +564,7 @@ def main():
                            "embedder, scan, attention and the CLS tail unchanged",
                    "rank_quality_vs_fp32": quality}
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -557,7 +602,7 @@ def main():
             del emb3, rr3
             torch.cuda.empty_cache()
             if world > 1:
-                t = torch.tensor([dt3], dtype=torch.float64, device=dev)
+                t = torch.tensor([dt3], dtype=torch.float64)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 dt3 = float(t.item())
             return {"queries_per_s": world * Bq * args.steps / dt3, "ms_per_step": dt3 / args.steps * 1e3,
@@ -609,7 +654,7 @@ def main():
         del emb16, rr16
         torch.cuda.empty_cache()
         if world > 1:
-            t = torch.tensor([dt16], dtype=torch.float64, device=dev)
+            t = torch.tensor([dt16], dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt16 = float(t.item())
         fp16_leg = {"queries_per_s": world * Bq * args.steps / dt16, "ms_per_step": dt16 / args.steps * 1e3,
@@ -637,7 +682,7 @@ def main():
         prof_e = read_prof()
         lib.tt_prof_enable(0)
         if world > 1:
-            t = torch.tensor([dt_embed], dtype=torch.float64, device=dev)
+            t = torch.tensor([dt_embed], dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt_embed = float(t.item())
         chunks_per_s = world * args.embed_chunks / dt_embed
@@ -668,7 +713,7 @@ def main():
             dt8e = (time.perf_counter() - t1) / 2
             embedder.w.set_gemm_dtype("bf16")
             if world > 1:
-                t = torch.tensor([dt8e], dtype=torch.float64, device=dev)
+                t = torch.tensor([dt8e], dtype=torch.float64)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 dt8e = float(t.item())
             fp8_leg["chunks_embedded_per_s"] = world * args.embed_chunks / dt8e
@@ -677,10 +722,10 @@ def main():
     # the reference's executor threads do (rag_engine.py:418-424, api/routes/chat.py:367-374); the coalescing front
     # merges them into shared embed / scan / rerank batches.  Strings in, NodeWithScore out; the SAME resident corpus.
     surface = None
-    hard_exit = False
+    hard_exit = comm_hung        # (a pre-flight thread still sits in an RCCL call: leave without destroying the groups)
     if not args.headline_only and not args.no_surface_leg and (world == 1 or args.surface_leg):
         if world == 1:
-            surface = surface_leg(args, dev, shard_rows, emb_cfg, rr_cfg, world, rank, lo)
+            surface = surface_leg(args, dev, shard_rows, emb_cfg, rr_cfg, world, rank, lo, data_group)
         else:
             # Several ranks: the leg's collectives run over RCCL, which no box available to this build could exercise (two
             # ranks cannot share a GPU under RCCL; the gloo runs are the evidence).  The headline above is measured and must
@@ -694,7 +739,7 @@ def main():
             def _run_surface():
                 torch.cuda.set_device(dev)
                 try:
-                    box["result"] = surface_leg(args, dev, shard_rows, emb_cfg, rr_cfg, world, rank, lo)
+                    box["result"] = surface_leg(args, dev, shard_rows, emb_cfg, rr_cfg, world, rank, lo, data_group)
                 except BaseException as exc:  # noqa: BLE001
                     box["error"] = exc
 
@@ -813,6 +858,8 @@ def main():
             "ranks_share_one_device": one_device,   # TT_BENCH_ONE_DEVICE=1 (debugging aid): all ranks on GPU 0 over gloo -- not a scaling number
             # multi-process GPU work on this pool needs dmabuf IPC (0); a self-launched run that died before its JSON line is
             # retried once with the other setting (self_launch): this is the one the printed numbers were measured under
+            # world > 1: what carried the step's collectives -- "nccl" (RCCL over xGMI) or "gloo (...)" with the reason RCCL was not used
+            "collective_backend": collective_backend,
             "ipc_mode_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"), "ipc_mode_retry": os.environ.get("TT_BENCH_IPC_RETRY") == "1",
             # the rate INSIDE north_star's score tolerance (1e-3 relative): the same step with both encoders in the
             # reference's own precision -- what an unchanged reference call (no dtype) gets; `value` is the bf16 mode
@@ -1003,7 +1050,7 @@ def _run_threads(n_threads, work_items, fn):
     return dt, out
 
 
-def surface_leg(args, dev, shard_rows, emb_cfg, rr_cfg, world=1, rank=0, row_lo=0):
+def surface_leg(args, dev, shard_rows, emb_cfg, rr_cfg, world=1, rank=0, row_lo=0, group=None):
     """world > 1: every rank runs its OWN request threads against the row-sharded index; the retriever's lock-step tick front
     keeps the ranks' collective rounds aligned, each rank embeds and reranks only its own callers' queries
     (sharded_index._TickFront).  Reported rate = all ranks' queries / the slowest rank's time."""
@@ -1019,7 +1066,7 @@ def surface_leg(args, dev, shard_rows, emb_cfg, rr_cfg, world=1, rank=0, row_lo=
                                       model_kwargs={"encoder_config": rr_cfg, "synthetic_seed": 2, "torch_dtype": "bfloat16"})
     n = shard_rows.shape[0] if world == 1 else args.corpus_rows
     index = ShardedHipVectorIndex(shard_rows.shape[1], shard_rows, row_lo, n, _RowIds(n), _SynthDocstore(args.chunk_len),
-                                  embed_model=emb, score_mode="cosine", queries="partitioned" if world > 1 else "replicated")
+                                  embed_model=emb, score_mode="cosine", queries="partitioned" if world > 1 else "replicated", group=group)
     if world > 1:
         import torch.distributed as dist
 
@@ -1053,7 +1100,7 @@ def surface_leg(args, dev, shard_rows, emb_cfg, rr_cfg, world=1, rank=0, row_lo=
         if tick is not None and tick._thread.is_alive():
             # close() came back on its timeout: the tick thread still owns the communicator -- no collective from this thread
             raise RuntimeError("the retriever's tick thread did not stop within 600 s of close()")
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     return {"queries_per_s": world * len(queries) / dt, "threads": args.surface_threads, "queries": world * len(queries),
@@ -1127,7 +1174,9 @@ def config5_leg(args, dev, emb_cfg, rr_cfg):
             "queries_per_s": len(queries) / dt, "mean_sources": float(np.mean(res)), "reranker": "bf16",
             "fp8_reranker_variant": {"queries_per_s": len(queries) / dt8, "mean_sources": float(np.mean(res8)),
                                      "note": "e4m3 layer projections, its own 128 query strings (no LRU hits); Kendall tau ~0.5 "
-                                             "against fp32 at 24 layers (config.fp8_reranker.rank_quality_vs_fp32)"},
+                                             "against fp32 at 24 layers (config.fp8_reranker.rank_quality_vs_fp32); at this leg's "
+                                             "short pairs and small coalesced batches it has measured BELOW the bf16 reranker "
+                                             "(215 vs 248 queries/s at 2048 documents) -- the token-level fp8 leg is config.fp8_reranker"},
             "host_peak_rss_gb": __import__("resource").getrusage(__import__("resource").RUSAGE_SELF).ru_maxrss / 1048576.0,
             "ingest_workers": __import__("tensor_truth_amd.ingest_workers", fromlist=["default_workers"]).default_workers(),
             "what": ("build_index(chunking_strategy='semantic_hierarchical', chunk_sizes=[512,128,64]) on the bge-m3-shaped "

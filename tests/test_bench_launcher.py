@@ -128,3 +128,42 @@ def test_preflight_collectives_on_two_gloo_ranks():
     assert sorted(g for g in got if g[1] == "ok") == [(0, "ok"), (1, "ok")]
     rest = [g for g in got if g[1] != "ok"]
     assert len(rest) == 2 and all(g[1].startswith("caught: pre-flight:") for g in rest), rest
+
+
+def _data_plane_rank(rank, world, port, ret):
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        cpu = torch.device("cpu")
+        # a backend that cannot come up here (no GPU in this container): every rank must end on the default gloo group, agreed
+        g, label, hung = bench.open_data_plane(dist, torch, cpu, rank, world, backend="nccl", deadline_s=60.0)
+        bench.preflight_collectives(dist, torch, cpu, rank, world, group=g)
+        ret.put((rank, "fallback", g is None, label, hung))
+        # a backend that works: the step's collectives get their own group
+        g2, label2, hung2 = bench.open_data_plane(dist, torch, cpu, rank, world, backend="gloo", deadline_s=60.0)
+        bench.preflight_collectives(dist, torch, cpu, rank, world, group=g2)
+        ret.put((rank, "own", g2 is not None, label2, hung2))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_plane_falls_back_to_gloo_by_agreement():
+    """bench.py at world > 1: the step's collectives run on an RCCL group when RCCL passes the pre-flight on EVERY rank, on the
+    default gloo group otherwise -- decided by agreement, reported in the JSON line (`collective_backend`)."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = bench._free_port()
+    procs = [ctx.Process(target=_data_plane_rank, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [ret.get(timeout=180) for _ in range(4)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    fb = sorted(g for g in got if g[1] == "fallback")
+    assert [g[0] for g in fb] == [0, 1] and all(g[2] and g[3].startswith("gloo (nccl pre-flight failed") and not g[4] for g in fb), fb
+    own = sorted(g for g in got if g[1] == "own")
+    assert [g[0] for g in own] == [0, 1] and all(g[2] and g[3] == "gloo" and not g[4] for g in own), own
