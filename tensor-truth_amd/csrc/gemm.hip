@@ -1309,10 +1309,19 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
     // (Moving half of the copies into the C slots was measured neutral-to-worse: an LDS-DMA issue
     // costs ~100 cycles wherever it sits, and the C slot is then as long as the L slot.)
     // (f8c: the tile's flavour in the f16c stream -- false: fp16 MFMAs, true: scaled e4m3 MFMAs; always false otherwise)
+    // Energy ablations (diagnostic library only, TT_GEMM_ENERGY; wrong results): from the third K-tile on, 1 = no operand copies
+    // (the MFMAs run on stale LDS tiles: no LDS-DMA, L2 or HBM traffic), 2 = no fragment reads (stale registers: no LDS reads),
+    // 3 = both.  Run under the power cap with random operands, the rate each gains is that part's share of the energy per flop.
+#if TT_DIAG
+    const int eabl = (p.xp & 0x80000) ? ((p.xp >> 4) & 15) : 0;
+#else
+    constexpr int eabl = 0;
+#endif
     auto tile4 = [&](int t, auto bufc, auto f8c) {
         constexpr int B = decltype(bufc)::value;
         constexpr bool F8T = XC && decltype(f8c)::value;
-        const bool more1 = t + 1 < nk, more2 = t + 2 < nk;
+        const bool dma_on = !((eabl & 1) && t >= 2), rd_on = !((eabl & 2) && t >= 2);
+        const bool more1 = t + 1 < nk && dma_on, more2 = t + 2 < nk && dma_on;
         // f16c: vector-memory operations that may still be in flight at the two counted waits -- the copies of Lb(t - 1)
         // resp. Lb(t) include one scale strip when the tile they prefetch (t + 1 resp. t + 2) is an e4m3 tile
         // (a group of four e4m3 tiles, when the tile prefetched there opens one)
@@ -1328,9 +1337,11 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
             stage_res(1);                          // last tile (B = 1): hi slots of buffer 0
         }
         stamp(t);                                  // 1: copies issued
-        read_a(smem + slot_off(0, 0, B));
-        read_w(wf0, smem + slot_off(1, 0, B));
-        read_w(wf1, smem + slot_off(1, 1, B));
+        if (rd_on) {
+            read_a(smem + slot_off(0, 0, B));
+            read_w(wf0, smem + slot_off(1, 0, B));
+            read_w(wf1, smem + slot_off(1, 1, B));
+        }
         if constexpr (F8T) {
             sa_reg[0] = *reinterpret_cast<const uint32_t*>(sbuf + sa_off);
             sw_reg = *reinterpret_cast<const uint32_t*>(sbuf + sw_off);
@@ -1359,7 +1370,7 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
             stage_res(B == 0 ? 0 : 2);             // tile nk-2 (B = 0): lo slots of buffer 0; tile nk-1: of buffer 1
         }
         stamp(t);                                  // 7
-        read_a(smem + slot_off(0, 1, B));
+        if (rd_on) read_a(smem + slot_off(0, 1, B));
         if constexpr (F8T) sa_reg[1] = *reinterpret_cast<const uint32_t*>(sbuf + 512 + sa_off);
         stamp(t);                                  // 8
         if (SLOTS == 46) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -2041,6 +2052,8 @@ int launch(const GemmParams& p, hipStream_t st) {
         if (head_major) q.xp |= 0x40000;
         static const int stamp_block = TT_DIAG_ENV_INT("TT_GEMM_STAMP_BLOCK", 0);
         q.xp |= stamp_block << 20;
+        static const int energy = TT_DIAG_ENV_INT("TT_GEMM_ENERGY", 0);                 // (wrong results: diagnostic library only)
+        if (energy) q.xp |= 0x80000 | ((energy & 15) << 4);
         {
             TtProfScope prof(TT_K_GEMM, st);
             hipLaunchKernelGGL(kern, dim3(blocks), dim3(v3::kThreads3), v3::kLds3, st, q);

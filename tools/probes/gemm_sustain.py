@@ -33,6 +33,14 @@ else:
     units = 3.0
 fn(); torch.cuda.synchronize()
 flops = 2.0 * M * N * K * units
+import bench
+sampler = bench.ClockSampler(0, period_s=0.2)
+t_warm = time.perf_counter()
+while time.perf_counter() - t_warm < 1.5:      # let the clock settle under the cap before sampling
+    for _ in range(20):
+        fn()
+    torch.cuda.synchronize()
+sampler.start()
 t0 = time.perf_counter()
 marks = []
 while time.perf_counter() - t0 < secs:
@@ -42,6 +50,10 @@ while time.perf_counter() - t0 < secs:
         fn()
     e1.record(); e1.synchronize()
     marks.append(e0.elapsed_time(e1) / 20)
+clock = sampler.stop()
 third = marks[len(marks) * 2 // 3:]
 print(f"{mode} ({data} operands): {len(marks) * 20} launches, {flops / (sum(marks) / len(marks) * 1e-3) / 1e12:.0f} TF/s of MFMA work over the window, "
-      f"{flops / (sum(third) / len(third) * 1e-3) / 1e12:.0f} in its last third; first 20 launches {flops / (marks[0] * 1e-3) / 1e12:.0f}")
+      f"{flops / (sum(third) / len(third) * 1e-3) / 1e12:.0f} in its last third; sclk median {clock['sclk_mhz_median']} MHz "
+      f"({clock['sclk_mhz_min']}-{clock['sclk_mhz_max']}), socket power {clock['socket_power_w_mean'] and round(clock['socket_power_w_mean'])} W "
+      f"[{os.environ.get('TT_LIB_NAME', 'libtt_hip.so')} ENERGY={os.environ.get('TT_GEMM_ENERGY')} A0={os.environ.get('TT_GEMM_DEBUG_A0')} "
+      f"TRAFFIC={os.environ.get('TT_GEMM_DEBUG_TRAFFIC')}]")
