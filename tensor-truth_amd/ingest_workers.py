@@ -316,6 +316,21 @@ class IngestWorkers:
                 p.kill()
         self.conns, self.procs = [], []
 
+    def abort(self) -> None:
+        """Kill the workers without a handshake (a build failed half-way: chunks in flight, half-read frames)."""
+        for p in self.procs:
+            try:
+                p.kill()
+            except Exception:  # noqa: BLE001
+                pass
+        for p in self.procs:
+            try:
+                p.wait(timeout=5)
+            except Exception:  # noqa: BLE001
+                pass
+        self.conns, self.procs = [], []
+        self.buffers = []
+
     def __enter__(self):
         return self
 
@@ -341,7 +356,16 @@ class IngestWorkers:
             chunk_docs: int = 48, inflight_per_worker: int = 3) -> None:
         """``embed_tokens(list of int32 arrays) -> embeddings`` (enqueues GPU work), ``distances(embeddings) -> (host array,
         ready())`` (adjacent distances copied back asynchronously; ``ready(block)`` tells / waits), ``on_nodes(nodes,
-        leaf positions, leaf embeddings)`` (docstore + index rows), called in document order."""
+        leaf positions, leaf embeddings)`` (docstore + index rows), called in document order.
+        A build that raises -- in a worker, in a callback, on a dead pipe -- leaves chunks in flight and replies unread: the pool
+        is killed (``abort``) and the error re-raised; ``get_workers`` starts a fresh pool for the next build."""
+        try:
+            self._run(documents, semantic, embed_tokens, distances, on_nodes, chunk_docs, inflight_per_worker)
+        except BaseException:
+            self.abort()
+            raise
+
+    def _run(self, documents, semantic, embed_tokens, distances, on_nodes, chunk_docs, inflight_per_worker) -> None:
         W = len(self.conns)
         docs = [_doc_record(d) for d in documents]
         # small first chunks put the GPU to work early; then chunk_docs

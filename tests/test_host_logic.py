@@ -1177,3 +1177,41 @@ def test_ingest_worker_processes_build_the_same_nodes_in_order(tmp_path):
     # a worker that cannot even start (an invalid hierarchy) is an error of the caller's, not a hang
     with pytest.raises((EOFError, RuntimeError)):
         iw.IngestWorkers({**spec, "chunk_sizes": [16, 32]}, 1)
+
+
+def test_failed_build_discards_the_worker_pool():
+    """A build that raises half-way (here: the index callback) leaves chunks in flight and replies unread in the pipes.  The pool
+    must not be reused: it is killed, and the next build of the same configuration gets fresh workers and the right nodes."""
+    import numpy as np
+
+    from tensor_truth_amd import ingest_workers as iw
+    from tensor_truth_amd.schema import TextNode
+
+    spec = {"tokenizer": ("hash", "xlmr", 250002), "max_length": 64, "text_instruction": "", "buffer_size": 1, "percentile": 90,
+            "chunk_sizes": [128, 32, 16], "chunk_overlap": 4}
+    rng = np.random.default_rng(5)
+    docs = [TextNode(text=" ".join(" ".join(f"w{rng.integers(0, 300)}" for _ in range(10)) + "." for _ in range(25)), metadata={"title": str(i)})
+            for i in range(80)]
+    embed = lambda seqs: np.stack([np.array([len(s), int(s[0]) % 7 + 1.0]) for s in seqs])                      # noqa: E731
+    dist = lambda e: (np.abs(np.diff(e[:, 0])).astype(np.float32), (lambda block=False: True))                     # noqa: E731
+    pool = iw.get_workers(spec, 2)
+    pids = [p.pid for p in pool.procs]
+    calls = []
+
+    def failing(nodes, pos, emb):
+        calls.append(len(nodes))
+        if len(calls) == 2:
+            raise ValueError("index refused the rows")
+
+    with pytest.raises(ValueError, match="index refused"):
+        pool.run(docs, True, embed, dist, failing, chunk_docs=8)
+    assert not pool.alive() and pool.procs == []
+    pool2 = iw.get_workers(spec, 2)
+    assert pool2 is not pool and pool2.alive() and not set(pids) & {p.pid for p in pool2.procs}
+    got = []
+    pool2.run(docs, True, embed, dist, lambda nodes, pos, emb: got.append(nodes), chunk_docs=8)
+    host = iw._Host(spec)
+    recs = [iw._doc_record(d) for d in docs]
+    _, flat, lens = host.split(0, recs)
+    nodes, _, _, _ = host.cut(0, dist(embed(iw.unflatten(flat, lens)))[0])
+    assert [n.text for g in got for n in g] == [n.text for n in nodes]
