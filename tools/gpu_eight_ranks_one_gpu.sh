@@ -7,7 +7,7 @@
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
 export TT_BENCH_ONE_DEVICE=1 HSA_ENABLE_IPC_MODE_LEGACY=0
-timeout 1500 python bench.py --gpus 8 --steps 2 --warmup 1 --no-cpu-baseline --no-fp8-leg --no-reference-leg --no-fp16-leg \
+timeout 1500 python bench.py --gpus 8 --steps 2 --warmup 1 --no-cpu-baseline --no-fp8-leg --no-reference-leg --no-fp16-leg --surface-leg \
   > gpurun_out/eight_ranks.json 2> gpurun_out/eight_ranks.err
 echo "rc=$?"; tail -4 gpurun_out/eight_ranks.err
 python - <<PY
@@ -16,7 +16,7 @@ d = json.loads(open("gpurun_out/eight_ranks.json").readline())
 c = d["config"]
 print({k: d[k] for k in ("value", "n_gpus", "ms_per_step", "scaling")})
 print("workload:", c["workload"])
-print("ranks_share_one_device:", c["ranks_share_one_device"])
+print("ranks_share_one_device:", c["ranks_share_one_device"], "| ranks:", d.get("ranks"), "| collective_backend:", c.get("collective_backend"))
 print("surface:", {k: v for k, v in (c.get("plugin_surface") or {}).items() if k != "what"})
 print("roofline_scan:", {k: d["roofline_scan"][k] for k in ("queries_per_launch", "avg_launch_ms", "frac")})
 PY
