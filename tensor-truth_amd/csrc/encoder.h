@@ -34,6 +34,9 @@ struct GemmParams {
     int32_t* scan_idx;        // [N][scan_cap]
     int scan_cap;
     int32_t scan_idx_base;    // emitted index = scan_idx_base + A row
+    float* scan_dense;        // SAMPLE form (round 4): not null -> no filtering; tile t covers A rows [t * 256 * scan_tile_stride, + 256) and
+    int scan_dense_stride;    // writes the maximum of each of its eight 32-row groups per query: scan_dense[q * stride + 8 t + group]
+    int scan_tile_stride;
     int scan_rows;            // rows of the shard (0 = M).  Not a multiple of 256: M = rows rounded up, and the LAST tile is the
                               // shard's last 256 rows (it overlaps its predecessor; the rows scored twice are reported once)
     // ---- split-bf16 ("bf16x3") operands: reference precision on the bf16 matrix cores (x3_path.hip) -------------------
@@ -71,6 +74,11 @@ struct GemmParams {
 // thr256 [256] fp32 (+inf for rows beyond the batch).  ONE pass over the corpus whatever the batch size.
 int tt_scan_gemm_launch(const uint16_t* corpus, int64_t rows, int dim, const uint16_t* queries256, const float* thr256,
                         int32_t* cnt, float* cand_scores, int32_t* cand_idx, int cap, int32_t idx_base, hipStream_t st);
+// Threshold sample of the tiled scan on the same contraction: `tiles` row tiles of 256 rows, tile t at row t * 256 * tile_stride;
+// dense[q * dense_stride + 8 t + g] = max over the tile's g-th 32-row group of q . row (NaN rows ignored).  One read of the sample
+// rows for all 256 queries (the streaming sample kernel reads them once per 64-query tile).
+int tt_scan_gemm_sample_launch(const uint16_t* corpus, int tiles, int tile_stride, int dim, const uint16_t* queries256, const float* thr256,
+                               float* dense, int dense_stride, hipStream_t st);
 int tt_gemm_launch(const GemmParams& p, int epilogue, hipStream_t st);
 // M <= 256 (a multiple of 64) runs on the weight-streaming skinny kernel unless TT_GEMM_SKINNY=0 (A/B switch)
 bool tt_gemm_skinny_enabled();

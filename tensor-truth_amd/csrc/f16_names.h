@@ -3,6 +3,7 @@
 // launch functions (encoder.h)
 #define tt_gemm_launch tt_gemm_launch_f16
 #define tt_scan_gemm_launch tt_scan_gemm_launch_f16
+#define tt_scan_gemm_sample_launch tt_scan_gemm_sample_launch_f16
 #define tt_gemm_skinny_enabled tt_gemm_skinny_enabled_f16
 #define tt_attention_launch tt_attention_launch_f16
 #define tt_attention_cls_launch tt_attention_cls_launch_f16

@@ -987,6 +987,41 @@ __device__ __forceinline__ void scan_filter_epilogue(const GemmParams& p, f32x4 
     }
 }
 
+// Sample form of the scan contraction (GemmParams.scan_dense): per query the maximum of every 32-row group of the tile.  A lane
+// holds 4 queries x 1 row of each 16 x 16 MFMA tile (row = lane & 15): the two MFMA tiles of a group are combined in registers,
+// the 16 rows of a tile across lanes with four DPP steps (quad_perm xor 1, xor 2, row_half_mirror, row_mirror: max is symmetric,
+// so every lane ends with the group's maximum); v_max_f32 drops NaN operands, so tombstoned rows do not count.
+__device__ __forceinline__ float dpp_max16(float v) {
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)));
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true)));
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true)));
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true)));
+    return v;
+}
+__device__ __forceinline__ void scan_sample_epilogue(const GemmParams& p, f32x4 (&acc)[2][2][2][4], int tile, int wm, int wn, int lane) {
+    const int g = lane >> 4, l15 = lane & 15;
+#pragma unroll
+    for (int qn = 0; qn < 2; ++qn)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int q0 = wn * 64 + qn * 32 + nt * 16 + g * 4;
+#pragma unroll
+            for (int qm = 0; qm < 2; ++qm)
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const f32x4 a = acc[qm][qn][nt][2 * half], b = acc[qm][qn][nt][2 * half + 1];
+                    float m[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) m[r] = dpp_max16(fmaxf(a[r], b[r]));
+                    if (l15 == 0) {
+                        const int grp = tile * 8 + qm * 4 + wm * 2 + half;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) p.scan_dense[(size_t)(q0 + r) * p.scan_dense_stride + grp] = m[r];
+                    }
+                }
+        }
+}
+
 #define TT_SLOT_END()                                         \
     do {                                                      \
         __builtin_amdgcn_sched_barrier(0);                    \
@@ -1064,6 +1099,7 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
     if (tm >= mt_n || tn >= nt_n) return;
     int m0_nominal = tm * BM3;
     if constexpr (EPI == TT_EPI_SCAN) {
+        if (p.scan_tile_stride > 1) m0_nominal *= p.scan_tile_stride;                           // sample form: every S-th row tile
         if (p.scan_rows && m0_nominal + BM3 > p.scan_rows) m0_nominal = p.scan_rows - BM3;      // the shard's last 256 rows
     }
     const int m0 = m0_nominal, n0 = tn * BN3;
@@ -1431,7 +1467,8 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
             for (int qn = 0; qn < 2; ++qn)
                 gemm_epilogue_wide<EPI, 2, 4>(p, acc[qm][qn], m0 + qm * 128 + wm * 64, n0 + wn * 64 + qn * 32, lane);
     } else if constexpr (EPI == TT_EPI_SCAN) {
-        if (p.xp & 0x10000) scan_filter_epilogue<2>(p, acc, smem, kBiasOff, m0, wm, wn, lane);
+        if (p.scan_dense) scan_sample_epilogue(p, acc, tm, wm, wn, lane);
+        else if (p.xp & 0x10000) scan_filter_epilogue<2>(p, acc, smem, kBiasOff, m0, wm, wn, lane);
         else scan_filter_epilogue<1>(p, acc, smem, kBiasOff, m0, wm, wn, lane);
     } else if constexpr (SLOTS == 47) {
 #pragma unroll
@@ -2189,6 +2226,39 @@ int tt_gemm_launch(const GemmParams& p, int epilogue, hipStream_t st) {
 #ifndef TT_SCAN_PERSIST_DEFAULT
 #define TT_SCAN_PERSIST_DEFAULT 1        // persistent + wave-private lists: -3.6 % per batch (profiles/r03_scan_wave_private_ab.log)
 #endif
+int tt_scan_gemm_sample_launch(const uint16_t* corpus, int tiles, int tile_stride, int dim, const uint16_t* queries256, const float* thr256,
+                               float* dense, int dense_stride, hipStream_t st) {
+    if (tiles <= 0) return TT_OK;
+    if constexpr (kF16) { tt_set_error("scan gemm: the corpus is bf16 (bf16 instantiation only)"); return TT_E_UNSUPPORTED; }
+    else
+    if (dim % 128 || dim <= 0 || tile_stride < 1 || !dense || dense_stride < tiles * 8 || (int64_t)tiles * tile_stride * v3::BM3 > INT32_MAX) {
+        tt_set_error("scan gemm sample: tiles=%d stride=%d dim=%d dense_stride=%d", tiles, tile_stride, dim, dense_stride);
+        return TT_E_UNSUPPORTED;
+    }
+    GemmParams p{};
+    p.A = corpus;
+    p.W = queries256;
+    p.bias = thr256;            // (staged like the filter pass's thresholds, not read)
+    p.M = tiles * v3::BM3;
+    p.N = v3::BN3;
+    p.K = dim;
+    p.lda = dim;
+    p.ldc = 8;
+    p.scan_dense = dense;
+    p.scan_dense_stride = dense_stride;
+    p.scan_tile_stride = tile_stride;
+    p.sn = 1;
+    const int blocks = (tiles + 31) / 32 * 32;
+    constexpr int kLdsOne = v3::kLdsScan > v3::kLdsScanW ? v3::kLdsScan : v3::kLdsScanW;
+    TT_SET_MAX_LDS((v3::gemm_kernel_v3<TT_EPI_SCAN, 4>), kLdsOne);
+    {
+        TtProfScope prof(TT_K_SCAN_SAMPLE, st);
+        hipLaunchKernelGGL((v3::gemm_kernel_v3<TT_EPI_SCAN, 4>), dim3(blocks), dim3(v3::kThreads3), kLdsOne, st, p);
+    }
+    TT_CHECK_LAUNCH();
+    return TT_OK;
+}
+
 int tt_scan_gemm_launch(const uint16_t* corpus, int64_t rows, int dim, const uint16_t* queries256, const float* thr256,
                         int32_t* cnt, float* cand_scores, int32_t* cand_idx, int cap, int32_t idx_base, hipStream_t st) {
     if (rows <= 0) return TT_OK;

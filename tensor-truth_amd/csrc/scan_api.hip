@@ -101,6 +101,7 @@ Plan make_plan(int64_t n_rows, int dim, int n_queries, int k, int cus) {
             while (n0 > 32768 && n0 * 64 > n_rows) n0 /= 2;
         if (n0 < (int64_t)512 * k) n0 = (int64_t)512 * k;
         if (n0 > n_rows / 2) n0 = n_rows / 2 / 32 * 32;
+        n0 = n0 / 256 * 256;     // (the sample runs on the same 256-row tiles as the filter pass: tt_scan_gemm_sample_launch)
         pl.q256 = (n_queries + 255) / 256 * 256;
         pl.qpad = pl.q256;
         int64_t cap = 4 * (int64_t)k * n_rows / n0 + 4096;
@@ -295,6 +296,14 @@ int tt_scan_topk(const void* corpus_bf16, int64_t n_rows, int dim, const void* q
     const int mode = scan_mode_from_env();
     const int cus = tt_cu_count_cached();
 
+    // (tiled path) the 256-query blocks the contraction reads: the batch itself when it is full, else a zero-padded copy
+    const uint16_t* q256 = (const uint16_t*)queries_bf16;
+    if (pl.gemm && n_queries != pl.q256) {
+        uint16_t* qpad256 = (uint16_t*)(ws + pl.off_q256);
+        TT_CHECK_HIP(hipMemsetAsync(qpad256 + (size_t)n_queries * dim, 0, (size_t)(pl.q256 - n_queries) * dim * sizeof(uint16_t), st));
+        TT_CHECK_HIP(hipMemcpyAsync(qpad256, queries_bf16, (size_t)n_queries * dim * sizeof(uint16_t), hipMemcpyDeviceToDevice, st));
+        q256 = qpad256;
+    }
     // 1. sample: group maxima of rows [0, n0)
     ScanParams sp{};
     sp.corpus = (const uint16_t*)corpus_bf16;
@@ -308,8 +317,23 @@ int tt_scan_topk(const void* corpus_bf16, int64_t n_rows, int dim, const void* q
     // the n0 / 32 sampled groups are spread evenly over the shard (every group_stride-th 32-row group)
     sp.group_stride = (n_rows / 32) / ((pl.n0 + 31) / 32);
     sp.phys_rows = n_rows;
-    rc = tt_scan_launch(sp, dim, mode, 2, cus, st);
-    if (rc) return rc;
+    // Tiled path (round 4): the sample runs on the filter pass's own contraction -- n0 / 256 row tiles spread evenly over the
+    // shard, ONE read of the sample rows for all 256 queries and the same MFMA arithmetic as the pass that applies the
+    // thresholds (the streaming sample kernel reads the rows once per 64-query tile: 63 of the shard batch's 730 us).
+    // TT_SCAN_GEMM_SAMPLE=0: the streaming sample, the A/B switch.
+    static const bool gemm_sample = [] { const char* e = getenv("TT_SCAN_GEMM_SAMPLE"); return !(e && e[0] == '0'); }();
+    if (pl.gemm && gemm_sample) {
+        const int tiles = (int)(pl.n0 / 256);
+        const int tile_stride = (int)((n_rows / 256) / tiles);
+        for (int b = 0; b < pl.q256 / 256; ++b) {
+            rc = tt_scan_gemm_sample_launch((const uint16_t*)corpus_bf16, tiles, tile_stride, dim, q256 + (size_t)b * 256 * dim, thr + b * 256,
+                                            dense + (size_t)b * 256 * pl.stride, (int)pl.stride, st);
+            if (rc) return rc;
+        }
+    } else {
+        rc = tt_scan_launch(sp, dim, mode, 2, cus, st);
+        if (rc) return rc;
+    }
 
     // 2. thr[q] = k-th best group maximum (the selected rows themselves are re-found by
     //    the filter pass, so the outputs of this selection are scratch)
@@ -361,13 +385,7 @@ int tt_scan_topk(const void* corpus_bf16, int64_t n_rows, int dim, const void* q
     if (pl.gemm) {
         // 3'. filter pass as a tiled contraction: rows [0, rows256) x 256 queries per launch, ONE pass over the corpus per
         //     256 queries; the < 256 tail rows through the streaming kernel (private lists of one block)
-        const uint16_t* q256 = (const uint16_t*)queries_bf16;
-        if (n_queries != pl.q256) {     // a ragged batch: zero-padded copy (a full 256-query batch is read where it lies)
-            uint16_t* qpad256 = (uint16_t*)(ws + pl.off_q256);
-            TT_CHECK_HIP(hipMemsetAsync(qpad256 + (size_t)n_queries * dim, 0, (size_t)(pl.q256 - n_queries) * dim * sizeof(uint16_t), st));
-            TT_CHECK_HIP(hipMemcpyAsync(qpad256, queries_bf16, (size_t)n_queries * dim * sizeof(uint16_t), hipMemcpyDeviceToDevice, st));
-            q256 = qpad256;
-        }
+        // (q256: the batch itself when it is full, else the zero-padded copy made before the sample)
         // (rows not a multiple of 256: the contraction's last tile is the shard's last 256 rows -- no separate pass over the tail;
         //  TT_SCAN_GEMM_TAIL=1: rounds 2-3's form, the < 256 tail rows through the streaming kernel, the A/B switch)
         static const bool tail_pass = [] { const char* e = getenv("TT_SCAN_GEMM_TAIL"); return e && e[0] == '1'; }();

@@ -153,3 +153,42 @@ def test_wave_select_equals_lds_network_in_a_child_process(dev, built_lib, tmp_p
                    check=True, env=env, cwd=root, timeout=900, capture_output=True)
     theirs = torch.load(str(other))
     assert len(mine) == len(theirs) and all(torch.equal(a, b) for a, b in zip(mine, theirs))
+
+
+def test_contraction_sample_equals_streaming_sample_in_a_child_process(dev, built_lib, tmp_path):
+    """A/B: the tiled scan's threshold sample on the contraction kernel (round 4) against the streaming sample kernel
+    (TT_SCAN_GEMM_SAMPLE=0).  The two samples look at different rows, so the thresholds differ -- the RESULT may not: top-k scores
+    and indices bit-identical, on a full 256-query batch, a ragged one (zero-padded copy), one with NaN tombstones in the sampled
+    tiles, and a shard whose rows are not a multiple of 256."""
+    import os
+    import subprocess
+    import sys
+
+    from tensor_truth_amd import scan as tscan
+
+    def run():
+        out = []
+        for n, nq, k, holes in ((300_032, 256, 50, False), (300_007, 100, 7, False), (524_288, 256, 50, True), (1_250_001, 130, 50, False)):
+            corpus = osc.synth_corpus(n, 1024, seed=15)
+            queries, _ = osc.synth_queries(corpus, nq, seed=16)
+            if holes:      # tombstone whole sampled tiles and scattered rows (after the queries were planted on live rows)
+                corpus[:512] = float("nan")
+                corpus[torch.arange(1000, n, 997)] = float("nan")
+            s, i = tscan.scan_topk(corpus.to(dev), queries.to(dev), k)
+            out += [s.cpu(), i.cpu()]
+        return out
+
+    mine = run()
+    if os.environ.get("TT_SAMPLE_AB_CHILD"):
+        torch.save(mine, os.environ["TT_SAMPLE_AB_CHILD"])
+        return
+    other = tmp_path / "streaming_sample.pt"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TT_SCAN_GEMM_SAMPLE="0", TT_SAMPLE_AB_CHILD=str(other))
+    subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu",
+                    os.path.abspath(__file__) + "::test_contraction_sample_equals_streaming_sample_in_a_child_process"],
+                   check=True, env=env, cwd=root, timeout=900, capture_output=True)
+    theirs = torch.load(str(other))
+    assert len(mine) == len(theirs) and all(torch.equal(a, b) for a, b in zip(mine, theirs))
+    for s, i in zip(mine[0::2], mine[1::2]):
+        assert torch.isfinite(s).all() and (i >= 0).all()
