@@ -33,7 +33,9 @@ def main(pmc_dir, out):
         if "GRBM_GUI_ACTIVE" not in d:
             continue
         if "gemm_kernel_v3<6" in n or "gemm_kernel_p<6" in n:
-            fam["scan_tiled_filter_pass"].append(d)
+            # (round 4: the threshold sample runs on the same kernel with a grid of n0 / 256 <= 512 row tiles; a filter pass has
+            #  one workgroup per CU in the persistent form or >= 4883 tiles)
+            fam["scan_tiled_filter_pass" if ("gemm_kernel_p<6" in n or d["grid"] > 1024 * 512) else "scan_tiled_sample"].append(d)
         elif "attention_kernel" in n and "cls" not in n:
             if d["grid"] * 1 >= 1000 * 256:
                 fam["attention (rerank batch)"].append(d)

@@ -43,8 +43,13 @@ def main(fetch_dir, write_dir, out):
     if fr and wr:
         # the process runs the tiled pass at two sizes (same kernel, same grid in the persistent form): over the whole corpus
         # (scan_only leg) and over corpus / 8 rows (scan_only_shard leg) -- told apart by the bytes they fetch
-        order = sorted(range(len(fr)), key=lambda i: float(fr[i]["Counter_Value"]))
-        for name, i in (("scan_tiled_256q", order[-1]), ("scan_tiled_256q_shard", order[0])):
+        # (round 4: the threshold SAMPLE runs on the same kernel over n0 <= 131072 rows -- < 0.3 GB; a filter pass reads >= 2.5 GB)
+        order = sorted((i for i in range(len(fr)) if float(fr[i]["Counter_Value"]) * 2048 >= 1e9), key=lambda i: float(fr[i]["Counter_Value"]))
+        samples = sorted((i for i in range(len(fr)) if float(fr[i]["Counter_Value"]) * 2048 < 1e9), key=lambda i: float(fr[i]["Counter_Value"]))
+        picks = [("scan_tiled_256q", order[-1]), ("scan_tiled_256q_shard", order[0])] if order else []
+        if samples:
+            picks += [("scan_tiled_sample", samples[-1]), ("scan_tiled_sample_shard", samples[0])]
+        for name, i in picks:
             fetch = float(fr[i]["Counter_Value"]) * 1024 * 2
             write = float(wr[i]["Counter_Value"]) * 1024
             res[name] = {"launches": 1, "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write,
