@@ -52,6 +52,8 @@ struct GemmParams {
     int c_lo_off;             // planes output: column offset of the lo plane
     float* C32;               // fp32 output [M][ldc] (x3 residual epilogue)
     const float* res32;       // fp32 residual [M][ldr]
+    const uint16_t* res_planes;   // (round 4) the residual as the two planes of the same activation instead: res = hi + lo, hi at
+    int res_lo_off;               // res_planes[m * ldr + n], lo res_lo_off columns further -- the LayerNorm then writes no fp32 copy
     uint16_t* vt_lo;          // lo plane of the V8 output
     int x3_zero_lo;           // diagnostic (TT_X3_ROUND_MASK): planes outputs are written with lo = 0, i.e. rounded to bf16
     // ---- f16c operands: reference precision on TWO matrix-time units (f16c_path.hip; fp16 instantiation only) ---------------

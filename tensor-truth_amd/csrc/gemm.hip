@@ -637,7 +637,7 @@ __device__ __forceinline__ void epilogue_all(const GemmParams& p, f32x4 (&acc)[2
 //   lo = bf16(v - hi), 16 bytes each per lane;  RESIDUAL: fp32 out = acc + bias + fp32 residual, 32 bytes per lane.
 __device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 
-template <int EPI>
+template <int EPI, bool RP = false>   // RP: the residual comes as the two planes of the activation (GemmParams.res_planes), not as fp32
 __device__ __forceinline__ void epilogue_x3(const GemmParams& p, f32x4 (&acc)[2][2][2][4], const char* smem, int bias_off, int m0,
                                             int n0, int wm, int wn, int lane) {
     const int g = lane >> 4;
@@ -671,9 +671,16 @@ __device__ __forceinline__ void epilogue_x3(const GemmParams& p, f32x4 (&acc)[2]
                 for (int qn = 0; qn < 2; ++qn)
 #pragma unroll
                     for (int nt = 0; nt < 2; ++nt) {
-                        const float* rp = p.res32 + (size_t)m * p.ldr + n0 + qn * 32 + nt * 16 + ncol;
-                        r0[qn][nt] = *reinterpret_cast<const float4*>(rp);
-                        r1[qn][nt] = *reinterpret_cast<const float4*>(rp + 4);
+                        if constexpr (RP) {      // 8 columns of both planes: 16 + 16 bytes instead of 32 of fp32
+                            const uint16_t* rp = p.res_planes + (size_t)m * p.ldr + n0 + qn * 32 + nt * 16 + ncol;
+                            const uint4 h = *reinterpret_cast<const uint4*>(rp), l = *reinterpret_cast<const uint4*>(rp + p.res_lo_off);
+                            r0[qn][nt] = float4{__uint_as_float(h.x), __uint_as_float(h.y), __uint_as_float(h.z), __uint_as_float(h.w)};
+                            r1[qn][nt] = float4{__uint_as_float(l.x), __uint_as_float(l.y), __uint_as_float(l.z), __uint_as_float(l.w)};
+                        } else {
+                            const float* rp = p.res32 + (size_t)m * p.ldr + n0 + qn * 32 + nt * 16 + ncol;
+                            r0[qn][nt] = *reinterpret_cast<const float4*>(rp);
+                            r1[qn][nt] = *reinterpret_cast<const float4*>(rp + 4);
+                        }
                     }
             }
 #pragma unroll
@@ -694,7 +701,13 @@ __device__ __forceinline__ void epilogue_x3(const GemmParams& p, f32x4 (&acc)[2]
                     v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
                     const int n = n0 + qn * 32 + nt * 16 + ncol;
                     if constexpr (EPI == TT_EPI_RESIDUAL) {
-                        const float4 a = r0[qn][nt], b = r1[qn][nt];
+                        float4 a = r0[qn][nt], b = r1[qn][nt];
+                        if constexpr (RP) {      // a = the hi plane's 8 elements, b = the lo plane's: residual = hi + lo
+                            const uint32_t h0 = __float_as_uint(a.x), h1 = __float_as_uint(a.y), h2 = __float_as_uint(a.z), h3 = __float_as_uint(a.w);
+                            const uint32_t l0 = __float_as_uint(b.x), l1 = __float_as_uint(b.y), l2 = __float_as_uint(b.z), l3 = __float_as_uint(b.w);
+                            a = float4{elo(h0) + elo(l0), ehi(h0) + ehi(l0), elo(h1) + elo(l1), ehi(h1) + ehi(l1)};
+                            b = float4{elo(h2) + elo(l2), ehi(h2) + ehi(l2), elo(h3) + elo(l3), ehi(h3) + ehi(l3)};
+                        }
                         float* cp = p.C32 + (size_t)m * p.ldc + n;
                         *reinterpret_cast<float4*>(cp) = float4{v[0] + a.x, v[1] + a.y, v[2] + a.z, v[3] + a.w};
                         *reinterpret_cast<float4*>(cp + 4) = float4{v[4] + b.x, v[5] + b.y, v[6] + b.z, v[7] + b.w};
@@ -1072,7 +1085,7 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
-template <int EPI, int SLOTS, bool FP8 = false, bool X3 = false, bool XC = false>
+template <int EPI, int SLOTS, bool FP8 = false, bool X3 = false, bool XC = false, bool RP = false>
 __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
     static_assert(!(FP8 && X3), "split-bf16 operands are bf16");
     static_assert(!XC || (!FP8 && !X3 && kF16), "f16c operands: the fp16 instantiation, no other operand mode");
@@ -1452,7 +1465,7 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
             for (int qn = 0; qn < 2; ++qn)
                 gemm_epilogue_vt<2, 4, FP8, X3>(p, acc[qm][qn], m0 + qm * 128 + wm * 64, n0 + wn * 64 + qn * 32, lane);
     } else if constexpr (X3) {
-        epilogue_x3<EPI>(p, acc, smem, kBiasOff, m0, n0, wm, wn, lane);
+        epilogue_x3<EPI, RP>(p, acc, smem, kBiasOff, m0, n0, wm, wn, lane);
     } else if constexpr (XC && EPI == TT_EPI_RESIDUAL) {
         epilogue_x3<EPI>(p, acc, smem, kBiasOff, m0, n0, wm, wn, lane);          // fp32 out = acc + bias + fp32 residual
     } else if constexpr (XC && EPI == TT_EPI_GELU) {
@@ -1816,7 +1829,14 @@ __device__ __forceinline__ void gemm_epilogue_tile_x3(const GemmParams& p, f32x4
             const int m = mw + j * 16 + (lane & 15);
             float v[4] = {acc[i][j][0] + b4.x, acc[i][j][1] + b4.y, acc[i][j][2] + b4.z, acc[i][j][3] + b4.w};
             if constexpr (EPI == TT_EPI_RESIDUAL) {
-                const float4 r = *reinterpret_cast<const float4*>(p.res32 + (size_t)m * p.ldr + n);
+                float4 r;
+                if (p.res_planes) {      // (same values, same operations as epilogue_x3)
+                    const uint16_t* rp = p.res_planes + (size_t)m * p.ldr + n;
+                    const uint2 h = *reinterpret_cast<const uint2*>(rp), l = *reinterpret_cast<const uint2*>(rp + p.res_lo_off);
+                    r = float4{elo(h.x) + elo(l.x), ehi(h.x) + ehi(l.x), elo(h.y) + elo(l.y), ehi(h.y) + ehi(l.y)};
+                } else {
+                    r = *reinterpret_cast<const float4*>(p.res32 + (size_t)m * p.ldr + n);
+                }
                 *reinterpret_cast<float4*>(p.C32 + (size_t)m * p.ldc + n) = float4{v[0] + r.x, v[1] + r.y, v[2] + r.z, v[3] + r.w};
             } else {
                 if constexpr (EPI == TT_EPI_GELU) {
@@ -1912,7 +1932,7 @@ int launch_x3(const GemmParams& p, hipStream_t st) {
         if (tt_gemm_skinny_enabled() && p.M > 0 && p.M <= 256 && p.M % 64 == 0 && p.N % 16 == 0 && p.K % 32 == 0 && p.lda >= 2 * p.K &&
             ldw >= 2 * p.K && p.lda % 8 == 0 && ldw % 8 == 0 && p.A && p.W && p.bias) {
             if constexpr (EPI == TT_EPI_RESIDUAL) {
-                if (!p.C32 || !p.res32 || p.ldc % 4 || p.ldr % 4) { tt_set_error("gemm x3: residual epilogue needs fp32 C32 / res32"); return TT_E_INVALID; }
+                if (!p.C32 || (!p.res32 && !p.res_planes) || p.ldc % 4 || p.ldr % 4 || (p.res_planes && (p.ldr % 8 || p.res_lo_off % 8))) { tt_set_error("gemm x3: residual epilogue needs fp32 C32 and res32 or res_planes"); return TT_E_INVALID; }
             } else if constexpr (EPI == TT_EPI_VT) {
                 if (!p.vt || !p.vt_lo) { tt_set_error("gemm x3: V^T epilogue needs vt / vt_lo"); return TT_E_INVALID; }
             } else {
@@ -1934,7 +1954,7 @@ int launch_x3(const GemmParams& p, hipStream_t st) {
             return TT_E_UNSUPPORTED;
         }
         if constexpr (EPI == TT_EPI_RESIDUAL) {
-            if (!p.C32 || !p.res32 || p.ldc % 4 || p.ldr % 4) { tt_set_error("gemm x3: residual epilogue needs fp32 C32 / res32"); return TT_E_INVALID; }
+            if (!p.C32 || (!p.res32 && !p.res_planes) || p.ldc % 4 || p.ldr % 4 || (p.res_planes && (p.ldr % 8 || p.res_lo_off % 8))) { tt_set_error("gemm x3: residual epilogue needs fp32 C32 and res32 or res_planes"); return TT_E_INVALID; }
         } else if constexpr (EPI == TT_EPI_VT) {
             if (!p.vt || !p.vt_lo || p.ldvt % 8) { tt_set_error("gemm x3: V^T epilogue needs vt / vt_lo"); return TT_E_INVALID; }
         } else {
@@ -1951,7 +1971,16 @@ int launch_x3(const GemmParams& p, hipStream_t st) {
             GemmParams q = p;
             q.sn = SN;
             q.ldw = ldw;
-            hipLaunchKernelGGL((v3::gemm_kernel_v3<EPI, 4, false, true>), dim3(blocks), dim3(v3::kThreads3), v3::kLds3, st, q);
+            if constexpr (EPI == TT_EPI_RESIDUAL) {
+                if (p.res_planes) {
+                    TT_SET_MAX_LDS((v3::gemm_kernel_v3<EPI, 4, false, true, false, true>), v3::kLds3);
+                    hipLaunchKernelGGL((v3::gemm_kernel_v3<EPI, 4, false, true, false, true>), dim3(blocks), dim3(v3::kThreads3), v3::kLds3, st, q);
+                } else {
+                    hipLaunchKernelGGL((v3::gemm_kernel_v3<EPI, 4, false, true>), dim3(blocks), dim3(v3::kThreads3), v3::kLds3, st, q);
+                }
+            } else {
+                hipLaunchKernelGGL((v3::gemm_kernel_v3<EPI, 4, false, true>), dim3(blocks), dim3(v3::kThreads3), v3::kLds3, st, q);
+            }
         }
         TT_CHECK_LAUNCH();
         return TT_OK;

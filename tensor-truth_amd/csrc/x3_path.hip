@@ -661,6 +661,12 @@ int forward_x3_impl(const tt_encoder_weights_x3* w, const int32_t* ids, const in
     // encoder_x3.EncoderWeightsX3(round_weights=True).)
     const int rmask = TT_DIAG_ENV_INT("TT_X3_ROUND_MASK", 0);
     const int ln_out = (rmask & 32) ? 2 : 0, ln_in = (rmask & 16) ? 1 : 0;
+    // fp16 planes (22 significand bits; the default reference implementation): the residual branch is REBUILT from the planes of the
+    // LayerNorm output, hi + lo (abs. error <= max(2^-22 |x|, 2^-25)), instead of carried as a separate fp32 copy -- a LayerNorm
+    // pass then writes 8 bytes per element (two planes) instead of 12 and the residual epilogue reads the same 4.  bf16 planes
+    // (16 bits) keep the fp32 copy.  TT_X3_RES_PLANES=0: the fp32 copy, the A/B switch; the rounding diagnostics (rmask) keep it too.
+    static const bool res_planes_env = [] { const char* e_ = getenv("TT_X3_RES_PLANES"); return !(e_ && e_[0] == '0'); }();
+    const bool res_planes = kF16 && res_planes_env && rmask == 0;
     float* x = (w->layers == 0 && hidden_out) ? hidden_out : xa;
     {
         TtProfScope prof(TT_K_ROWOPS, st);
@@ -743,12 +749,13 @@ int forward_x3_impl(const tt_encoder_weights_x3* w, const int32_t* ids, const in
         go.x3 = 1;
         go.A = ctx; go.lda = 2 * H; go.W = (const uint16_t*)lw.o_w; go.ldw = 2 * H; go.bias = lw.o_b;
         go.res32 = x; go.ldr = H; go.C32 = y; go.ldc = H; go.M = T; go.N = H; go.K = H;
+        if (res_planes) { go.res32 = nullptr; go.res_planes = xpl; go.res_lo_off = H; go.ldr = 2 * H; }
         if (int rc = tt_gemm_launch(go, TT_EPI_RESIDUAL, st)) return rc;
         float* x1 = (x == xa) ? xb : xa;
         {
             TtProfScope prof(TT_K_ROWOPS, st);
-            hipLaunchKernelGGL(layernorm_x3_kernel, row_grid_x(T), dim3(kRowThreadsX), 0, st, y, x1, xpl, lw.ln1_g, lw.ln1_b, T, H, w->ln_eps,
-                               ln_in | ln_out);
+            hipLaunchKernelGGL(layernorm_x3_kernel, row_grid_x(T), dim3(kRowThreadsX), 0, st, y, res_planes ? (float*)nullptr : x1, xpl, lw.ln1_g,
+                               lw.ln1_b, T, H, w->ln_eps, ln_in | ln_out);
             TT_CHECK_LAUNCH();
         }
         GemmParams g1{};
@@ -761,13 +768,16 @@ int forward_x3_impl(const tt_encoder_weights_x3* w, const int32_t* ids, const in
         g2.x3 = 1;
         g2.A = ffn; g2.lda = 2 * F; g2.W = (const uint16_t*)lw.ffn2_w; g2.ldw = 2 * F; g2.bias = lw.ffn2_b;
         g2.res32 = x1; g2.ldr = H; g2.C32 = y; g2.ldc = H; g2.M = T; g2.N = H; g2.K = F;
+        if (res_planes) { g2.res32 = nullptr; g2.res_planes = xpl; g2.res_lo_off = H; g2.ldr = 2 * H; }
         if (int rc = tt_gemm_launch(g2, TT_EPI_RESIDUAL, st)) return rc;
         const bool last = l == w->layers - 1;
         float* dst = last ? hidden_out : x;
+        // (the fp32 copy is still written where something reads it: the forward's output, and the input of a first-rows-only last layer)
+        const bool want32 = !res_planes || last || (cls_tail && l == w->layers - 2);
         {
             TtProfScope prof(TT_K_ROWOPS, st);
-            hipLaunchKernelGGL(layernorm_x3_kernel, row_grid_x(T), dim3(kRowThreadsX), 0, st, y, dst, last ? (uint16_t*)nullptr : xpl,
-                               lw.ln2_g, lw.ln2_b, T, H, w->ln_eps, ln_in | ln_out);
+            hipLaunchKernelGGL(layernorm_x3_kernel, row_grid_x(T), dim3(kRowThreadsX), 0, st, y, want32 ? dst : (float*)nullptr,
+                               last ? (uint16_t*)nullptr : xpl, lw.ln2_g, lw.ln2_b, T, H, w->ln_eps, ln_in | ln_out);
             TT_CHECK_LAUNCH();
         }
         x = dst;
