@@ -2,6 +2,8 @@
 occasional different bit) and agree with torch on fresh random data every time."""
 import sys, time
 sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from tensor_truth_amd import _lib
 from tensor_truth_amd.encoder import BGE_RERANKER_V2_M3, Encoder, EncoderConfig, EncoderWeights, pack_token_matrix, synthetic_state_device
@@ -34,6 +36,33 @@ for i in range(n_rep):
 torch.cuda.synchronize()
 print(f"fp16: {n_rep} repeated forwards (6 layers, 800x292), non-identical results: {bad}  ({time.time()-t0:.1f}s)", flush=True)
 del rr16
+# ---- 1c. the reference-precision implementations (round 4): split-fp16 planes (three MFMAs per fragment pair, residual from the planes)
+#          and f16c (fp16 + block-scaled e4m3 K stream with its own counted waits): identical bits across repetitions
+from tensor_truth_amd.encoder_x3 import EncoderWeightsX3, EncoderX3
+from tensor_truth_amd.encoder_f16c import EncoderF16C, EncoderWeightsF16C
+state32 = synthetic_state_device(cfg, dev, seed=2, dtype=torch.float32)
+for name, make in (("f16x3", lambda: EncoderX3(EncoderWeightsX3(cfg, state32, dev, dtype=torch.float16))),
+                   ("f16c", lambda: EncoderF16C(EncoderWeightsF16C(cfg, state32, dev)))):
+    enc = make()
+    ref = enc.rerank_packed(batch).clone(); bad = 0
+    t0 = time.time()
+    for i in range(max(4, n_rep // 3)):
+        if not torch.equal(enc.rerank_packed(batch), ref): bad += 1
+    torch.cuda.synchronize()
+    print(f"{name}: {max(4, n_rep // 3)} repeated forwards (6 layers, 800x292), non-identical results: {bad}  ({time.time()-t0:.1f}s)", flush=True)
+    del enc
+# ---- 1d. tiled scan (contraction-based sample, wave-register select): identical bits across repetitions, 256 and 100 queries
+from tensor_truth_amd import scan as tscan
+import bench as _bench
+corpus = _bench.synth_corpus_shard(1_250_000, 1024, 1234, dev)
+for nq in (256, 100):
+    q = torch.nn.functional.normalize(torch.randn(nq, 1024, device=dev, generator=torch.Generator(device=dev).manual_seed(nq)), dim=1).to(torch.bfloat16)
+    s0, i0 = tscan.scan_topk(corpus, q, 50); bad = 0
+    for i in range(n_rep):
+        s1, i1 = tscan.scan_topk(corpus, q, 50)
+        if not (torch.equal(s0, s1) and torch.equal(i0, i1)): bad += 1
+    print(f"scan 1.25M x 1024, {nq} queries, top-50: {n_rep} repetitions, non-identical results: {bad}", flush=True)
+del corpus
 # ---- 2. GEMM epilogues vs torch on fresh data
 shapes = [(3072, 1024), (1024, 1024), (4096, 1024), (1024, 4096)]
 worst = 0.0
