@@ -134,7 +134,8 @@ def open_data_plane(dist, torch, dev, rank, world, backend="nccl", deadline_s=18
     (`collective_backend`), and a scaling number exists instead of a dead run.  The attempt runs in a thread under a deadline: a
     rank whose peers failed fast would otherwise wait in its first collective for the communicator's whole timeout.  The ranks
     AGREE on the outcome over gloo (MIN of the ok flags), so either all use the RCCL group or none does.
-    -> (None, "gloo (...)") means: use the default group."""
+    -> (group or None, label, hung): group None = use the default gloo group; hung = the attempt's thread is still inside the
+    backend (leave with os._exit, never destroy the groups)."""
     import datetime
     import threading
 
@@ -892,7 +893,10 @@ def main():
                                       if clock.get("sclk_mhz_median") and clock.get("sclk_mhz_spec") else None),
             # CONSTANT, not measured by this run: what the chip sustained in round 3 on a stream of nothing but
             # v_mfma_f32_16x16x32_bf16, no operand traffic (tools/gemm4w_bench variant 14, profiles/r03_gemm_4wave_ab.log)
-            "mfma_only_stream_TFLOPs": {"value": 1803.0, "measured_by_this_run": False, "source": "profiles/r03_gemm_4wave_ab.log"},
+            # (round 4: that figure IS the 1400 W power cap on random operands -- the same stream holds 2.39 PF on low-entropy
+            # operands and 2.45 PF on zeros, profiles/r04_power_cap.log)
+            "mfma_only_stream_TFLOPs": {"value": 1803.0, "measured_by_this_run": False, "source": "profiles/r03_gemm_4wave_ab.log",
+                                        "note": "power-capped (random operands); 2388 on low-entropy operands: profiles/r04_power_cap.log"},
         },
         "roofline_scan": {
             "kernel": ("gemm_kernel_v3<TT_EPI_SCAN> (tiled MFMA filter pass over the corpus shard)" if tiled
