@@ -51,8 +51,11 @@ __device__ __forceinline__ void lds_wait2n(u32x4& a, u32x4& b) {
 // exponentials (the scaled difference goes on as the "probability"), 2 = no softmax at all (no mask, maximum, FMAs,
 // exponentials, sums or rescale: the raw scores are packed as P), 3 = 2 without the V reads and the P.V MFMAs,
 // 4 = everything, but every workgroup reads the K / V rows of sequence 0 (L2 hits: what the K / V misses cost)
-template <int DH, bool STAMP = false, int ABL = 0>
-__global__ __launch_bounds__(64 * kWaves, 4) void attention_kernel(AttnParams p) {
+// NW (round 4): waves = 32-row query blocks per workgroup.  4 is the shape of rounds 1-3; 5 (160 rows) is taken for batches of
+// 129-160 tokens, where it makes ONE workgroup of a sequence's two (tt_attention_launch; measured slower everywhere else).  A
+// row's arithmetic does not depend on NW.
+template <int DH, bool STAMP = false, int ABL = 0, int NW = kWaves>
+__global__ __launch_bounds__(64 * NW, 4) void attention_kernel(AttnParams p) {
     constexpr int RB = DH * 2;              // bytes per K row
     constexpr int CH = RB / 16;             // 16-B chunks per K row
     constexpr int RPB = 256 / RB;           // K rows per 256-B bank row
@@ -60,7 +63,9 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attention_kernel(AttnParams p)
     constexpr int DT = DH / 32;             // 32-row d tiles of O^T
     constexpr int NPK = kKTile * RB / 1024; // 1-KiB copy pieces of a K tile
     constexpr int NPV = 8 * DH * 16 / 1024; // ... of a V tile (8 token groups x DH features x 16 B)
-    constexpr int KPW = NPK / kWaves, VPW = NPV / kWaves;   // pieces per wave: 2 + 2 (dh 64), 1 + 1 (dh 32)
+    constexpr int KPW = NPK / kWaves, VPW = NPV / kWaves;   // pieces per wave (NW = 4): 2 + 2 (dh 64), 1 + 1 (dh 32)
+    constexpr bool kEvenPieces = NW == kWaves;              // NW = 5: piece j of the tile's NPK + NPV goes to wave j % NW
+    static_assert(kEvenPieces || (DH == 64 && NPK == 8 && NPV == 8), "the uneven piece map is written for head_dim 64");
     constexpr int BUF = (NPK + NPV) * 1024;
     // Two buffers: tile kt + 1 is copied while tile kt is computed.  (Three -- copies two tiles ahead, a copy needs about 3 us
     // to land under load and a tile 2-2.5 us to compute -- cost a workgroup per CU at 48 KiB each and measured 20 % slower,
@@ -93,7 +98,7 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attention_kernel(AttnParams p)
     if (pair >= p.heads * p.n_seq) return;
     const int head = pair % p.heads, seq = pair / p.heads;
     const int len = p.seq_len[seq];
-    if (qt * 32 * kWaves >= len) return;
+    if (qt * 32 * NW >= len) return;
     const int t0 = p.seq_start[seq];
     // Sequences may start at any row.  Keys are walked in the ALIGNED frame of the V8 token groups: aligned key ka is
     // global row t0a + ka, t0a = t0 rounded down to 8; the off = t0 - t0a rows in front of the sequence (the tail of its
@@ -112,13 +117,13 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attention_kernel(AttnParams p)
     // -- the kernel is not SIMD-issue bound: a key tile costs one LDS-DMA round trip whatever is computed in it (round 3's
     // ablations), so what a tail costs is its workgroup's walk over the key tiles, not the lanes it keeps busy.  Off by default.
     int wslot = wave;
-    if (p.rotate) {
+    if (p.rotate && NW == kWaves) {
         const int left = len - qt * 32 * kWaves;
         const int n_live = left >= 32 * kWaves ? kWaves : (left + 31) >> 5;
         if (n_live < kWaves) wslot = (wave + ((pair * n_live) & (kWaves - 1))) & (kWaves - 1);
     }
     // ---- Q fragments (B operand), straight from global ---------------------------------
-    const int q_row = (qt * kWaves + wslot) * 32 + ql;     // row inside the sequence
+    const int q_row = (qt * NW + wslot) * 32 + ql;         // row inside the sequence
     const int q_row_c = q_row < len ? q_row : len - 1;     // clamp: result discarded
     const uint16_t* qp = p.qk + (size_t)(t0 + q_row_c) * p.ld_qk + p.q_col0 + head * DH + hh * 8;
     ex8 qf[KS];
@@ -146,9 +151,11 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attention_kernel(AttnParams p)
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
     uint32_t kvoff0, vvoff0;             // byte offsets of this lane inside the wave's piece 0 of an unclamped tile
     {
-        const int e = wave * KPW * 64 + lane, r = e / CH, pos = e % CH;
+        // (uneven map: the lane offsets of K piece 0 / V piece 0 -- the piece index is in the scalar base and, for K, in bit 2 of
+        //  the chunk index of odd pieces, as below)
+        const int e = (kEvenPieces ? wave * KPW * 64 : 0) + lane, r = e / CH, pos = e % CH;
         kvoff0 = ((uint32_t)r * (uint32_t)p.ld_qk + (uint32_t)((pos ^ ((r / RPB) & (CH - 1))) << 3)) * 2u;
-        const int ev = wave * VPW * 64 + lane;
+        const int ev = (kEvenPieces ? wave * VPW * 64 : 0) + lane;
         vvoff0 = ((uint32_t)(ev / DH) * (uint32_t)p.ldvt + (uint32_t)((ev % DH) * 8)) * 2u;
     }
     auto sbase = [](const void* ptr) {      // keep a wave-uniform pointer in SGPRs
@@ -163,13 +170,23 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attention_kernel(AttnParams p)
         const uint32_t buf = lds_base + (uint32_t)(kt & 1) * BUF;
         const bool clamp = (kt + 1) * kKTile > alen || (kt == 0 && off != 0);   // wave-uniform
         if (!clamp) {
+            if constexpr (kEvenPieces) {
 #pragma unroll
-            for (int i = 0; i < KPW; ++i)
-                glds16(sbase(kbase + ((size_t)kt * kKTile + i * kRowsPerPiece) * p.ld_qk), (i & 1) ? (kvoff0 ^ 64u) : kvoff0,
-                       buf + (uint32_t)(wave * KPW + i) * 1024u);
+                for (int i = 0; i < KPW; ++i)
+                    glds16(sbase(kbase + ((size_t)kt * kKTile + i * kRowsPerPiece) * p.ld_qk), (i & 1) ? (kvoff0 ^ 64u) : kvoff0,
+                           buf + (uint32_t)(wave * KPW + i) * 1024u);
 #pragma unroll
-            for (int i = 0; i < VPW; ++i)
-                glds16(sbase(vbase + ((size_t)kt * 8 + i * kGroupsPerPiece) * p.ldvt), vvoff0, buf + (uint32_t)(NPK + wave * VPW + i) * 1024u);
+                for (int i = 0; i < VPW; ++i)
+                    glds16(sbase(vbase + ((size_t)kt * 8 + i * kGroupsPerPiece) * p.ldvt), vvoff0, buf + (uint32_t)(NPK + wave * VPW + i) * 1024u);
+            } else {
+                for (int j = wave; j < NPK + NPV; j += NW) {          // wave-uniform: 3 or 4 pieces
+                    if (j < NPK)
+                        glds16(sbase(kbase + ((size_t)kt * kKTile + j * kRowsPerPiece) * p.ld_qk), (j & 1) ? (kvoff0 ^ 64u) : kvoff0,
+                               buf + (uint32_t)j * 1024u);
+                    else
+                        glds16(sbase(vbase + ((size_t)kt * 8 + (j - NPK) * kGroupsPerPiece) * p.ldvt), vvoff0, buf + (uint32_t)j * 1024u);
+                }
+            }
             return;
         }
         // first / last tile: rows / token groups outside the sequence are clamped to its nearest one (finite values; their
@@ -178,20 +195,29 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attention_kernel(AttnParams p)
         const char* vb = sbase(vbase);
         int lane_c = lane;
         asm volatile("" : "+v"(lane_c));
-#pragma unroll
-        for (int i = 0; i < KPW; ++i) {
-            const int e = (wave * KPW + i) * 64 + lane_c, r = e / CH, pos = e % CH;
+        auto clamped_k = [&](int piece) {
+            const int e = piece * 64 + lane_c, r = e / CH, pos = e % CH;
             int row = kt * kKTile + r;
             row = row < off ? off : (row < alen ? row : alen - 1);               // rows of this sequence only
             glds16(kb, ((uint32_t)row * (uint32_t)p.ld_qk + (uint32_t)((pos ^ ((r / RPB) & (CH - 1))) << 3)) * 2u,
-                   buf + (uint32_t)(wave * KPW + i) * 1024u);
-        }
-#pragma unroll
-        for (int i = 0; i < VPW; ++i) {
-            const int e = (wave * VPW + i) * 64 + lane_c;
+                   buf + (uint32_t)piece * 1024u);
+        };
+        auto clamped_v = [&](int piece) {
+            const int e = piece * 64 + lane_c;
             int g8 = kt * 8 + e / DH;
             g8 = g8 < n_g8 ? g8 : n_g8 - 1;
-            glds16(vb, ((uint32_t)g8 * (uint32_t)p.ldvt + (uint32_t)((e % DH) * 8)) * 2u, buf + (uint32_t)(NPK + wave * VPW + i) * 1024u);
+            glds16(vb, ((uint32_t)g8 * (uint32_t)p.ldvt + (uint32_t)((e % DH) * 8)) * 2u, buf + (uint32_t)(NPK + piece) * 1024u);
+        };
+        if constexpr (kEvenPieces) {
+#pragma unroll
+            for (int i = 0; i < KPW; ++i) clamped_k(wave * KPW + i);
+#pragma unroll
+            for (int i = 0; i < VPW; ++i) clamped_v(wave * VPW + i);
+        } else {
+            for (int j = wave; j < NPK + NPV; j += NW) {
+                if (j < NPK) clamped_k(j);
+                else clamped_v(j - NPK);
+            }
         }
     };
 
@@ -203,7 +229,7 @@ __global__ __launch_bounds__(64 * kWaves, 4) void attention_kernel(AttnParams p)
     float m_run = -__builtin_inff();
     float l_run = 0.f;
     const float sc = p.scale * 1.4426950408889634f;  // fold log2(e): softmax via exp2
-    const bool wave_active = (qt * kWaves + wslot) * 32 < len;  // wave-uniform; idle waves only help staging
+    const bool wave_active = (qt * NW + wslot) * 32 < len;      // wave-uniform; idle waves only help staging
 
     // per-lane LDS offsets: K row perm(ql) (bits 2 and 3 of the row swapped), chunk (2s + hh) ^ swizzle(row)
     const int krow = (ql & 0x13) | ((ql & 4) << 1) | ((ql & 8) >> 1);
@@ -532,7 +558,16 @@ int tt_attention_launch(const AttnParams& p, hipStream_t st) {
         tt_set_error("attention: leading dimensions / column offsets must keep 16-byte alignment");
         return TT_E_INVALID;
     }
-    const int n_qt = (p.max_len + 32 * kWaves - 1) / (32 * kWaves);
+    // Waves per workgroup.  Five (160 rows) pay exactly where they turn a sequence's two workgroups into one: 129-160 tokens
+    // (measured at 1600 sequences: 130 tokens 0.692 -> 0.562 ms, 160 tokens 0.760 -> 0.619 ms).  Everywhere else they LOSE --
+    // 292 tokens 1.27 -> 1.42 ms although a pair is 2 x 5 key-tile walks instead of 3 x 5; 200 / 258 / 320 / 420 / 512 tokens
+    // +45 / +24 / +13 / +7 / +43 %: five waves put two of a workgroup's waves on one SIMD, and that SIMD's compute, not the
+    // LDS-DMA round trip, then sets the time of every key tile (profiles/r04_attention_five_waves_ab.log).
+    // TT_ATT_WAVES=4|5 forces one (the A/B switch; a row's arithmetic does not depend on it).
+    static const int waves_env = [] { const char* e = getenv("TT_ATT_WAVES"); return e && e[0] ? atoi(e) : 0; }();
+    int nw = kWaves;
+    if (p.head_dim == 64 && (waves_env == 5 || (waves_env != 4 && p.max_len > 128 && p.max_len <= 160))) nw = 5;
+    const int n_qt = (p.max_len + 32 * nw - 1) / (32 * nw);
     const long long pairs8 = ((long long)p.heads * p.n_seq + 7) / 8 * 8;
     if (pairs8 * n_qt > 0x7FFFFFFFLL) {
         tt_set_error("attention: %lld workgroups exceed the grid limit", pairs8 * n_qt);
@@ -552,6 +587,10 @@ int tt_attention_launch(const AttnParams& p, hipStream_t st) {
     q.rotate = rotate ? 1 : 0;
     TtProfScope prof(TT_K_ATTENTION, st);
 #if TT_DIAG   // stamped / ablated instantiations: the diagnostic library only (tools/att_stamps, tools/gpu_att_ablate.sh)
+    if (p.head_dim == 64 && (p.dbg || TT_DIAG_ENV_INT("TT_ATT_ABLATE", 0) != 0) && nw != kWaves) {
+        tt_set_error("attention: the stamped / ablated kernels are four-wave (set TT_ATT_WAVES=4)");
+        return TT_E_UNSUPPORTED;
+    }
     if (p.head_dim == 64 && p.dbg) {
         hipLaunchKernelGGL((attention_kernel<64, true>), grid, dim3(64 * kWaves), 0, st, q);
     } else if (p.head_dim == 64 && TT_DIAG_ENV_INT("TT_ATT_ABLATE", 0) != 0) {
@@ -562,7 +601,9 @@ int tt_attention_launch(const AttnParams& p, hipStream_t st) {
         else hipLaunchKernelGGL((attention_kernel<64, false, 4>), grid, dim3(64 * kWaves), 0, st, q);
     } else
 #endif
-    if (p.head_dim == 64) {
+    if (p.head_dim == 64 && nw == 5) {
+        hipLaunchKernelGGL((attention_kernel<64, false, 0, 5>), grid, dim3(64 * 5), 0, st, q);
+    } else if (p.head_dim == 64) {
         hipLaunchKernelGGL(attention_kernel<64>, grid, dim3(64 * kWaves), 0, st, q);
     } else if (p.head_dim == 32) {
         hipLaunchKernelGGL(attention_kernel<32>, grid, dim3(64 * kWaves), 0, st, q);
