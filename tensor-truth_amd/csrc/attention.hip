@@ -51,8 +51,8 @@ __device__ __forceinline__ void lds_wait2n(u32x4& a, u32x4& b) {
 // exponentials (the scaled difference goes on as the "probability"), 2 = no softmax at all (no mask, maximum, FMAs,
 // exponentials, sums or rescale: the raw scores are packed as P), 3 = 2 without the V reads and the P.V MFMAs,
 // 4 = everything, but every workgroup reads the K / V rows of sequence 0 (L2 hits: what the K / V misses cost)
-// NW (round 4): waves = 32-row query blocks per workgroup.  4 is the shape of rounds 1-3; 5 (160 rows) is taken for batches of
-// 129-160 tokens, where it makes ONE workgroup of a sequence's two (tt_attention_launch; measured slower everywhere else).  A
+// NW (round 4): waves = 32-row query blocks per workgroup.  4 is the shape of rounds 1-3; 8 (256 rows) is taken where a sequence's
+// last workgroup stays mostly full (tt_attention_launch: the measured rule); 5 exists as an experiment (uneven piece map).  A
 // row's arithmetic does not depend on NW.
 template <int DH, bool STAMP = false, int ABL = 0, int NW = kWaves>
 __global__ __launch_bounds__(64 * NW, 4) void attention_kernel(AttnParams p) {
@@ -63,8 +63,8 @@ __global__ __launch_bounds__(64 * NW, 4) void attention_kernel(AttnParams p) {
     constexpr int DT = DH / 32;             // 32-row d tiles of O^T
     constexpr int NPK = kKTile * RB / 1024; // 1-KiB copy pieces of a K tile
     constexpr int NPV = 8 * DH * 16 / 1024; // ... of a V tile (8 token groups x DH features x 16 B)
-    constexpr int KPW = NPK / kWaves, VPW = NPV / kWaves;   // pieces per wave (NW = 4): 2 + 2 (dh 64), 1 + 1 (dh 32)
-    constexpr bool kEvenPieces = NW == kWaves;              // NW = 5: piece j of the tile's NPK + NPV goes to wave j % NW
+    constexpr bool kEvenPieces = NPK % NW == 0 && NPV % NW == 0;     // NW = 5: piece j of the tile's NPK + NPV goes to wave j % NW
+    constexpr int KPW = kEvenPieces ? NPK / NW : 1, VPW = kEvenPieces ? NPV / NW : 1;   // pieces per wave: NW = 4: 2 + 2 (dh 64), 1 + 1 (dh 32); NW = 8: 1 + 1
     static_assert(kEvenPieces || (DH == 64 && NPK == 8 && NPV == 8), "the uneven piece map is written for head_dim 64");
     constexpr int BUF = (NPK + NPV) * 1024;
     // Two buffers: tile kt + 1 is copied while tile kt is computed.  (Three -- copies two tiles ahead, a copy needs about 3 us
@@ -558,15 +558,22 @@ int tt_attention_launch(const AttnParams& p, hipStream_t st) {
         tt_set_error("attention: leading dimensions / column offsets must keep 16-byte alignment");
         return TT_E_INVALID;
     }
-    // Waves per workgroup.  Five (160 rows) pay exactly where they turn a sequence's two workgroups into one: 129-160 tokens
-    // (measured at 1600 sequences: 130 tokens 0.692 -> 0.562 ms, 160 tokens 0.760 -> 0.619 ms).  Everywhere else they LOSE --
-    // 292 tokens 1.27 -> 1.42 ms although a pair is 2 x 5 key-tile walks instead of 3 x 5; 200 / 258 / 320 / 420 / 512 tokens
-    // +45 / +24 / +13 / +7 / +43 %: five waves put two of a workgroup's waves on one SIMD, and that SIMD's compute, not the
-    // LDS-DMA round trip, then sets the time of every key tile (profiles/r04_attention_five_waves_ab.log).
-    // TT_ATT_WAVES=4|5 forces one (the A/B switch; a row's arithmetic does not depend on it).
+    // Waves (32-row query blocks) per workgroup, chosen per batch from B = ceil(max_len / 32) (measured at 1600 sequences x 16 heads,
+    // profiles/r04_attention_five_waves_ab.log, ...eight_waves...): EIGHT waves (256 rows: half the K / V copies and barriers per
+    // query row, two waves per SIMD like two four-wave workgroups) win where the last workgroup of a sequence is at least
+    // five-eighths full -- B = 5..8 (130 tokens +32 %, 160 +26 %, 200 +13 %) and B = 13..16 (420 +6 %, 512 +5 %) -- and lose where
+    // it is nearly empty (B = 9, 10: 258 / 292 / 320 tokens -20...-23 %); FIVE waves (two of them on one SIMD) never beat the
+    // better of four and eight.  TT_ATT_WAVES=4|5|8 forces one (the A/B switch; a row's arithmetic does not depend on it).
     static const int waves_env = [] { const char* e = getenv("TT_ATT_WAVES"); return e && e[0] ? atoi(e) : 0; }();
     int nw = kWaves;
-    if (p.head_dim == 64 && (waves_env == 5 || (waves_env != 4 && p.max_len > 128 && p.max_len <= 160))) nw = 5;
+    if (p.head_dim == 64) {
+        const int B = (p.max_len + 31) / 32, r8 = B % 8;
+        if (waves_env == 4 || waves_env == 5 || waves_env == 8) nw = waves_env;
+        // ... and only for batches of SIMILAR lengths (rerank pairs, length-sorted embedding windows): a short sequence in an
+        // eight-wave launch is one workgroup with mostly idle waves (64 tokens: +20 %), so the mean length must be near max_len
+        // (rows are padded to 8 per sequence; unknown total: the caller is a test or a tool with uniform lengths)
+        else if (B >= 5 && (r8 == 0 || r8 >= 5) && (p.total_rows <= 0 || (long long)p.total_rows * 10 >= (long long)p.n_seq * p.max_len * 7)) nw = 8;
+    }
     const int n_qt = (p.max_len + 32 * nw - 1) / (32 * nw);
     const long long pairs8 = ((long long)p.heads * p.n_seq + 7) / 8 * 8;
     if (pairs8 * n_qt > 0x7FFFFFFFLL) {
@@ -601,7 +608,9 @@ int tt_attention_launch(const AttnParams& p, hipStream_t st) {
         else hipLaunchKernelGGL((attention_kernel<64, false, 4>), grid, dim3(64 * kWaves), 0, st, q);
     } else
 #endif
-    if (p.head_dim == 64 && nw == 5) {
+    if (p.head_dim == 64 && nw == 8) {
+        hipLaunchKernelGGL((attention_kernel<64, false, 0, 8>), grid, dim3(64 * 8), 0, st, q);
+    } else if (p.head_dim == 64 && nw == 5) {
         hipLaunchKernelGGL((attention_kernel<64, false, 0, 5>), grid, dim3(64 * 5), 0, st, q);
     } else if (p.head_dim == 64) {
         hipLaunchKernelGGL(attention_kernel<64>, grid, dim3(64 * kWaves), 0, st, q);

@@ -93,6 +93,7 @@ struct AttnParams {
     const int32_t* seq_start; // [B] first token row of each sequence (multiple of 8)
     const int32_t* seq_len;   // [B]
     int n_seq, heads, head_dim, max_len;
+    int total_rows;           // token rows of the batch (0 = unknown): the launcher's wave-count choice wants the MEAN length too
     int ld_qk, q_col0, k_col0, ldvt, ld_out;
     float scale;              // 1/sqrt(head_dim)
     float lazy;               // set by the launcher: log2 slack of the running softmax reference

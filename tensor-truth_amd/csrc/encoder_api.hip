@@ -218,7 +218,7 @@ static int forward_impl(const tt_encoder_weights* w, const int32_t* ids, const i
         AttnParams a{};
         a.qk = qk; a.ld_qk = 2 * H; a.q_col0 = 0; a.k_col0 = H; a.vt = vt; a.ldvt = 8 * H;
         a.out = ctx; a.ld_out = H; a.seq_start = seq_start; a.seq_len = seq_len;
-        a.n_seq = n_seq; a.heads = w->heads; a.head_dim = dh; a.max_len = max_len;
+        a.n_seq = n_seq; a.heads = w->heads; a.head_dim = dh; a.max_len = max_len; a.total_rows = n_rows;
         a.scale = 1.0f / sqrtf((float)dh);
         if (int rc = tt_attention_launch(a, st)) return rc;
         // attention output projection + residual, LayerNorm
