@@ -167,3 +167,12 @@ def test_data_plane_falls_back_to_gloo_by_agreement():
     assert [g[0] for g in fb] == [0, 1] and all(g[2] and g[3].startswith("gloo (nccl pre-flight failed") and not g[4] for g in fb), fb
     own = sorted(g for g in got if g[1] == "own")
     assert [g[0] for g in own] == [0, 1] and all(g[2] and g[3] == "gloo" and not g[4] for g in own), own
+
+
+def test_clock_sampler_degrades_to_nulls_without_a_driver():
+    """bench.py's clock / power sampler (amdsmi): on a box without the GPU driver every field is null and the error is carried --
+    the JSON line is printed either way."""
+    got = bench.ClockSampler(0, period_s=0.01).start().stop()
+    assert set(got) >= {"sclk_mhz_median", "sclk_mhz_spec", "socket_power_w_mean", "power_cap_w", "samples", "error"}
+    if got["samples"] == 0:
+        assert got["sclk_mhz_median"] is None and got["socket_power_w_mean"] is None and got["error"]
