@@ -362,10 +362,12 @@ static int launch_d(const ScanParams& p, int mode, int out, int blocks, int q_ti
         // tuning / ablation variants exist for the headline shape only
         if (out == 0 && load_mode == 1) {
             switch (var) {
-                case 1: return launch_one<D, 1, 0, 1>(p, blocks, q_tiles, stream);
+                case 1: return launch_one<D, 1, 0, 1>(p, blocks, q_tiles, stream);       // plain instead of non-temporal loads (same results)
+#if TT_DIAG     // ablation variants (loads only / + LDS writes / MFMAs only: WRONG results by design): the diagnostic library only
                 case 2: return launch_one<D, 1, 0, 2>(p, blocks, q_tiles, stream);
                 case 4: return launch_one<D, 1, 0, 4>(p, blocks, q_tiles, stream);
                 case 8: return launch_one<D, 1, 0, 8>(p, blocks, q_tiles, stream);
+#endif
                 default: break;
             }
         }
