@@ -727,6 +727,13 @@ def main():
     if not args.headline_only and not args.no_surface_leg and (world == 1 or args.surface_leg):
         if world == 1:
             surface = surface_leg(args, dev, shard_rows, emb_cfg, rr_cfg, world, rank, lo, data_group)
+            # ... and what an UNCHANGED reference call gets through the same surface: constructors without a dtype (the reference's
+            # own default, fp32 semantics) -- fewer queries, the models run at about a third of the bf16 rate
+            if not args.no_reference_leg:
+                sd = surface_leg(args, dev, shard_rows, emb_cfg, rr_cfg, world, rank, lo, data_group, default_precision=True,
+                                 n_queries=max(args.surface_threads * 3, 96))
+                surface["default_precision"] = {k: sd[k] for k in ("queries_per_s", "queries", "threads", "single_caller_ms_per_query",
+                                                                   "scan_batches", "rerank_batches", "precision")}
         else:
             # Several ranks: the leg's collectives run over RCCL, which no box available to this build could exercise (two
             # ranks cannot share a GPU under RCCL; the gloo runs are the evidence).  The headline above is measured and must
@@ -1054,7 +1061,7 @@ def _run_threads(n_threads, work_items, fn):
     return dt, out
 
 
-def surface_leg(args, dev, shard_rows, emb_cfg, rr_cfg, world=1, rank=0, row_lo=0, group=None):
+def surface_leg(args, dev, shard_rows, emb_cfg, rr_cfg, world=1, rank=0, row_lo=0, group=None, default_precision=False, n_queries=None):
     """world > 1: every rank runs its OWN request threads against the row-sharded index; the retriever's lock-step tick front
     keeps the ranks' collective rounds aligned, each rank embeds and reranks only its own callers' queries
     (sharded_index._TickFront).  Reported rate = all ranks' queries / the slowest rank's time."""
@@ -1064,10 +1071,13 @@ def surface_leg(args, dev, shard_rows, emb_cfg, rr_cfg, world=1, rank=0, row_lo=
     from tensor_truth_amd.sharded_index import ShardedHipVectorIndex
 
     K, topn = args.top_k, args.top_n
+    # default_precision: the constructors exactly as the reference calls them -- no dtype -> the reference's fp32 semantics
+    # (precision.DEFAULT_MODE); otherwise the reference's `torch_dtype: bfloat16` option, as BASELINE's configurations name it
+    dt_kw = {} if default_precision else {"torch_dtype": "bfloat16"}
     emb = HipHuggingFaceEmbedding("BAAI/bge-m3", device=str(dev), embed_batch_size=128,
-                                  model_kwargs={"encoder_config": emb_cfg, "synthetic_seed": 1, "torch_dtype": "bfloat16"})
+                                  model_kwargs={"encoder_config": emb_cfg, "synthetic_seed": 1, **dt_kw})
     rr = HipSentenceTransformerRerank(model="BAAI/bge-reranker-v2-m3", top_n=topn, device=str(dev), batch_pairs=4096,
-                                      model_kwargs={"encoder_config": rr_cfg, "synthetic_seed": 2, "torch_dtype": "bfloat16"})
+                                      model_kwargs={"encoder_config": rr_cfg, "synthetic_seed": 2, **dt_kw})
     n = shard_rows.shape[0] if world == 1 else args.corpus_rows
     index = ShardedHipVectorIndex(shard_rows.shape[1], shard_rows, row_lo, n, _RowIds(n), _SynthDocstore(args.chunk_len),
                                   embed_model=emb, score_mode="cosine", queries="partitioned" if world > 1 else "replicated", group=group)
@@ -1077,7 +1087,7 @@ def surface_leg(args, dev, shard_rows, emb_cfg, rr_cfg, world=1, rank=0, row_lo=
         dist.barrier()     # BEFORE the retriever exists: its tick thread owns the process group's collectives from then on (two
         #                    threads issuing collectives on one RCCL communicator is not safe) until retr.close() below
     retr = index.as_retriever(similarity_top_k=K, max_batch=64 if world == 1 else max(8, 256 // world))
-    queries = [synth_text(10_000_000_000 + 1_000_000 * rank + i, args.query_len) for i in range(args.surface_queries)]
+    queries = [synth_text(10_000_000_000 + 1_000_000 * rank + i, args.query_len) for i in range(n_queries or args.surface_queries)]
 
     def one(q):
         nodes = retr.retrieve(q)
@@ -1110,6 +1120,7 @@ def surface_leg(args, dev, shard_rows, emb_cfg, rr_cfg, world=1, rank=0, row_lo=
     return {"queries_per_s": world * len(queries) / dt, "threads": args.surface_threads, "queries": world * len(queries),
             "ranks": world, "scan_batches": n_scan, "rerank_batches": n_rr,
             "single_caller_ms_per_query": lat * 1e3,
+            "precision": getattr(rr, "precision", None) or ("reference (default)" if default_precision else "bf16"),
             "what": (f"{args.surface_threads} threads each calling retriever.retrieve(str) (top-{K} over the resident "
                      f"{n} x {shard_rows.shape[1]} corpus) then reranker.postprocess_nodes(nodes, QueryBundle) -> top-{topn}; "
                      f"strings in ({args.query_len}-word queries, {args.chunk_len}-word chunks, hashing tokenizer), NodeWithScore out; "
