@@ -135,7 +135,33 @@ def main_stress():
     print("wrote", t.STRESS_GOLDEN_NAME)
 
 
+def main_stress_embeddings():
+    """The bi-encoder side of the stress fixture: L2-normalised first-row (CLS) hidden states of 16 pairs under the COMMITTED stress
+    weights (factors and head read from the scores fixture, nothing re-calibrated) -> tests/golden/<STRESS_EMB_GOLDEN_NAME>."""
+    import stress_weights
+
+    torch.set_num_threads(max(1, min(len(os.sched_getaffinity(0)), 64)))
+    ocfg = oe.EncoderConfig(**t.SHAPE)
+    z = np.load(os.path.join(HERE, t.STRESS_GOLDEN_NAME))
+    W = stress_weights.with_head(stress_weights.apply(oe.synth_weights(ocfg, seed=t.WEIGHT_SEED), ocfg, qk_scales=z["qk_scales"]),
+                                 z["head_w"], z["head_b"])
+    assert str(z["weights_sha256"]) == weights_checksum(W)
+    pairs = t._pairs()
+    ids = torch.from_numpy(np.concatenate([pairs[q][:t.STRESS_EMB_PAIRS // t.N_QUERIES] for q in range(t.N_QUERIES)]))
+    with torch.no_grad():
+        cls = stress_forward(ids, W, ocfg, {})
+        emb = torch.nn.functional.normalize(cls.double(), dim=1).float()
+        # the restated forward IS the oracle's
+        chk = oe.embed(ids[:2], torch.ones_like(ids[:2]), W, ocfg)
+        assert (chk - emb[:2]).abs().max().item() < 2e-5, (chk - emb[:2]).abs().max().item()
+    np.savez(os.path.join(HERE, t.STRESS_EMB_GOLDEN_NAME), embeddings=emb.numpy().astype(np.float32),
+             ids_sha256=hashlib.sha256(ids.numpy().tobytes()).hexdigest(), weights_sha256=weights_checksum(W), torch_version=torch.__version__)
+    print("wrote", t.STRESS_EMB_GOLDEN_NAME, tuple(emb.shape), "component range", float(emb.min()), float(emb.max()))
+
+
 def main():
+    if "--stress-embeddings" in sys.argv:
+        return main_stress_embeddings()
     if "--stress" in sys.argv:
         return main_stress()
     ocfg = oe.EncoderConfig(**t.SHAPE)

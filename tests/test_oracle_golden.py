@@ -141,3 +141,32 @@ def test_full_depth_rank_fixture_matches_the_oracle_on_sampled_pairs(golden_dir)
         with torch.no_grad():
             got = oe.rerank_scores(ids, torch.ones_like(ids), W, ocfg)
         assert abs(float(got[0]) - float(z["scores"][q, j])) < 2e-5, (q, j, float(got[0]), float(z["scores"][q, j]))
+
+
+def test_stress_fixtures_match_the_oracle_on_sampled_pairs(golden_dir):
+    """The two stress fixtures (scores of 200 pairs; normalised first-row hidden states of 16) are what oracle/encoder.py computes
+    on the weights rebuilt from the recipe (tests/stress_weights.py + the factors and head stored in the scores fixture): one
+    pair's score and one pair's embedding are re-derived here."""
+    import hashlib
+
+    import stress_weights
+    import test_rank_agreement_gpu as t
+    from rank_checks import weights_checksum
+
+    z = np.load(os.path.join(golden_dir, t.STRESS_GOLDEN_NAME))
+    ze = np.load(os.path.join(golden_dir, t.STRESS_EMB_GOLDEN_NAME))
+    ocfg = oe.EncoderConfig(**t.SHAPE)
+    W = stress_weights.with_head(stress_weights.apply(oe.synth_weights(ocfg, seed=t.WEIGHT_SEED), ocfg, qk_scales=z["qk_scales"]),
+                                 z["head_w"], z["head_b"])
+    pairs = t._pairs()
+    assert str(z["pairs_sha256"]) == hashlib.sha256(pairs.tobytes()).hexdigest()
+    assert str(z["weights_sha256"]) == weights_checksum(W) == str(ze["weights_sha256"])
+    ids16 = np.concatenate([pairs[q][:t.STRESS_EMB_PAIRS // t.N_QUERIES] for q in range(t.N_QUERIES)]).astype(np.int64)
+    assert str(ze["ids_sha256"]) == hashlib.sha256(ids16.tobytes()).hexdigest() and ze["embeddings"].shape == (t.STRESS_EMB_PAIRS, ocfg.hidden)
+    assert np.allclose(np.linalg.norm(ze["embeddings"], axis=1), 1.0, atol=1e-5)
+    ids = torch.from_numpy(pairs[2, 7:8])
+    with torch.no_grad():
+        got = oe.rerank_scores(ids, torch.ones_like(ids), W, ocfg)
+        emb = oe.embed(torch.from_numpy(ids16[5:6]), torch.ones(1, ids16.shape[1], dtype=torch.int64), W, ocfg)
+    assert abs(float(got[0]) - float(z["scores"][2, 7])) < 1e-4 * max(1.0, 1.0), (float(got[0]), float(z["scores"][2, 7]))
+    assert np.abs(emb[0].numpy() - ze["embeddings"][5]).max() < 2e-5

@@ -21,6 +21,8 @@ SHAPE = dict(arch="xlmr", vocab_size=8192, hidden=1024, layers=24, heads=16, ffn
              pad_id=1, ln_eps=1e-5, num_labels=1)
 WEIGHT_SEED = 17
 GOLDEN_NAME = "rank_oracle_24L_4x50x292.npz"   # tests/golden/make_rank_golden.py
+STRESS_EMB_GOLDEN_NAME = "embed_oracle_stress_24L_16x292.npz"     # ... --stress-embeddings: normalised first-row hidden states, same weights
+STRESS_EMB_PAIRS = 16
 STRESS_GOLDEN_NAME = "rank_oracle_stress_24L_4x50x292.npz"   # ... --stress: trained-model statistics (tests/stress_weights.py)
 BF16_BOUND = 2e-2      # stated absolute bound of the bf16 mode on a sigmoid score after 24 layers
 FP16_BOUND = 3e-3      # ... of the fp16 mode (same rate, three more mantissa bits per rounding point; measured 2.4e-3)
@@ -414,3 +416,45 @@ def test_f16x3_scores_within_1e3_relative_at_full_depth(dev, built_lib, oracle_s
     print(f"f16x3 @24L: max relative score error {rel:.2e}; {n_sep} pairs separable at 2e-4 all ordered as the oracle; Kendall tau min "
           f"{min(taus):.4f}; top-{TOP_N} overlap min {min(over):.2f}; {dt_b * 1e3:.1f} ms per query in a batch of {N_QUERIES} ({1.0 / dt_b:.1f} q/s)")
     assert min(taus) >= 0.999 and min(over) == 1.0
+
+
+# ---- the bi-encoder side of the stress fixture: embeddings (normalised first-row hidden states) under the same hostile weights ----
+STRESS_EMB_BOUNDS = {            # mode -> (min cosine, max |component error|); measured values in the test's report line
+    # measured: f16x3 1.000000000 / 1.9e-6, bf16x3 0.999999998 / 8.1e-6, f16c 0.99999979 / 9.6e-5, fp16 0.99996853 / 8.5e-4,
+    # bf16 0.99911500 / 5.5e-3 (largest component 0.55) -- bf16 holds SURVEY's 0.999 on these weights too, narrowly
+    "f16x3": (0.99999999, 1e-5), "bf16x3": (0.9999999, 4e-5), "f16c": (0.999999, 4e-4), "fp16": (0.9999, 4e-3), "bf16": (0.999, 2.5e-2)}
+
+
+@pytest.mark.parametrize("mode", ["f16x3", "bf16x3", "f16c", "fp16", "bf16"])
+def test_stress_weights_embeddings(dev, built_lib, stress_oracle_scores, mode):
+    """SURVEY section 8d's embedding gate (cosine >= 0.999) on the stress weights, per precision: 16 pairs' first-row hidden states,
+    L2-normalised, against the fp64-accumulated oracle (tests/golden/make_rank_golden.py --stress-embeddings).  The outlier
+    dimensions dominate these vectors as they do in trained encoders, so the cosine is a weak gate by itself -- the component-wise
+    error is asserted too."""
+    import hashlib
+    import os
+
+    from tensor_truth_amd.encoder import Encoder, EncoderConfig, EncoderWeights, pack_token_matrix
+
+    ocfg, W, pairs, _ = stress_oracle_scores
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", STRESS_EMB_GOLDEN_NAME))
+    ids = np.concatenate([pairs[q][:STRESS_EMB_PAIRS // N_QUERIES] for q in range(N_QUERIES)]).astype(np.int64)
+    assert str(z["ids_sha256"]) == hashlib.sha256(ids.tobytes()).hexdigest(), "the embedding fixture belongs to other token ids"
+    want = torch.from_numpy(z["embeddings"])
+    cfg = EncoderConfig(**SHAPE)
+    if mode == "f16c":
+        from tensor_truth_amd.encoder_f16c import EncoderF16C, EncoderWeightsF16C
+        enc = EncoderF16C(EncoderWeightsF16C(cfg, W, dev))
+    elif mode in ("bf16x3", "f16x3"):
+        from tensor_truth_amd.encoder_x3 import EncoderWeightsX3, EncoderX3
+        enc = EncoderX3(EncoderWeightsX3(cfg, W, dev, dtype=torch.float16 if mode == "f16x3" else torch.bfloat16))
+    else:
+        enc = Encoder(EncoderWeights(cfg, W, dev, dtype=torch.float16 if mode == "fp16" else torch.bfloat16))
+    got = enc.embed_packed(pack_token_matrix(ids.astype(np.int32), cfg))[0].cpu()
+    torch.cuda.synchronize()
+    cos = torch.nn.functional.cosine_similarity(got.double(), want.double(), dim=1).min().item()
+    err = (got - want).abs().max().item()
+    print(f"stress @24L embeddings {mode}: min cosine {cos:.9f}, max |component error| {err:.2e} (largest component {want.abs().max().item():.2f})")
+    assert torch.isfinite(got).all()
+    lo, hi = STRESS_EMB_BOUNDS[mode]
+    assert cos >= lo and err <= hi, (mode, cos, err)
