@@ -143,6 +143,8 @@ def open_data_plane(dist, torch, dev, rank, world, backend="nccl", deadline_s=18
 
     def attempt():
         try:
+            if dev.type == "cuda":
+                torch.cuda.set_device(dev)        # (the current device is per thread)
             g = dist.new_group(backend=backend, timeout=datetime.timedelta(minutes=30),
                                **({"device_id": dev} if backend == "nccl" else {}))
             preflight_collectives(dist, torch, dev, rank, world, group=g)
