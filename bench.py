@@ -113,7 +113,7 @@ def preflight_collectives(dist, torch, dev, rank, world, group=None):
         want = torch.arange(Q * K, device=dev, dtype=torch.float32).view(Q, K) + 1000.0 * r
         if not (torch.equal(out[r, ..., 0], want) and bool((out[r, ..., 1] == float(r)).all())):
             raise RuntimeError(f"pre-flight: rank {rank} received a wrong all-gather block from rank {r}")
-    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64, device=dev)
     dist.barrier(group=group)
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     if t.item() != float(world):
