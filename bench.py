@@ -345,6 +345,9 @@ def main():
     data_group, collective_backend, comm_hung = None, None, False
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost"):
+            # one node: gloo pairs over the loopback interface instead of whatever the container's hostname resolves to (it may not)
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
         import datetime
 
         # (rank 0 alone runs the accuracy / CPU legs while the others wait at a barrier: keep the collective watchdog well above that)
