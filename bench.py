@@ -928,7 +928,11 @@ def main():
     if hard_exit:
         sys.stdout.flush()
         sys.stderr.flush()
-        os._exit(0)        # (see the plugin-surface leg: a worker thread may still sit in a collective)
+        # (see the plugin-surface leg: a worker thread may still sit in a collective.)  Exit status: 0 when the only reason is an
+        # abandoned RCCL attempt (the run is complete, on the gloo data plane); 4 when a leg the caller asked for (--surface-leg at
+        # world > 1) failed or timed out -- the headline line is printed and valid either way, but torchrun / a self-launching
+        # parent must not report success for a run whose requested leg did not finish
+        os._exit(4 if isinstance(surface, dict) and surface.get("surface_failed") else 0)
     if world > 1:
         dist.destroy_process_group()
 
