@@ -196,3 +196,31 @@ def test_two_ranks_with_the_hip_kernels_equal_one_process(dev, built_lib, mode):
         assert outs[0][1][0] == outs[1][1][0]                             # the same collective rounds on both ranks
         assert outs[0][1][1] == 12 and outs[1][1][1] == 10                # ... each embedding / serving only its own callers
         assert outs[0][1][0] < 22                                         # rounds were shared by concurrent callers
+
+
+def test_bench_self_launches_two_ranks_and_falls_back_from_rccl_by_agreement(built_lib):
+    """`python bench.py --gpus 2` as the driver calls it at N > 1, on this 1-GPU box: the parent starts two ranks (a child process,
+    never exec), both share GPU 0 (TT_BENCH_ONE_DEVICE=1) and ATTEMPT the RCCL data plane (TT_BENCH_TRY_NCCL=1) -- RCCL refuses two
+    ranks on one device, the ranks agree on the failure over gloo and the step's collectives run on the gloo group: one JSON line,
+    exit 0, `ranks: 2`, `n_gpus: 1`, the backend that carried the step named with RCCL's own error text.  (Reduced model depth and
+    corpus: this checks the start-up, the sharded step and the line, not a rate.)"""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TT_BENCH_ONE_DEVICE="1", TT_BENCH_TRY_NCCL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--layers", "2",
+                        "--corpus-rows", "600000", "--headline-only", "--no-cpu-baseline"],
+                       env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1000:]
+    d = json.loads(lines[0])
+    assert d["ranks"] == 2 and d["n_gpus"] == 1 and d["value"] > 0 and d["scaling"] == "weak"
+    cb = d["config"]["collective_backend"]
+    assert cb.startswith("gloo (nccl pre-flight failed") and "Duplicate GPU" in cb, cb
+    assert d["config"]["ranks_share_one_device"] is True
+    assert "nccl data plane unusable" in r.stderr
