@@ -34,7 +34,10 @@ def main():
                 sents.append(" ".join(w[band + int(j)] for j in rng.integers(0, 1000, size=k)) + ".")
         docs.append(TextNode(text=" ".join(sents), metadata={"title": f"doc {d}"}))
     mgr = mm.ModelManager.get_instance()
-    mgr.model_kwargs_overrides["BAAI/bge-m3"] = {"encoder_config": BGE_M3, "synthetic_seed": 1, "torch_dtype": "bfloat16"}
+    _kw = {"encoder_config": BGE_M3, "synthetic_seed": 1}
+    if os.environ.get("INGEST_PRECISION", "bf16") != "default":      # INGEST_PRECISION=default: the constructor without a dtype (reference precision)
+        _kw["torch_dtype"] = "bfloat16"
+    mgr.model_kwargs_overrides["BAAI/bge-m3"] = _kw
     emb = mgr.get_embedder("BAAI/bge-m3", "cuda")
     build_index(docs[:64], emb, chunking_strategy="semantic_hierarchical", chunk_sizes=[512, 128, 64], chunk_overlap=8)   # warm-up
     if os.environ.get("SWITCH_INTERVAL"):
