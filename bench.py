@@ -1215,7 +1215,7 @@ def config5_leg(args, dev, emb_cfg, rr_cfg):
             "queries_per_s": len(queries) / dt, "mean_sources": float(np.mean(res)), "reranker": "bf16",
             "fp8_reranker_variant": {"queries_per_s": len(queries) / dt8, "mean_sources": float(np.mean(res8)),
                                      "bf16_on_the_same_query_strings": len(queries8) / dt8b,
-                                     "note": "e4m3 layer projections, its own 128 query strings (no LRU hits); Kendall tau ~0.5 "
+                                     "note": "e4m3 layer projections, its own 384 query strings (no LRU hits); Kendall tau ~0.5 "
                                              "against fp32 at 24 layers (config.fp8_reranker.rank_quality_vs_fp32); this leg is host-bound at "
                                              "its short pairs: fp8 ~ bf16 on the same query strings -- the token-level fp8 leg is "
                                              "config.fp8_reranker"},
