@@ -934,7 +934,19 @@ def main():
         # parent must not report success for a run whose requested leg did not finish
         os._exit(4 if isinstance(surface, dict) and surface.get("surface_failed") else 0)
     if world > 1:
-        dist.destroy_process_group()
+        # tear-down must not be able to hang a finished run (the line is printed): destroy the groups from a thread, give it 30 s,
+        # then leave either way
+        import threading
+
+        sys.stdout.flush()
+        sys.stderr.flush()
+        th = threading.Thread(target=dist.destroy_process_group, daemon=True)
+        th.start()
+        th.join(timeout=30.0)
+        if th.is_alive():
+            sys.stderr.write(f"[bench rank {rank}] destroy_process_group did not return within 30 s; leaving\n")
+            sys.stderr.flush()
+            os._exit(0)
 
 
 def rank_quality(reranker, rr_cfg, pair_ids, K, topn, dev, modes=("bf16", "fp8")):
