@@ -538,7 +538,8 @@ def main():
                       # rate (~0.8-1.0 PF), not a stream: 0.6 of the HBM peak at this arithmetic intensity would need 1.5 PF sustained.
                       # The <= 64-query streaming pass, which IS HBM-bound, reaches 0.79 (roofline_scan at 32 queries per step).
                       "ridge_note": "256 queries x 2 flops per corpus byte-pair = 256 FLOP/B vs the ridge at 312: MFMA-bound at the "
-                                    "K=1024 GEMM rate; 0.6 of HBM peak here = 1.5 PF sustained (chip's MFMA-only stream: 1.8 PF)"}
+                                    "K=1024 GEMM rate; 0.6 of HBM peak here = 1.5 PF sustained.  Run alone, this pass holds 1.64 GHz of 2.4 at the "
+                                    "1400 W cap (HBM stream + contraction; profiles/r04_leg_power.log): the MFMA peak at that clock is 1.7 PF"}
 
     # ---- BASELINE config 5's "fp8 MFMA reranker": the same steps with the cross-encoder's Q/K/V and FFN-up
     # projections on e4m3 operands.  Reported beside the headline (which stays bf16), never as it.
