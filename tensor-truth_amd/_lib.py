@@ -26,6 +26,12 @@ def lib_path() -> str:
     return os.path.join(_HERE, os.environ.get("TT_LIB_NAME") or _LIB_NAME)
 
 
+def is_diag() -> bool:
+    """True when the diagnostic build is the one loaded (TT_LIB_NAME=libtt_hip_diag.so, `make DIAG=1`) -- the only build that
+    reads the kernels' A/B environment switches; the product library reads no environment variable at all."""
+    return "diag" in (os.environ.get("TT_LIB_NAME") or "")
+
+
 _isa_ok = None
 
 

@@ -564,7 +564,7 @@ int tt_attention_launch(const AttnParams& p, hipStream_t st) {
     // five-eighths full -- B = 5..8 (130 tokens +32 %, 160 +26 %, 200 +13 %) and B = 13..16 (420 +6 %, 512 +5 %) -- and lose where
     // it is nearly empty (B = 9, 10: 258 / 292 / 320 tokens -20...-23 %); FIVE waves (two of them on one SIMD) never beat the
     // better of four and eight.  TT_ATT_WAVES=4|5|8 forces one (the A/B switch; a row's arithmetic does not depend on it).
-    static const int waves_env = [] { const char* e = getenv("TT_ATT_WAVES"); return e && e[0] ? atoi(e) : 0; }();
+    static const int waves_env = TT_DIAG_ENV_INT("TT_ATT_WAVES", 0);
     int nw = kWaves;
     if (p.head_dim == 64) {
         const int B = (p.max_len + 31) / 32, r8 = B % 8;
@@ -582,15 +582,15 @@ int tt_attention_launch(const AttnParams& p, hipStream_t st) {
     }
     const dim3 grid((unsigned)(pairs8 * n_qt));
     // log2 slack of the running softmax reference (TT_ATT_LAZY=0: classic running maximum, the A/B switch)
-    static const float lazy = [] { const char* e = getenv("TT_ATT_LAZY"); return e && e[0] ? (float)atof(e) : 8.0f; }();
+    static const float lazy = TT_DIAG_ENV_FLOAT("TT_ATT_LAZY", 8.0f);
     AttnParams q = p;
     q.lazy = lazy;
     // default: the plain order.  Stand-alone the XCD-aware order is 2-9 % faster, inside the encoder (K / V fresh from the
     // QKV GEMM) it measured 1.8 % slower -- see DESIGN.md section 4.4.
-    static const bool xcd = [] { const char* e = getenv("TT_ATT_XCD"); return e && e[0] == '1'; }();
+    static const bool xcd = TT_DIAG_ENV_INT("TT_ATT_XCD", 0) == 1;
     q.n_qt = xcd ? n_qt : -n_qt;
     // TT_ATT_ROTATE=1: tail tiles deal their live row blocks to different waves (A/B switch, measured neutral; same bits either way)
-    static const bool rotate = [] { const char* e = getenv("TT_ATT_ROTATE"); return e && e[0] == '1'; }();
+    static const bool rotate = TT_DIAG_ENV_INT("TT_ATT_ROTATE", 0) == 1;
     q.rotate = rotate ? 1 : 0;
     TtProfScope prof(TT_K_ATTENTION, st);
 #if TT_DIAG   // stamped / ablated instantiations: the diagnostic library only (tools/att_stamps, tools/gpu_att_ablate.sh)
@@ -610,8 +610,10 @@ int tt_attention_launch(const AttnParams& p, hipStream_t st) {
 #endif
     if (p.head_dim == 64 && nw == 8) {
         hipLaunchKernelGGL((attention_kernel<64, false, 0, 8>), grid, dim3(64 * 8), 0, st, q);
+#if TT_DIAG   // five waves: measured slower than the better of four and eight at every length (EXPERIMENTS.md round 4)
     } else if (p.head_dim == 64 && nw == 5) {
         hipLaunchKernelGGL((attention_kernel<64, false, 0, 5>), grid, dim3(64 * 5), 0, st, q);
+#endif
     } else if (p.head_dim == 64) {
         hipLaunchKernelGGL(attention_kernel<64>, grid, dim3(64 * kWaves), 0, st, q);
     } else if (p.head_dim == 32) {

@@ -31,10 +31,15 @@
 #ifndef TT_DIAG
 #define TT_DIAG 0
 #endif
+// Round 5: the A/B switches of measured-and-rejected variants (TT_GEMM_XP, TT_GEMM_VARIANT, TT_ATT_WAVES, TT_SCAN_GEMM_*, ...) are
+// diagnostic-only too: the product library reads NO environment variable (tests/test_lib_abi.py greps its strings), every switch
+// is its default as a compile-time constant, and the instantiations only a non-default value could reach are not linked.
 #if TT_DIAG
 #define TT_DIAG_ENV_INT(name, dflt) ([]() -> int { const char* e_ = getenv(name); return e_ && e_[0] ? (int)strtol(e_, nullptr, 0) : (dflt); }())
+#define TT_DIAG_ENV_FLOAT(name, dflt) ([]() -> float { const char* e_ = getenv(name); return e_ && e_[0] ? (float)atof(e_) : (dflt); }())
 #else
 #define TT_DIAG_ENV_INT(name, dflt) (dflt)
+#define TT_DIAG_ENV_FLOAT(name, dflt) (dflt)
 #endif
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));

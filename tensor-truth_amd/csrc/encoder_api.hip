@@ -161,7 +161,7 @@ static int forward_impl(const tt_encoder_weights* w, const int32_t* ids, const i
         // first rows below.  Same kernels, same K order per output element: bit-identical to the full projection.  Not for the e4m3
         // projection (byte-sized weights); TT_CLS_KV_ONLY=0 restores the full projection (A/B; both sides give the same bits,
         // tests/test_encoder_gpu.py compares them from two processes: the switch is read ONCE).
-        static const bool kv_only_on = [] { const char* ev = getenv("TT_CLS_KV_ONLY"); return !(ev && ev[0] == '0'); }();
+        static const bool kv_only_on = TT_DIAG_ENV_INT("TT_CLS_KV_ONLY", 1) != 0;
         const bool kv_only = cls_tail && l == w->layers - 1 && !g.fp8 && kv_only_on;
         if (kv_only) {
             g.W = (const uint16_t*)lw.qkv_w + (size_t)H * H; g.bias = lw.qkv_b + H;
@@ -427,7 +427,7 @@ int tt_gemm_fp8_ex(const void* a8, const float* a_scale, const void* w8, const f
 
 // diagnostic only (not in tt_hip.h): the varlen attention with s_memtime stamps of one workgroup (tools/att_stamps)
 #endif
-#if !TT_F16   // bf16 instantiation only
+#if !TT_F16 && TT_DIAG   // bf16 instantiation of the DIAGNOSTIC library only (make DIAG=1): libtt_hip.so exports exactly include/tt_hip.h
 int tt_attention_debug_stamps(const void* qk, int ld_qk, int q_col0, int k_col0, const void* vt, int ldvt, void* out,
                               int ld_out, const int32_t* seq_start, const int32_t* seq_len, int n_seq, int heads,
                               int head_dim, int max_len, void* stamps, void* stream) {

@@ -1760,7 +1760,7 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_p(GemmParams p, int 
 // Super-tile shape: the 32 tiles an XCD works on at a time are SM row-blocks x SN column-blocks (SM * SN = 32); the A
 // row-blocks of a super-tile are shared through that XCD's L2 by its SN column tiles.
 inline int super_sn(int nt_n) {
-    static const int env = [] { const char* e = getenv("TT_GEMM_SN"); return e && e[0] ? atoi(e) : 0; }();
+    static const int env = TT_DIAG_ENV_INT("TT_GEMM_SN", 0);
     int sn = env > 0 ? env : 4;
     if (sn > nt_n) sn = nt_n;
     while (32 % sn) --sn;
@@ -1768,7 +1768,7 @@ inline int super_sn(int nt_n) {
 }
 
 inline bool small_grid_v1() {
-    static const bool on = [] { const char* e = getenv("TT_GEMM_SMALL_V1"); return !(e && e[0] == '0'); }();
+    static const bool on = TT_DIAG_ENV_INT("TT_GEMM_SMALL_V1", 1) != 0;
     return on;
 }
 
@@ -1918,7 +1918,7 @@ __global__ __launch_bounds__(64) void gemm_skinny_kernel(GemmParams p) {
 
 // TT_GEMM_SKINNY_MT=4: round 2's shape (four row tiles per wave, 8 steps in flight), the A/B switch
 inline bool skinny_mt4() {
-    static const bool on = [] { const char* e = getenv("TT_GEMM_SKINNY_MT"); return e && e[0] == '4'; }();
+    static const bool on = TT_DIAG_ENV_INT("TT_GEMM_SKINNY_MT", 0) == 4;
     return on;
 }
 
@@ -2054,9 +2054,9 @@ int launch_skinny(const GemmParams& p, hipStream_t st) {
 template <int EPI>
 int launch(const GemmParams& p, hipStream_t st) {
     if constexpr (!kF16) if (p.fp8) return launch_fp8<EPI>(p, st);
-    static const bool trace = [] { const char* e = getenv("TT_GEMM_TRACE"); return e && e[0] == '1'; }();
+    static const bool trace = TT_DIAG_ENV_INT("TT_GEMM_TRACE", 0) == 1;
     if (trace) fprintf(stderr, "gemm launch<%d> M=%d N=%d K=%d lda=%d ldc=%d ldr=%d\n", EPI, p.M, p.N, p.K, p.lda, p.ldc, p.ldr);
-    static const int variant = [] { const char* e = getenv("TT_GEMM_VARIANT"); return e && e[0] ? atoi(e) : 5; }();
+    static const int variant = TT_DIAG_ENV_INT("TT_GEMM_VARIANT", 5);
     // (the residual epilogue stages the residual tile as two pseudo K-tiles: needs an even number of K-tiles)
     // Fewer than half a CU-wave of 256x256 tiles (query embedding, the CLS tail): the 128x128 kernel spreads the
     // work over 4x the workgroups and is 1.3-1.7x faster there (M = 768: 15 vs 23 us per K = 1024 GEMM).
@@ -2070,7 +2070,7 @@ int launch(const GemmParams& p, hipStream_t st) {
         blocks = (blocks + 7) / 8 * 8;
         // measured (M = 236800): the persistent kernel wins where the epilogue is VALU-heavy (GELU: 1.74 vs 1.78 ms), the
         // one-tile kernel with LDS-transposed full-line stores where it is store-bound (bias: 1.39 vs 1.40 ms)
-        static const int xp = [] { const char* e = getenv("TT_GEMM_XP"); return e && e[0] ? (int)strtol(e, nullptr, 0) : 0; }();
+        static const int xp = TT_DIAG_ENV_INT("TT_GEMM_XP", 0);
         if constexpr (EPI == TT_EPI_GELU || EPI == TT_EPI_BIAS) {
             const int cus = tt_cu_count_cached() / 8 * 8;
             if (variant == 5 && (EPI == TT_EPI_GELU || (xp & 1)) && (p.K / BK) % 2 == 0 && p.K / BK >= 2 && blocks > cus && cus >= 8) {
@@ -2109,7 +2109,7 @@ int launch(const GemmParams& p, hipStream_t st) {
         GemmParams q = p;
         // whole-line stores as streaming stores: +1...3 % on the bias-only shapes, -0.7 ms per bench step (with the old 32-byte
         // runs the same hint cost 18 %: no write combining in L2)
-        static const int nts = [] { const char* e = getenv("TT_GEMM_NT_STORE"); return e && e[0] ? atoi(e) : 1; }();
+        static const int nts = TT_DIAG_ENV_INT("TT_GEMM_NT_STORE", 1);
         q.nt_store = nts;
         q.sn = SN;
         static const bool a0 = TT_DIAG_ENV_INT("TT_GEMM_DEBUG_A0", 0) == 1;      // (wrong results: diagnostic library only)
@@ -2149,7 +2149,7 @@ int launch(const GemmParams& p, hipStream_t st) {
 }  // namespace
 
 bool tt_gemm_skinny_enabled() {
-    static const bool on = [] { const char* e = getenv("TT_GEMM_SKINNY"); return !(e && e[0] == '0'); }();
+    static const bool on = TT_DIAG_ENV_INT("TT_GEMM_SKINNY", 1) != 0;
     return on;
 }
 
@@ -2227,10 +2227,10 @@ int tt_gemm_launch(const GemmParams& p, int epilogue, hipStream_t st) {
         case TT_EPI_TANH: return launch<TT_EPI_TANH>(p, st);
         case TT_EPI_QKV: {
             if (!p.vt) { tt_set_error("gemm: qkv epilogue without vt"); return TT_E_INVALID; }
-            static const int variant = [] { const char* e = getenv("TT_GEMM_VARIANT"); return e && e[0] ? atoi(e) : 5; }();
+            static const int variant = TT_DIAG_ENV_INT("TT_GEMM_VARIANT", 5);
             const int nv = p.N - p.vt_col0;
             // (TT_GEMM_QKV_SPLIT=0: one launch with the mixed epilogue -- measured 2 % slower end to end)
-            static const int split = [] { const char* e = getenv("TT_GEMM_QKV_SPLIT"); return e && e[0] ? atoi(e) : 1; }();
+            static const int split = TT_DIAG_ENV_INT("TT_GEMM_QKV_SPLIT", 1);
             const bool small_grid = (long long)(p.M / v3::BM3) * (p.N / v3::BN3) < 128 && small_grid_v1();
             if (variant >= 3 && split && !small_grid && p.M % v3::BM3 == 0 && p.vt_col0 % v3::BN3 == 0 && nv % v3::BN3 == 0 &&
                 nv > 0 && p.ldc % 8 == 0 && p.ldvt % 8 == 0) {
@@ -2323,10 +2323,10 @@ int tt_scan_gemm_launch(const uint16_t* corpus, int64_t rows, int dim, const uin
     // Round 3: survivors go to WAVE-PRIVATE LDS lists (scan_filter_epilogue<2>: no workgroup barrier), which is what the
     // persistent form needs.  TT_SCAN_GEMM_PERSIST: 1 = persistent + wave-private lists, 2 = one tile per workgroup +
     // wave-private lists, 0 = one tile per workgroup + the workgroup-shared list (round 2's form), default = see below.
-    static const int persist = [] { const char* e = getenv("TT_SCAN_GEMM_PERSIST"); return e && e[0] ? atoi(e) : TT_SCAN_PERSIST_DEFAULT; }();
+    static const int persist = TT_DIAG_ENV_INT("TT_SCAN_GEMM_PERSIST", TT_SCAN_PERSIST_DEFAULT);
     const int cus = tt_cu_count_cached() / 8 * 8;
     if (persist == 1 && blocks > cus && cus >= 8) {
-        static const int sxp = [] { const char* e = getenv("TT_SCAN_GEMM_XP"); return e && e[0] ? (int)strtol(e, nullptr, 0) : 0; }();
+        static const int sxp = TT_DIAG_ENV_INT("TT_SCAN_GEMM_XP", 0);
         p.xp = sxp;      // (experiment switches of the persistent kernel: bit 2 = wave groups NOT aligned at the tile boundary)
         TT_SET_MAX_LDS(v3::gemm_kernel_p<TT_EPI_SCAN>, v3::kLdsScanW);
         {

@@ -362,7 +362,7 @@ int tt_layernorm_launch(const uint16_t* in, uint16_t* out, const float* gamma, c
     if (int rc = check_h(H)) return rc;
     // default 5 = streaming loads + streaming stores: 0.197 -> 0.172 ms for 236800 x 1024 (4.9 -> 5.6 TB/s) with the
     // caches cold as they are between two GEMMs, -0.8 ms per bench step; two rows per wave (3) measured slower
-    static const int nt = [] { const char* e = getenv("TT_LN_NT"); return e && e[0] ? atoi(e) : 5; }();
+    static const int nt = TT_DIAG_ENV_INT("TT_LN_NT", 5);
     if (nt == 3)
         hipLaunchKernelGGL(layernorm_kernel<3>, row_grid((rows + 1) / 2), dim3(kRowThreads), 0, st, in, out, gamma, beta, rows, H,
                            eps, q8, q8_scale);

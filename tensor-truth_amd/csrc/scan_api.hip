@@ -75,7 +75,7 @@ int filter_blocks(int64_t rows, int cus) {
 }
 
 bool scan_gemm_enabled() {
-    static const bool on = [] { const char* e = getenv("TT_SCAN_GEMM"); return !(e && e[0] == '0'); }();
+    static const bool on = TT_DIAG_ENV_INT("TT_SCAN_GEMM", 1) != 0;
     return on;
 }
 
@@ -92,7 +92,7 @@ Plan make_plan(int64_t n_rows, int dim, int n_queries, int k, int cus) {
     // expected survivors ~ k * rows / sample rows per query) and a list sized for 4x that expectation.
     pl.gemm = scan_gemm_enabled() && n_queries > 64 && dim % 128 == 0 && n_rows >= 262144 && n_rows >= (int64_t)2048 * k;
     if (pl.gemm) {
-        static const int64_t n0_env = [] { const char* e = getenv("TT_SCAN_GEMM_N0"); return e && e[0] ? (int64_t)atoll(e) : (int64_t)0; }();
+        static const int64_t n0_env = TT_DIAG_ENV_INT("TT_SCAN_GEMM_N0", 0);
         n0 = n0_env > 0 ? n0_env : 131072;   // (measured, 10M x 1024 x 256 queries: 65536 -> 5.50, 131072 -> 5.35, 262144 -> 5.52 ms per batch)
         // ... in proportion to the shard: the sample pass and its selection are a fixed cost per batch (0.3 ms at 131072 rows),
         // a third of the whole batch on the 1.25M-row shard of an 8-GPU step; expected survivors per query ~ k * rows / n0 stay
@@ -179,8 +179,10 @@ __global__ void fill_pad_kernel(float* s, int32_t* ix, int64_t n) {
 int scan_mode_from_env() {
     // TT_SCAN_MODE = load path (0 direct fragments | 1 LDS transpose) + 16 * variant; default 1
     // (bench/ablation knob, see scan.hip).
+#if TT_DIAG
     const char* e = getenv("TT_SCAN_MODE");
     if (e && e[0]) return atoi(e);
+#endif
     return 1;  // LDS-transpose load path (non-temporal corpus loads)
 }
 
@@ -321,7 +323,7 @@ int tt_scan_topk(const void* corpus_bf16, int64_t n_rows, int dim, const void* q
     // shard, ONE read of the sample rows for all 256 queries and the same MFMA arithmetic as the pass that applies the
     // thresholds (the streaming sample kernel reads the rows once per 64-query tile: 63 of the shard batch's 730 us).
     // TT_SCAN_GEMM_SAMPLE=0: the streaming sample, the A/B switch.
-    static const bool gemm_sample = [] { const char* e = getenv("TT_SCAN_GEMM_SAMPLE"); return !(e && e[0] == '0'); }();
+    static const bool gemm_sample = TT_DIAG_ENV_INT("TT_SCAN_GEMM_SAMPLE", 1) != 0;
     if (pl.gemm && gemm_sample) {
         const int tiles = (int)(pl.n0 / 256);
         const int tile_stride = (int)((n_rows / 256) / tiles);
@@ -383,12 +385,12 @@ int tt_scan_topk(const void* corpus_bf16, int64_t n_rows, int dim, const void* q
     if (!fused) TT_CHECK_HIP(hipMemsetAsync(cnt, 0, (size_t)pl.qpad * sizeof(int32_t), st));
 
     if (pl.gemm) {
-        // 3'. filter pass as a tiled contraction: rows [0, rows256) x 256 queries per launch, ONE pass over the corpus per
-        //     256 queries; the < 256 tail rows through the streaming kernel (private lists of one block)
+        // 3'. filter pass as a tiled contraction: ALL rows x 256 queries per launch, ONE pass over the corpus per 256 queries
         // (q256: the batch itself when it is full, else the zero-padded copy made before the sample)
-        // (rows not a multiple of 256: the contraction's last tile is the shard's last 256 rows -- no separate pass over the tail;
-        //  TT_SCAN_GEMM_TAIL=1: rounds 2-3's form, the < 256 tail rows through the streaming kernel, the A/B switch)
-        static const bool tail_pass = [] { const char* e = getenv("TT_SCAN_GEMM_TAIL"); return e && e[0] == '1'; }();
+        // (rows not a multiple of 256: the contraction's last tile is the shard's last 256 rows, overlapping its predecessor -- no
+        //  separate pass over the tail.  Diagnostic library only, TT_SCAN_GEMM_TAIL=1: rounds 2-3's form, rows [0, rows256) tiled and
+        //  the < 256 tail rows through the streaming kernel, the A/B switch)
+        static const bool tail_pass = TT_DIAG_ENV_INT("TT_SCAN_GEMM_TAIL", 0) == 1;
         const int64_t rows256 = tail_pass ? n_rows / 256 * 256 : n_rows;
         for (int b = 0; b < pl.q256 / 256; ++b) {
             rc = tt_scan_gemm_launch((const uint16_t*)corpus_bf16, rows256, dim, q256 + (size_t)b * 256 * dim, thr + b * 256,

@@ -589,7 +589,7 @@ __global__ __launch_bounds__(64 * kWaveSelMaxWaves) void select_wave_kernel(Sele
 
 static bool select_wave_on() {
     // TT_SELECT_WAVE=0: the LDS network for every k (the A/B switch; both kernels are exact: the same outputs)
-    static const bool on = [] { const char* e = getenv("TT_SELECT_WAVE"); return !(e && e[0] == '0'); }();
+    static const bool on = TT_DIAG_ENV_INT("TT_SELECT_WAVE", 1) != 0;
     return on;
 }
 
@@ -601,6 +601,14 @@ int tt_select_launch(const SelectParams& p, int n_queries, hipStream_t stream) {
         tt_set_error("top-k: k=%d outside [1,%d]", p.k, kMaxK);
         return TT_E_INVALID;
     }
+    //  the wave kernel tests bit (min_valid - 1) of a 64-bit ballot and the LDS network reads buf[min_valid - 1]: a
+    // request for more valid outputs than the kernel writes is a caller's error, not a shift by >= 64
+    if (p.min_valid < 0 || p.min_valid > p.k) {
+        tt_set_error("top-k: min_valid=%d outside [0, k=%d]", p.min_valid, p.k);
+        return TT_E_INVALID;
+    }
+    // thr_out (and cnt_out / zero_cnt) are indexed by the GRID's query index: with n_real < n_queries the padding blocks write
+    // thr_out[q] = +inf for q up to n_queries, so those buffers must hold n_queries entries (scan_api.hip's Plan sizes them by qpad)
     const bool wave_on = select_wave_on();
     SelectParams q = p;
     if (q.n_real <= 0) q.n_real = n_queries;

@@ -665,7 +665,7 @@ int forward_x3_impl(const tt_encoder_weights_x3* w, const int32_t* ids, const in
     // LayerNorm output, hi + lo (abs. error <= max(2^-22 |x|, 2^-25)), instead of carried as a separate fp32 copy -- a LayerNorm
     // pass then writes 8 bytes per element (two planes) instead of 12 and the residual epilogue reads the same 4.  bf16 planes
     // (16 bits) keep the fp32 copy.  TT_X3_RES_PLANES=0: the fp32 copy, the A/B switch; the rounding diagnostics (rmask) keep it too.
-    static const bool res_planes_env = [] { const char* e_ = getenv("TT_X3_RES_PLANES"); return !(e_ && e_[0] == '0'); }();
+    static const bool res_planes_env = TT_DIAG_ENV_INT("TT_X3_RES_PLANES", 1) != 0;
     const bool res_planes = kF16 && res_planes_env && rmask == 0;
     float* x = (w->layers == 0 && hidden_out) ? hidden_out : xa;
     {

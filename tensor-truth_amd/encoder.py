@@ -349,7 +349,8 @@ class PackedBatch:
 def _round_rows(used: int) -> int:
     """Token rows of a batch: a multiple of the 256-row GEMM tile; up to 256 rows (one query, a few short texts) a
     multiple of 64 -- the projections then run as weight-streaming skinny GEMMs (csrc/gemm.hip)."""
-    if used <= 256 and os.environ.get("TT_GEMM_SKINNY", "1") != "0":   # (=0: A/B switch of tools/gpu_skinny.sh)
+    # (TT_GEMM_SKINNY=0: the A/B switch of tools/gpu_skinny.sh -- honoured with the diagnostic library only, like the kernels' own read)
+    if used <= 256 and not (_lib.is_diag() and os.environ.get("TT_GEMM_SKINNY", "1") == "0"):
         return max(64, (used + 63) // 64 * 64)
     return (used + 255) // 256 * 256
 

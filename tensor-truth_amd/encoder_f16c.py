@@ -2,14 +2,15 @@
 
 The reference builds its embedder and reranker without a dtype (``services/model_manager.py:218-229,333-337``;
 ``app_utils/config_schema.py:66-76``: ``torch_dtype: None``), i.e. in fp32, and north_star's score tolerance (1e-3
-relative) is an fp32 tolerance.  ``encoder_x3`` (split-bf16) meets it at a third of the bf16 matrix rate; this path meets
-it at HALF: every GEMM operand is carried as "c-planes" -- ``hi = fp16(x)`` plus two OCP e4m3 planes (``x`` and ``x - hi``)
+relative) is an fp32 tolerance.  ``encoder_x3`` (split planes, three products) meets it at a third of the bf16 matrix rate -- on
+ordinary AND hostile weights -- and is what the default mode runs; this path is the FAST VARIANT at half the rate
+(``TT_REFERENCE_IMPL=f16c``; 9e-5 relative on ordinary weights, 7e-3 on the stress fixture: DESIGN.md section 4.9): every GEMM operand is carried as "c-planes" -- ``hi = fp16(x)`` plus two OCP e4m3 planes (``x`` and ``x - hi``)
 with one E8M0 block exponent per 32 elements -- and a product runs as ``hi.hi`` on the fp16 matrix cores plus two
 block-scaled e4m3 cross terms at twice the rate (``a.w ~= a_hi.w_hi + e4m3(a).e4m3(w_lo) + e4m3(a_lo).e4m3(w)``; the cross
 terms are 2^-12 of the result, the dropped term 2^-24).  Attention on single fp16 products with fp32 softmax; the residual
-stream, LayerNorm, exact-erf GELU and the classification head stay fp32.  It is what ``precision.resolve()``'s default
-mode ("reference") runs whenever the model shape fits (hidden a multiple of 256 with 64-wide heads: bge-m3,
-bge-reranker-v2-m3, bge-reranker-base); ``TT_REFERENCE_IMPL=bf16x3`` / ``fp32`` select the older implementations.
+stream, LayerNorm, exact-erf GELU and the classification head stay fp32.  ``precision.reference_impl()`` selects it only on
+request, and only where the model shape fits (hidden a multiple of 256 with 64-wide heads: bge-m3, bge-reranker-v2-m3,
+bge-reranker-base); the default is ``f16x3`` (``encoder_x3`` on fp16 planes), ``bf16x3`` / ``fp32`` the older implementations.
 Same token packing and surface as ``encoder.Encoder``.
 """
 from __future__ import annotations

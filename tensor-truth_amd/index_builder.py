@@ -145,8 +145,6 @@ def _build_with_workers(index, documents, embed_model, chunking_strategy, chunk_
             "buffer_size": buffer_size, "percentile": percentile,
             "chunk_sizes": list(chunk_sizes) if chunk_sizes is not None else list(DEFAULT_CHUNK_SIZES),
             "chunk_overlap": DEFAULT_CHUNK_OVERLAP if chunk_overlap is None else chunk_overlap}
-    pool = iw.get_workers(spec, W)
-
     def distances(emb):
         # the copy back is enqueued behind this chunk's own forward passes, with an event of its own: waiting for it waits for
         # this chunk only, not for what was enqueued after it
@@ -169,8 +167,10 @@ def _build_with_workers(index, documents, embed_model, chunking_strategy, chunk_
         if emb is not None:
             index.add([nodes[i] for i in leaf_pos], embeddings=emb)      # VectorStoreIndex(leaf_nodes, ...), builder.py:437-442
 
-    pool.run(documents, chunking_strategy == "semantic_hierarchical", embed_model.embed_token_batches, distances, on_nodes,
-             chunk_docs=int(os.environ.get("TT_INGEST_CHUNK_DOCS", "48")))
+    # (a pool serves one build at a time: a second thread building with the same configuration gets a private pool)
+    with iw.lease_workers(spec, W) as pool:
+        pool.run(documents, chunking_strategy == "semantic_hierarchical", embed_model.embed_token_batches, distances, on_nodes,
+                 chunk_docs=int(os.environ.get("TT_INGEST_CHUNK_DOCS", "48")))
     return True
 
 

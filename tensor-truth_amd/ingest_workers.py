@@ -23,12 +23,14 @@ touched the GPU (nothing is forked).  Workers are kept for the life of the proce
 from __future__ import annotations
 
 import atexit
+import contextlib
 import os
 import pickle
 import select
 import struct
 import subprocess
 import sys
+import threading
 from collections import deque
 from typing import Callable, Dict, List, Optional, Sequence
 
@@ -262,22 +264,46 @@ def default_workers() -> int:
 
 
 _POOLS: Dict[bytes, "IngestWorkers"] = {}
+_POOLS_LOCK = threading.Lock()
 
 
 def get_workers(spec: Dict, workers: int) -> "IngestWorkers":
-    """The process's worker pool for this host configuration (started on first use, reused by later builds, closed at exit)."""
+    """The process's worker pool for this host configuration (started on first use, reused by later builds, closed at exit).
+    A pool serves ONE build at a time (``run`` holds its lock): concurrent builds go through ``lease_workers``."""
     key = pickle.dumps((sorted(spec.items(), key=lambda kv: kv[0]), workers))
-    pool = _POOLS.get(key)
-    if pool is None or not pool.alive():
-        pool = _POOLS[key] = IngestWorkers(spec, workers)
-    return pool
+    with _POOLS_LOCK:
+        pool = _POOLS.get(key)
+        if pool is None or not pool.alive():
+            pool = _POOLS[key] = IngestWorkers(spec, workers)
+        return pool
+
+
+@contextlib.contextmanager
+def lease_workers(spec: Dict, workers: int):
+    """A pool nobody else is using: the shared one of ``get_workers`` if it is idle, otherwise a PRIVATE pool started for
+    this build and closed after it.  Two threads calling ``build_index`` with the same configuration used to share the pipes and the
+    ``buffers[w][(op, chunk_id)]`` keys -- both builds number their chunks from 0, so replies of one were consumed by the other,
+    and an ``abort`` of one killed the workers under the other."""
+    pool = get_workers(spec, workers)
+    private = not pool._busy.acquire(blocking=False)
+    if private:
+        pool = IngestWorkers(spec, workers)
+        pool._busy.acquire()
+    try:
+        yield pool
+    finally:
+        pool._busy.release()
+        if private:
+            pool.close()
 
 
 @atexit.register
 def _close_pools() -> None:
-    for pool in list(_POOLS.values()):
+    with _POOLS_LOCK:
+        pools = list(_POOLS.values())
+        _POOLS.clear()
+    for pool in pools:
         pool.close()
-    _POOLS.clear()
 
 
 class IngestWorkers:
@@ -292,6 +318,7 @@ class IngestWorkers:
             self.procs.append(p)
             self.conns.append(_PipeConn(p.stdout.fileno(), p.stdin.fileno(), duplex_safe=True))
         self.buffers: List[Dict] = [dict() for _ in range(workers)]
+        self._busy = threading.RLock()              # held for the whole of run(): pipes and reply buffers belong to one build
         for c in self.conns:
             c.send(spec)
         for c in self.conns:                      # (interpreter start + imports: a few tenths of a second, paid once per process)
@@ -359,11 +386,12 @@ class IngestWorkers:
         leaf positions, leaf embeddings)`` (docstore + index rows), called in document order.
         A build that raises -- in a worker, in a callback, on a dead pipe -- leaves chunks in flight and replies unread: the pool
         is killed (``abort``) and the error re-raised; ``get_workers`` starts a fresh pool for the next build."""
-        try:
-            self._run(documents, semantic, embed_tokens, distances, on_nodes, chunk_docs, inflight_per_worker)
-        except BaseException:
-            self.abort()
-            raise
+        with self._busy:
+            try:
+                self._run(documents, semantic, embed_tokens, distances, on_nodes, chunk_docs, inflight_per_worker)
+            except BaseException:
+                self.abort()
+                raise
 
     def _run(self, documents, semantic, embed_tokens, distances, on_nodes, chunk_docs, inflight_per_worker) -> None:
         W = len(self.conns)

@@ -55,6 +55,7 @@ def scan_topk(
     exact_dense: bool = False,
     check_overflow: bool = True,
     return_flag: bool = False,
+    _packed: Optional[torch.Tensor] = None,
 ):
     """corpus [N,D] bf16, queries [Q,D] bf16 (same HIP device) ->
     (scores [Q,k] fp32, idx [Q,k] int32), idx = idx_base + row, padding (-inf, -1).
@@ -78,8 +79,12 @@ def scan_topk(
     n, d = corpus.shape
     q = queries.shape[0]
     dev = corpus.device
-    out_s = torch.empty((q, k), dtype=torch.float32, device=dev)
-    out_i = torch.empty((q, k), dtype=torch.int32, device=dev)
+    if _packed is not None:      # scan_topk_host: scores, indices and the status word in ONE buffer (one copy back, one sync)
+        out_s = _packed[: q * k].view(torch.float32).view(q, k)
+        out_i = _packed[q * k: 2 * q * k].view(q, k)
+    else:
+        out_s = torch.empty((q, k), dtype=torch.float32, device=dev)
+        out_i = torch.empty((q, k), dtype=torch.int32, device=dev)
     if q == 0:
         return out_s, out_i
     with torch.cuda.device(dev):
@@ -94,16 +99,40 @@ def scan_topk(
         need = lib.tt_scan_workspace_bytes(n, d, q, k)
         ws = _ws.get(dev, need + 256)
         base = (ws.data_ptr() + 255) // 256 * 256
-        flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        if _packed is not None:
+            flag = _packed[2 * q * k:]
+            flag.zero_()
+        else:
+            flag = torch.zeros(1, dtype=torch.int32, device=dev)
         rc = lib.tt_scan_topk(corpus.data_ptr(), n, d, queries.data_ptr(), q, k, idx_base,
                               out_s.data_ptr(), out_i.data_ptr(), base, ws.numel() - (base - ws.data_ptr()),
                               flag.data_ptr(), st)
         _lib.check(rc, "tt_scan_topk")
+        if _packed is not None:
+            return out_s, out_i
         if return_flag:
             return out_s, out_i, int(flag.item()) != 0
         if check_overflow and int(flag.item()) != 0:
             return scan_topk(corpus, queries, k, idx_base, exact_dense=True)
     return out_s, out_i
+
+
+def scan_topk_host(corpus: torch.Tensor, queries: torch.Tensor, k: int, idx_base: int = 0):
+    """``scan_topk`` for callers that need the hits ON THE HOST (the retriever turns rows into nodes): scores, indices and the
+    overflow status word live in one device buffer and come back in ONE copy -- the wait for the hits is the only host sync of a
+    scan batch (``scan_topk`` itself reads the flag with its own ``.item()`` before the caller's ``.cpu()``: two syncs, 0.04 ms of
+    a 0.74 ms shard batch).  A flagged overflow re-runs the dense exact path, as ``scan_topk`` does.
+    -> (scores [Q,k] fp32, idx [Q,k] int32), CPU tensors."""
+    q = queries.shape[0]
+    if q == 0:
+        return torch.empty((0, k), dtype=torch.float32), torch.empty((0, k), dtype=torch.int32)
+    packed = torch.empty(2 * q * k + 1, dtype=torch.int32, device=corpus.device)
+    scan_topk(corpus, queries, k, idx_base, _packed=packed)
+    host = packed.cpu()                                   # the one sync (current stream only)
+    if int(host[-1]) != 0:
+        s, i = scan_topk(corpus, queries, k, idx_base, exact_dense=True)
+        return s.cpu(), i.cpu()
+    return host[: q * k].view(torch.float32).view(q, k), host[q * k: 2 * q * k].view(q, k)
 
 
 def scan_topk_segmented(corpus: torch.Tensor, queries: torch.Tensor, k: int, seg_offsets) -> Tuple[torch.Tensor, torch.Tensor]:

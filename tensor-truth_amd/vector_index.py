@@ -188,6 +188,11 @@ class HipVectorIndex:
         mat, _ = snapshot if snapshot is not None else self.snapshot()
         return _scan.scan_topk(mat, self._unit_bf16(query_emb), k)
 
+    def search_host(self, query_emb: torch.Tensor, k: int, snapshot=None):
+        """``search`` with the hits on the host (CPU tensors): one copy back, one sync per scan batch (``scan.scan_topk_host``)."""
+        mat, _ = snapshot if snapshot is not None else self.snapshot()
+        return _scan.scan_topk_host(mat, self._unit_bf16(query_emb), k)
+
     def node_score(self, cos: float) -> float:
         return math.exp(-(2.0 - 2.0 * cos)) if self.score_mode == "chroma" else cos
 
@@ -488,15 +493,15 @@ class HipVectorRetriever:
             return [[] for _ in bundles]
         stream = self._gpu_stream()
         if stream is None:
-            scores, rows = idx.search(self._query_matrix(bundles), k, snapshot=snap)
-            scores, rows = scores.cpu().tolist(), rows.cpu().tolist()
+            scores, rows = idx.search_host(self._query_matrix(bundles), k, snapshot=snap)
+            scores, rows = scores.tolist(), rows.tolist()
         else:
             written = getattr(idx, "_written", None)        # (read after the snapshot: covers every row the snapshot holds)
             with torch.cuda.stream(stream):
                 if written is not None:
                     stream.wait_event(written)
-                scores, rows = idx.search(self._query_matrix(bundles), k, snapshot=snap)
-                scores, rows = scores.cpu().tolist(), rows.cpu().tolist()     # waits for THIS stream only
+                scores, rows = idx.search_host(self._query_matrix(bundles), k, snapshot=snap)     # waits for THIS stream only
+                scores, rows = scores.tolist(), rows.tolist()
         return [self.nodes_from_hits(s, r, leaf_ids) for s, r in zip(scores, rows)]
 
     def nodes_from_hits(self, scores: Sequence[float], rows: Sequence[int], leaf_ids=None) -> List[NodeWithScore]:

@@ -69,6 +69,21 @@ def built_lib():
 
 
 @pytest.fixture(scope="session")
+def diag_lib_env(built_lib):
+    """Environment of a CHILD process that loads the diagnostic build of the library (csrc `make DIAG=1` ->
+    libtt_hip_diag.so): the only build in which the kernels' A/B switches exist -- the product library reads no environment
+    variable (tests/test_lib_abi.py).  A/B tests run their "other side" in such a child and compare bits with the product."""
+    import subprocess
+
+    from tensor_truth_amd import _lib
+
+    path = os.path.join(os.path.dirname(_lib.lib_path()), "libtt_hip_diag.so")
+    if not os.path.exists(path):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "tensor-truth_amd", "csrc"), "DIAG=1", "-j4"], check=True)
+    return dict(os.environ, TT_LIB_NAME="libtt_hip_diag.so")
+
+
+@pytest.fixture(scope="session")
 def dev():
     import torch
 

@@ -123,7 +123,7 @@ def test_wave_register_select_list_lengths(dev, built_lib, m, k):
     assert torch.equal(gv == 0, wv == 0) and torch.equal(torch.where(gv == 0, torch.zeros_like(gv), gv), torch.where(wv == 0, torch.zeros_like(wv), wv))
 
 
-def test_wave_select_equals_lds_network_in_a_child_process(dev, built_lib, tmp_path):
+def test_wave_select_equals_lds_network_in_a_child_process(dev, built_lib, tmp_path, diag_lib_env):
     """A/B: TT_SELECT_WAVE=0 (the LDS network of rounds 1-3, still the kernel for k > 64) returns the same bits as the
     wave-register kernel on a sampled-threshold scan (sample select with the fused threshold outputs + final select over private
     and shared candidate lists) and on a tiled 256-query batch."""
@@ -148,14 +148,14 @@ def test_wave_select_equals_lds_network_in_a_child_process(dev, built_lib, tmp_p
         return
     other = tmp_path / "lds.pt"
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, TT_SELECT_WAVE="0", TT_SELECT_AB_CHILD=str(other))
+    env = dict(diag_lib_env, TT_SELECT_WAVE="0", TT_SELECT_AB_CHILD=str(other))
     subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.abspath(__file__) + "::test_wave_select_equals_lds_network_in_a_child_process"],
                    check=True, env=env, cwd=root, timeout=900, capture_output=True)
     theirs = torch.load(str(other))
     assert len(mine) == len(theirs) and all(torch.equal(a, b) for a, b in zip(mine, theirs))
 
 
-def test_contraction_sample_equals_streaming_sample_in_a_child_process(dev, built_lib, tmp_path):
+def test_contraction_sample_equals_streaming_sample_in_a_child_process(dev, built_lib, tmp_path, diag_lib_env):
     """A/B: the tiled scan's threshold sample on the contraction kernel (round 4) against the streaming sample kernel
     (TT_SCAN_GEMM_SAMPLE=0).  The two samples look at different rows, so the thresholds differ -- the RESULT may not: top-k scores
     and indices bit-identical, on a full 256-query batch, a ragged one (zero-padded copy), one with NaN tombstones in the sampled
@@ -184,7 +184,7 @@ def test_contraction_sample_equals_streaming_sample_in_a_child_process(dev, buil
         return
     other = tmp_path / "streaming_sample.pt"
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, TT_SCAN_GEMM_SAMPLE="0", TT_SAMPLE_AB_CHILD=str(other))
+    env = dict(diag_lib_env, TT_SCAN_GEMM_SAMPLE="0", TT_SAMPLE_AB_CHILD=str(other))
     subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu",
                     os.path.abspath(__file__) + "::test_contraction_sample_equals_streaming_sample_in_a_child_process"],
                    check=True, env=env, cwd=root, timeout=900, capture_output=True)

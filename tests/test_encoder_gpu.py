@@ -349,7 +349,7 @@ def test_cls_only_last_layer_matches_full_forward(dev, built_lib, shape):
 
 @pytest.mark.parametrize("shape,dtype", [("xlmr256", torch.bfloat16), ("bert384", torch.bfloat16), ("xlmr1024", torch.bfloat16),
                                          ("xlmr1024", torch.float16), ("xlmr1024-one", torch.bfloat16)])
-def test_cls_tail_kv_only_projection_is_bit_identical(dev, built_lib, tmp_path, shape, dtype):
+def test_cls_tail_kv_only_projection_is_bit_identical(dev, built_lib, tmp_path, diag_lib_env, shape, dtype):
     """Last layer of the CLS tail: K and V from the big projection, the first rows' queries from a small GEMM over the gathered
     rows (encoder_api.hip) -- the same bits as the full Q,K,V projection it replaces (TT_CLS_KV_ONLY=0), on the mixed-epilogue path
     (small grids), the split path (>= 4096 rows) and the skinny path (one query), bf16 and fp16.  The library reads the switch once
@@ -360,7 +360,7 @@ def test_cls_tail_kv_only_projection_is_bit_identical(dev, built_lib, tmp_path, 
     cls_new, emb_new, score_new = _kv_only_case(shape, dtype, dev)
     out = tmp_path / "old.pt"
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, TT_CLS_KV_ONLY="0", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    env = dict(diag_lib_env, TT_CLS_KV_ONLY="0", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
     subprocess.run([sys.executable, os.path.abspath(__file__), "kv_only_child", shape, str(dtype), str(out)], check=True, env=env, timeout=600)
     cls_old, emb_old, score_old = torch.load(str(out))
     assert torch.isfinite(cls_new.float()).all()

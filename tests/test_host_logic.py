@@ -1215,3 +1215,65 @@ def test_failed_build_discards_the_worker_pool():
     _, flat, lens = host.split(0, recs)
     nodes, _, _, _ = host.cut(0, dist(embed(iw.unflatten(flat, lens)))[0])
     assert [n.text for g in got for n in g] == [n.text for n in nodes]
+
+
+def test_two_threads_building_with_the_same_configuration_do_not_share_a_pool():
+    """get_workers() hands every caller the process's one pool per configuration, and both builds number their
+    chunks from 0 -- two threads calling build_index at once read each other's replies.  lease_workers() gives the second builder a
+    private pool (closed after its build); run() holds the pool's lock, so even a direct get_workers() user is serialised.  Two
+    concurrent builds over DIFFERENT documents must each return exactly their own nodes, in document order."""
+    import threading
+
+    import numpy as np
+
+    from tensor_truth_amd import ingest_workers as iw
+    from tensor_truth_amd.schema import TextNode
+
+    spec = {"tokenizer": ("hash", "xlmr", 250002), "max_length": 64, "text_instruction": "", "buffer_size": 1, "percentile": 90,
+            "chunk_sizes": [128, 32, 16], "chunk_overlap": 4}
+    embed = lambda seqs: np.stack([np.array([len(s), int(s[0]) % 7 + 1.0]) for s in seqs])                      # noqa: E731
+    dist = lambda e: (np.abs(np.diff(e[:, 0])).astype(np.float32), (lambda block=False: True))                     # noqa: E731
+
+    def corpus(seed):
+        rng = np.random.default_rng(seed)
+        return [TextNode(text=" ".join(" ".join(f"s{seed}w{rng.integers(0, 300)}" for _ in range(10)) + "." for _ in range(25)),
+                         metadata={"title": f"{seed}-{i}"}) for i in range(72)]
+
+    def expected(docs):
+        host = iw._Host(spec)
+        recs = [iw._doc_record(d) for d in docs]
+        _, flat, lens = host.split(0, recs)
+        return [n.text for n in host.cut(0, dist(embed(iw.unflatten(flat, lens)))[0])[0]]
+
+    results, errors, pools = {}, [], {}
+    gate = threading.Barrier(3)
+
+    def build(seed, use_lease):
+        try:
+            docs, got = corpus(seed), []
+            gate.wait(timeout=60)
+            if use_lease:
+                with iw.lease_workers(spec, 2) as pool:
+                    pools[seed] = pool
+                    pool.run(docs, True, embed, dist, lambda nodes, pos, emb: got.append(nodes), chunk_docs=8)
+            else:
+                pool = pools[seed] = iw.get_workers(spec, 2)
+                pool.run(docs, True, embed, dist, lambda nodes, pos, emb: got.append(nodes), chunk_docs=8)
+            results[seed] = [n.text for g in got for n in g]
+        except BaseException as exc:  # noqa: BLE001
+            errors.append((seed, exc))
+
+    threads = [threading.Thread(target=build, args=(11, True)), threading.Thread(target=build, args=(12, True)),
+               threading.Thread(target=build, args=(13, False))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
+    for seed in (11, 12, 13):
+        assert results[seed] == expected(corpus(seed)), f"build {seed} returned another build's nodes"
+    # at least one of the leased builds ran on a private pool, which is closed again; the shared pool lives on
+    shared = iw.get_workers(spec, 2)
+    assert shared.alive()
+    private = [p for p in pools.values() if p is not shared]
+    assert all(not p.alive() for p in private)

@@ -31,6 +31,22 @@ def test_header_symbols_exported_and_bound(built_lib):
     assert isinstance(lib.tt_last_error(), bytes)
 
 
+def test_product_library_exports_exactly_the_header_and_reads_no_environment(built_lib):
+    """`nm -D libtt_hip.so` = the names include/tt_hip.h declares -- no debug entry point rides along -- and the
+    binary holds no TT_* string: every A/B switch of a measured-and-rejected variant is a compile-time constant in the product
+    (csrc/common.h TT_DIAG_ENV_INT) and exists only in the diagnostic build (`make DIAG=1`, libtt_hip_diag.so)."""
+    import subprocess
+
+    out = subprocess.run(["nm", "-D", "--defined-only", built_lib], check=True, capture_output=True, text=True).stdout
+    exported = sorted({ln.split()[-1] for ln in out.splitlines() if " T " in ln and ln.split()[-1].startswith("tt_")})
+    assert exported == _declared_symbols(), sorted(set(exported) ^ set(_declared_symbols()))
+    data = open(built_lib, "rb").read()
+    # (TT_EPI_* are the epilogue enumerators of tt_hip.h quoted in the text of a HIP error message, not switches)
+    env_names = sorted({m.group(0).decode() for m in re.finditer(rb"TT_[A-Z0-9_]{3,}", data)} - {"TT_EPI_SCAN"})
+    assert not env_names, f"the product library names environment switches: {env_names}"
+    assert b"getenv" not in data, "the product library imports getenv"
+
+
 def test_workspace_sizing_is_pure_host(built_lib):
     from tensor_truth_amd import _lib
 

@@ -155,16 +155,29 @@ def test_tiled_filter_pass_skips_tombstones_and_reports_overflow(dev, built_lib)
     assert torch.equal(i3.cpu(), torch.arange(10, dtype=torch.int32).repeat(70, 1))
 
 
-@pytest.mark.parametrize("mode", ["0", "1"])
-def test_both_corpus_load_modes(dev, built_lib, mode, monkeypatch):
+def test_both_corpus_load_modes(dev, built_lib, tmp_path, diag_lib_env):
+    """The streaming kernel's two corpus load paths: LDS-transposed full lines (the product) against the oracle, and direct
+    fragment-shaped loads (TT_SCAN_MODE=0, round 1's first form: a switch of the diagnostic library, run in a child process)
+    against the product, bit for bit."""
+    import subprocess
+    import sys
+
     from tensor_truth_amd import scan as tscan
 
-    monkeypatch.setenv("TT_SCAN_MODE", mode)
     corpus = osc.synth_corpus(90_000, 1024, seed=5)
     queries, _ = osc.synth_queries(corpus, 20, seed=6)
-    want = osc.scan_topk(corpus, queries, 50)
     s, i = _run(tscan, dev, corpus, queries, 50)
-    _check(s, i, *want)
+    if os.environ.get("TT_SCAN_MODE_AB_CHILD"):
+        torch.save((s.cpu(), i.cpu()), os.environ["TT_SCAN_MODE_AB_CHILD"])
+        return
+    _check(s, i, *osc.scan_topk(corpus, queries, 50))
+    other = tmp_path / "mode0.pt"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(diag_lib_env, TT_SCAN_MODE="0", TT_SCAN_MODE_AB_CHILD=str(other))
+    subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.abspath(__file__) + "::test_both_corpus_load_modes"],
+                   check=True, env=env, cwd=root, timeout=900, capture_output=True)
+    s0, i0 = torch.load(str(other))
+    assert torch.equal(i0, i.cpu()) and torch.allclose(s0, s.cpu(), rtol=1e-6, atol=1e-7)
 
 
 def test_topic_ordered_corpus_keeps_the_filter_path(dev, built_lib):
@@ -243,6 +256,27 @@ def test_candidate_overflow_falls_back_exact(dev, built_lib):
     # ... and the Python wrapper falls back to the dense path and stays exact
     s, i = tscan.scan_topk(c_dev, q_dev, 50)
     _check(s, i, *want)
+
+
+def test_scan_topk_host_one_copy_equals_scan_topk_and_falls_back_on_overflow(dev, built_lib):
+    """The retriever's form (scan.scan_topk_host): scores, indices and the status word come back in ONE copy -- same bits as
+    scan_topk on the streaming and on the tiled path, and an overflowing scan (all rows identical: every row passes the filter)
+    still returns the exact answer through the dense path."""
+    from tensor_truth_amd import scan as tscan
+
+    corpus = osc.synth_corpus(300_007, 1024, seed=21)
+    for nq in (1, 20, 130):
+        queries, _ = osc.synth_queries(corpus, nq, seed=22)
+        c, q = corpus.to(dev), queries.to(dev)
+        s, i = tscan.scan_topk(c, q, 50)
+        hs, hi = tscan.scan_topk_host(c, q, 50, idx_base=7)
+        assert not hs.is_cuda and torch.equal(hs, s.cpu()) and torch.equal(hi, i.cpu() + 7)
+    same = corpus[:1].repeat(70_000, 1).contiguous().to(dev)
+    q1 = corpus[:1].contiguous().to(dev)
+    _, _, overflowed = tscan.scan_topk(same, q1, 50, return_flag=True)
+    assert overflowed
+    hs, hi = tscan.scan_topk_host(same, q1, 50)
+    assert torch.equal(hi, torch.arange(50, dtype=torch.int32).view(1, 50)) and torch.isfinite(hs).all()
 
 
 def test_full_size_config_c2_against_oracle(dev, built_lib):
@@ -352,6 +386,78 @@ def test_full_size_config_c4_shard_layouts_vs_torch(dev, built_lib):
         parts.append(tscan.scan_topk(corpus[lo:hi], queries, k, idx_base=lo))
     ms, mi = tscan.topk_merge(torch.cat([p[0] for p in parts], 1), torch.cat([p[1] for p in parts], 1), k)
     assert torch.equal(ms, s) and torch.equal(mi[tie_free], i[tie_free])
+
+
+def _planted_queries(corpus, q, seed, dev):
+    """Half of the queries are a corpus row + 0.5 x a unit direction (cos ~ 0.89: the known top-1), half pure noise."""
+    n, d = corpus.shape
+    g = torch.Generator(device=dev).manual_seed(seed)
+    planted = torch.randint(0, n, (q // 2,), generator=g, device=dev)
+    u = torch.randn(q // 2, d, generator=g, device=dev)
+    u = u / u.norm(dim=1, keepdim=True)
+    qa = corpus[planted].float() + 0.5 * u
+    qb = torch.randn(q - q // 2, d, generator=g, device=dev)
+    queries = torch.cat([qa, qb])
+    return (queries / queries.norm(dim=1, keepdim=True)).to(torch.bfloat16), planted
+
+
+def _running_topk_checker(corpus, queries, k, piece=500_000):
+    """Independent full-size checker: torch matmul of the same bf16 data with fp32 accumulation, exact running top-k over pieces."""
+    dev = corpus.device
+    q, n = queries.shape[0], corpus.shape[0]
+    best_s = torch.full((q, k), -float("inf"), device=dev)
+    best_i = torch.zeros((q, k), dtype=torch.int64, device=dev)
+    qf = queries.float()
+    for lo in range(0, n, piece):
+        sc = qf @ corpus[lo:lo + piece].float().T
+        ps, pi = torch.topk(sc, min(k, sc.shape[1]), dim=1)
+        cat_s, cat_i = torch.cat([best_s, ps], 1), torch.cat([best_i, pi + lo], 1)
+        order = torch.argsort(cat_s, dim=1, descending=True, stable=True)[:, :k]
+        best_s, best_i = torch.gather(cat_s, 1, order), torch.gather(cat_i, 1, order)
+        del sc
+    return best_s, best_i
+
+
+@pytest.mark.parametrize("n", [1_250_000, 10_000_000])
+def test_tiled_scan_256_queries_at_bench_sizes_vs_torch(dev, built_lib, n):
+    """The path an 8-GPU step takes, at its own sizes: 256 gathered queries over one GPU's 1.25 M x 1024 shard
+    and over the whole 10 M x 1024 corpus THROUGH tt_scan_topk's tiled MFMA filter pass (65+ queries; the threshold sample shrinks
+    with the shard, scan_api.hip) -- indices bit-exact against the fp32 running top-k checker on every tie-free query, status flag
+    clear, planted neighbours first; at 10 M rows also eight row shards of 256 queries each + tt_topk_merge = the single pass."""
+    from tensor_truth_amd import scan as tscan
+    from tensor_truth_amd.sharded import shard_bounds
+    import bench
+
+    d, q, k = 1024, 256, 50
+    free, _ = torch.cuda.mem_get_info(dev)
+    if free < (40 if n > 2_000_000 else 12) * 2 ** 30:
+        pytest.skip("not enough free HBM")
+    corpus = bench.synth_corpus_shard(n, d, 1234, dev)
+    queries, planted = _planted_queries(corpus, q, 4321 + n % 97, dev)
+    s, i, overflowed = tscan.scan_topk(corpus, queries, k, return_flag=True)
+    assert not overflowed, "the tiled pass flagged a candidate-list overflow on the bench's own data"
+    assert (i[: q // 2, 0].long() == planted).all()
+    assert (s[:, :-1] >= s[:, 1:]).all() and (i >= 0).all() and (i < n).all()
+    best_s, best_i = _running_topk_checker(corpus, queries, k)
+    assert torch.allclose(s, best_s, rtol=REL_TOL, atol=1e-6)
+    gap = (best_s[:, :-1] - best_s[:, 1:]).min(dim=1).values
+    tie_free = gap > 1e-6
+    assert tie_free.float().mean().item() >= 0.5, f"tie-free fraction {tie_free.float().mean().item():.2f}"
+    assert torch.equal(i[tie_free].long(), best_i[tie_free])
+    # every returned index appears once, and the streaming kernel (<= 64 queries per pass) gives the same bits for the same queries
+    assert all(len(set(row.tolist())) == k for row in i[::16].cpu())
+    s64, i64 = tscan.scan_topk(corpus, queries[:64].contiguous(), k)
+    assert torch.equal(i64[tie_free[:64]], i[:64][tie_free[:64]])
+    assert torch.allclose(s64, s[:64], rtol=1e-5, atol=1e-6)
+    if n == 10_000_000:
+        parts = []
+        for r in range(8):
+            lo, hi = shard_bounds(n, 8, r)
+            ps, pi, ov = tscan.scan_topk(corpus[lo:hi], queries, k, idx_base=lo, return_flag=True)
+            assert not ov
+            parts.append((ps, pi))
+        ms, mi = tscan.topk_merge(torch.cat([p[0] for p in parts], 1), torch.cat([p[1] for p in parts], 1), k)
+        assert torch.equal(ms, s) and torch.equal(mi[tie_free], i[tie_free])
 
 
 @pytest.mark.parametrize("offsets,k,nq", [

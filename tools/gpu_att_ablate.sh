@@ -1,4 +1,6 @@
 #!/bin/bash
+# round 5: the kernels' A/B switches exist in the diagnostic library only (csrc: make DIAG=1); the product library reads no environment
+export TT_LIB_NAME=${TT_LIB_NAME:-libtt_hip_diag.so}
 # What each part of the attention key-tile loop costs: diagnostic builds of attention_kernel (TT_ATT_ABLATE, wrong results by
 # design) timed stand-alone on the bench shape (1600 sequences x 292 tokens, 16 heads x 64).
 cd "$GRAFT_REPO_ROOT" || exit 1

@@ -1,4 +1,6 @@
 #!/bin/bash
+# round 5: the kernels' A/B switches exist in the diagnostic library only (csrc: make DIAG=1); the product library reads no environment
+export TT_LIB_NAME=${TT_LIB_NAME:-libtt_hip_diag.so}
 # Attention tail tiles: live 32-row blocks dealt to different waves per (sequence, head) (TT_ATT_ROTATE, default on) vs plain order.
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out

@@ -1,4 +1,6 @@
 #!/bin/bash
+# round 5: the kernels' A/B switches exist in the diagnostic library only (csrc: make DIAG=1); the product library reads no environment
+export TT_LIB_NAME=${TT_LIB_NAME:-libtt_hip_diag.so}
 # What do the A-operand L2 misses cost the one-tile GEMM, and WHERE in the K-tile?  TT_GEMM_DEBUG_A0=1 makes every tile read
 # row-block 0's A rows (wrong results, every A read an L2 hit); stamps of a mid-grid workgroup + whole-kernel times both ways.
 cd "$GRAFT_REPO_ROOT" || exit 1

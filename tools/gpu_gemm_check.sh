@@ -1,4 +1,6 @@
 #!/bin/bash
+# round 5: the kernels' A/B switches exist in the diagnostic library only (csrc: make DIAG=1); the product library reads no environment
+export TT_LIB_NAME=${TT_LIB_NAME:-libtt_hip_diag.so}
 # GEMM shapes (epilogue-isolating) + encoder parity tests
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out

@@ -1,4 +1,6 @@
 #!/bin/bash
+# round 5: the kernels' A/B switches exist in the diagnostic library only (csrc: make DIAG=1); the product library reads no environment
+export TT_LIB_NAME=${TT_LIB_NAME:-libtt_hip_diag.so}
 # GEMM write-back A/B (VERDICT r03 item 7 i): the bias epilogue's output head-major (a wave's 32 rows x 128 B = one 4-KiB run) vs row-major
 # (32 lines 2 N bytes apart), diagnostic library; with TT_GEMM_DEBUG_TRAFFIC=1 (every C row -> row 0: no write-back at all) as the bound.
 cd "$GRAFT_REPO_ROOT" || exit 1

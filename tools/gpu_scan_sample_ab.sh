@@ -1,4 +1,6 @@
 #!/bin/bash
+# round 5: the kernels' A/B switches exist in the diagnostic library only (csrc: make DIAG=1); the product library reads no environment
+export TT_LIB_NAME=${TT_LIB_NAME:-libtt_hip_diag.so}
 # Threshold sample of the tiled scan on the contraction kernel (round 4) vs the streaming sample kernel: parity tests, then per-stage times
 # of the 256-query batch on the 1.25 M-row shard and on 10 M rows, both ways.
 cd "$GRAFT_REPO_ROOT" || exit 1

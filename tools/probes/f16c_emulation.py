@@ -21,6 +21,7 @@ Usage: python tools/probes/f16c_emulation.py [--small] [--variants a,b,...] [--s
 import argparse
 import math
 import os
+import re
 import sys
 import time
 
@@ -71,8 +72,31 @@ class Split:
         self.lo = lo
 
 
-def lin_f16c(x, w_split, b, variant):
+OUTLIER_PERM = {}
+
+
+def outlier_perm(K):
+    """Round 5: a static permutation of a K = hidden axis that moves the stress fixture's six outlier dimensions
+    (tests/stress_weights.py OUTLIER_DIMS) into ONE 32-wide block (block 0) -- an exact re-indexing of the hidden dimension."""
+    if K not in OUTLIER_PERM:
+        import stress_weights
+        dims = [d for d in stress_weights.OUTLIER_DIMS if d < K]
+        rest = [d for d in range(K) if d not in dims]
+        OUTLIER_PERM[K] = torch.tensor(dims + rest)
+    return OUTLIER_PERM[K]
+
+
+def lin_f16c(x, w_split, b, variant, perm=False, side=False, wperm=None):
+    """perm: both operands' K axis re-indexed so the outlier dimensions share block 0 (w_split is then the split of the permuted
+    weight); side: block 0's two cross terms on exact fp16 lo planes (a <= 32-column fp16 side product) instead of e4m3."""
+    if perm or side:
+        x = x[..., outlier_perm(x.shape[-1])]
     xs = Split(x)
+    if side:
+        y = xs.hi @ w_split.hi.T
+        y = y + xs.x8[..., 32:] @ w_split.lo8[:, 32:].T + xs.lo8[..., 32:] @ w_split.x8[:, 32:].T
+        y = y + xs.hi[..., :32] @ f16(w_split.lo[:, :32]).T + f16(xs.lo[..., :32]) @ w_split.hi[:, :32].T
+        return y + b
     y = xs.hi @ w_split.hi.T
     if variant == "f16_only":
         return y + b
@@ -87,10 +111,33 @@ def forward(ids, mask, W, cfg, variant, wcache):
     """oracle.encoder.encoder_forward with the projections (and attention) of the scheme under test."""
     f = lambda name: W[name].to(torch.float32)  # noqa: E731
 
+    do_perm = "+perm" in variant or "+side" in variant
+    do_side = "+side" in variant
+
     def wsplit(name):
         if name not in wcache:
-            wcache[name] = Split(f(name))
+            w = f(name)
+            if do_perm and w.shape[1] == cfg.hidden:
+                w = w[:, outlier_perm(cfg.hidden)]
+            wcache[name] = Split(w)
         return wcache[name]
+
+    # "mix=<families>": the listed projection families (qk, v, o, up, down, joined by '.') run f16c, the others f16x3
+    mix = None
+    mm = re.search(r"mix=([a-z.]*)", variant)
+    if mm:
+        mix = set(x for x in mm.group(1).split(".") if x)
+
+    def family(wn):
+        if ".query." in wn or ".key." in wn:
+            return "qk"
+        if ".value." in wn:
+            return "v"
+        if "attention.output.dense" in wn:
+            return "o"
+        if "intermediate.dense" in wn:
+            return "up"
+        return "down"
 
     if variant == "fp32":
         lin = lambda x, wn, bn: x @ f(wn).T + f(bn)  # noqa: E731
@@ -121,10 +168,14 @@ def forward(ids, mask, W, cfg, variant, wcache):
             # "+qkh3": the query / key projections on three fp16 products (their outputs ARE the logits' operands), the rest f16c
             if "+qkh3" in variant and (".query." in wn or ".key." in wn):
                 return lin_h3(x, wn, bn)
-            return lin_f16c(x, wsplit(wn), f(bn), variant.split("+")[0])
+            if mix is not None and family(wn) not in mix:
+                return lin_h3(x, wn, bn)
+            hidden_k = W[wn].shape[1] == cfg.hidden
+            return lin_f16c(x, wsplit(wn), f(bn), "f16c" if mix is not None else variant.split("+")[0],
+                            perm=do_perm and hidden_k, side=do_side and hidden_k)
     att16 = variant not in ("fp32", "bf16x3") and "+att32" not in variant
     ra = f16 if att16 else (lambda t: t)
-    if variant.startswith("f16x3"):
+    if variant.startswith("f16x3") or "+att3" in variant:
         ra = lambda t: f16(t) + f16(t - f16(t))  # noqa: E731   (hi + lo planes everywhere in the attention)
     # "+qk32": Q and K at full precision in the score product (what hi + lo planes for Q / K would give), V and P still fp16
     rqk = (lambda t: t) if "+qk32" in variant else ra
