@@ -208,7 +208,10 @@ def parse():
     ap.add_argument("--no-config5-leg", action="store_true", help="skip the composed BASELINE config 5 leg (semantic-hierarchical ingest + auto-merging retrieval + fp8 reranker)")
     ap.add_argument("--surface-threads", type=int, default=32)
     ap.add_argument("--surface-queries", type=int, default=256, help="queries the surface leg issues in all (N=1 only)")
-    ap.add_argument("--config5-docs", type=int, default=2048)
+    ap.add_argument("--config5-docs", type=int, default=256, help="documents of the config-5 leg at the reference's chunk geometry")
+    ap.add_argument("--config5-doc-words", default="4000-8000", help="words per document, lo-hi (a 2048-token root fills)")
+    ap.add_argument("--config5-queries", type=int, default=256)
+    ap.add_argument("--config5-small-docs", type=int, default=1024, help="documents of the labelled small-geometry ingest (0 = skip)")
     ap.add_argument("--no-fp8-leg", action="store_true", help="skip the extra fp8-reranker timing (BASELINE config 5)")
     ap.add_argument("--no-reference-leg", action="store_true", help="skip the reference-precision (bf16x3) timing")
     ap.add_argument("--no-fp16-leg", action="store_true", help="skip the fp16-mode timing")
@@ -743,6 +746,12 @@ def main():
     if not args.headline_only and not args.no_surface_leg and (world == 1 or args.surface_leg):
         if world == 1:
             surface = surface_leg(args, dev, shard_rows, emb_cfg, rr_cfg, world, rank, lo, data_group)
+            # rounds 1-4's stand-in beside it (one hashed id per word: no sub-word cost), and what pair tokenisation costs one host thread
+            sh = surface_leg(args, dev, shard_rows, emb_cfg, rr_cfg, world, rank, lo, data_group, tokenizer="hash",
+                             n_queries=max(args.surface_threads * 4, 128))
+            surface["hash_tokenizer_variant"] = {k: sh[k] for k in ("queries_per_s", "queries", "single_caller_ms_per_query", "tokenizer_detail")}
+            surface["host_tokenize"] = {"unigram-250k": surface_texts(args, "unigram-250k").host_rate(),
+                                        "hash": surface_texts(args, "hash").host_rate()}
             # ... and what an UNCHANGED reference call gets through the same surface: constructors without a dtype (the reference's
             # own default, fp32 semantics) -- fewer queries, the models run at about a third of the bf16 rate
             if not args.no_reference_leg:
@@ -1036,6 +1045,51 @@ def synth_text(key: int, n_words: int) -> str:
     return " ".join(w[j] for j in idx)
 
 
+class _Texts:
+    """Where a surface leg's strings come from, and what tokenizes them.
+
+    ``unigram-250k`` (the default since round 5): running text over a 400 000-word pseudo-lexicon (Zipf's law over the most
+    frequent ``TOP`` words) through a TRAINED 250 002-piece SentencePiece-style Unigram model with XLM-R's layout and pair template --
+    the tokenizer class, vocabulary size and Rust code path of the reference's bge-m3 / bge-reranker-v2-m3 tokenizers
+    (services/model_manager.py:254-260; tools/synth_text.py, fixture tests/golden/unigram250k_tokenizer.json.xz).  Word counts are
+    calibrated on a sample so that the MEAN query / pair token counts equal the token-level headline's (34 / 292).
+    ``hash``: one blake2b id per word (tokenization.HashTokenizer), rounds 1-4's stand-in: no sub-word cost on the clock."""
+
+    TOP = 100_000
+
+    def __init__(self, kind: str, query_tokens: int, chunk_tokens: int):
+        self.kind = kind
+        if kind == "hash":
+            self.tokenizer, self.q_words, self.c_words, self.tokens_per_word = None, query_tokens, chunk_tokens, 1.0
+            self.query = lambda key: synth_text(key, self.q_words)
+            self.chunk = lambda key: synth_text(key, self.c_words)
+            return
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import synth_text as st
+
+        self.tokenizer = st.unigram_tokenizer()
+        sample = [st.zipf_text(77_000 + i, 200, self.TOP) for i in range(64)]
+        n_tok = sum(len(ids) - 2 for ids in self.tokenizer.encode_batch(sample))
+        self.tokens_per_word = n_tok / (64 * 200)
+        self.q_words = max(2, round(query_tokens / self.tokens_per_word))
+        self.c_words = max(4, round(chunk_tokens / self.tokens_per_word))
+        self.query = lambda key: st.zipf_text(key, self.q_words, self.TOP)
+        self.chunk = lambda key: st.zipf_text(key, self.c_words, self.TOP)
+
+    def host_rate(self, n_pairs: int = 512):
+        """Pair tokenisation on ONE host thread (what a lone request thread pays): pairs/s and tokens/s."""
+        tk = self.tokenizer
+        if tk is None:
+            from tensor_truth_amd.tokenization import HashTokenizer
+
+            tk = HashTokenizer("xlmr", 250002)
+        pairs = [(self.query(5_000_000 + i), self.chunk(6_000_000 + i)) for i in range(n_pairs)]      # (fresh strings: no text cache hits)
+        t0 = time.perf_counter()
+        n_tok = sum(len(ids) for ids, _ in (tk.encode_pair(a, b, 512) for a, b in pairs))
+        dt = time.perf_counter() - t0
+        return {"pairs_per_s_one_thread": n_pairs / dt, "tokens_per_s_one_thread": n_tok / dt, "mean_pair_tokens": n_tok / n_pairs}
+
+
 class _RowIds:
     """row -> node id for a corpus whose ids derive from the row: no 10M-string table on the host."""
 
@@ -1055,8 +1109,8 @@ class _SynthDocstore:
 
     POOL = 4096
 
-    def __init__(self, chunk_words):
-        self.texts = [synth_text(i, chunk_words) for i in range(self.POOL)]
+    def __init__(self, chunk_words, text_fn=None):
+        self.texts = [text_fn(i) if text_fn is not None else synth_text(i, chunk_words) for i in range(self.POOL)]
 
     def get(self, nid, default=None):
         from tensor_truth_amd.schema import TextNode
@@ -1093,7 +1147,17 @@ def _run_threads(n_threads, work_items, fn):
     return dt, out
 
 
-def surface_leg(args, dev, shard_rows, emb_cfg, rr_cfg, world=1, rank=0, row_lo=0, group=None, default_precision=False, n_queries=None):
+_TEXTS = {}
+
+
+def surface_texts(args, kind):
+    if kind not in _TEXTS:
+        _TEXTS[kind] = _Texts(kind, args.query_len, args.chunk_len)
+    return _TEXTS[kind]
+
+
+def surface_leg(args, dev, shard_rows, emb_cfg, rr_cfg, world=1, rank=0, row_lo=0, group=None, default_precision=False, n_queries=None,
+                tokenizer="unigram-250k"):
     """world > 1: every rank runs its OWN request threads against the row-sharded index; the retriever's lock-step tick front
     keeps the ranks' collective rounds aligned, each rank embeds and reranks only its own callers' queries
     (sharded_index._TickFront).  Reported rate = all ranks' queries / the slowest rank's time."""
@@ -1106,12 +1170,15 @@ def surface_leg(args, dev, shard_rows, emb_cfg, rr_cfg, world=1, rank=0, row_lo=
     # default_precision: the constructors exactly as the reference calls them -- no dtype -> the reference's fp32 semantics
     # (precision.DEFAULT_MODE); otherwise the reference's `torch_dtype: bfloat16` option, as BASELINE's configurations name it
     dt_kw = {} if default_precision else {"torch_dtype": "bfloat16"}
+    texts = surface_texts(args, tokenizer)
+    if texts.tokenizer is not None:
+        dt_kw = {**dt_kw, "tokenizer": texts.tokenizer}
     emb = HipHuggingFaceEmbedding("BAAI/bge-m3", device=str(dev), embed_batch_size=128,
                                   model_kwargs={"encoder_config": emb_cfg, "synthetic_seed": 1, **dt_kw})
     rr = HipSentenceTransformerRerank(model="BAAI/bge-reranker-v2-m3", top_n=topn, device=str(dev), batch_pairs=4096,
                                       model_kwargs={"encoder_config": rr_cfg, "synthetic_seed": 2, **dt_kw})
     n = shard_rows.shape[0] if world == 1 else args.corpus_rows
-    index = ShardedHipVectorIndex(shard_rows.shape[1], shard_rows, row_lo, n, _RowIds(n), _SynthDocstore(args.chunk_len),
+    index = ShardedHipVectorIndex(shard_rows.shape[1], shard_rows, row_lo, n, _RowIds(n), _SynthDocstore(args.chunk_len, texts.chunk),
                                   embed_model=emb, score_mode="cosine", queries="partitioned" if world > 1 else "replicated", group=group)
     if world > 1:
         import torch.distributed as dist
@@ -1119,7 +1186,7 @@ def surface_leg(args, dev, shard_rows, emb_cfg, rr_cfg, world=1, rank=0, row_lo=
         dist.barrier()     # BEFORE the retriever exists: its tick thread owns the process group's collectives from then on (two
         #                    threads issuing collectives on one RCCL communicator is not safe) until retr.close() below
     retr = index.as_retriever(similarity_top_k=K, max_batch=64 if world == 1 else max(8, 256 // world))
-    queries = [synth_text(10_000_000_000 + 1_000_000 * rank + i, args.query_len) for i in range(n_queries or args.surface_queries)]
+    queries = [texts.query(10_000_000_000 + 1_000_000 * rank + i) for i in range(n_queries or args.surface_queries)]
 
     def one(q):
         nodes = retr.retrieve(q)
@@ -1153,16 +1220,50 @@ def surface_leg(args, dev, shard_rows, emb_cfg, rr_cfg, world=1, rank=0, row_lo=
             "ranks": world, "scan_batches": n_scan, "rerank_batches": n_rr,
             "single_caller_ms_per_query": lat * 1e3,
             "precision": getattr(rr, "precision", None) or ("reference (default)" if default_precision else "bf16"),
+            "tokenizer": tokenizer,
+            "tokenizer_detail": ("trained Unigram model, 250 002 pieces, XLM-R layout and pair template (tools/synth_text.py; Rust `tokenizers`, "
+                                 f"the reference's code path); text = Zipfian running words, {texts.tokens_per_word:.2f} pieces per word"
+                                 if tokenizer != "hash" else "HashTokenizer: one blake2b id per word + a whole-text LRU (rounds 1-4's stand-in)"),
+            "words": {"query": texts.q_words, "chunk": texts.c_words},
             "what": (f"{args.surface_threads} threads each calling retriever.retrieve(str) (top-{K} over the resident "
                      f"{n} x {shard_rows.shape[1]} corpus) then reranker.postprocess_nodes(nodes, QueryBundle) -> top-{topn}; "
-                     f"strings in ({args.query_len}-word queries, {args.chunk_len}-word chunks, hashing tokenizer), NodeWithScore out; "
+                     f"strings in ({texts.q_words}-word queries, {texts.c_words}-word chunks: mean {args.query_len + 2} / "
+                     f"{args.query_len + args.chunk_len + 4} tokens per query / pair), NodeWithScore out; "
                      "concurrent callers are coalesced into shared embed / scan / rerank batches")}
 
 
+def _c5_docs_reference_geometry(n_docs, words_lo, words_hi, rng):
+    """Multi-topic documents of ``words_lo``-``words_hi`` words over the pseudo-lexicon of tools/synth_text.py: five topic blocks per
+    document, a topic = a band of 1000 consecutive frequency ranks, sentences of 10-23 words."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import synth_text as st
+    from tensor_truth_amd.schema import TextNode
+
+    lex = st.lexicon()
+    docs, n_sent, n_words = [], 0, 0
+    for d in range(n_docs):
+        target = int(rng.integers(words_lo, words_hi + 1))
+        sents, words = [], 0
+        for block in range(5):
+            band = int(rng.integers(0, 100)) * 1000
+            while words < target * (block + 1) // 5:
+                k = int(rng.integers(10, 24))
+                sents.append(" ".join(lex[band + int(j)] for j in rng.integers(0, 1000, size=k)) + ".")
+                words += k
+        n_sent += len(sents)
+        n_words += words
+        docs.append(TextNode(text=" ".join(sents), metadata={"title": f"doc {d}"}))
+    return docs, n_sent, n_words
+
+
 def config5_leg(args, dev, emb_cfg, rr_cfg):
-    """BASELINE config 5 as one workload, at a size that fits the default run: semantic-hierarchical ingest of synthetic
-    multi-topic documents (sentence-group embedding -> adjacent-cosine breakpoints -> hierarchical parse -> leaf
-    embedding -> index), then queries through build_retrieval_service (auto-merging retriever + fp8 reranker)."""
+    """BASELINE config 5 as one workload: semantic-hierarchical ingest (sentence-group embedding -> adjacent-cosine breakpoints ->
+    hierarchical parse -> leaf embedding -> index), then queries through build_retrieval_service (auto-merging retriever +
+    reranker).  PRIMARY (round 5, VERDICT r04 items 2 + 3): the REFERENCE's chunk geometry -- build_index called with no chunk
+    sizes = [2048, 512, 256] / overlap 64 (indexing/builder.py:304-307), sizes counted in sub-word tokens as llama-index counts
+    them (token_counter="embedder": the offline stand-in for its tiktoken count) -- on documents of 4-8 k words through the trained
+    250 002-piece Unigram tokenizer.  SECONDARY, labelled: rounds 2-4's small geometry ([512, 128, 64] / 8 on ~1.1 k-word documents,
+    hashing tokenizer; ingest only), kept for comparison with the earlier rounds' numbers."""
     from tensor_truth_amd import model_manager as mm
     from tensor_truth_amd.encoder import pack_token_matrix
     from tensor_truth_amd.index_builder import build_index
@@ -1170,50 +1271,56 @@ def config5_leg(args, dev, emb_cfg, rr_cfg):
     from tensor_truth_amd.schema import TextNode
 
     rng = np.random.default_rng(55)
-    w = _words()
-    docs = []
-    n_sent = 0
-    for d in range(args.config5_docs):
-        sents = []
-        for block in range(4):                       # four topics per document: vocabulary bands
-            band = int(rng.integers(0, 40)) * 1000
-            for _ in range(int(rng.integers(12, 20))):
-                k = int(rng.integers(10, 24))
-                sents.append(" ".join(w[band + int(j)] for j in rng.integers(0, 1000, size=k)) + ".")
-        n_sent += len(sents)
-        docs.append(TextNode(text=" ".join(sents), metadata={"title": f"doc {d}"}))
+    texts = surface_texts(args, "unigram-250k")
+    lo_w, hi_w = (int(x) for x in args.config5_doc_words.split("-"))
+    t0 = time.perf_counter()
+    docs, n_sent, n_words = _c5_docs_reference_geometry(args.config5_docs, lo_w, hi_w, rng)
+    t_gen = time.perf_counter() - t0
     mm.ModelManager.reset_instance()
     mgr = mm.ModelManager.get_instance()
-    mgr.model_kwargs_overrides["BAAI/bge-m3"] = {"encoder_config": emb_cfg, "synthetic_seed": 1, "torch_dtype": "bfloat16"}
-    mgr.model_kwargs_overrides["BAAI/bge-reranker-v2-m3"] = {"encoder_config": rr_cfg, "synthetic_seed": 2, "gemm_dtype": "fp8"}
+    mgr.model_kwargs_overrides["BAAI/bge-m3"] = {"encoder_config": emb_cfg, "synthetic_seed": 1, "torch_dtype": "bfloat16",
+                                                 "tokenizer": texts.tokenizer}
+    mgr.model_kwargs_overrides["BAAI/bge-reranker-v2-m3"] = {"encoder_config": rr_cfg, "synthetic_seed": 2, "gemm_dtype": "fp8",
+                                                             "tokenizer": texts.tokenizer}
     emb = mgr.get_embedder("BAAI/bge-m3", "cuda")
+    ref_kw = dict(chunking_strategy="semantic_hierarchical", chunk_sizes=None, chunk_overlap=None, token_counter="embedder")
     # a serving process ingests with WARM host workers and kernels: one small untimed build first (worker processes are kept
     # for the life of the process, ingest_workers.get_workers)
-    build_index(docs[:96], emb, chunking_strategy="semantic_hierarchical", chunk_sizes=[512, 128, 64], chunk_overlap=8)
+    build_index(docs[:64], emb, **ref_kw)
     torch.cuda.synchronize()
+    st0 = dict(emb.stats)
     t0 = time.perf_counter()
-    index = build_index(docs, emb, chunking_strategy="semantic_hierarchical", chunk_sizes=[512, 128, 64], chunk_overlap=8)
+    index = build_index(docs, emb, **ref_kw)
     torch.cuda.synchronize()
     t_ingest = time.perf_counter() - t0
+    tok = emb.stats["tokens"] - st0["tokens"]
+    seqs = emb.stats["sequences"] - st0["sequences"]
+    sq = emb.stats["sum_len_sq"] - st0["sum_len_sq"]
+    H, F, L = emb_cfg.hidden, emb_cfg.ffn, emb_cfg.layers
+    gemm_flops = tok * ((L - 1) * 2 * (4 * H * H + 2 * H * F) + 4 * H * H) + seqs * 2 * (2 * H * H + 2 * H * F)
+    attn_flops = 4.0 * sq * H * L
+    leaf_lens = [len(ids) for ids in texts.tokenizer.encode_batch([index.docstore[i].text for i in [x for x in index.leaf_ids[:4096] if x is not None]])]
     params = {"reranker_top_n": args.top_n, "similarity_top_k": args.top_k, "confidence_cutoff": 0.35}
     svc = build_retrieval_service([index], params, device="cuda", manager=mgr)
     rr = mgr.get_reranker("BAAI/bge-reranker-v2-m3", top_n=args.top_n, device="cuda")
     cal = rng.integers(4, rr_cfg.vocab_size, size=(64, 128), dtype=np.int32)
     cal[:, 0], cal[:, -1] = 0, 2
     rr._encoder.calibrate_fp8(pack_token_matrix(cal, rr_cfg))     # static e4m3 scales of the FFN intermediate
-    rr.model.set_gemm_dtype("fp8")
     # distinct query strings per leg and for the warm-up calls: MultiIndexRetriever keeps the reference's LRU(128) on the query
     # string (rag_engine.py:399-404), and a repeated query would skip embed + scan + auto-merge
-    queries, queries8, warm = ([" ".join(w[int(j)] for j in rng.integers(0, 40000, size=args.query_len)) for _ in range(n)]
-                               for n in (384, 384, 2 + 2 * args.surface_threads))
+    nq = args.config5_queries
+    queries, queries8, warm = ([texts.query(20_000_000_000 + 1_000_000 * g + i) for i in range(n)]
+                               for g, n in enumerate((nq, nq, 2 + 2 * args.surface_threads)))
     # PRIMARY number: the bf16 reranker (rank agreement with fp32: tau ~0.89); the fp8 (e4m3) reranker BASELINE config 5 names
     # is the labelled variant beside it -- at depth it reorders about half of a candidate list (tau ~0.5)
     # (warm-up: one call, then one untimed pass from all threads -- the first concurrent pass pays for workspaces, staging slots and
-    #  the allocator's growth at the coalesced batch shapes: measured 213 q/s cold against ~320 for every later pass)
+    #  the allocator's growth at the coalesced batch shapes)
     rr.model.set_gemm_dtype("bf16")
     svc.retrieve(warm[0])
     _run_threads(args.surface_threads, warm[2:2 + args.surface_threads], lambda q: svc.retrieve(q).num_sources)
+    rst0 = dict(getattr(rr, "stats", {}) or {})
     dt, res = _run_threads(args.surface_threads, queries, lambda q: svc.retrieve(q).num_sources)
+    rst1 = dict(getattr(rr, "stats", {}) or {})
     rr.model.set_gemm_dtype("fp8")
     svc.retrieve(warm[1])
     _run_threads(args.surface_threads, warm[2 + args.surface_threads:], lambda q: svc.retrieve(q).num_sources)
@@ -1224,30 +1331,64 @@ def config5_leg(args, dev, emb_cfg, rr_cfg):
     if hasattr(svc._retriever, "clear_cache"):
         svc._retriever.clear_cache()
     dt8b, _ = _run_threads(args.surface_threads, queries8, lambda q: svc.retrieve(q).num_sources)
-    if os.environ.get("TT_BENCH_C5_DEBUG") == "1":      # (order / warm-up diagnosis: the first leg's strings once more, last)
-        svc._retriever.clear_cache()
-        dta2, _ = _run_threads(args.surface_threads, queries, lambda q: svc.retrieve(q).num_sources)
-        svc._retriever.clear_cache()
-        dtb3, _ = _run_threads(args.surface_threads, queries8, lambda q: svc.retrieve(q).num_sources)
-        sys.stderr.write(f"[c5 debug] bf16 A first {len(queries) / dt:.1f} q/s, fp8 B {len(queries8) / dt8:.1f}, bf16 B {len(queries8) / dt8b:.1f}, "
-                         f"bf16 A again {len(queries) / dta2:.1f}, bf16 B again {len(queries8) / dtb3:.1f}\n")
+    pair_stats = None
+    if rst1.get("pairs", 0) > rst0.get("pairs", 0):
+        dp = rst1["pairs"] - rst0["pairs"]
+        pair_stats = {"pairs_per_query": dp / len(queries), "mean_pair_tokens": (rst1["tokens"] - rst0["tokens"]) / dp}
+    # ---- secondary: rounds 2-4's small geometry, ingest only (hashing tokenizer, ~1.1 k-word documents)
+    small = None
+    if args.config5_small_docs > 0:
+        w = _words()
+        sdocs, s_sent = [], 0
+        for d in range(args.config5_small_docs):
+            sents = []
+            for block in range(4):
+                band = int(rng.integers(0, 40)) * 1000
+                for _ in range(int(rng.integers(12, 20))):
+                    k = int(rng.integers(10, 24))
+                    sents.append(" ".join(w[band + int(j)] for j in rng.integers(0, 1000, size=k)) + ".")
+            s_sent += len(sents)
+            sdocs.append(TextNode(text=" ".join(sents), metadata={"title": f"doc {d}"}))
+        mgr.model_kwargs_overrides["BAAI/bge-m3"] = {"encoder_config": emb_cfg, "synthetic_seed": 1, "torch_dtype": "bfloat16"}
+        emb_h = mgr.get_embedder("BAAI/bge-m3", "cuda")
+        skw = dict(chunking_strategy="semantic_hierarchical", chunk_sizes=[512, 128, 64], chunk_overlap=8)
+        build_index(sdocs[:96], emb_h, **skw)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        sidx = build_index(sdocs, emb_h, **skw)
+        torch.cuda.synchronize()
+        ts = time.perf_counter() - t0
+        small = {"docs": len(sdocs), "docs_per_s": len(sdocs) / ts, "leaves": sidx.n, "sentences": s_sent, "ingest_s": ts,
+                 "what": "rounds 2-4's geometry: chunk_sizes=[512,128,64] / overlap 8 in WORDS, ~1.1 k-word documents, hashing tokenizer "
+                         "(one id per word): 64-token leaves, 4x smaller than the reference's -- for comparison with earlier rounds only"}
     mm.ModelManager.reset_instance()
-    return {"docs": len(docs), "sentences": n_sent, "leaves": index.n, "nodes": len(index.docstore),
+    return {"docs": len(docs), "doc_words": [lo_w, hi_w], "words": n_words, "sentences": n_sent, "leaves": index.n, "nodes": len(index.docstore),
+            "geometry": "reference: chunk_sizes [2048, 512, 256], overlap 64 (indexing/builder.py:304-307), counted in sub-word tokens",
+            "tokenizer": "unigram-250k",
+            "mean_leaf_tokens": float(np.mean(leaf_lens)), "max_leaf_tokens": int(np.max(leaf_lens)),
             "ingest_s": t_ingest, "docs_per_s": len(docs) / t_ingest, "leaves_per_s": index.n / t_ingest,
-            "sentence_groups_per_s": n_sent / t_ingest,
-            "queries_per_s": len(queries) / dt, "mean_sources": float(np.mean(res)), "reranker": "bf16",
-            "fp8_reranker_variant": {"queries_per_s": len(queries) / dt8, "mean_sources": float(np.mean(res8)),
+            "sentence_groups_per_s": n_sent / t_ingest, "words_per_s": n_words / t_ingest,
+            "tokens_embedded": tok, "sequences_embedded": seqs, "tokens_embedded_per_s": tok / t_ingest,
+            "roofline_ingest": {"bound": "mfma", "achieved": gemm_flops / t_ingest / 1e12, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
+                                "frac": gemm_flops / t_ingest / 1e12 / MFMA_BF16_PEAK_TF,
+                                "attention_TFLOPs_beside": attn_flops / t_ingest / 1e12,
+                                "note": "GEMM flops of BOTH embedding passes (sentence groups with their buffer neighbours + leaves; "
+                                        "tokens x 604 MFLOP) over the WALL time of build_index from strings -- host work, copies and "
+                                        "the row kernels included; the kernel-level figure is roofline_embed"},
+            "doc_generation_s": t_gen,
+            "queries": len(queries), "queries_per_s": len(queries) / dt, "mean_sources": float(np.mean(res)), "reranker": "bf16",
+            "rerank_pairs": pair_stats,
+            "fp8_reranker_variant": {"queries_per_s": len(queries8) / dt8, "mean_sources": float(np.mean(res8)),
                                      "bf16_on_the_same_query_strings": len(queries8) / dt8b,
-                                     "note": "e4m3 layer projections, its own 384 query strings (no LRU hits); Kendall tau ~0.5 "
-                                             "against fp32 at 24 layers (config.fp8_reranker.rank_quality_vs_fp32); this leg is host-bound at "
-                                             "its short pairs: fp8 ~ bf16 on the same query strings -- the token-level fp8 leg is "
-                                             "config.fp8_reranker"},
+                                     "note": "e4m3 layer projections, its own query strings (no LRU hits); Kendall tau ~0.5 "
+                                             "against fp32 at 24 layers (config.fp8_reranker.rank_quality_vs_fp32)"},
+            "small_geometry_r04": small,
             "host_peak_rss_gb": __import__("resource").getrusage(__import__("resource").RUSAGE_SELF).ru_maxrss / 1048576.0,
             "ingest_workers": __import__("tensor_truth_amd.ingest_workers", fromlist=["default_workers"]).default_workers(),
-            "what": ("build_index(chunking_strategy='semantic_hierarchical', chunk_sizes=[512,128,64]) on the bge-m3-shaped "
-                     "embedder, then 384 queries from 32 threads through build_retrieval_service: auto-merging retriever "
-                     f"(top-{args.top_k}) + bge-reranker-v2-m3-shaped postprocessor -> top-{args.top_n}; primary rate with the bf16 "
-                     "reranker, fp8_reranker_variant = the same with its layer projections in e4m3")}
+            "what": ("build_index(chunking_strategy='semantic_hierarchical') with the reference's default chunk geometry on the "
+                     f"bge-m3-shaped embedder, then {len(queries)} queries from {args.surface_threads} threads through build_retrieval_service: "
+                     f"auto-merging retriever (top-{args.top_k}) + bge-reranker-v2-m3-shaped postprocessor -> top-{args.top_n}; primary rate "
+                     "with the bf16 reranker, fp8_reranker_variant = the same with its layer projections in e4m3")}
 
 
 def cpu_baseline(args, emb_cfg, rr_cfg, embedder, reranker, corpus, q_tok, vocab):

@@ -25,6 +25,12 @@
 
 namespace {
 
+#ifndef TT_ATT_RESIDENT_DEFAULT
+#define TT_ATT_RESIDENT_DEFAULT 0        // measured neutral (-2 % at 292 tokens, -13 % at 200, +3 % at 64 / 130): profiles/r05_attention_resident_ab.log
+#endif
+#ifndef TT_ATT_RESIDENT_MIN_LEN
+#define TT_ATT_RESIDENT_MIN_LEN 1
+#endif
 constexpr int kKTile = 64;    // keys per LDS tile
 constexpr int kWaves = 4;     // 128 query rows per workgroup, one wave per SIMD
 
@@ -448,6 +454,266 @@ __global__ __launch_bounds__(64 * NW, 4) void attention_kernel(AttnParams p) {
 }
 
 
+#if TT_DIAG   // measured, not kept: the diagnostic library only (TT_ATT_RESIDENT=1; tools/gpu_att_resident.sh)
+// ---- Resident form (round 5): the whole K and V8 of one (sequence, head) staged ONCE, no key-tile round trips -------------------
+// The streaming kernel above pays one LDS-DMA round trip + one workgroup barrier per 64-key tile whatever is computed in it
+// (round 3's ablations: a kernel that only copies, waits and issues the S MFMAs still takes 76 % of the time), three times over
+// for a 292-token pair (three 128-row workgroups each walk all five key tiles).  For sequences whose aligned key frame fits
+// kResMaxTiles tiles (<= 320 keys: 80 KiB of K + V8) ONE four-wave workgroup per (sequence, head) copies every tile up front
+// (the same pieces, swizzle and clamping as the streaming kernel: tile kt lands at kt * BUF), waits once, passes ONE barrier, and
+// its waves then walk the sequence's 32-row query blocks (block b -> wave (b + rot) % 4: 3 + 3 + 2 + 2 blocks at 292 tokens) with
+// nothing but LDS reads, MFMAs and the softmax in the loop.  80 KiB per workgroup = two workgroups per CU, two waves per SIMD,
+// out of phase: one loads while the other computes.  A row's arithmetic -- key-tile order, MFMA order, the lazy running reference,
+// the P packing -- is the streaming kernel's, so its bits do not depend on which kernel served it (tests: the parity suite with
+// either forced; a query alone vs in a batch).
+constexpr int kResMaxTiles = 5;
+
+template <int DH>
+__global__ __launch_bounds__(64 * kWaves, 2) void attention_resident_kernel(AttnParams p) {
+    constexpr int RB = DH * 2, CH = RB / 16, RPB = 256 / RB, KS = DH / 16, DT = DH / 32;
+    constexpr int NPK = kKTile * RB / 1024, NPV = 8 * DH * 16 / 1024, NW = kWaves;
+    constexpr int KPW = NPK / NW, VPW = NPV / NW;
+    static_assert(DH == 64 && NPK % NW == 0 && NPV % NW == 0, "written for head_dim 64");
+    constexpr int BUF = (NPK + NPV) * 1024;
+    extern __shared__ __attribute__((aligned(1024))) char lds_dyn[];
+
+    const int pair = blockIdx.x;
+    if (pair >= p.heads * p.n_seq) return;
+    const int head = pair % p.heads, seq = pair / p.heads;
+    const int len = p.seq_len[seq];
+    if (len <= 0) return;
+    const int t0 = p.seq_start[seq];
+    const int t0a = t0 & ~7, off = t0 - t0a, alen = off + len;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ql = lane & 31, hh = lane >> 5;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds_dyn;
+    const int n_kt = (alen + kKTile - 1) / kKTile;
+    const int n_g8 = (alen + 7) >> 3;
+    const int n_blk = (len + 31) >> 5;
+    // which blocks this wave walks: b = first, first + 4, ... ; the rotation spreads the waves with one block more over the SIMDs
+    // of the two workgroups that share a CU (wave w of every workgroup runs on SIMD w)
+    const int rot = (int)((blockIdx.x >> 8) * 2 + (blockIdx.x & 1)) & 3;
+    const int first = (wave - rot) & 3;
+
+    auto q_ptr = [&](int b) {
+        const int q_row = b * 32 + ql;
+        const int q_row_c = q_row < len ? q_row : len - 1;
+        return p.qk + (size_t)(t0 + q_row_c) * p.ld_qk + p.q_col0 + head * DH + hh * 8;
+    };
+    ex8 qf[KS];
+    if (first < n_blk) {
+        const uint16_t* qp = q_ptr(first);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) qf[s] = *reinterpret_cast<const ex8*>(qp + s * 16);
+    }
+
+    // ---- stage every key tile (the streaming kernel's issue_tile with buffer kt instead of kt & 1)
+    const uint16_t* kbase = p.qk + (size_t)t0a * p.ld_qk + p.k_col0 + head * DH;
+    const uint16_t* vbase = p.vt + (size_t)(t0a >> 3) * p.ldvt + (size_t)head * DH * 8;
+    constexpr int kRowsPerPiece = 64 / CH, kGroupsPerPiece = 1;
+    uint32_t kvoff0, vvoff0;
+    {
+        const int e = wave * KPW * 64 + lane, r = e / CH, pos = e % CH;
+        kvoff0 = ((uint32_t)r * (uint32_t)p.ld_qk + (uint32_t)((pos ^ ((r / RPB) & (CH - 1))) << 3)) * 2u;
+        const int ev = wave * VPW * 64 + lane;
+        vvoff0 = ((uint32_t)(ev / DH) * (uint32_t)p.ldvt + (uint32_t)((ev % DH) * 8)) * 2u;
+    }
+    auto sbase = [](const void* ptr) {
+        const unsigned long long b = reinterpret_cast<unsigned long long>(ptr);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+        return reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
+    };
+    auto glds16 = [](const char* base, uint32_t voff, uint32_t lds_addr) {
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(lds_addr) : "memory", "m0");
+    };
+    for (int kt = 0; kt < n_kt; ++kt) {
+        const uint32_t buf = lds0 + (uint32_t)kt * BUF;
+        const bool clamp = (kt + 1) * kKTile > alen || (kt == 0 && off != 0);   // wave-uniform
+        if (!clamp) {
+#pragma unroll
+            for (int i = 0; i < KPW; ++i)
+                glds16(sbase(kbase + ((size_t)kt * kKTile + i * kRowsPerPiece) * p.ld_qk), (i & 1) ? (kvoff0 ^ 64u) : kvoff0,
+                       buf + (uint32_t)(wave * KPW + i) * 1024u);
+#pragma unroll
+            for (int i = 0; i < VPW; ++i)
+                glds16(sbase(vbase + ((size_t)kt * 8 + i * kGroupsPerPiece) * p.ldvt), vvoff0, buf + (uint32_t)(NPK + wave * VPW + i) * 1024u);
+        } else {
+            const char* kb = sbase(kbase);
+            const char* vb = sbase(vbase);
+#pragma unroll
+            for (int i = 0; i < KPW; ++i) {
+                const int piece = wave * KPW + i;
+                const int e = piece * 64 + lane, r = e / CH, pos = e % CH;
+                int row = kt * kKTile + r;
+                row = row < off ? off : (row < alen ? row : alen - 1);
+                glds16(kb, ((uint32_t)row * (uint32_t)p.ld_qk + (uint32_t)((pos ^ ((r / RPB) & (CH - 1))) << 3)) * 2u, buf + (uint32_t)piece * 1024u);
+            }
+#pragma unroll
+            for (int i = 0; i < VPW; ++i) {
+                const int piece = wave * VPW + i;
+                const int e = piece * 64 + lane;
+                int g8 = kt * 8 + e / DH;
+                g8 = g8 < n_g8 ? g8 : n_g8 - 1;
+                glds16(vb, ((uint32_t)g8 * (uint32_t)p.ldvt + (uint32_t)((e % DH) * 8)) * 2u, buf + (uint32_t)(NPK + piece) * 1024u);
+            }
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): this wave's copies (and its Q fragments) have landed
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();                // ... everyone's: the only barrier of the kernel
+    __builtin_amdgcn_sched_barrier(0);
+
+    const float sc = p.scale * 1.4426950408889634f;
+    const int krow = (ql & 0x13) | ((ql & 4) << 1) | ((ql & 8) >> 1);
+    uint32_t koff[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) koff[s] = lds0 + krow * RB + (((2 * s + hh) ^ ((krow / RPB) & (CH - 1))) << 4);
+    const uint32_t voff = lds0 + NPK * 1024 + (hh * DH + ql) * 16;
+
+    for (int b = first; b < n_blk; b += NW) {
+        // the next block's Q fragments travel while this block is computed
+        ex8 qn[KS];
+        const bool more = b + NW < n_blk;
+        if (more) {
+            const uint16_t* qp = q_ptr(b + NW);
+#pragma unroll
+            for (int s = 0; s < KS; ++s) qn[s] = *reinterpret_cast<const ex8*>(qp + s * 16);
+        }
+        f32x16 acc_o[DT];
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc_o[d][r] = 0.f;
+        float m_run = -__builtin_inff();
+        float l_run = 0.f;
+        for (int kt = 0; kt < n_kt; ++kt) {
+            const int k0 = kt * kKTile;
+            const uint32_t bufo = (uint32_t)kt * BUF;
+            f32x16 acc_s[2];
+            {
+                u32x4 kf[2][4];
+                uint32_t ka[KS];
+#pragma unroll
+                for (int s = 0; s < KS; ++s) ka[s] = koff[s] + bufo;
+#pragma unroll
+                for (int s = 0; s < KS; ++s) kf[0][s] = lds_read128_async<0>(ka[s]);
+#pragma unroll
+                for (int s = 0; s < KS; ++s) kf[1][s] = lds_read128_async<32 * RB>(ka[s]);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (j == 0) lds_wait4n<KS>(kf[0][0], kf[0][1], kf[0][2], kf[0][3]);
+                    else lds_wait4n<0>(kf[1][0], kf[1][1], kf[1][2], kf[1][3]);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc_s[j][r] = 0.f;
+#pragma unroll
+                    for (int s = 0; s < KS; ++s)
+                        acc_s[j] = TT_MFMA_32x32x16(__builtin_bit_cast(ex8, kf[j][s]), qf[s], acc_s[j]);
+                }
+            }
+            u32x4 vf[2][2];
+            const uint32_t vaddr = voff + bufo;
+            vf[0][0] = lds_read128_async<0>(vaddr);
+            vf[0][1] = lds_read128_async<512>(vaddr);
+            vf[1][0] = lds_read128_async<2 * DH * 16>(vaddr);
+            vf[1][1] = lds_read128_async<2 * DH * 16 + 512>(vaddr);
+            if (kt == 0 && off != 0) {
+                if (hh == 0) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r)
+                        if (r < off) acc_s[0][r] = -__builtin_inff();
+                }
+            }
+            if (k0 + kKTile > alen) {
+                const int lim = alen - k0 - 8 * hh;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (32 * j + 16 * (r >> 3) + (r & 7) >= lim) acc_s[j][r] = -__builtin_inff();
+            }
+            float mx = -__builtin_inff();
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, acc_s[j][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float mt = mx * sc;
+            const float m_new = (mt > m_run + p.lazy) ? mt : m_run;
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            m_run = m_new;
+            f32x2 psum2 = f32x2{0.f, 0.f};
+            const f32x2 sc2 = f32x2{sc, sc}, mn2 = f32x2{m_new, m_new};
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const f32x2 t = f32x2{acc_s[j][r], acc_s[j][r + 1]} * sc2 - mn2;
+                    const f32x2 e = f32x2{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+                    acc_s[j][r] = e.x;
+                    acc_s[j][r + 1] = e.y;
+                    psum2 += e;
+                }
+            l_run = l_run * alpha + (psum2.x + psum2.y);
+            if (kt > 0 && !__all(alpha == 1.0f)) {
+#pragma unroll
+                for (int d = 0; d < DT; ++d)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc_o[d][r] *= alpha;
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                lds_wait4n<0>(vf[0][0], vf[0][1], vf[1][0], vf[1][1]);
+                ex8 va[2][2];
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int d = 0; d < DT; ++d) va[s2][d] = __builtin_bit_cast(ex8, vf[s2][d]);
+                if (j == 0) {
+                    vf[0][0] = lds_read128_async<4 * DH * 16>(vaddr);
+                    vf[0][1] = lds_read128_async<4 * DH * 16 + 512>(vaddr);
+                    vf[1][0] = lds_read128_async<6 * DH * 16>(vaddr);
+                    vf[1][1] = lds_read128_async<6 * DH * 16 + 512>(vaddr);
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    uint4 pb;
+                    pb.x = pack_e2_inrange(acc_s[j][8 * s2 + 0], acc_s[j][8 * s2 + 1]);
+                    pb.y = pack_e2_inrange(acc_s[j][8 * s2 + 2], acc_s[j][8 * s2 + 3]);
+                    pb.z = pack_e2_inrange(acc_s[j][8 * s2 + 4], acc_s[j][8 * s2 + 5]);
+                    pb.w = pack_e2_inrange(acc_s[j][8 * s2 + 6], acc_s[j][8 * s2 + 7]);
+                    const ex8 pf = __builtin_bit_cast(ex8, pb);
+#pragma unroll
+                    for (int d = 0; d < DT; ++d)
+                        acc_o[d] = TT_MFMA_32x32x16(va[s2][d], pf, acc_o[d]);
+                }
+            }
+        }
+        const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+        const float inv = 1.0f / l_tot;
+        const int q_row = b * 32 + ql;
+        if (q_row < len) {
+            uint16_t* op = p.out + (size_t)(t0 + q_row) * p.ld_out + head * DH;
+#pragma unroll
+            for (int d = 0; d < DT; ++d)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    uint2 o;
+                    o.x = pack_e2(acc_o[d][4 * g + 0] * inv, acc_o[d][4 * g + 1] * inv);
+                    o.y = pack_e2(acc_o[d][4 * g + 2] * inv, acc_o[d][4 * g + 3] * inv);
+                    *reinterpret_cast<uint2*>(op + 32 * d + 8 * g + 4 * hh) = o;
+                }
+        }
+        if (more) {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) qf[s] = qn[s];
+        }
+    }
+}
+
+
+#endif   // TT_DIAG
 // ---- CLS-only attention (last layer): one wave per (sequence, head), the single query row t0 -------------
 // Scores with the key on the lane (fp32 dot products, K rows read as 16-B pieces), softmax across the wave,
 // then the value sum with the FEATURE on the lane (V8 layout: one 16-B load brings 8 keys of a feature).
@@ -593,6 +859,19 @@ int tt_attention_launch(const AttnParams& p, hipStream_t st) {
     static const bool rotate = TT_DIAG_ENV_INT("TT_ATT_ROTATE", 0) == 1;
     q.rotate = rotate ? 1 : 0;
     TtProfScope prof(TT_K_ATTENTION, st);
+#if TT_DIAG
+    // Resident form (round 5): every sequence's aligned key frame (up to 7 rows of its predecessor in front) fits kResMaxTiles key tiles
+    // -- one workgroup per (sequence, head), K and V8 staged once.  TT_ATT_RESIDENT (diagnostic library): 0 = never, 1 = whenever it fits.
+    static const int resident = TT_DIAG_ENV_INT("TT_ATT_RESIDENT", TT_ATT_RESIDENT_DEFAULT);
+    if (resident && p.head_dim == 64 && !p.out_scales && !p.dbg && p.max_len + 7 <= kResMaxTiles * kKTile && p.max_len >= TT_ATT_RESIDENT_MIN_LEN) {
+        const int tiles = (p.max_len + 7 + kKTile - 1) / kKTile;
+        const size_t lds = (size_t)tiles * 16384;
+        TT_SET_MAX_LDS(attention_resident_kernel<64>, 160 * 1024);
+        hipLaunchKernelGGL(attention_resident_kernel<64>, dim3((unsigned)(p.heads * p.n_seq)), dim3(64 * kWaves), lds, st, q);
+        TT_CHECK_LAUNCH();
+        return TT_OK;
+    }
+#endif
 #if TT_DIAG   // stamped / ablated instantiations: the diagnostic library only (tools/att_stamps, tools/gpu_att_ablate.sh)
     if (p.head_dim == 64 && (p.dbg || TT_DIAG_ENV_INT("TT_ATT_ABLATE", 0) != 0) && nw != kWaves) {
         tt_set_error("attention: the stamped / ablated kernels are four-wave (set TT_ATT_WAVES=4)");

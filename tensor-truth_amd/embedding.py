@@ -96,6 +96,8 @@ class HipHuggingFaceEmbedding:
         # (shorter ones: the window is sorted by length) until it holds ``forward_tokens`` tokens; results do not depend
         # on the batching (bit-identical embeddings, tests/test_configs_gpu.py).
         self.forward_tokens = int((model_kwargs or {}).get("forward_tokens", 131072))
+        # running totals of what went through the encoder (bench.py prices an ingest against the matrix roofline with them)
+        self.stats = {"sequences": 0, "tokens": 0, "sum_len_sq": 0}
 
     # ---- token-id level (what the kernels see) ------------------------------------------------
     def embed_token_batches(self, seqs: Sequence[Sequence[int]]) -> torch.Tensor:
@@ -109,6 +111,10 @@ class HipHuggingFaceEmbedding:
                 tokens += min(len(seqs[order[hi]]), self.max_length)
                 hi += 1
             sel = order[lo:hi]
+            lens = [min(len(seqs[i]), self.max_length) for i in sel]
+            self.stats["sequences"] += len(sel)
+            self.stats["tokens"] += sum(lens)
+            self.stats["sum_len_sq"] += sum(n * n for n in lens)
             emb, _ = self._encoder.embed_packed(pack_tokens([seqs[i] for i in sel], self.config, None, self.max_length),
                                                 pooling=self.pooling)
             parts.append(emb)

@@ -23,7 +23,7 @@ CHUNKING_STRATEGIES = ("hierarchical", "semantic", "semantic_hierarchical")   # 
 def iter_parsed(documents: Sequence, embed_model, chunking_strategy: str = "hierarchical",
                 chunk_sizes: Optional[Sequence[int]] = None, chunk_overlap: Optional[int] = None,
                 semantic_buffer_size: int = 1, semantic_breakpoint_threshold: float = 95, node_parser=None,
-                sub_batch: int = 2048):
+                sub_batch: int = 2048, token_counter: str = "words"):
     """Strategy dispatch of builder.py:383-420, yielding the nodes in document order in pieces of about ``sub_batch`` inputs
     of the (host-only) hierarchical pass, so that a caller can hand each piece's leaves to the GPU while the next piece
     is being split.  ``node_parser``: any object with ``get_nodes_from_documents`` (e.g. llama-index's own
@@ -33,7 +33,8 @@ def iter_parsed(documents: Sequence, embed_model, chunking_strategy: str = "hier
     documents = list(documents)
     sizes = list(chunk_sizes) if chunk_sizes is not None else list(DEFAULT_CHUNK_SIZES)
     overlap = DEFAULT_CHUNK_OVERLAP if chunk_overlap is None else chunk_overlap
-    hier = node_parser or HierarchicalNodeParser.from_defaults(chunk_sizes=sizes, chunk_overlap=overlap)
+    hier = node_parser or HierarchicalNodeParser.from_defaults(chunk_sizes=sizes, chunk_overlap=overlap,
+                                                               tokenizer=_counter(token_counter, embed_model))
     step = max(1, sub_batch)
 
     def pieces(items):
@@ -61,6 +62,18 @@ def iter_parsed(documents: Sequence, embed_model, chunking_strategy: str = "hier
         yield hier.get_nodes_from_documents(piece)
 
 
+def _counter(token_counter: str, embed_model):
+    """"words": word / punctuation count (node_parser.count_tokens); "embedder": sub-word tokens of the embedding model's own
+    tokenizer (node_parser.tokenizer_counter) -- the stand-in for llama-index's tiktoken count on hosts without it."""
+    if token_counter == "words":
+        return None
+    if token_counter == "embedder":
+        from .node_parser import tokenizer_counter
+
+        return tokenizer_counter(embed_model._tokenizer)
+    raise ValueError(f"token_counter '{token_counter}': expected 'words' or 'embedder'")
+
+
 def parse_documents(documents: Sequence, embed_model, chunking_strategy: str = "hierarchical",
                     chunk_sizes: Optional[Sequence[int]] = None, chunk_overlap: Optional[int] = None,
                     semantic_buffer_size: int = 1, semantic_breakpoint_threshold: float = 95, node_parser=None) -> List:
@@ -77,7 +90,7 @@ def build_index(documents: Sequence, embed_model, persist_dir: Optional[str] = N
                 chunk_overlap: Optional[int] = None, semantic_buffer_size: int = 1,
                 semantic_breakpoint_threshold: float = 95, embedding_model: Optional[str] = None, node_parser=None,
                 progress_callback: Optional[Callable[[str, int, int], None]] = None,
-                window_docs: int = 8192, workers: Optional[int] = None) -> HipVectorIndex:
+                window_docs: int = 8192, workers: Optional[int] = None, token_counter: str = "words") -> HipVectorIndex:
     """-> the module's HipVectorIndex (persisted under ``persist_dir`` when given).
 
     ``workers`` (default: ``TT_INGEST_WORKERS``, else up to 8 of the host's cores; 0 = everything in this process): sentence
@@ -92,7 +105,9 @@ def build_index(documents: Sequence, embed_model, persist_dir: Optional[str] = N
     index is the one the reference's whole-corpus order of operations (builder.py:383-442) builds.  (A second thread
     parsing window i + 1 while this one embeds window i was measured SLOWER -- 250-255 vs 270 docs/s at 8000 documents:
     smaller windows mean shorter forward passes, and the overlap is already there without a thread, see the loop below.)
-    ``window_docs <= 0``: one window."""
+    ``window_docs <= 0``: one window.
+    ``token_counter``: what the hierarchy's chunk sizes count -- "words" (default) or "embedder" (sub-word tokens of the embedding
+    model's tokenizer, the offline stand-in for llama-index's tiktoken count: ``_counter``)."""
     documents = list(documents)
     n_docs = len(documents)
     if chunking_strategy not in CHUNKING_STRATEGIES:
@@ -101,15 +116,16 @@ def build_index(documents: Sequence, embed_model, persist_dir: Optional[str] = N
         progress_callback("parsing", 0, n_docs)
     index = HipVectorIndex(embed_model.config.hidden if hasattr(embed_model, "config") else len(embed_model.get_text_embedding("x")),
                            embed_model=embed_model)
+    _counter(token_counter, embed_model)          # (validates the name)
     if _build_with_workers(index, documents, embed_model, chunking_strategy, chunk_sizes, chunk_overlap, semantic_buffer_size,
-                           semantic_breakpoint_threshold, node_parser, workers):
+                           semantic_breakpoint_threshold, node_parser, workers, token_counter):
         n_docs = 0        # (done: skip the in-process loop below)
     step = max(n_docs, 1) if window_docs <= 0 else window_docs
     for lo in range(0, n_docs, step):
         # the leaf forward passes of one piece are only ENQUEUED by index.add (nothing below waits for the GPU except the
         # staging ring's back-pressure), so the GPU embeds piece i while this thread splits piece i + 1
         for nodes in iter_parsed(documents[lo:lo + step], embed_model, chunking_strategy, chunk_sizes, chunk_overlap,
-                                 semantic_buffer_size, semantic_breakpoint_threshold, node_parser):
+                                 semantic_buffer_size, semantic_breakpoint_threshold, node_parser, token_counter=token_counter):
             index.add_to_docstore(nodes)                   # storage_context.docstore.add_documents(nodes), builder.py:430
             index.add(get_leaf_nodes(nodes), show_progress=True)   # VectorStoreIndex(leaf_nodes, ...), builder.py:437-442
         if progress_callback and lo + step < n_docs:
@@ -125,7 +141,7 @@ def build_index(documents: Sequence, embed_model, persist_dir: Optional[str] = N
 
 
 def _build_with_workers(index, documents, embed_model, chunking_strategy, chunk_sizes, chunk_overlap, buffer_size, percentile,
-                        node_parser, workers) -> bool:
+                        node_parser, workers, token_counter: str = "words") -> bool:
     """The worker-process form of the build loop (``ingest_workers.IngestWorkers.run``).  -> False when it does not apply."""
     import torch
 
@@ -144,7 +160,8 @@ def _build_with_workers(index, documents, embed_model, chunking_strategy, chunk_
     spec = {"tokenizer": tk_spec, "max_length": embed_model.max_length, "text_instruction": getattr(embed_model, "text_instruction", "") or "",
             "buffer_size": buffer_size, "percentile": percentile,
             "chunk_sizes": list(chunk_sizes) if chunk_sizes is not None else list(DEFAULT_CHUNK_SIZES),
-            "chunk_overlap": DEFAULT_CHUNK_OVERLAP if chunk_overlap is None else chunk_overlap}
+            "chunk_overlap": DEFAULT_CHUNK_OVERLAP if chunk_overlap is None else chunk_overlap,
+            "token_counter": token_counter}
     def distances(emb):
         # the copy back is enqueued behind this chunk's own forward passes, with an event of its own: waiting for it waits for
         # this chunk only, not for what was enqueued after it

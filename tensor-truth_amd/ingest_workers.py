@@ -145,12 +145,29 @@ class _Host:
         from .node_parser import HierarchicalNodeParser
 
         self.tk = _tokenizer_from_spec(spec["tokenizer"])
+        self.state: Dict[int, tuple] = {}
+        if spec.get("role") == "pairs":            # a rerank front's pair tokeniser (PairTokenizerPool): the tokenizer and nothing else
+            return
         self.max_length = spec["max_length"]
         self.prefix = spec["text_instruction"] or ""
         self.buffer_size = spec["buffer_size"]
         self.percentile = spec["percentile"]
-        self.hier = HierarchicalNodeParser.from_defaults(chunk_sizes=spec["chunk_sizes"], chunk_overlap=spec["chunk_overlap"])
-        self.state: Dict[int, tuple] = {}
+        counter = None
+        if spec.get("token_counter", "words") == "embedder":       # chunk sizes in the embedder's sub-word tokens (index_builder._counter)
+            from .node_parser import tokenizer_counter
+
+            counter = tokenizer_counter(self.tk)
+        self.hier = HierarchicalNodeParser.from_defaults(chunk_sizes=spec["chunk_sizes"], chunk_overlap=spec["chunk_overlap"],
+                                                         tokenizer=counter)
+
+    def pairs(self, pairs: List[tuple], max_length: int):
+        """(query, passage) strings -> (flat ids, lengths, flat token-type ids or None): CrossEncoder's tokenizer call on a slice."""
+        enc = self.tk.encode_pair_batch(pairs, max_length)
+        flat, lens = _flatten([e[0] for e in enc])
+        types = None
+        if enc and enc[0][1] is not None:
+            types, _ = _flatten([e[1] for e in enc])
+        return flat, lens, types
 
     def _tokens(self, texts: List[str]):
         full = [self.prefix + t for t in texts] if self.prefix else texts
@@ -246,6 +263,8 @@ def _worker_main(conn, spec):
                 conn.send(("cut", msg[1]) + tuple(host.cut(msg[1], msg[2])))
             elif op == "parse":
                 conn.send(("cut", msg[1]) + tuple(host.parse(msg[2])))
+            elif op == "pairs":
+                conn.send(("pairs", msg[1]) + tuple(host.pairs(msg[2], msg[3])))
         except Exception as exc:  # noqa: BLE001 - reported to the feeder, which raises
             import traceback
 
@@ -260,7 +279,9 @@ def default_workers() -> int:
         cpus = len(os.sched_getaffinity(0))
     except AttributeError:
         cpus = os.cpu_count() or 1
-    return max(0, min(8, cpus - 2))
+    # up to 8 by default on small hosts; a large host (the 256-thread GPU box) gives a sixteenth of its cores, at most 24: with a real
+    # sub-word tokenizer at the reference's chunk geometry one worker prepares ~6-10 documents/s and the GPU consumes ~30
+    return max(0, min(max(8, min(24, cpus // 16)), cpus - 2))
 
 
 _POOLS: Dict[bytes, "IngestWorkers"] = {}
@@ -309,12 +330,19 @@ def _close_pools() -> None:
 class IngestWorkers:
     """W host workers behind pipes.  ``run`` drives one build's chunks through them in document order."""
 
-    def __init__(self, spec: Dict, workers: int):
+    def __init__(self, spec: Dict, workers: int, worker_threads: Optional[int] = None):
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))          # where the tensor_truth_amd import shim lives
         code = f"import sys; sys.path.insert(0, {root!r}); from tensor_truth_amd.ingest_workers import _stdio_worker; _stdio_worker()"
         self.conns, self.procs = [], []
+        # The Rust tokenizer starts one thread per host core in EVERY process that uses it (rayon's default): eight workers + the
+        # feeder on a 256-core host are ~2300 threads contending for the same cores, and a worker's reply took 2-3x its single-thread
+        # time (profiles/r05_ingest_ref_geometry_profile.log: the feeder blocked on worker replies for half of the build).  The
+        # workers are the parallelism here: each gets a small pool of its own (TT_INGEST_WORKER_THREADS, default 2).
+        env = dict(os.environ)
+        env["RAYON_NUM_THREADS"] = str(worker_threads) if worker_threads else os.environ.get("TT_INGEST_WORKER_THREADS", "2")
+        env.setdefault("TOKENIZERS_PARALLELISM", "true")
         for _ in range(workers):
-            p = subprocess.Popen([sys.executable, "-c", code], stdin=subprocess.PIPE, stdout=subprocess.PIPE, bufsize=0)
+            p = subprocess.Popen([sys.executable, "-c", code], stdin=subprocess.PIPE, stdout=subprocess.PIPE, bufsize=0, env=env)
             self.procs.append(p)
             self.conns.append(_PipeConn(p.stdout.fileno(), p.stdin.fileno(), duplex_safe=True))
         self.buffers: List[Dict] = [dict() for _ in range(workers)]
@@ -396,10 +424,16 @@ class IngestWorkers:
     def _run(self, documents, semantic, embed_tokens, distances, on_nodes, chunk_docs, inflight_per_worker) -> None:
         W = len(self.conns)
         docs = [_doc_record(d) for d in documents]
-        # small first chunks put the GPU to work early; then chunk_docs
-        bounds, size = [0], max(4, chunk_docs // 8)
+        # small first chunks put the GPU to work early; then chunk_docs -- counted in documents of ~7000 characters (the ~1.1 k-word
+        # documents chunk_docs was tuned on): a chunk of 48 documents of 6 k words each would be six times the work unit, and a
+        # 256-document build only eight chunks for sixteen workers
+        bounds, size, unit = [0], max(4, chunk_docs // 8), 7000
         while bounds[-1] < len(docs):
-            bounds.append(min(len(docs), bounds[-1] + size))
+            hi, chars = bounds[-1], 0
+            while hi < len(docs) and (hi == bounds[-1] or (hi - bounds[-1] < size and chars + len(docs[hi][0]) <= size * unit)):
+                chars += len(docs[hi][0])
+                hi += 1
+            bounds.append(hi)
             size = min(chunk_docs, size * 2)
         chunks = list(zip(bounds[:-1], bounds[1:]))
         n = len(chunks)
@@ -450,3 +484,96 @@ class IngestWorkers:
                 dist_q[0][2](True)
             elif n_split < sent:
                 self.buffers[n_split % W][("split", n_split)] = self.wait(n_split % W, ("split", n_split))
+
+
+class PairTokenizerPool:
+    """Pair tokenisation of a coalesced rerank batch in worker PROCESSES.
+
+    With a real sub-word tokenizer (XLM-R's 250 002-piece Unigram model) the 400 pairs x ~292 tokens of a coalesced batch cost
+    ~25 ms in the request process -- the Rust library's thread pool tops out at ~5x on this job whatever its size (16 or 256
+    threads: profiles/r05_tokenizer_threads.log), its result lists are built under the GIL, and a retrieval batch's query
+    tokenisation queues behind it in the same pool -- which the plugin-surface leg showed as GPU idle gaps (0.84 busy, 83 q/s
+    against 107 with one hashed id per word).  Here the pairs are dealt in slices to W single-threaded workers (the ingest workers'
+    process + pipe machinery, ``role: pairs``): 133 ms of tokenisation / W in parallel, the parent only pickles strings and
+    concatenates int32 arrays.  Results are the in-process tokenizer's, id for id (tests/test_host_logic.py)."""
+
+    MIN_PAIRS = 96
+
+    def __init__(self, tokenizer, workers: int):
+        self.pool = IngestWorkers({"role": "pairs", "tokenizer": tokenizer_spec(tokenizer)}, workers, worker_threads=1)
+        self.lock = threading.Lock()
+        self._seq = 0
+
+    def alive(self) -> bool:
+        return self.pool.alive()
+
+    def close(self) -> None:
+        self.pool.close()
+
+    def encode(self, pairs: Sequence, max_length: int):
+        """-> (list of int32 arrays, list of type-id arrays or None per pair), in order; None when the pool is busy (another thread's
+        batch is in it: the caller tokenises in process)."""
+        if not self.lock.acquire(blocking=False):
+            return None
+        try:
+            pool, W = self.pool, len(self.pool.conns)
+            n = len(pairs)
+            per = (n + W - 1) // W
+            jobs = []
+            for w in range(W):
+                lo, hi = w * per, min(n, (w + 1) * per)
+                if lo >= hi:
+                    break
+                self._seq += 1
+                pool.conns[w].send(("pairs", self._seq, [tuple(p) for p in pairs[lo:hi]], max_length))
+                jobs.append((w, self._seq))
+            ids, types = [], []
+            for w, key in jobs:
+                flat, lens, tflat = pool.wait(w, ("pairs", key))
+                ids.extend(unflatten(flat, lens))
+                types.extend(unflatten(tflat, lens) if tflat is not None else [None] * len(lens))
+            return ids, types
+        except BaseException:
+            self.pool.abort()
+            raise
+        finally:
+            self.lock.release()
+
+
+_PAIR_POOLS: Dict[bytes, PairTokenizerPool] = {}
+
+
+def pair_workers_default() -> int:
+    env = os.environ.get("TT_PAIR_WORKERS")
+    if env is not None and env != "":
+        return max(0, int(env))
+    try:
+        cpus = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cpus = os.cpu_count() or 1
+    return 0 if cpus < 16 else min(16, cpus // 8)      # small hosts tokenise in process
+
+
+def get_pair_pool(tokenizer) -> Optional[PairTokenizerPool]:
+    """The process's pair-tokenisation pool for this tokenizer (None: disabled, or a tokenizer the workers cannot rebuild)."""
+    W = pair_workers_default()
+    if W <= 0:
+        return None
+    try:
+        key = pickle.dumps((tokenizer_spec(tokenizer), W))
+    except TypeError:
+        return None
+    with _POOLS_LOCK:
+        pool = _PAIR_POOLS.get(key)
+        if pool is None or not pool.alive():
+            pool = _PAIR_POOLS[key] = PairTokenizerPool(tokenizer, W)
+        return pool
+
+
+@atexit.register
+def _close_pair_pools() -> None:
+    with _POOLS_LOCK:
+        pools = list(_PAIR_POOLS.values())
+        _PAIR_POOLS.clear()
+    for pool in pools:
+        pool.close()

@@ -29,6 +29,17 @@ def count_tokens(text: str) -> int:
     return len(_TOKEN.findall(text))
 
 
+def tokenizer_counter(tk) -> Callable[[str], int]:
+    """A chunk-size counter that counts with a real sub-word tokenizer (``tk.encode(text)`` minus its two specials) -- what the
+    reference's splitters do with llama-index's global tokenizer (tiktoken): chunk sizes are SUB-WORD token counts
+    there, so a 256-token leaf is ~256 sub-word tokens, not 256 words.  Memoised like ``count_tokens``."""
+    @functools.lru_cache(maxsize=1 << 16)
+    def count(text: str) -> int:
+        return max(0, len(tk.encode(text)) - 2)
+
+    return count
+
+
 class SentenceSplitter:
     """Greedy sentence packing: consecutive sentences are joined until ``chunk_size`` tokens would be exceeded; the
     next chunk starts with the trailing sentences of the previous one worth at most ``chunk_overlap`` tokens; a

@@ -56,6 +56,7 @@ class HipSentenceTransformerRerank:
         # rag_service.py:343-346,617-620) share ONE tokenizer call and ONE encoder batch; scores do not depend on the
         # batch a pair travels in (tests/test_configs_gpu.py), so callers see exactly their serial results
         # two-phase: the host side of a batch (tokenise + pack) runs while the previous batch is on the GPU
+        self.stats = {"pairs": 0, "tokens": 0}
         self._front = (Coalescer(self._prepare_many, max_coalesced_calls, coalesce_wait_s, execute=self._enqueue_many,
                                  finish=self._collect_many) if coalesce else None)
 
@@ -85,11 +86,29 @@ class HipSentenceTransformerRerank:
     def _tokenize_pairs(self, pairs: Sequence[Sequence[str]]):
         """-> (ids per pair, token type ids per pair)."""
         tk = self._tokenizer
-        if hasattr(tk, "encode_pair_batch"):
+        enc = None
+        from .tokenization import HFTokenizer
+
+        if isinstance(tk, HFTokenizer) and len(pairs) >= 96:
+            # a coalesced batch's pairs go to single-threaded worker processes (ingest_workers.PairTokenizerPool): same ids, a
+            # third of the time, and not under this process's GIL; a lone caller's 50 pairs stay here (3 ms)
+            from . import ingest_workers as iw
+
+            pool = iw.get_pair_pool(tk)
+            got = pool.encode(list(pairs), self.max_length) if pool is not None else None
+            if got is not None:
+                enc = list(zip(*got))
+        if enc is not None:
+            pass
+        elif hasattr(tk, "encode_pair_batch"):
             enc = tk.encode_pair_batch(list(pairs), self.max_length)
         else:
             enc = [tk.encode_pair(q, p, self.max_length) for q, p in pairs]
-        return [e[0] for e in enc], [e[1] for e in enc]
+        ids = [e[0] for e in enc]
+        st = self.stats                                   # running totals (bench.py reports the pair lengths a leg really ran)
+        st["pairs"] += len(ids)
+        st["tokens"] += sum(len(x) for x in ids)
+        return ids, [e[1] for e in enc]
 
     def _predict_flat(self, pairs: Sequence[Sequence[str]]) -> List[float]:
         return self.score_token_pairs(*self._tokenize_pairs(pairs)).cpu().tolist()

@@ -18,6 +18,22 @@ from typing import List, Optional, Sequence, Tuple
 _WORD = re.compile(r"\w+|[^\w\s]", re.UNICODE)
 
 
+def _cap_tokenizer_threads() -> None:
+    """The Rust ``tokenizers`` library starts one rayon thread per host core the first time a batch is encoded.  On the 256-thread
+    GPU host that buys nothing -- 400 rerank pairs x 292 tokens take 26.5 ms with 256 threads and 27.1 ms with 16
+    (tools/probes/tokenizer_threads.py, profiles/r05_tokenizer_threads.log) -- and costs a lot as soon as two request threads encode
+    at once (a rerank batch's pairs beside a retrieval batch's queries: 0.4 ms of query tokenisation became 5.5 ms in the surface
+    leg).  Unless the deployment says otherwise (``RAYON_NUM_THREADS``), the pool is capped at 16 threads; must run before the
+    library's first parallel call."""
+    if "RAYON_NUM_THREADS" not in os.environ:
+        try:
+            cpus = len(os.sched_getaffinity(0))
+        except AttributeError:
+            cpus = os.cpu_count() or 1
+        if cpus > 16:
+            os.environ["RAYON_NUM_THREADS"] = "16"
+
+
 class SpecialTokens:
     def __init__(self, arch: str):
         if arch == "xlmr":
@@ -97,6 +113,7 @@ class HFTokenizer:
     encoding with it, and the ingest pipeline tokenizes from background threads."""
 
     def __init__(self, tokenizer_json: Optional[str], arch: str, json_str: Optional[str] = None):
+        _cap_tokenizer_threads()
         from tokenizers import Tokenizer  # local import: optional dependency
 
         self._path = tokenizer_json
@@ -124,7 +141,18 @@ class HFTokenizer:
     def encode_batch(self, texts: Sequence[str], max_length: Optional[int] = None) -> List[List[int]]:
         """Whole batch in one call: the Rust tokenizer fans it out over the host cores and releases the GIL, so
         background threads can tokenize the next windows while this one is packed and enqueued (embedding.py)."""
-        return [self._cut(enc.ids, max_length) for enc in self.tk.encode_batch(list(texts))]
+        texts = list(texts)
+        if len(texts) <= 8:
+            # a retrieval batch's few query strings: one by one on this thread -- a batch call would queue behind whatever large
+            # job (a rerank batch's pairs) occupies the library's shared thread pool (0.4 ms became 5-8 ms in the surface leg)
+            return [self._cut(self.tk.encode(t).ids, max_length) for t in texts]
+        return [self._cut(enc.ids, max_length) for enc in self._batch(self.tk, texts)]
+
+    @staticmethod
+    def _batch(tk, inputs):
+        # encode_batch_fast (tokenizers >= 0.20) skips the character offsets nothing here reads
+        fast = getattr(tk, "encode_batch_fast", None)
+        return fast(inputs) if fast is not None else tk.encode_batch(inputs)
 
     def _pairs(self, max_length: int):
         from tokenizers import Tokenizer
@@ -142,7 +170,12 @@ class HFTokenizer:
         return enc.ids, enc.type_ids
 
     def encode_pair_batch(self, pairs: Sequence[Tuple[str, str]], max_length: int = 512):
-        return [(enc.ids, enc.type_ids) for enc in self._pairs(max_length).encode_batch([(a, b) for a, b in pairs])]
+        encs = self._batch(self._pairs(max_length), [(a, b) for a, b in pairs])
+        if self.arch == "xlmr":
+            # XLM-R has ONE token type (type_vocab 1): the segment ids are all zero and no caller reads them -- building 400 x 292
+            # more Python ints per rerank batch under the GIL is a third of this call
+            return [(enc.ids, None) for enc in encs]
+        return [(enc.ids, enc.type_ids) for enc in encs]
 
 
 def load_tokenizer(model_dir: Optional[str], arch: str, vocab_size: int):

@@ -300,7 +300,9 @@ def test_hf_tokenizer_adapter_batches_pairs_and_threads(tmp_path):
     assert ids == [0, vocab["w1"], vocab["w2"], 2, 2, vocab["w3"], vocab["w4"], vocab["w5"], 2] and len(types) == len(ids)
     pairs = [(texts[i], texts[63 - i]) for i in range(64)]
     pb = tk.encode_pair_batch(pairs, 24)
-    assert pb == [tk.encode_pair(a, b, 24) for a, b in pairs] and max(len(p[0]) for p in pb) == 24
+    # (XLM-R has one token type: the batch form does not build the all-zero segment lists, round 5)
+    assert [p[0] for p in pb] == [tk.encode_pair(a, b, 24)[0] for a, b in pairs] and max(len(p[0]) for p in pb) == 24
+    assert all(p[1] is None for p in pb)
     got, errs = {}, []
 
     def work(i):
@@ -1277,3 +1279,73 @@ def test_two_threads_building_with_the_same_configuration_do_not_share_a_pool():
     assert shared.alive()
     private = [p for p in pools.values() if p is not shared]
     assert all(not p.alive() for p in private)
+
+
+def test_unigram_fixture_and_subword_counted_hierarchy():
+    """Round 5: the trained 250 002-piece Unigram tokenizer fixture (tools/synth_text.py) has XLM-R's layout -- specials 0-3, single
+    and pair templates -- and the hierarchy parser, told to count chunk sizes with the embedder's tokenizer (the offline stand-in
+    for llama-index's tiktoken count), produces leaves within the reference's default leaf size in SUB-WORD tokens, identically
+    in process and in a worker process."""
+    import sys
+
+    import numpy as np
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import synth_text as st
+    from tensor_truth_amd import ingest_workers as iw
+    from tensor_truth_amd.node_parser import HierarchicalNodeParser, get_leaf_nodes, tokenizer_counter
+    from tensor_truth_amd.schema import TextNode
+
+    tk = st.unigram_tokenizer()
+    assert tk.tk.get_vocab_size() == 250_002
+    assert [tk.tk.token_to_id(t) for t in ("<s>", "<pad>", "</s>", "<unk>")] == [0, 1, 2, 3]
+    a, b = st.zipf_text(1, 12), st.zipf_text(2, 40)
+    ia, ib = tk.encode(a), tk.encode(b)
+    assert ia[0] == 0 and ia[-1] == 2 and 3 not in ia and len(ia) > 14            # more pieces than words, no <unk>
+    ids, types = tk.encode_pair(a, b, 512)
+    assert ids == ia + [2] + ib[1:]                                                # <s> A </s></s> B </s>
+    ids, _ = tk.encode_pair(a, st.zipf_text(3, 600), 512)
+    assert len(ids) == 512 and ids[-1] == 2                                        # longest-first truncation keeps the specials
+    # hierarchy in sub-word tokens
+    count = tokenizer_counter(tk)
+    doc = TextNode(text=" ".join(st.zipf_text(100 + i, 14) + "." for i in range(300)), metadata={})
+    nodes = HierarchicalNodeParser.from_defaults(chunk_sizes=[2048, 512, 256], chunk_overlap=64, tokenizer=count).get_nodes_from_documents([doc])
+    leaves = get_leaf_nodes(nodes)
+    sizes = [count(n.text) for n in leaves]
+    assert max(sizes) <= 256 and np.mean(sizes) > 150 and len(leaves) > 20
+    words = [len(n.text.split()) for n in leaves]
+    assert np.mean(words) < 140                                                   # ~2 pieces per word: a 256-token leaf is ~110 words
+    # the worker processes honour the same counter
+    spec = {"tokenizer": iw.tokenizer_spec(tk), "max_length": 8192, "text_instruction": "", "buffer_size": 1, "percentile": 95,
+            "chunk_sizes": [2048, 512, 256], "chunk_overlap": 64, "token_counter": "embedder"}
+    host = iw._Host(spec)
+    got, leaf_pos, flat, lens = host.parse([iw._doc_record(doc)])
+    assert [n.text for n in got] == [n.text for n in nodes]
+    assert int(lens.max()) <= 256 + 2
+
+
+def test_pair_tokenizer_pool_returns_the_in_process_ids(monkeypatch):
+    """ingest_workers.PairTokenizerPool: the pairs of a coalesced rerank batch tokenised in worker processes are, id for id and in
+    order, what HFTokenizer.encode_pair_batch returns in process -- including longest-first truncation at 512 and ragged slices."""
+    import sys
+
+    import numpy as np
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import synth_text as st
+    from tensor_truth_amd import ingest_workers as iw
+
+    tk = st.unigram_tokenizer()
+    pairs = [(st.zipf_text(900 + i, 5 + i % 20), st.zipf_text(5000 + i, 30 + (i * 37) % 400)) for i in range(131)]
+    want = tk.encode_pair_batch(pairs, 512)
+    monkeypatch.setenv("TT_PAIR_WORKERS", "3")
+    pool = iw.get_pair_pool(tk)
+    assert pool is not None and pool is iw.get_pair_pool(tk)
+    ids, types = pool.encode(pairs, 512)
+    assert len(ids) == len(want) and max(len(x) for x in ids) == 512
+    assert all(np.array_equal(a, np.asarray(w[0], dtype=np.int32)) for a, w in zip(ids, want))
+    assert all(t is None for t in types)                       # XLM-R: one token type
+    ids2, _ = pool.encode(pairs[:2], 512)                      # fewer pairs than workers
+    assert [a.tolist() for a in ids2] == [w[0] for w in want[:2]]
+    monkeypatch.setenv("TT_PAIR_WORKERS", "0")
+    assert iw.get_pair_pool(tk) is None

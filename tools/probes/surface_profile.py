@@ -38,10 +38,12 @@ def wrap(obj, name, label=None):
 def main():
     from tensor_truth_amd import encoder as enc_mod, rerank as rr_mod, vector_index as vi
     from tensor_truth_amd.encoder import BGE_M3, BGE_RERANKER_V2_M3, Encoder
-    from tensor_truth_amd.tokenization import HashTokenizer
+    from tensor_truth_amd.tokenization import HashTokenizer, HFTokenizer
 
     wrap(HashTokenizer, "encode_pair_batch")
     wrap(HashTokenizer, "encode_batch")
+    wrap(HFTokenizer, "encode_pair_batch", "hf.encode_pair_batch")
+    wrap(HFTokenizer, "encode_batch", "hf.encode_batch")
     wrap(vi.HipVectorRetriever, "nodes_from_hits")
     wrap(vi.HipVectorRetriever, "_query_matrix")
     wrap(Encoder, "rerank_packed")
@@ -65,7 +67,8 @@ def main():
     dev = torch.device("cuda", 0)
     rows = bench.synth_corpus_shard(int(os.environ.get("ROWS", "1000000")), 1024, 1234, dev)
     t0 = time.perf_counter()
-    res = bench.surface_leg(args, dev, rows, BGE_M3, BGE_RERANKER_V2_M3)
+    # TOKENIZER=unigram-250k (default: the trained sub-word model, round 5) | hash
+    res = bench.surface_leg(args, dev, rows, BGE_M3, BGE_RERANKER_V2_M3, tokenizer=os.environ.get("TOKENIZER", "unigram-250k"))
     print({k: v for k, v in res.items() if k != "what"})
     print(f"leg wall {time.perf_counter() - t0:.2f}s (includes model construction + warm-up)")
     for k in sorted(acc, key=lambda k: -acc[k]):
