@@ -211,7 +211,7 @@ def parse():
     ap.add_argument("--config5-docs", type=int, default=256, help="documents of the config-5 leg at the reference's chunk geometry")
     ap.add_argument("--config5-doc-words", default="4000-8000", help="words per document, lo-hi (a 2048-token root fills)")
     ap.add_argument("--config5-queries", type=int, default=256)
-    ap.add_argument("--config5-small-docs", type=int, default=1024, help="documents of the labelled small-geometry ingest (0 = skip)")
+    ap.add_argument("--config5-small-docs", type=int, default=2048, help="documents of the labelled small-geometry ingest (0 = skip)")
     ap.add_argument("--no-fp8-leg", action="store_true", help="skip the extra fp8-reranker timing (BASELINE config 5)")
     ap.add_argument("--no-reference-leg", action="store_true", help="skip the reference-precision (bf16x3) timing")
     ap.add_argument("--no-fp16-leg", action="store_true", help="skip the fp16-mode timing")
@@ -1308,9 +1308,17 @@ def config5_leg(args, dev, emb_cfg, rr_cfg):
     rr._encoder.calibrate_fp8(pack_token_matrix(cal, rr_cfg))     # static e4m3 scales of the FFN intermediate
     # distinct query strings per leg and for the warm-up calls: MultiIndexRetriever keeps the reference's LRU(128) on the query
     # string (rag_engine.py:399-404), and a repeated query would skip embed + scan + auto-merge
+    # A query = words of ONE leaf (a question about something the corpus says), so that what is retrieved -- and reranked -- are
+    # typical leaves and their neighbours; random Zipf words matched the SHORT tail leaves of semantic chunks (mean pair 122 tokens)
     nq = args.config5_queries
-    queries, queries8, warm = ([texts.query(20_000_000_000 + 1_000_000 * g + i) for i in range(n)]
-                               for g, n in enumerate((nq, nq, 2 + 2 * args.surface_threads)))
+    live = [x for x in index.leaf_ids if x is not None]
+
+    def leaf_query(i):
+        words = index.docstore[live[int(rng.integers(0, len(live)))]].text.replace(".", " ").split()
+        pick = rng.choice(len(words), size=min(texts.q_words, len(words)), replace=False)
+        return " ".join(words[int(j)] for j in pick)
+
+    queries, queries8, warm = ([leaf_query(i) for i in range(n)] for n in (nq, nq, 2 + 2 * args.surface_threads))
     # PRIMARY number: the bf16 reranker (rank agreement with fp32: tau ~0.89); the fp8 (e4m3) reranker BASELINE config 5 names
     # is the labelled variant beside it -- at depth it reorders about half of a candidate list (tau ~0.5)
     # (warm-up: one call, then one untimed pass from all threads -- the first concurrent pass pays for workspaces, staging slots and

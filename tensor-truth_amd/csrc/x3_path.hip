@@ -357,18 +357,24 @@ __global__ __launch_bounds__(64 * kXWaves, 2) void attention_x3_kernel(AttnX3Par
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float mt = mx * sc;
         const float m_new = (mt > m_run + p.lazy) ? mt : m_run;
-        const float alpha = exp2f(m_run - m_new);
+        // Round 5: raw v_exp_f32 on packed FMAs, as in the 16-bit kernel (libm's exp2f wraps the same instruction in ~6 more per value
+        // to rescale results below 2^-126, which are zero probabilities either way: arguments are <= 2^lazy, and a p of 1e-38 adds
+        // nothing to a sum that holds at least one p >= 2^-lazy) -- the softmax was the VALU half of a loop that issues 48 MFMAs per tile
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
         m_run = m_new;
-        float psum = 0.f;
+        f32x2 psum2 = f32x2{0.f, 0.f};
+        const f32x2 sc2 = f32x2{sc, sc}, mn2 = f32x2{m_new, m_new};
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float e = exp2f(fmaf(acc_s[j][r], sc, -m_new));     // libm exp2f: full fp32 accuracy, denormal-safe
-                acc_s[j][r] = e;
-                psum += e;
+            for (int r = 0; r < 16; r += 2) {
+                const f32x2 t = f32x2{acc_s[j][r], acc_s[j][r + 1]} * sc2 - mn2;
+                const f32x2 e = f32x2{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+                acc_s[j][r] = e.x;
+                acc_s[j][r + 1] = e.y;
+                psum2 += e;
             }
-        l_run = l_run * alpha + psum;
+        l_run = l_run * alpha + (psum2.x + psum2.y);
         if (kt > 0 && !__all(alpha == 1.0f)) {
 #pragma unroll
             for (int d = 0; d < DT; ++d)

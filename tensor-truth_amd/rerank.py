@@ -57,8 +57,11 @@ class HipSentenceTransformerRerank:
         # batch a pair travels in (tests/test_configs_gpu.py), so callers see exactly their serial results
         # two-phase: the host side of a batch (tokenise + pack) runs while the previous batch is on the GPU
         self.stats = {"pairs": 0, "tokens": 0}
+        # depth 3 (round 5): with a real sub-word tokenizer the host turn-around of a batch's callers (retrieve + tokenise + pack: ~100 ms
+        # for 8 callers) is longer than ONE batch on the GPU, so with two unfinished batches the GPU waited for the third
+        # (profiles/r05_surface_busy.log: 97.6 -> 102.3 q/s from 32 threads); TT_COALESCE_DEPTH overrides
         self._front = (Coalescer(self._prepare_many, max_coalesced_calls, coalesce_wait_s, execute=self._enqueue_many,
-                                 finish=self._collect_many) if coalesce else None)
+                                 finish=self._collect_many, depth=3) if coalesce else None)
 
     # ---- token-id level ---------------------------------------------------------------------------
     def _pack(self, pair_ids: Sequence[Sequence[int]], type_ids: Optional[Sequence[Sequence[int]]] = None):

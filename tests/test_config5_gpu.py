@@ -341,3 +341,89 @@ def test_worker_process_ingest_builds_the_same_index(dev, built_lib, strategy):
     pb = sorted((n.text, len(n.child_ids), n.parent_id is None) for n in b.docstore.values())
     assert pa == pb
     mm.ModelManager.reset_instance()
+
+
+def test_reference_geometry_with_subword_tokenizer_workers_and_pair_pool(dev, built_lib, monkeypatch):
+    """Round 5 (VERDICT r04 items 2 + 3): the reference's own chunk geometry -- build_index with NO chunk sizes = [2048, 512, 256] /
+    64 (indexing/builder.py:304-307), sizes counted in sub-word tokens (token_counter="embedder") -- through the trained 250 002-piece
+    Unigram tokenizer: (a) leaves hold at most 256 sub-word tokens and the worker-process build equals the in-process build bit for
+    bit; (b) a coalesced rerank batch tokenised in the pair-tokeniser worker processes scores exactly as the in-process path, and
+    both equal the serial per-call results."""
+    import os
+    import sys
+    import threading
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import synth_text as st
+    from tensor_truth_amd import ingest_workers as iw
+    from tensor_truth_amd import model_manager as mm
+    from tensor_truth_amd.encoder import EncoderConfig
+    from tensor_truth_amd.index_builder import DEFAULT_CHUNK_OVERLAP, DEFAULT_CHUNK_SIZES, build_index
+    from tensor_truth_amd.schema import NodeWithScore, QueryBundle, TextNode
+
+    assert DEFAULT_CHUNK_SIZES == [2048, 512, 256] and DEFAULT_CHUNK_OVERLAP == 64
+    tk = st.unigram_tokenizer()
+    ecfg = EncoderConfig(**{**XENC, "vocab_size": 250_002, "max_pos": 2100, "num_labels": 0})
+    rcfg = EncoderConfig(**{**XENC, "vocab_size": 250_002, "max_pos": 514})
+    mm.ModelManager.reset_instance()
+    mgr = mm.ModelManager.get_instance()
+    mgr.model_kwargs_overrides["test/emb-u"] = {"encoder_config": ecfg, "synthetic_seed": 5, "torch_dtype": "bfloat16", "tokenizer": tk}
+    mgr.model_kwargs_overrides["test/rr-u"] = {"encoder_config": rcfg, "synthetic_seed": 6, "torch_dtype": "bfloat16", "tokenizer": tk}
+    emb = mgr.get_embedder("test/emb-u", "cuda")
+    rng = np.random.default_rng(8)
+    lex = st.lexicon()
+    docs = []
+    for d in range(70):
+        sents = []
+        for block in range(3):
+            band = int(rng.integers(0, 50)) * 1000
+            for _ in range(int(rng.integers(25, 45))):
+                sents.append(" ".join(lex[band + int(j)] for j in rng.integers(0, 1000, size=int(rng.integers(8, 20)))) + ".")
+        docs.append(TextNode(text=" ".join(sents), metadata={"title": f"doc {d}"}))
+    kw = dict(chunking_strategy="semantic_hierarchical", token_counter="embedder")          # no chunk sizes: the reference's defaults
+    a = build_index(docs, emb, workers=0, **kw)
+    b = build_index(docs, emb, workers=3, **kw)
+    torch.cuda.synchronize()
+    ta = [a.docstore[i].text for i in a.leaf_ids]
+    assert a.n == b.n > 150 and ta == [b.docstore[i].text for i in b.leaf_ids]
+    assert torch.equal(a._mat[: a.n], b._mat[: b.n])
+    leaf_tokens = [len(x) - 2 for x in tk.encode_batch(ta)]
+    assert max(leaf_tokens) <= 256 and np.mean(leaf_tokens) > 120, (max(leaf_tokens), np.mean(leaf_tokens))
+    roots = [n for n in a.docstore.values() if n.parent_id is None]
+    assert max(len(tk.encode(n.text)) - 2 for n in roots) <= 2048
+
+    # (b) rerank: 6 concurrent callers x 40 candidates through the coalescing front -> one batch of 240 pairs (>= 96: the pool)
+    rr = mgr.get_reranker("test/rr-u", top_n=5, device="cuda")
+    cands = [[NodeWithScore(node=TextNode(text=ta[int(j)], id_=f"n{int(j)}"), score=0.0) for j in rng.choice(len(ta), 40, replace=False)]
+             for _ in range(6)]
+    queries = [" ".join(ta[int(rng.integers(0, len(ta)))].replace(".", " ").split()[:12]) for _ in range(6)]
+
+    def run_all():
+        out, errs = [None] * 6, []
+
+        def one(i):
+            try:
+                out[i] = [(x.node.id_, x.score) for x in rr.postprocess_nodes(list(cands[i]), query_bundle=QueryBundle(query_str=queries[i]))]
+            except Exception as exc:  # noqa: BLE001
+                errs.append(exc)
+
+        gate = threading.Barrier(6)
+        threads = [threading.Thread(target=lambda i=i: (gate.wait(), one(i))) for i in range(6)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not errs, errs
+        return out
+
+    monkeypatch.setenv("TT_PAIR_WORKERS", "3")
+    pairs0 = rr.stats["pairs"]
+    pooled = run_all()
+    pool = iw.get_pair_pool(tk)
+    assert pool is not None and rr.stats["pairs"] - pairs0 == 240
+    monkeypatch.setenv("TT_PAIR_WORKERS", "0")
+    local = run_all()
+    serial = [[(x.node.id_, x.score) for x in rr.postprocess_nodes(list(cands[i]), query_bundle=QueryBundle(query_str=queries[i]))] for i in range(6)]
+    assert pooled == local == serial
+    assert all(len(r) == 5 and r[0][1] >= r[-1][1] for r in serial)
+    mm.ModelManager.reset_instance()

@@ -31,6 +31,8 @@ def child():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "child":
         child()
+    elif len(sys.argv) > 1:
+        pass
     else:
         for n in (None, 4, 8, 16, 32, 64, 128):
             env = dict(os.environ)
@@ -39,3 +41,30 @@ if __name__ == "__main__":
             else:
                 env["RAYON_NUM_THREADS"] = str(n)
             subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env=env, check=False)
+
+
+def pool_child(workers):
+    """the same 400 pairs through ingest_workers.PairTokenizerPool with `workers` single-threaded processes"""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import synth_text as st
+    from tensor_truth_amd import ingest_workers as iw
+
+    os.environ["TT_PAIR_WORKERS"] = str(workers)
+    tk = st.unigram_tokenizer()
+    pairs = [(st.zipf_text(10 ** 9 + i, 15, 100000), st.zipf_text(i, 124, 100000)) for i in range(400)]
+    pool = iw.get_pair_pool(tk)
+    pool.encode(pairs, 512)
+    pool.encode(pairs, 512)
+    best = best50 = 1e9
+    for _ in range(7):
+        t0 = time.perf_counter(); pool.encode(pairs, 512); best = min(best, time.perf_counter() - t0)
+        t0 = time.perf_counter(); pool.encode(pairs[:100], 512); best50 = min(best50, time.perf_counter() - t0)
+    print(f"PairTokenizerPool, {workers:3d} workers x 1 thread: 400 pairs {best * 1e3:7.2f} ms, 100 pairs {best50 * 1e3:6.2f} ms", flush=True)
+
+
+if __name__ == "__main__" and len(sys.argv) > 2 and sys.argv[1] == "pool":
+    pool_child(int(sys.argv[2]))
+elif __name__ == "__main__" and len(sys.argv) == 1:
+    for w in (4, 8, 16, 32):
+        subprocess.run([sys.executable, os.path.abspath(__file__), "pool", str(w)], check=False)
