@@ -124,6 +124,39 @@ class HipHuggingFaceEmbedding:
             out[torch.tensor(order, dtype=torch.int64).to(self.device, non_blocking=True)] = torch.cat(parts)
         return out
 
+    def embed_flat(self, flat: np.ndarray, lens: np.ndarray) -> torch.Tensor:
+        """``embed_token_batches`` for sequences handed over as one flat int32 array + lengths (what the ingest workers send): the
+        same batches (sorted by length, ``embed_batch_size`` texts topped up to ``forward_tokens`` tokens), the same embeddings bit for
+        bit, no per-sequence Python (argsort, cumulative sums, ``encoder.pack_flat``)."""
+        from .encoder import pack_flat
+
+        lens = np.asarray(lens, dtype=np.int64)
+        n = len(lens)
+        out = torch.empty((n, self.config.hidden), dtype=torch.float32, device=self.device)
+        if n == 0:
+            return out
+        flat = np.asarray(flat, dtype=np.int32)
+        first = np.zeros(n, dtype=np.int64)
+        np.cumsum(lens[:-1], out=first[1:])
+        order = np.argsort(-lens, kind="stable")               # = sorted(range(n), key=lambda i: -len(seqs[i])): stable, longest first
+        eff = np.minimum(lens[order], self.max_length)
+        csum = np.cumsum(eff)
+        parts, lo = [], 0
+        while lo < n:
+            # texts lo .. hi-1: at least embed_batch_size of them, then more while the tokens BEFORE the next one stay below forward_tokens
+            base = int(csum[lo - 1]) if lo else 0
+            hi_tok = int(np.searchsorted(csum, base + self.forward_tokens, side="left")) + 1     # first hi with tokens(lo..hi-1) >= forward_tokens
+            hi = min(n, max(lo + self.embed_batch_size, hi_tok))
+            sel = order[lo:hi]
+            self.stats["sequences"] += hi - lo
+            self.stats["tokens"] += int(csum[hi - 1]) - base
+            self.stats["sum_len_sq"] += int((eff[lo:hi] * eff[lo:hi]).sum())
+            emb, _ = self._encoder.embed_packed(pack_flat(flat, first, lens, sel, self.config, self.max_length), pooling=self.pooling)
+            parts.append(emb)
+            lo = hi
+        out[torch.from_numpy(order).to(self.device, non_blocking=True)] = torch.cat(parts)
+        return out
+
     def _tokenize(self, texts: Sequence[str], prefix: str):
         tk = self._tokenizer
         full = [prefix + t for t in texts] if prefix else list(texts)

@@ -187,7 +187,7 @@ def _build_with_workers(index, documents, embed_model, chunking_strategy, chunk_
     # (a pool serves one build at a time: a second thread building with the same configuration gets a private pool)
     with iw.lease_workers(spec, W) as pool:
         pool.run(documents, chunking_strategy == "semantic_hierarchical", embed_model.embed_token_batches, distances, on_nodes,
-                 chunk_docs=int(os.environ.get("TT_INGEST_CHUNK_DOCS", "48")))
+                 chunk_docs=int(os.environ.get("TT_INGEST_CHUNK_DOCS", "48")), embed_flat=getattr(embed_model, "embed_flat", None))
     return True
 
 

@@ -47,8 +47,36 @@ class _PipeConn:
         # while the feeder sits in write(): both would wait forever.  The write end is non-blocking and the send loop reads
         # whatever arrives in between.
         self.duplex_safe = duplex_safe
+        self.out, self.out_pos = bytearray(), 0          # (feeder's end) bytes posted but not yet written: post() / pump()
         if duplex_safe:
             os.set_blocking(wfd, False)
+
+    # ---- non-blocking sends (round 5).  The feeder hands a worker its NEXT work unit while it is still busy with the current one; the
+    # unit (hundreds of KB of document text) is larger than the pipe, so a blocking send parked the feeder until that worker came
+    # back to read -- 44 of 78 seconds of a 6000-document build at the reference's chunk geometry, the GPU idle meanwhile
+    # (profiles/r05_ingest_ref_geometry_profile_6000_before.log).  post() queues the bytes, pump() writes what the pipe takes now.
+    def post(self, obj) -> None:
+        data = pickle.dumps(obj, protocol=pickle.HIGHEST_PROTOCOL)
+        if self.out_pos and self.out_pos == len(self.out):
+            self.out, self.out_pos = bytearray(), 0
+        self.out += struct.pack("<Q", len(data))
+        self.out += data
+        self.pump()
+
+    def pending(self) -> bool:
+        return self.out_pos < len(self.out)
+
+    def pump(self) -> bool:
+        """-> True when nothing is left to write."""
+        while self.out_pos < len(self.out):
+            try:
+                n = os.write(self.wfd, memoryview(self.out)[self.out_pos:self.out_pos + (1 << 16)])
+            except BlockingIOError:
+                return False
+            self.out_pos += n
+        if self.out_pos:
+            self.out, self.out_pos = bytearray(), 0
+        return True
 
     def send(self, obj) -> None:
         data = pickle.dumps(obj, protocol=pickle.HIGHEST_PROTOCOL)
@@ -91,6 +119,12 @@ class _PipeConn:
 
     def recv(self):
         while not self._complete():
+            if self.pending():                       # posted bytes first: the reply may be the answer to them
+                readable, writable, _ = select.select([self.rfd], [self.wfd], [])
+                if writable:
+                    self.pump()
+                if not readable:
+                    continue
             if not self._fill(True):
                 raise EOFError("ingest worker closed its pipe")
         n = struct.unpack_from("<Q", self.buf)[0]
@@ -397,18 +431,40 @@ class IngestWorkers:
             raise RuntimeError(f"ingest worker {w} failed on chunk {msg[1]}: {msg[2]}")
         self.buffers[w][(msg[0], msg[1])] = msg[2:]
 
+    def pump_all(self) -> None:
+        for c in self.conns:
+            if c.pending():
+                c.pump()
+
     def poll(self, w: int, key) -> Optional[tuple]:
         while key not in self.buffers[w] and self.conns[w].poll():
             self._store(w, self.conns[w].recv())
         return self.buffers[w].pop(key, None)
 
     def wait(self, w: int, key) -> tuple:
+        """Blocks until worker ``w`` has answered ``key`` -- serving every OTHER pipe meanwhile: posted work units keep flowing to
+        the workers that can take them and their replies are stored as they arrive (nobody idles because the feeder waits for one)."""
         while key not in self.buffers[w]:
-            self._store(w, self.conns[w].recv())
+            self.serve(None)
         return self.buffers[w].pop(key)
 
+    def serve(self, timeout: Optional[float]) -> None:
+        """One select() over every pipe: write posted bytes where a pipe takes them, store the replies that have arrived."""
+        rfds = {c.rfd: i for i, c in enumerate(self.conns)}
+        wfds = {c.wfd: i for i, c in enumerate(self.conns) if c.pending()}
+        readable, writable, _ = select.select(list(rfds), list(wfds), [], timeout)
+        for fd in writable:
+            self.conns[wfds[fd]].pump()
+        for fd in readable:
+            i = rfds[fd]
+            c = self.conns[i]
+            if not c._fill(False):
+                raise EOFError(f"ingest worker {i} closed its pipe")
+            while c._complete():
+                self._store(i, c.recv())
+
     def run(self, documents: Sequence, semantic: bool, embed_tokens: Callable, distances: Callable, on_nodes: Callable,
-            chunk_docs: int = 48, inflight_per_worker: int = 3) -> None:
+            chunk_docs: int = 48, inflight_per_worker: int = 3, embed_flat: Optional[Callable] = None) -> None:
         """``embed_tokens(list of int32 arrays) -> embeddings`` (enqueues GPU work), ``distances(embeddings) -> (host array,
         ready())`` (adjacent distances copied back asynchronously; ``ready(block)`` tells / waits), ``on_nodes(nodes,
         leaf positions, leaf embeddings)`` (docstore + index rows), called in document order.
@@ -416,12 +472,14 @@ class IngestWorkers:
         is killed (``abort``) and the error re-raised; ``get_workers`` starts a fresh pool for the next build."""
         with self._busy:
             try:
-                self._run(documents, semantic, embed_tokens, distances, on_nodes, chunk_docs, inflight_per_worker)
+                if embed_flat is None:       # (flat int32 array + lengths, as the workers send them: no per-sequence Python in the feeder)
+                    embed_flat = lambda flat, lens: embed_tokens(unflatten(flat, lens))      # noqa: E731
+                self._run(documents, semantic, embed_flat, distances, on_nodes, chunk_docs, inflight_per_worker)
             except BaseException:
                 self.abort()
                 raise
 
-    def _run(self, documents, semantic, embed_tokens, distances, on_nodes, chunk_docs, inflight_per_worker) -> None:
+    def _run(self, documents, semantic, embed_flat, distances, on_nodes, chunk_docs, inflight_per_worker) -> None:
         W = len(self.conns)
         docs = [_doc_record(d) for d in documents]
         # small first chunks put the GPU to work early; then chunk_docs -- counted in documents of ~7000 characters (the ~1.1 k-word
@@ -442,9 +500,10 @@ class IngestWorkers:
         max_ahead = W * inflight_per_worker
         while done < n:
             progressed = False
+            self.pump_all()
             while sent < n and sent - done < max_ahead:                                   # a) hand out chunks
                 lo, hi = chunks[sent]
-                self.conns[sent % W].send(("split" if semantic else "parse", sent, docs[lo:hi]))
+                self.conns[sent % W].post(("split" if semantic else "parse", sent, docs[lo:hi]))
                 sent += 1
                 progressed = True
             if semantic:
@@ -454,7 +513,7 @@ class IngestWorkers:
                         break
                     spans, flat, lens = r
                     if len(lens):
-                        host, ready = distances(embed_tokens(unflatten(flat, lens)))
+                        host, ready = distances(embed_flat(flat, lens))
                     else:
                         host, ready = np.zeros(0, np.float32), (lambda block=False: True)
                     dist_q.append((n_split, host, ready))
@@ -462,7 +521,7 @@ class IngestWorkers:
                     progressed = True
                 while dist_q and dist_q[0][2](False):                                     # c) distances -> worker
                     c, host, _ = dist_q.popleft()
-                    self.conns[c % W].send(("cut", c, np.array(host, copy=True)))
+                    self.conns[c % W].post(("cut", c, np.array(host, copy=True)))
                     n_cut_sent += 1
                     progressed = True
             else:
@@ -472,7 +531,7 @@ class IngestWorkers:
                 if r is None:
                     break
                 nodes, leaf_pos, flat, lens = r
-                on_nodes(nodes, leaf_pos, embed_tokens(unflatten(flat, lens)) if len(lens) else None)
+                on_nodes(nodes, leaf_pos, embed_flat(flat, lens) if len(lens) else None)
                 done += 1
                 progressed = True
             if progressed:
@@ -481,7 +540,8 @@ class IngestWorkers:
             if done < n_cut_sent:
                 self.buffers[done % W][("cut", done)] = self.wait(done % W, ("cut", done))
             elif dist_q:
-                dist_q[0][2](True)
+                while not dist_q[0][2](False):          # the GPU owes us distances: keep the pipes moving meanwhile
+                    self.serve(0.0005)
             elif n_split < sent:
                 self.buffers[n_split % W][("split", n_split)] = self.wait(n_split % W, ("split", n_split))
 

@@ -1,6 +1,6 @@
 """Where does build_index spend its wall time at the REFERENCE's chunk geometry ([2048, 512, 256] / 64, sub-word counted, Unigram
 tokenizer, 4-8 k-word documents)?  Wraps the feeder's steps with wall-clock accumulators and reads the kernels' HIP-event totals.
-Usage: python tools/probes/ingest_ref_geometry.py [n_docs] [workers]"""
+Usage: python tools/probes/ingest_ref_geometry.py [n_docs] [workers | -] [words lo-hi]"""
 import ctypes
 import os
 import sys
@@ -39,13 +39,14 @@ def main():
     from tensor_truth_amd.index_builder import build_index
 
     n_docs = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-    workers = int(sys.argv[2]) if len(sys.argv) > 2 else None
+    workers = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2] != "-" else None
+    lo_w, hi_w = (int(x) for x in (sys.argv[3] if len(sys.argv) > 3 else "4000-8000").split("-"))
 
     class A:
         query_len, chunk_len = 32, 256
 
     texts = bench.surface_texts(A(), "unigram-250k")
-    docs, n_sent, n_words = bench._c5_docs_reference_geometry(n_docs, 4000, 8000, np.random.default_rng(55))
+    docs, n_sent, n_words = bench._c5_docs_reference_geometry(n_docs, lo_w, hi_w, np.random.default_rng(55))
     emb = HipHuggingFaceEmbedding("BAAI/bge-m3", device="cuda", embed_batch_size=128,
                                   model_kwargs={"encoder_config": BGE_M3, "synthetic_seed": 1, "torch_dtype": "bfloat16", "tokenizer": texts.tokenizer})
     kw = dict(chunking_strategy="semantic_hierarchical", chunk_sizes=None, chunk_overlap=None, token_counter="embedder", workers=workers)
@@ -55,15 +56,27 @@ def main():
     wrap(iw.IngestWorkers, "poll", "feeder: poll (recv + unpickle of ready replies)")
     wrap(iw._PipeConn, "send", "feeder: send to worker (pickle + write)")
     wrap(HipHuggingFaceEmbedding, "embed_token_batches", "feeder: embed_token_batches (sort, pack, upload, enqueue)")
+    wrap(HipHuggingFaceEmbedding, "embed_flat", "feeder: embed_flat (argsort, pack, upload, enqueue)")
     wrap(vi.HipVectorIndex, "add", "feeder: index.add")
     wrap(vi.HipVectorIndex, "add_to_docstore", "feeder: index.add_to_docstore")
     lib = _lib.load_library()
     lib.tt_prof_enable(1)
     st0 = dict(emb.stats)
+    prof = None
+    if os.environ.get("CPROFILE") == "1":
+        import cProfile
+
+        prof = cProfile.Profile()
+        prof.enable()
     t0 = time.perf_counter()
     index = build_index(docs, emb, **kw)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if prof is not None:
+        import pstats
+
+        prof.disable()
+        pstats.Stats(prof).sort_stats("cumulative").print_stats(28)
     names = {1: "scan_filter", 2: "scan_sample", 3: "select", 4: "gemm", 5: "attention", 6: "rowops", 7: "scan_tail"}
     gpu_ms = 0.0
     for kid in range(8):
