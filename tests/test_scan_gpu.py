@@ -433,9 +433,12 @@ def test_tiled_scan_256_queries_at_bench_sizes_vs_torch(dev, built_lib, n):
     assert not overflowed, "the tiled pass flagged a candidate-list overflow on the bench's own data"
     assert (i[: q // 2, 0].long() == planted).all()
     assert (s[:, :-1] >= s[:, 1:]).all() and (i >= 0).all() and (i < n).all()
-    best_s, best_i = _running_topk_checker(corpus, queries, k)
-    assert torch.allclose(s, best_s, rtol=REL_TOL, atol=1e-6)
+    # the checker keeps k + 1 rows: a query is tie-free when every adjacent gap INCLUDING the one between rank k and rank k + 1 exceeds
+    # 1e-6 (with 256 queries a near-tie at the cut -- two fp32 evaluations of the same dot product differ by ~1e-7 -- is likely in a run)
+    best_s, best_i = _running_topk_checker(corpus, queries, k + 1)
     gap = (best_s[:, :-1] - best_s[:, 1:]).min(dim=1).values
+    best_s, best_i = best_s[:, :k], best_i[:, :k]
+    assert torch.allclose(s, best_s, rtol=REL_TOL, atol=1e-6)
     tie_free = gap > 1e-6
     assert tie_free.float().mean().item() >= 0.5, f"tie-free fraction {tie_free.float().mean().item():.2f}"
     assert torch.equal(i[tie_free].long(), best_i[tie_free])
