@@ -1357,8 +1357,14 @@ def config5_leg(args, dev, emb_cfg, rr_cfg):
                     sents.append(" ".join(w[band + int(j)] for j in rng.integers(0, 1000, size=k)) + ".")
             s_sent += len(sents)
             sdocs.append(TextNode(text=" ".join(sents), metadata={"title": f"doc {d}"}))
+        # (a fresh manager: get_embedder reuses the loaded model for the same (name, device) -- it would hand back the Unigram-tokenizer embedder)
+        mm.ModelManager.reset_instance()
+        mgr = mm.ModelManager.get_instance()
         mgr.model_kwargs_overrides["BAAI/bge-m3"] = {"encoder_config": emb_cfg, "synthetic_seed": 1, "torch_dtype": "bfloat16"}
         emb_h = mgr.get_embedder("BAAI/bge-m3", "cuda")
+        from tensor_truth_amd.tokenization import HashTokenizer
+
+        assert isinstance(emb_h._tokenizer, HashTokenizer)
         skw = dict(chunking_strategy="semantic_hierarchical", chunk_sizes=[512, 128, 64], chunk_overlap=8)
         build_index(sdocs[:96], emb_h, **skw)
         torch.cuda.synchronize()

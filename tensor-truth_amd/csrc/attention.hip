@@ -468,7 +468,7 @@ __global__ __launch_bounds__(64 * NW, 4) void attention_kernel(AttnParams p) {
 // either forced; a query alone vs in a batch).
 constexpr int kResMaxTiles = 5;
 
-template <int DH>
+template <int DH, bool PIPE = false>
 __global__ __launch_bounds__(64 * kWaves, 2) void attention_resident_kernel(AttnParams p) {
     constexpr int RB = DH * 2, CH = RB / 16, RPB = 256 / RB, KS = DH / 16, DT = DH / 32;
     constexpr int NPK = kKTile * RB / 1024, NPV = 8 * DH * 16 / 1024, NW = kWaves;
@@ -572,6 +572,161 @@ __global__ __launch_bounds__(64 * kWaves, 2) void attention_resident_kernel(Attn
     for (int s = 0; s < KS; ++s) koff[s] = lds0 + krow * RB + (((2 * s + hh) ^ ((krow / RPB) & (CH - 1))) << 4);
     const uint32_t voff = lds0 + NPK * 1024 + (hh * DH + ql) * 16;
 
+    if constexpr (PIPE) {
+        // ---- software-pipelined walk (TT_ATT_RESIDENT=2): S = K.Q^T of tile kt + 1 is ISSUED before the softmax of tile kt, so its eight
+        // MFMAs (and the K / V fragment reads) run under the softmax's VALU instead of in front of it; a row's arithmetic is unchanged.
+        auto issue_k = [&](int kt, u32x4 (&kf)[2][4]) {
+            const uint32_t bufo = (uint32_t)kt * BUF;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) kf[0][s] = lds_read128_async<0>(koff[s] + bufo);
+#pragma unroll
+            for (int s = 0; s < KS; ++s) kf[1][s] = lds_read128_async<32 * RB>(koff[s] + bufo);
+        };
+        for (int b = first; b < n_blk; b += NW) {
+            ex8 qn[KS];
+            const bool more = b + NW < n_blk;
+            if (more) {
+                const uint16_t* qp = q_ptr(b + NW);
+#pragma unroll
+                for (int s = 0; s < KS; ++s) qn[s] = *reinterpret_cast<const ex8*>(qp + s * 16);
+            }
+            f32x16 acc_o[DT];
+#pragma unroll
+            for (int d = 0; d < DT; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc_o[d][r] = 0.f;
+            float m_run = -__builtin_inff();
+            float l_run = 0.f;
+            f32x16 s_cur[2], s_nxt[2];
+            u32x4 kf[2][4];
+            issue_k(0, kf);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (j == 0) lds_wait4n<KS>(kf[0][0], kf[0][1], kf[0][2], kf[0][3]);
+                else lds_wait4n<0>(kf[1][0], kf[1][1], kf[1][2], kf[1][3]);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s_cur[j][r] = 0.f;
+#pragma unroll
+                for (int s = 0; s < KS; ++s) s_cur[j] = TT_MFMA_32x32x16(__builtin_bit_cast(ex8, kf[j][s]), qf[s], s_cur[j]);
+            }
+            for (int kt = 0; kt < n_kt; ++kt) {
+                const int k0 = kt * kKTile;
+                const uint32_t vaddr = voff + (uint32_t)kt * BUF;
+                const bool has_next = kt + 1 < n_kt;              // wave-uniform
+                u32x4 vf[2][2];
+                vf[0][0] = lds_read128_async<0>(vaddr);
+                vf[0][1] = lds_read128_async<512>(vaddr);
+                vf[1][0] = lds_read128_async<2 * DH * 16>(vaddr);
+                vf[1][1] = lds_read128_async<2 * DH * 16 + 512>(vaddr);
+                issue_k(has_next ? kt + 1 : kt, kf);              // (last tile: a harmless re-read, its S is never used)
+                if (kt == 0 && off != 0) {
+                    if (hh == 0) {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r)
+                            if (r < off) s_cur[0][r] = -__builtin_inff();
+                    }
+                }
+                if (k0 + kKTile > alen) {
+                    const int lim = alen - k0 - 8 * hh;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            if (32 * j + 16 * (r >> 3) + (r & 7) >= lim) s_cur[j][r] = -__builtin_inff();
+                }
+                // ---- one straight-line region: next tile's S MFMAs beside this tile's softmax
+                lds_wait4n<KS>(kf[0][0], kf[0][1], kf[0][2], kf[0][3]);        // V first half + K first 32 keys have landed (in-order returns)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s_nxt[0][r] = 0.f;
+#pragma unroll
+                for (int s = 0; s < KS; ++s) s_nxt[0] = TT_MFMA_32x32x16(__builtin_bit_cast(ex8, kf[0][s]), qf[s], s_nxt[0]);
+                float mx = -__builtin_inff();
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s_cur[j][r]);
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                const float mt = mx * sc;
+                const float m_new = (mt > m_run + p.lazy) ? mt : m_run;
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+                m_run = m_new;
+                lds_wait4n<0>(kf[1][0], kf[1][1], kf[1][2], kf[1][3]);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s_nxt[1][r] = 0.f;
+#pragma unroll
+                for (int s = 0; s < KS; ++s) s_nxt[1] = TT_MFMA_32x32x16(__builtin_bit_cast(ex8, kf[1][s]), qf[s], s_nxt[1]);
+                f32x2 psum2 = f32x2{0.f, 0.f};
+                const f32x2 sc2 = f32x2{sc, sc}, mn2 = f32x2{m_new, m_new};
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        const f32x2 t = f32x2{s_cur[j][r], s_cur[j][r + 1]} * sc2 - mn2;
+                        const f32x2 e = f32x2{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+                        s_cur[j][r] = e.x;
+                        s_cur[j][r + 1] = e.y;
+                        psum2 += e;
+                    }
+                l_run = l_run * alpha + (psum2.x + psum2.y);
+                if (kt > 0 && !__all(alpha == 1.0f)) {
+#pragma unroll
+                    for (int d = 0; d < DT; ++d)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc_o[d][r] *= alpha;
+                }
+                // ---- O^T += V^T . P^T
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    ex8 va[2][2];
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                        for (int d = 0; d < DT; ++d) va[s2][d] = __builtin_bit_cast(ex8, vf[s2][d]);
+                    if (j == 0) {
+                        vf[0][0] = lds_read128_async<4 * DH * 16>(vaddr);
+                        vf[0][1] = lds_read128_async<4 * DH * 16 + 512>(vaddr);
+                        vf[1][0] = lds_read128_async<6 * DH * 16>(vaddr);
+                        vf[1][1] = lds_read128_async<6 * DH * 16 + 512>(vaddr);
+                    }
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        uint4 pb;
+                        pb.x = pack_e2_inrange(s_cur[j][8 * s2 + 0], s_cur[j][8 * s2 + 1]);
+                        pb.y = pack_e2_inrange(s_cur[j][8 * s2 + 2], s_cur[j][8 * s2 + 3]);
+                        pb.z = pack_e2_inrange(s_cur[j][8 * s2 + 4], s_cur[j][8 * s2 + 5]);
+                        pb.w = pack_e2_inrange(s_cur[j][8 * s2 + 6], s_cur[j][8 * s2 + 7]);
+                        const ex8 pf = __builtin_bit_cast(ex8, pb);
+#pragma unroll
+                        for (int d = 0; d < DT; ++d)
+                            acc_o[d] = TT_MFMA_32x32x16(va[s2][d], pf, acc_o[d]);
+                    }
+                    if (j == 0) lds_wait4n<0>(vf[0][0], vf[0][1], vf[1][0], vf[1][1]);
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) s_cur[j] = s_nxt[j];
+            }
+            const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+            const float inv = 1.0f / l_tot;
+            const int q_row = b * 32 + ql;
+            if (q_row < len) {
+                uint16_t* op = p.out + (size_t)(t0 + q_row) * p.ld_out + head * DH;
+#pragma unroll
+                for (int d = 0; d < DT; ++d)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        uint2 o;
+                        o.x = pack_e2(acc_o[d][4 * g + 0] * inv, acc_o[d][4 * g + 1] * inv);
+                        o.y = pack_e2(acc_o[d][4 * g + 2] * inv, acc_o[d][4 * g + 3] * inv);
+                        *reinterpret_cast<uint2*>(op + 32 * d + 8 * g + 4 * hh) = o;
+                    }
+            }
+            if (more) {
+#pragma unroll
+                for (int s = 0; s < KS; ++s) qf[s] = qn[s];
+            }
+        }
+        return;
+    }
     for (int b = first; b < n_blk; b += NW) {
         // the next block's Q fragments travel while this block is computed
         ex8 qn[KS];
@@ -866,8 +1021,13 @@ int tt_attention_launch(const AttnParams& p, hipStream_t st) {
     if (resident && p.head_dim == 64 && !p.out_scales && !p.dbg && p.max_len + 7 <= kResMaxTiles * kKTile && p.max_len >= TT_ATT_RESIDENT_MIN_LEN) {
         const int tiles = (p.max_len + 7 + kKTile - 1) / kKTile;
         const size_t lds = (size_t)tiles * 16384;
-        TT_SET_MAX_LDS(attention_resident_kernel<64>, 160 * 1024);
-        hipLaunchKernelGGL(attention_resident_kernel<64>, dim3((unsigned)(p.heads * p.n_seq)), dim3(64 * kWaves), lds, st, q);
+        if (resident == 2) {
+            TT_SET_MAX_LDS((attention_resident_kernel<64, true>), 160 * 1024);
+            hipLaunchKernelGGL((attention_resident_kernel<64, true>), dim3((unsigned)(p.heads * p.n_seq)), dim3(64 * kWaves), lds, st, q);
+        } else {
+            TT_SET_MAX_LDS(attention_resident_kernel<64>, 160 * 1024);
+            hipLaunchKernelGGL(attention_resident_kernel<64>, dim3((unsigned)(p.heads * p.n_seq)), dim3(64 * kWaves), lds, st, q);
+        }
         TT_CHECK_LAUNCH();
         return TT_OK;
     }
