@@ -501,8 +501,9 @@ __global__ __launch_bounds__(64 * kWaves, 2) void attention_resident_kernel(Attn
         const int q_row_c = q_row < len ? q_row : len - 1;
         return p.qk + (size_t)(t0 + q_row_c) * p.ld_qk + p.q_col0 + head * DH + hh * 8;
     };
-    ex8 qf[KS];
-    if (first < n_blk) {
+    const int abl = p.rotate;      // diagnostic (TT_ATT_RES_ABL): 1 = no output stores, 2 = no Q loads, 4 = no K / V copies -- wrong results by design
+    ex8 qf[KS] = {};
+    if (first < n_blk && !(abl & 2)) {
         const uint16_t* qp = q_ptr(first);
 #pragma unroll
         for (int s = 0; s < KS; ++s) qf[s] = *reinterpret_cast<const ex8*>(qp + s * 16);
@@ -527,7 +528,7 @@ __global__ __launch_bounds__(64 * kWaves, 2) void attention_resident_kernel(Attn
     auto glds16 = [](const char* base, uint32_t voff, uint32_t lds_addr) {
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(lds_addr) : "memory", "m0");
     };
-    for (int kt = 0; kt < n_kt; ++kt) {
+    for (int kt = 0; kt < ((abl & 4) ? 0 : n_kt); ++kt) {
         const uint32_t buf = lds0 + (uint32_t)kt * BUF;
         const bool clamp = (kt + 1) * kKTile > alen || (kt == 0 && off != 0);   // wave-uniform
         if (!clamp) {
@@ -585,7 +586,7 @@ __global__ __launch_bounds__(64 * kWaves, 2) void attention_resident_kernel(Attn
         for (int b = first; b < n_blk; b += NW) {
             ex8 qn[KS];
             const bool more = b + NW < n_blk;
-            if (more) {
+            if (more && !(abl & 2)) {
                 const uint16_t* qp = q_ptr(b + NW);
 #pragma unroll
                 for (int s = 0; s < KS; ++s) qn[s] = *reinterpret_cast<const ex8*>(qp + s * 16);
@@ -708,7 +709,7 @@ __global__ __launch_bounds__(64 * kWaves, 2) void attention_resident_kernel(Attn
             const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
             const float inv = 1.0f / l_tot;
             const int q_row = b * 32 + ql;
-            if (q_row < len) {
+            if (q_row < len && !(abl & 1)) {
                 uint16_t* op = p.out + (size_t)(t0 + q_row) * p.ld_out + head * DH;
 #pragma unroll
                 for (int d = 0; d < DT; ++d)
@@ -731,7 +732,7 @@ __global__ __launch_bounds__(64 * kWaves, 2) void attention_resident_kernel(Attn
         // the next block's Q fragments travel while this block is computed
         ex8 qn[KS];
         const bool more = b + NW < n_blk;
-        if (more) {
+        if (more && !(abl & 2)) {
             const uint16_t* qp = q_ptr(b + NW);
 #pragma unroll
             for (int s = 0; s < KS; ++s) qn[s] = *reinterpret_cast<const ex8*>(qp + s * 16);
@@ -848,7 +849,7 @@ __global__ __launch_bounds__(64 * kWaves, 2) void attention_resident_kernel(Attn
         const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
         const float inv = 1.0f / l_tot;
         const int q_row = b * 32 + ql;
-        if (q_row < len) {
+        if (q_row < len && !(abl & 1)) {
             uint16_t* op = p.out + (size_t)(t0 + q_row) * p.ld_out + head * DH;
 #pragma unroll
             for (int d = 0; d < DT; ++d)
@@ -1021,6 +1022,7 @@ int tt_attention_launch(const AttnParams& p, hipStream_t st) {
     if (resident && p.head_dim == 64 && !p.out_scales && !p.dbg && p.max_len + 7 <= kResMaxTiles * kKTile && p.max_len >= TT_ATT_RESIDENT_MIN_LEN) {
         const int tiles = (p.max_len + 7 + kKTile - 1) / kKTile;
         const size_t lds = (size_t)tiles * 16384;
+        q.rotate = TT_DIAG_ENV_INT("TT_ATT_RES_ABL", 0);
         if (resident == 2) {
             TT_SET_MAX_LDS((attention_resident_kernel<64, true>), 160 * 1024);
             hipLaunchKernelGGL((attention_resident_kernel<64, true>), dim3((unsigned)(p.heads * p.n_seq)), dim3(64 * kWaves), lds, st, q);
