@@ -13,7 +13,7 @@ BASELINE.json's configurations name bf16 (and fp8 for config 5): those are the m
                       (``TT_REFERENCE_IMPL``), all for hidden a multiple of 256 with 64-wide heads, else "fp32":
                         "f16x3"  (default, round 4) every operand as two fp16 planes, three fp16 MFMA products per product
                                  (``encoder_x3`` on fp16 planes): a third of the bf16 matrix rate, 22 significand bits -- holds
-                                 1e-3 with a margin even on weights with trained-model statistics (tests/stress_weights.py)
+                                 1e-3 with a margin even on the stress fixture (tests/stress_weights.py)
                         "f16c"   fp16 main products + block-scaled e4m3 correction terms (``encoder_f16c``): HALF the bf16
                                  rate, 1e-4 on the standard fixture, but 7e-3 relative on the stress fixture's smallest scores
                                  (ranking intact): the fast variant, for callers who accept that

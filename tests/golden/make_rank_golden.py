@@ -6,7 +6,7 @@ the GPU suite reads this fixture instead of recomputing it (and a CPU test re-de
     python tests/golden/make_rank_golden.py
     python tests/golden/make_rank_golden.py --stress     # -> rank_oracle_stress_24L_4x50x292.npz (tests/stress_weights.py)
 
---stress: the same token ids through weights with trained-model statistics (outlier LayerNorm gains, peaked attention on
+--stress: the same token ids through the stress fixture's hostile weights (outlier LayerNorm gains, peaked attention on
 half the heads) and a head CALIBRATED on these pairs: the first principal direction of the pre-head features tanh(dense(h)),
 scaled so that the 200 logits span +-3 (scores 0.05 .. 0.95).  The fixture carries the head (4 KiB), the fp32 oracle's
 scores, and what the generator measured about the stress it applies (attention entropy per head class, largest activation).

@@ -1,4 +1,6 @@
-"""Seeded weights with TRAINED-MODEL STATISTICS for the precision gates.
+"""The STRESS FIXTURE of the precision gates: seeded weights made hostile the way trained checkpoints are hostile.
+This is the builder's own construction -- outlier dimensions, peaked attention, a head that spreads the scores -- not a trained model
+and not fitted to one; no network, no real checkpoint exists here.
 
 ``oracle.encoder.synth_weights`` is HF's init (normal(0, 0.02)): no outlier features, near-uniform attention, and a
 classification head that squeezes a query's 50 candidates into ~0.3 of the sigmoid range -- the easy case for every

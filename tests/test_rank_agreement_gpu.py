@@ -23,7 +23,7 @@ WEIGHT_SEED = 17
 GOLDEN_NAME = "rank_oracle_24L_4x50x292.npz"   # tests/golden/make_rank_golden.py
 STRESS_EMB_GOLDEN_NAME = "embed_oracle_stress_24L_16x292.npz"     # ... --stress-embeddings: normalised first-row hidden states, same weights
 STRESS_EMB_PAIRS = 16
-STRESS_GOLDEN_NAME = "rank_oracle_stress_24L_4x50x292.npz"   # ... --stress: trained-model statistics (tests/stress_weights.py)
+STRESS_GOLDEN_NAME = "rank_oracle_stress_24L_4x50x292.npz"   # ... --stress: the stress fixture (tests/stress_weights.py: the builder's hostile construction, not a trained model)
 BF16_BOUND = 2e-2      # stated absolute bound of the bf16 mode on a sigmoid score after 24 layers
 FP16_BOUND = 3e-3      # ... of the fp16 mode (same rate, three more mantissa bits per rounding point; measured 2.4e-3)
 FP8_BOUND = 0.2        # stated bound of the fp8 throughput mode; its QUALITY gate is rank agreement, below
@@ -287,7 +287,7 @@ def test_f16c_scores_within_1e3_relative_at_full_depth(dev, built_lib, oracle_sc
     assert min(taus) >= 0.999 and min(over) == 1.0
 
 
-# ---- the same gate on weights with TRAINED-MODEL STATISTICS (tests/stress_weights.py) ----------------------
+# ---- the same gate on the STRESS FIXTURE (tests/stress_weights.py: hostile construction, not a trained model) ----------------------
 # Six hidden dimensions carry massive activations (20-60x the ordinary features) through every layer, half the heads attend with
 # an entropy of 1.5 bits (logits of tens), and the calibrated head spreads a query's candidates over ~6 logits.  There is no
 # network for real checkpoints: this is the offline stand-in for them.  Bounds below are MEASURED on this fixture and asserted
@@ -374,7 +374,7 @@ def test_stress_weights_reference_precision_implementations(dev, built_lib, stre
 @pytest.mark.parametrize("mode", ["fp16", "bf16", "fp8"])
 def test_stress_weights_16bit_modes_stay_finite_and_bounded(dev, built_lib, stress_oracle_scores, mode):
     """The named 16-bit modes (and the fp8 throughput mode) on the stress weights: finite -- fp16 saturates instead of overflowing
-    -- and inside their MEASURED bounds, which are what DESIGN.md states for weights with trained-model statistics."""
+    -- and inside their MEASURED bounds, which are what DESIGN.md states for the stress fixture."""
     ocfg, W, pairs, want = stress_oracle_scores
     got = _mode_scores(dev, W, pairs, mode)
     err, rel, tau, over = _report(mode, want, got)
