@@ -468,7 +468,7 @@ __global__ __launch_bounds__(64 * NW, 4) void attention_kernel(AttnParams p) {
 // either forced; a query alone vs in a batch).
 constexpr int kResMaxTiles = 5;
 
-template <int DH, bool PIPE = false>
+template <int DH, bool PIPE = false, bool EARLY = false>
 __global__ __launch_bounds__(64 * kWaves, 2) void attention_resident_kernel(AttnParams p) {
     constexpr int RB = DH * 2, CH = RB / 16, RPB = 256 / RB, KS = DH / 16, DT = DH / 32;
     constexpr int NPK = kKTile * RB / 1024, NPV = 8 * DH * 16 / 1024, NW = kWaves;
@@ -560,11 +560,33 @@ __global__ __launch_bounds__(64 * kWaves, 2) void attention_resident_kernel(Attn
             }
         }
     }
-    __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): this wave's copies (and its Q fragments) have landed
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();                // ... everyone's: the only barrier of the kernel
-    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (!EARLY) {
+        __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): this wave's copies (and its Q fragments) have landed
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();                // ... everyone's: the only barrier of the kernel
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // EARLY (TT_ATT_RESIDENT=3): the FIRST walk starts on tile 0 as soon as tile 0 has landed -- a counted wait (this wave issued four
+    // copies per later tile after it) + one barrier per tile, in the first walk only; every later block finds everything resident.
+    auto tile_landed = [&](int kt) {
+        switch (n_kt - 1 - kt) {
+            case 0: __builtin_amdgcn_s_waitcnt(0x0F70); break;                       // vmcnt(0)
+            case 1: __builtin_amdgcn_s_waitcnt(0x0F70 | 4); break;                   // vmcnt(4)
+            case 2: __builtin_amdgcn_s_waitcnt(0x0F70 | 8); break;
+            case 3: __builtin_amdgcn_s_waitcnt(0x0F70 | 12); break;
+            default: __builtin_amdgcn_s_waitcnt(0x4F70 | 0); break;                  // vmcnt(16): bit 4 of the count lives in bit 14
+        }
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    bool first_walk = EARLY;
+    if (EARLY && first >= n_blk) {                   // a wave without a block still owes the first walk its barriers
+        for (int kt = 0; kt < n_kt; ++kt) tile_landed(kt);
+        return;
+    }
 
     const float sc = p.scale * 1.4426950408889634f;
     const int krow = (ql & 0x13) | ((ql & 4) << 1) | ((ql & 8) >> 1);
@@ -729,10 +751,11 @@ __global__ __launch_bounds__(64 * kWaves, 2) void attention_resident_kernel(Attn
         return;
     }
     for (int b = first; b < n_blk; b += NW) {
-        // the next block's Q fragments travel while this block is computed
+        // the next block's Q fragments travel while this block is computed (EARLY, first walk: issued after the walk -- loads issued
+        // now would sit behind the copies in the in-order vmcnt queue and be counted by the per-tile waits)
         ex8 qn[KS];
         const bool more = b + NW < n_blk;
-        if (more && !(abl & 2)) {
+        if (more && !(abl & 2) && !first_walk) {
             const uint16_t* qp = q_ptr(b + NW);
 #pragma unroll
             for (int s = 0; s < KS; ++s) qn[s] = *reinterpret_cast<const ex8*>(qp + s * 16);
@@ -747,6 +770,9 @@ __global__ __launch_bounds__(64 * kWaves, 2) void attention_resident_kernel(Attn
         for (int kt = 0; kt < n_kt; ++kt) {
             const int k0 = kt * kKTile;
             const uint32_t bufo = (uint32_t)kt * BUF;
+            if constexpr (EARLY) {
+                if (first_walk) tile_landed(kt);
+            }
             f32x16 acc_s[2];
             {
                 u32x4 kf[2][4];
@@ -860,6 +886,14 @@ __global__ __launch_bounds__(64 * kWaves, 2) void attention_resident_kernel(Attn
                     o.y = pack_e2(acc_o[d][4 * g + 2] * inv, acc_o[d][4 * g + 3] * inv);
                     *reinterpret_cast<uint2*>(op + 32 * d + 8 * g + 4 * hh) = o;
                 }
+        }
+        if (EARLY && first_walk) {
+            first_walk = false;
+            if (more && !(abl & 2)) {
+                const uint16_t* qp = q_ptr(b + NW);
+#pragma unroll
+                for (int s = 0; s < KS; ++s) qn[s] = *reinterpret_cast<const ex8*>(qp + s * 16);
+            }
         }
         if (more) {
 #pragma unroll
@@ -1023,7 +1057,10 @@ int tt_attention_launch(const AttnParams& p, hipStream_t st) {
         const int tiles = (p.max_len + 7 + kKTile - 1) / kKTile;
         const size_t lds = (size_t)tiles * 16384;
         q.rotate = TT_DIAG_ENV_INT("TT_ATT_RES_ABL", 0);
-        if (resident == 2) {
+        if (resident == 3) {
+            TT_SET_MAX_LDS((attention_resident_kernel<64, false, true>), 160 * 1024);
+            hipLaunchKernelGGL((attention_resident_kernel<64, false, true>), dim3((unsigned)(p.heads * p.n_seq)), dim3(64 * kWaves), lds, st, q);
+        } else if (resident == 2) {
             TT_SET_MAX_LDS((attention_resident_kernel<64, true>), 160 * 1024);
             hipLaunchKernelGGL((attention_resident_kernel<64, true>), dim3((unsigned)(p.heads * p.n_seq)), dim3(64 * kWaves), lds, st, q);
         } else {
