@@ -26,14 +26,21 @@ def main():
     emb_cfg = EncoderConfig(**{**BGE_M3.__dict__, "layers": layers})
     rr_cfg = EncoderConfig(**{**BGE_RERANKER_V2_M3.__dict__, "layers": layers})
     rows = bench.synth_corpus_shard(1_000_000, 1024, 1234, dev)
+    # TOKENIZER=unigram-250k (round 5): the trained sub-word tokenizer; coalesced batches then tokenise their pairs in worker processes
+    # (ingest_workers.PairTokenizerPool) -- the answers must still be the first round's, bit for bit, whatever batches form
+    class A:
+        query_len, chunk_len = 32, 256
+
+    texts = bench.surface_texts(A(), os.environ.get("TOKENIZER", "hash"))
+    tk_kw = {"tokenizer": texts.tokenizer} if texts.tokenizer is not None else {}
     emb = HipHuggingFaceEmbedding("BAAI/bge-m3", device=str(dev), embed_batch_size=128,
-                                  model_kwargs={"encoder_config": emb_cfg, "synthetic_seed": 1})
+                                  model_kwargs={"encoder_config": emb_cfg, "synthetic_seed": 1, **tk_kw})
     rr = HipSentenceTransformerRerank(model="BAAI/bge-reranker-v2-m3", top_n=10, device=str(dev), batch_pairs=4096,
-                                      model_kwargs={"encoder_config": rr_cfg, "synthetic_seed": 2})
-    index = ShardedHipVectorIndex(1024, rows, 0, rows.shape[0], bench._RowIds(rows.shape[0]), bench._SynthDocstore(256),
+                                      model_kwargs={"encoder_config": rr_cfg, "synthetic_seed": 2, **tk_kw})
+    index = ShardedHipVectorIndex(1024, rows, 0, rows.shape[0], bench._RowIds(rows.shape[0]), bench._SynthDocstore(256, texts.chunk),
                                   embed_model=emb, score_mode="cosine")
     retr = index.as_retriever(similarity_top_k=50, max_batch=64)
-    queries = [bench.synth_text(10_000_000_000 + i, 32) for i in range(192)]
+    queries = [texts.query(10_000_000_000 + i) for i in range(192)]
 
     def one(q):
         nodes = retr.retrieve(q)
