@@ -1118,7 +1118,9 @@ class _SynthDocstore:
         if nid is None:
             return default
         row = int(nid[1:])
-        return TextNode(text=self.texts[row % self.POOL], id_=nid, metadata={"row": row})
+        nd = TextNode(text=self.texts[row % self.POOL], id_=nid, metadata={"row": row})
+        nd.excluded_embed_metadata_keys = ["row"]          # EMBED content = the chunk text (what the pool's stored token ids hold)
+        return nd
 
 
 def _run_threads(n_threads, work_items, fn):
@@ -1205,6 +1207,23 @@ def surface_leg(args, dev, shard_rows, emb_cfg, rr_cfg, world=1, rank=0, row_lo=
         torch.cuda.synchronize()
         lat = (time.perf_counter() - t1) / 8
         n_scan, n_rr = scan_batches() - b_r0, rr._front.batches - b_x0
+        # ... and a lone caller when the index kept its leaves' token ids at ingest (build_index(keep_leaf_token_ids=True)): here the
+        # synthetic docstore's 4096 pool texts tokenised once -- the reranker then tokenises only the query string
+        lat_ids = None
+        if texts.tokenizer is not None and world == 1:
+            from tensor_truth_amd.tokenization import tokenizer_signature
+
+            pool_ids = [np.asarray(x[1:-1], dtype=np.int32) for x in texts.tokenizer.encode_batch(index.docstore.texts)]
+            if rr.attach_token_source(lambda nid: pool_ids[int(nid[1:]) % len(pool_ids)], tokenizer_signature(texts.tokenizer), ""):
+                for q in queries[8:10]:
+                    one(q)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for q in queries[10:18]:
+                    one(q)
+                torch.cuda.synchronize()
+                lat_ids = (time.perf_counter() - t1) / 8
+                rr.detach_token_source()
     finally:
         if world > 1:
             retr.close(timeout=600)                # leave the lock-step front whatever happened (every rank does)
@@ -1219,6 +1238,7 @@ def surface_leg(args, dev, shard_rows, emb_cfg, rr_cfg, world=1, rank=0, row_lo=
     return {"queries_per_s": world * len(queries) / dt, "threads": args.surface_threads, "queries": world * len(queries),
             "ranks": world, "scan_batches": n_scan, "rerank_batches": n_rr,
             "single_caller_ms_per_query": lat * 1e3,
+            "single_caller_ms_per_query_with_leaf_token_ids": None if lat_ids is None else lat_ids * 1e3,
             "precision": getattr(rr, "precision", None) or ("reference (default)" if default_precision else "bf16"),
             "tokenizer": tokenizer,
             "tokenizer_detail": ("trained Unigram model, 250 002 pieces, XLM-R layout and pair template (tools/synth_text.py; Rust `tokenizers`, "
@@ -1283,7 +1303,9 @@ def config5_leg(args, dev, emb_cfg, rr_cfg):
     mgr.model_kwargs_overrides["BAAI/bge-reranker-v2-m3"] = {"encoder_config": rr_cfg, "synthetic_seed": 2, "gemm_dtype": "fp8",
                                                              "tokenizer": texts.tokenizer}
     emb = mgr.get_embedder("BAAI/bge-m3", "cuda")
-    ref_kw = dict(chunking_strategy="semantic_hierarchical", chunk_sizes=None, chunk_overlap=None, token_counter="embedder")
+    # keep_leaf_token_ids: the index keeps its leaves' token ids (embedder and reranker share XLM-R's tokenizer), so serving tokenises queries only
+    ref_kw = dict(chunking_strategy="semantic_hierarchical", chunk_sizes=None, chunk_overlap=None, token_counter="embedder",
+                  keep_leaf_token_ids=True)
     # a serving process ingests with WARM host workers and kernels: one small untimed build first (worker processes are kept
     # for the life of the process, ingest_workers.get_workers)
     build_index(docs[:64], emb, **ref_kw)
@@ -1319,6 +1341,7 @@ def config5_leg(args, dev, emb_cfg, rr_cfg):
         return " ".join(words[int(j)] for j in pick)
 
     queries, queries8, warm = ([leaf_query(i) for i in range(n)] for n in (nq, nq, 2 + 2 * args.surface_threads))
+    queries_txt, lone_a, lone_b = ([leaf_query(i) for i in range(n)] for n in (nq, 10, 10))
     # PRIMARY number: the bf16 reranker (rank agreement with fp32: tau ~0.89); the fp8 (e4m3) reranker BASELINE config 5 names
     # is the labelled variant beside it -- at depth it reorders about half of a candidate list (tau ~0.5)
     # (warm-up: one call, then one untimed pass from all threads -- the first concurrent pass pays for workspaces, staging slots and
@@ -1342,7 +1365,27 @@ def config5_leg(args, dev, emb_cfg, rr_cfg):
     pair_stats = None
     if rst1.get("pairs", 0) > rst0.get("pairs", 0):
         dp = rst1["pairs"] - rst0["pairs"]
-        pair_stats = {"pairs_per_query": dp / len(queries), "mean_pair_tokens": (rst1["tokens"] - rst0["tokens"]) / dp}
+        pair_stats = {"pairs_per_query": dp / len(queries), "mean_pair_tokens": (rst1["tokens"] - rst0["tokens"]) / dp,
+                      "passages_from_stored_ids_frac": (rst1.get("pretokenized", 0) - rst0.get("pretokenized", 0)) / dp}
+
+    # ... what the stored leaf ids buy: a lone caller's latency, and the threaded rate, with the reranker tokenising every passage string
+    def lone(qs):
+        for q in qs[:2]:
+            svc.retrieve(q)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for q in qs[2:]:
+            svc.retrieve(q)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t1) / (len(qs) - 2) * 1e3
+
+    lone_ids_ms = lone(lone_a)
+    src = index.token_source()
+    rr.detach_token_source()
+    lone_txt_ms = lone(lone_b)
+    dt_txt, _ = _run_threads(args.surface_threads, queries_txt, lambda q: svc.retrieve(q).num_sources)
+    if src is not None:
+        rr.attach_token_source(*src)
     # ---- secondary: rounds 2-4's small geometry, ingest only (hashing tokenizer, ~1.1 k-word documents)
     small = None
     if args.config5_small_docs > 0:
@@ -1392,6 +1435,13 @@ def config5_leg(args, dev, emb_cfg, rr_cfg):
             "doc_generation_s": t_gen,
             "queries": len(queries), "queries_per_s": len(queries) / dt, "mean_sources": float(np.mean(res)), "reranker": "bf16",
             "rerank_pairs": pair_stats,
+            "leaf_token_ids": {"kept_at_ingest": index.leaf_token_ids is not None and len(index.leaf_token_ids),
+                               "single_caller_ms_per_query": lone_ids_ms,
+                               "tokenising_every_passage": {"single_caller_ms_per_query": lone_txt_ms, "queries_per_s": len(queries_txt) / dt_txt},
+                               "what": "build_index(keep_leaf_token_ids=True): the index keeps the token ids of every leaf's EMBED content as the "
+                                       "embedder's tokenizer produced them; embedder and reranker share XLM-R's tokenizer, so the reranker assembles "
+                                       "<s> q </s></s> leaf </s> from the stored ids and tokenises only the query (auto-merged parents: text). "
+                                       "Scores bit-identical to the string path (tests/test_config5_gpu.py)"},
             "fp8_reranker_variant": {"queries_per_s": len(queries8) / dt8, "mean_sources": float(np.mean(res8)),
                                      "bf16_on_the_same_query_strings": len(queries8) / dt8b,
                                      "note": "e4m3 layer projections, its own query strings (no LRU hits); Kendall tau ~0.5 "

@@ -90,7 +90,8 @@ def build_index(documents: Sequence, embed_model, persist_dir: Optional[str] = N
                 chunk_overlap: Optional[int] = None, semantic_buffer_size: int = 1,
                 semantic_breakpoint_threshold: float = 95, embedding_model: Optional[str] = None, node_parser=None,
                 progress_callback: Optional[Callable[[str, int, int], None]] = None,
-                window_docs: int = 8192, workers: Optional[int] = None, token_counter: str = "words") -> HipVectorIndex:
+                window_docs: int = 8192, workers: Optional[int] = None, token_counter: str = "words",
+                keep_leaf_token_ids: bool = False) -> HipVectorIndex:
     """-> the module's HipVectorIndex (persisted under ``persist_dir`` when given).
 
     ``workers`` (default: ``TT_INGEST_WORKERS``, else up to 8 of the host's cores; 0 = everything in this process): sentence
@@ -107,7 +108,10 @@ def build_index(documents: Sequence, embed_model, persist_dir: Optional[str] = N
     smaller windows mean shorter forward passes, and the overlap is already there without a thread, see the loop below.)
     ``window_docs <= 0``: one window.
     ``token_counter``: what the hierarchy's chunk sizes count -- "words" (default) or "embedder" (sub-word tokens of the embedding
-    model's tokenizer, the offline stand-in for llama-index's tiktoken count: ``_counter``)."""
+    model's tokenizer, the offline stand-in for llama-index's tiktoken count: ``_counter``).
+    ``keep_leaf_token_ids`` (worker-process builds): the index keeps every leaf's token ids as the embedder's tokenizer produced them
+    (``HipVectorIndex.leaf_token_ids``, ~4 bytes per token of host memory), so that a reranker with the SAME tokenizer (bge-m3 and
+    bge-reranker-v2-m3 share XLM-R's) never tokenises a retrieved leaf again: ``build_retrieval_service`` wires it up."""
     documents = list(documents)
     n_docs = len(documents)
     if chunking_strategy not in CHUNKING_STRATEGIES:
@@ -118,7 +122,7 @@ def build_index(documents: Sequence, embed_model, persist_dir: Optional[str] = N
                            embed_model=embed_model)
     _counter(token_counter, embed_model)          # (validates the name)
     if _build_with_workers(index, documents, embed_model, chunking_strategy, chunk_sizes, chunk_overlap, semantic_buffer_size,
-                           semantic_breakpoint_threshold, node_parser, workers, token_counter):
+                           semantic_breakpoint_threshold, node_parser, workers, token_counter, keep_leaf_token_ids):
         n_docs = 0        # (done: skip the in-process loop below)
     step = max(n_docs, 1) if window_docs <= 0 else window_docs
     for lo in range(0, n_docs, step):
@@ -141,7 +145,7 @@ def build_index(documents: Sequence, embed_model, persist_dir: Optional[str] = N
 
 
 def _build_with_workers(index, documents, embed_model, chunking_strategy, chunk_sizes, chunk_overlap, buffer_size, percentile,
-                        node_parser, workers, token_counter: str = "words") -> bool:
+                        node_parser, workers, token_counter: str = "words", keep_leaf_token_ids: bool = False) -> bool:
     """The worker-process form of the build loop (``ingest_workers.IngestWorkers.run``).  -> False when it does not apply."""
     import torch
 
@@ -179,15 +183,17 @@ def _build_with_workers(index, documents, embed_model, chunking_strategy, chunk_
 
         return host.numpy(), ready
 
-    def on_nodes(nodes, leaf_pos, emb):
+    def on_nodes(nodes, leaf_pos, emb, tokens=None):
         index.add_to_docstore(nodes)                       # storage_context.docstore.add_documents(nodes), builder.py:430
         if emb is not None:
-            index.add([nodes[i] for i in leaf_pos], embeddings=emb)      # VectorStoreIndex(leaf_nodes, ...), builder.py:437-442
+            tok = iw.unflatten(*tokens) if (keep_leaf_token_ids and tokens is not None) else None
+            index.add([nodes[i] for i in leaf_pos], embeddings=emb, token_ids=tok)      # VectorStoreIndex(leaf_nodes, ...), builder.py:437-442
 
     # (a pool serves one build at a time: a second thread building with the same configuration gets a private pool)
     with iw.lease_workers(spec, W) as pool:
         pool.run(documents, chunking_strategy == "semantic_hierarchical", embed_model.embed_token_batches, distances, on_nodes,
-                 chunk_docs=int(os.environ.get("TT_INGEST_CHUNK_DOCS", "48")), embed_flat=getattr(embed_model, "embed_flat", None))
+                 chunk_docs=int(os.environ.get("TT_INGEST_CHUNK_DOCS", "48")), embed_flat=getattr(embed_model, "embed_flat", None),
+                 leaf_tokens=keep_leaf_token_ids)
     return True
 
 

@@ -464,7 +464,8 @@ class IngestWorkers:
                 self._store(i, c.recv())
 
     def run(self, documents: Sequence, semantic: bool, embed_tokens: Callable, distances: Callable, on_nodes: Callable,
-            chunk_docs: int = 48, inflight_per_worker: int = 3, embed_flat: Optional[Callable] = None) -> None:
+            chunk_docs: int = 48, inflight_per_worker: int = 3, embed_flat: Optional[Callable] = None,
+            leaf_tokens: bool = False) -> None:
         """``embed_tokens(list of int32 arrays) -> embeddings`` (enqueues GPU work), ``distances(embeddings) -> (host array,
         ready())`` (adjacent distances copied back asynchronously; ``ready(block)`` tells / waits), ``on_nodes(nodes,
         leaf positions, leaf embeddings)`` (docstore + index rows), called in document order.
@@ -474,7 +475,11 @@ class IngestWorkers:
             try:
                 if embed_flat is None:       # (flat int32 array + lengths, as the workers send them: no per-sequence Python in the feeder)
                     embed_flat = lambda flat, lens: embed_tokens(unflatten(flat, lens))      # noqa: E731
-                self._run(documents, semantic, embed_flat, distances, on_nodes, chunk_docs, inflight_per_worker)
+                if leaf_tokens:              # on_nodes(nodes, leaf positions, leaf embeddings, (flat leaf token ids, lengths))
+                    cb = on_nodes
+                else:
+                    cb = lambda nodes, pos, emb, _tok: on_nodes(nodes, pos, emb)              # noqa: E731
+                self._run(documents, semantic, embed_flat, distances, cb, chunk_docs, inflight_per_worker)
             except BaseException:
                 self.abort()
                 raise
@@ -531,7 +536,7 @@ class IngestWorkers:
                 if r is None:
                     break
                 nodes, leaf_pos, flat, lens = r
-                on_nodes(nodes, leaf_pos, embed_flat(flat, lens) if len(lens) else None)
+                on_nodes(nodes, leaf_pos, embed_flat(flat, lens) if len(lens) else None, (flat, lens))
                 done += 1
                 progressed = True
             if progressed:

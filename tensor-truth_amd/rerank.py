@@ -9,9 +9,12 @@ empty input -> ``[]``; missing query -> ``ValueError``.
 """
 from __future__ import annotations
 
+import logging
 from typing import Any, Dict, List, Optional, Sequence
 
 import torch
+
+logger = logging.getLogger(__name__)
 
 from . import weights as _weights
 from .coalesce import Coalescer
@@ -57,6 +60,7 @@ class HipSentenceTransformerRerank:
         # batch a pair travels in (tests/test_configs_gpu.py), so callers see exactly their serial results
         # two-phase: the host side of a batch (tokenise + pack) runs while the previous batch is on the GPU
         self.stats = {"pairs": 0, "tokens": 0}
+        self._token_source = None
         # depth 3 (round 5): with a real sub-word tokenizer the host turn-around of a batch's callers (retrieve + tokenise + pack: ~100 ms
         # for 8 callers) is longer than ONE batch on the GPU, so with two unfinished batches the GPU waited for the third
         # (profiles/r05_surface_busy.log: 97.6 -> 102.3 q/s from 32 threads); TT_COALESCE_DEPTH overrides
@@ -90,7 +94,26 @@ class HipSentenceTransformerRerank:
         """-> (ids per pair, token type ids per pair)."""
         tk = self._tokenizer
         enc = None
-        from .tokenization import HFTokenizer
+        from .tokenization import HFTokenizer, PreTokenized, assemble_pairs
+
+        pre = [i for i, pr in enumerate(pairs) if isinstance(pr[1], PreTokenized)]
+        if pre:
+            # passages whose ids the index kept at ingest: only their queries are tokenised (once per distinct string)
+            done = assemble_pairs(tk, [pairs[i] for i in pre], self.max_length)
+            rest = [i for i, pr in enumerate(pairs) if not isinstance(pr[1], PreTokenized)]
+            ids: List = [None] * len(pairs)
+            types: List = [None] * len(pairs)
+            for i, a in zip(pre, done):
+                ids[i] = a
+            if rest:
+                r_ids, r_types = self._tokenize_pairs([pairs[i] for i in rest])
+                for i, a, t in zip(rest, r_ids, r_types):
+                    ids[i], types[i] = a, t
+            st = self.stats
+            st["pairs"] += len(pre)
+            st["tokens"] += sum(len(a) for a in done)
+            st["pretokenized"] = st.get("pretokenized", 0) + len(pre)
+            return ids, types
 
         if isinstance(tk, HFTokenizer) and len(pairs) >= 96:
             # a coalesced batch's pairs go to single-threaded worker processes (ingest_workers.PairTokenizerPool): same ids, a
@@ -157,6 +180,24 @@ class HipSentenceTransformerRerank:
             return self._front.submit(pairs)
         return self._predict_flat(pairs)
 
+    # ---- passages tokenised once, at ingest -----------------------------------------------------------------
+    def attach_token_source(self, source, signature: str, instruction: str = "") -> bool:
+        """``source(node_id) -> int32 body ids (no specials) or None``: the ids of a node's EMBED-mode content as the index's
+        embedder tokenised them at ingest (``HipVectorIndex.leaf_token_ids``).  Accepted only when that tokenizer IS this model's
+        (same signature: bge-m3 and bge-reranker-v2-m3 share XLM-R's vocabulary), no text instruction was prepended, and the model has one
+        token type -- then ``postprocess_nodes`` hands known passages to the batch as ids and only queries are tokenised per call.
+        Scores are bit-identical to the string path (tests/test_config5_gpu.py).  -> whether it was accepted."""
+        from .tokenization import tokenizer_signature
+
+        ok = (not self._use_types and not instruction and signature == tokenizer_signature(self._tokenizer))
+        self._token_source = source if ok else None
+        if not ok:
+            logger.info("reranker: token source refused (another tokenizer, a text instruction, or a model with segment ids)")
+        return ok
+
+    def detach_token_source(self) -> None:
+        self._token_source = None
+
     # ---- postprocessor surface ------------------------------------------------------------------------
     def postprocess_nodes(self, nodes: List[NodeWithScore], query_bundle=None, query_str: Optional[str] = None):
         if query_bundle is None and query_str is None:
@@ -164,8 +205,17 @@ class HipSentenceTransformerRerank:
         q = query_str if query_bundle is None else query_bundle.query_str
         if len(nodes) == 0:
             return []
-        texts = [n.node.get_content(metadata_mode=MetadataMode.EMBED) for n in nodes]
-        scores = self.predict([(q, t) for t in texts])
+        src = self._token_source
+        if src is None:
+            passages = [n.node.get_content(metadata_mode=MetadataMode.EMBED) for n in nodes]
+        else:
+            from .tokenization import PreTokenized
+
+            passages = []
+            for n in nodes:
+                ids = src(n.node.id_)
+                passages.append(PreTokenized(ids) if ids is not None else n.node.get_content(metadata_mode=MetadataMode.EMBED))
+        scores = self.predict([(q, t) for t in passages])
         for n, s in zip(nodes, scores):
             if self.keep_retrieval_score:
                 n.node.metadata["retrieval_score"] = n.score

@@ -104,7 +104,25 @@ def build_retrieval_service(indexes: List[Any], params: Optional[Dict[str, Any]]
     k = params.get("similarity_top_k") or similarity_top_k_for(top_n)
     retrievers = [AutoMergingRetriever(ix.as_retriever(similarity_top_k=k), ix.docstore) for ix in indexes]
     multi = MultiIndexRetriever(retrievers, balance_strategy=params.get("balance_strategy", "top_k_per_index"))
-    post: List[Any] = [mgr.get_reranker(params.get("reranker_model"), top_n=top_n, device=device)]
+    rr = mgr.get_reranker(params.get("reranker_model"), top_n=top_n, device=device)
+    post: List[Any] = [rr]
+    # leaves tokenised once, at ingest (build_index(keep_leaf_token_ids=True)): if the indexes kept their leaves' token ids and the
+    # reranker's tokenizer is the embedder's, retrieved leaves reach the reranker as ids (auto-merged parents still as text)
+    if hasattr(rr, "attach_token_source"):
+        sources = [ts for ts in (ix.token_source() for ix in indexes if hasattr(ix, "token_source")) if ts is not None]
+        if sources and len({(sig, instr) for _, sig, instr in sources}) == 1:
+            getters = [g for g, _, _ in sources]
+
+            def lookup(node_id, _getters=getters):
+                for g in _getters:
+                    ids = g(node_id)
+                    if ids is not None:
+                        return ids
+                return None
+
+            rr.attach_token_source(lookup if len(getters) > 1 else getters[0], sources[0][1], sources[0][2])
+        else:
+            rr.detach_token_source()
     hard = params.get("confidence_cutoff_hard", 0.0)
     if hard and hard > 0:
         post.append(SimilarityPostprocessor(similarity_cutoff=hard))

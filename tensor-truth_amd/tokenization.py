@@ -34,6 +34,71 @@ def _cap_tokenizer_threads() -> None:
             os.environ["RAYON_NUM_THREADS"] = "16"
 
 
+class PreTokenized:
+    """A passage whose token ids are already known (the index kept its leaves' ids at ingest: ``HipVectorIndex.leaf_token_ids``):
+    the BODY ids, without special tokens.  Stands in for the passage string in a (query, passage) pair handed to the reranker."""
+
+    __slots__ = ("ids",)
+
+    def __init__(self, ids):
+        self.ids = ids
+
+
+def truncate_longest_first(n_a: int, n_b: int, budget: int):
+    """The lengths the Rust ``tokenizers`` library keeps of a pair under ``TruncationStrategy::LongestFirst`` with ``budget`` =
+    max_length minus the pair's special tokens (tokenizers/src/utils/truncation.rs, restated): nothing is cut while the pair fits;
+    otherwise the shorter side keeps what it has up to half the budget and the longer side gets the rest."""
+    if n_a + n_b <= budget:
+        return n_a, n_b
+    n1, n2, swap = n_a, n_b, False
+    if n1 > n2:
+        n1, n2, swap = n2, n1, True
+    n2 = n1 if n1 > budget else max(n1, budget - n1)
+    if n1 + n2 > budget:
+        n1 = budget // 2
+        n2 = n1 + budget % 2
+    if swap:
+        n1, n2 = n2, n1
+    return n1, n2
+
+
+def tokenizer_signature(tk) -> str:
+    """Two components may exchange token ids only if their tokenizers are the same function: a digest of the serialised tokenizer
+    (HFTokenizer) or of the stand-in's parameters."""
+    if isinstance(tk, HFTokenizer):
+        return "hf:" + hashlib.sha256(tk._json.encode("utf-8")).hexdigest()
+    if isinstance(tk, HashTokenizer):
+        return f"hash:{tk.arch}:{tk.vocab_size}"
+    return f"other:{id(tk)}"
+
+
+def assemble_pairs(tk, pairs, max_length: int):
+    """(query string, PreTokenized passage) pairs -> the ids ``tk.encode_pair(query, passage_text, max_length)`` would return, without
+    tokenising the passages again: the query is tokenised once per distinct string, the specials come from the tokenizer's layout,
+    the cut is the library's longest-first rule.  -> list of int32 arrays."""
+    import numpy as np
+
+    sp = tk.sp
+    sep = np.asarray(sp.pair_sep, dtype=np.int32)
+    budget = max_length - 2 - len(sp.pair_sep)
+    qcache = {}
+    out = []
+    for q, pre in pairs:
+        qi = qcache.get(q)
+        if qi is None:
+            qi = qcache[q] = np.asarray(tk.encode(q, None)[1:-1], dtype=np.int32)
+        pi = pre.ids
+        n1, n2 = truncate_longest_first(len(qi), len(pi), budget)
+        ids = np.empty(n1 + n2 + 2 + len(sep), dtype=np.int32)
+        ids[0] = sp.bos
+        ids[1:1 + n1] = qi[:n1]
+        ids[1 + n1:1 + n1 + len(sep)] = sep
+        ids[1 + n1 + len(sep):-1] = pi[:n2]
+        ids[-1] = sp.eos
+        out.append(ids)
+    return out
+
+
 class SpecialTokens:
     def __init__(self, arch: str):
         if arch == "xlmr":
@@ -95,11 +160,8 @@ class HashTokenizer:
         """-> (ids, token_type_ids); truncation 'longest_first' like CrossEncoder's tokenizer call."""
         ia, ib = self._ids(a), self._ids(b)
         budget = max_length - 2 - len(self.sp.pair_sep)
-        while len(ia) + len(ib) > budget and (ia or ib):
-            if len(ia) > len(ib):
-                ia.pop()
-            else:
-                ib.pop()
+        na, nb = truncate_longest_first(len(ia), len(ib), max(budget, 0))      # (the Rust library's rule: one definition for both tokenizers)
+        ia, ib = ia[:na], ib[:nb]
         ids = [self.sp.bos] + ia + self.sp.pair_sep + ib + [self.sp.eos]
         n_a = 1 + len(ia) + (1 if self.arch != "xlmr" else len(self.sp.pair_sep))
         types = [0] * n_a + [1] * (len(ids) - n_a) if self.arch != "xlmr" else [0] * len(ids)

@@ -56,6 +56,9 @@ class HipVectorIndex:
         self._mat = torch.empty((0, dim), dtype=torch.bfloat16, device=dev)
         self.n = 0
         self.leaf_ids: List[str] = []          # row -> node id
+        # node id -> int32 body ids of the leaf's EMBED content as the embedder tokenised it (filled by add(token_ids=...): the
+        # worker-process ingest with keep_leaf_token_ids; not persisted -- a loaded index reranks from strings)
+        self.leaf_token_ids: Optional[Dict[str, np.ndarray]] = None
         self.docstore: Dict[str, TextNode] = {}  # every node (leaves + parents), for auto-merging
         self.ref_docs: Dict[str, List[str]] = {}  # source document id -> ids of all its nodes (docstore ref_doc_info)
         self._lock = threading.RLock()
@@ -80,10 +83,13 @@ class HipVectorIndex:
             grown[: self.n] = self._mat[: self.n]
             self._mat = grown
 
-    def add(self, nodes: Sequence[TextNode], embeddings=None, show_progress: bool = False) -> List[str]:
+    def add(self, nodes: Sequence[TextNode], embeddings=None, show_progress: bool = False, token_ids=None) -> List[str]:
         """Insert leaf nodes (embedding them with ``embed_model`` unless ``embeddings`` is given).
         Mirrors ``VectorStoreIndex(leaf_nodes, ...)`` / ``index.insert_nodes`` (text embedded with
-        MetadataMode.EMBED, ``indexing/builder.py:437-442``, ``document_index.py:527``)."""
+        MetadataMode.EMBED, ``indexing/builder.py:437-442``, ``document_index.py:527``).
+        ``token_ids`` (optional, one int array per node, specials included, as the embedder's tokenizer produced them for the node's
+        EMBED content): kept in ``leaf_token_ids`` so that a reranker with the same tokenizer never tokenises these passages again
+        (``HipSentenceTransformerRerank.attach_token_source``); a sequence that hit the embedder's length limit is not kept."""
         if not nodes:
             return []
         if embeddings is None:
@@ -109,9 +115,24 @@ class HipVectorIndex:
                 self.docstore[nd.id_] = nd
                 if self._row_of is not None:
                     self._row_of[nd.id_] = self.n + j
+            if token_ids is not None:
+                if self.leaf_token_ids is None:
+                    self.leaf_token_ids = {}
+                limit = getattr(self.embed_model, "max_length", None)
+                for nd, ids in zip(nodes, token_ids):
+                    if limit is None or len(ids) < limit:
+                        self.leaf_token_ids[nd.id_] = np.asarray(ids[1:-1], dtype=np.int32)       # body only: the reranker adds its own specials
             self.n += len(nodes)
             self._version += 1
         return [nd.id_ for nd in nodes]
+
+    def token_source(self):
+        """-> (callable node id -> body ids or None, tokenizer signature, text instruction) for ``attach_token_source``, or None."""
+        if not self.leaf_token_ids or self.embed_model is None or not hasattr(self.embed_model, "_tokenizer"):
+            return None
+        from .tokenization import tokenizer_signature
+
+        return self.leaf_token_ids.get, tokenizer_signature(self.embed_model._tokenizer), getattr(self.embed_model, "text_instruction", "") or ""
 
     def add_to_docstore(self, nodes: Iterable[TextNode]) -> None:
         """Parents of the hierarchy (``storage_context.docstore.add_documents``, builder.py:430)."""
@@ -142,6 +163,8 @@ class HipVectorIndex:
                     self._compact()
             for nid in drop:
                 self.docstore.pop(nid, None)
+                if self.leaf_token_ids is not None:
+                    self.leaf_token_ids.pop(nid, None)
         return len(rows)
 
     def _compact(self) -> None:

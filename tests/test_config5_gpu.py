@@ -427,3 +427,93 @@ def test_reference_geometry_with_subword_tokenizer_workers_and_pair_pool(dev, bu
     assert pooled == local == serial
     assert all(len(r) == 5 and r[0][1] >= r[-1][1] for r in serial)
     mm.ModelManager.reset_instance()
+
+
+def test_leaves_tokenised_once_at_ingest_rerank_from_stored_ids(dev, built_lib, monkeypatch):
+    """Round 5: build_index(keep_leaf_token_ids=True) keeps every leaf's token ids (the embedder's tokenizer; bge-m3 and
+    bge-reranker-v2-m3 share XLM-R's); build_retrieval_service hands them to the reranker, which then tokenises only the query.
+    The composed service must return the same nodes with the SAME score bits as with the reranker tokenising every passage string --
+    from several threads (coalesced batches mixing leaves with auto-merged parents, which have no stored ids) and for a lone caller;
+    a reranker with another tokenizer refuses the ids."""
+    import os
+    import sys
+    import threading
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import synth_text as st
+    from tensor_truth_amd import model_manager as mm
+    from tensor_truth_amd.encoder import EncoderConfig
+    from tensor_truth_amd.index_builder import build_index
+    from tensor_truth_amd.retrieval_service import build_retrieval_service
+    from tensor_truth_amd.schema import TextNode
+    from tensor_truth_amd.tokenization import HashTokenizer
+
+    monkeypatch.setenv("TT_PAIR_WORKERS", "0")
+    tk = st.unigram_tokenizer()
+    ecfg = EncoderConfig(**{**XENC, "vocab_size": 250_002, "max_pos": 2100, "num_labels": 0})
+    rcfg = EncoderConfig(**{**XENC, "vocab_size": 250_002, "max_pos": 514})
+    mm.ModelManager.reset_instance()
+    mgr = mm.ModelManager.get_instance()
+    mgr.model_kwargs_overrides["BAAI/bge-m3"] = {"encoder_config": ecfg, "synthetic_seed": 5, "torch_dtype": "bfloat16", "tokenizer": tk}
+    mgr.model_kwargs_overrides["BAAI/bge-reranker-v2-m3"] = {"encoder_config": rcfg, "synthetic_seed": 6, "torch_dtype": "bfloat16", "tokenizer": tk}
+    emb = mgr.get_embedder("BAAI/bge-m3", "cuda")
+    rng = np.random.default_rng(18)
+    lex = st.lexicon()
+    docs = []
+    for d in range(80):
+        sents = []
+        for block in range(3):
+            band = int(rng.integers(0, 30)) * 1000
+            for _ in range(int(rng.integers(20, 40))):
+                sents.append(" ".join(lex[band + int(j)] for j in rng.integers(0, 1000, size=int(rng.integers(8, 20)))) + ".")
+        docs.append(TextNode(text=" ".join(sents), metadata={"title": f"doc {d}", "file_name": f"d{d}.md"}))
+    index = build_index(docs, emb, chunking_strategy="semantic_hierarchical", chunk_sizes=[256, 64, 32], chunk_overlap=8,
+                        token_counter="embedder", workers=3, keep_leaf_token_ids=True)
+    torch.cuda.synchronize()
+    assert index.leaf_token_ids is not None and len(index.leaf_token_ids) == index.n > 300
+    some = index.leaf_ids[7]
+    from tensor_truth_amd.schema import MetadataMode
+
+    assert index.leaf_token_ids[some].tolist() == tk.encode(index.docstore[some].get_content(metadata_mode=MetadataMode.EMBED))[1:-1]
+    params = {"reranker_top_n": 5, "similarity_top_k": 24, "confidence_cutoff": 0.0}
+    svc = build_retrieval_service([index], params, device="cuda", manager=mgr)
+    rr = mgr.get_reranker("BAAI/bge-reranker-v2-m3", top_n=5, device="cuda")
+    assert rr._token_source is not None
+    live = [x for x in index.leaf_ids if x is not None]
+    queries = [" ".join(index.docstore[live[int(rng.integers(0, len(live)))]].text.replace(".", " ").split()[:10]) + f" q{i}" for i in range(24)]
+
+    def run(qs, threads):
+        out, errs = [None] * len(qs), []
+
+        def work(t):
+            try:
+                for i in range(t, len(qs), threads):
+                    r = svc.retrieve(qs[i])
+                    out[i] = [(n.node.id_, n.score) for n in r.source_nodes]
+            except Exception as exc:  # noqa: BLE001
+                errs.append(exc)
+
+        ts = [threading.Thread(target=work, args=(t,)) for t in range(threads)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        assert not errs, errs
+        return out
+
+    pre0 = rr.stats.get("pretokenized", 0)
+    with_ids = run(queries, 6)
+    assert rr.stats.get("pretokenized", 0) - pre0 > 24 * 5           # most candidates are leaves with stored ids
+    lone = run(queries[:3], 1)
+    if hasattr(svc._retriever, "clear_cache"):
+        svc._retriever.clear_cache()
+    rr.detach_token_source()
+    from_text = run(queries, 6)
+    assert with_ids == from_text and lone == from_text[:3]
+    assert all(len(r) == 5 for r in from_text)
+    # another tokenizer: refused, strings stay the path
+    src, sig, instr = index.token_source()
+    assert rr.attach_token_source(src, sig, instr) is True
+    assert rr.attach_token_source(src, "hash:xlmr:250002", instr) is False and rr._token_source is None
+    assert rr.attach_token_source(src, sig, "passage: ") is False
+    mm.ModelManager.reset_instance()

@@ -1349,3 +1349,44 @@ def test_pair_tokenizer_pool_returns_the_in_process_ids(monkeypatch):
     assert [a.tolist() for a in ids2] == [w[0] for w in want[:2]]
     monkeypatch.setenv("TT_PAIR_WORKERS", "0")
     assert iw.get_pair_pool(tk) is None
+
+
+def test_pretokenized_pairs_equal_the_tokenizers_own_pair_encoding():
+    """Round 5: leaves are tokenised once, at ingest (HipVectorIndex.leaf_token_ids); the reranker then assembles
+    ``<s> q </s></s> passage </s>`` from the stored body ids instead of tokenising the passage again.  ``assemble_pairs`` must return
+    exactly what the tokenizer's own pair call returns -- specials, order and the Rust library's longest-first truncation (restated in
+    ``truncate_longest_first`` and checked here against the library itself over every regime: no cut, only the longer side cut, both
+    sides cut, odd and even budgets) -- for the trained Unigram tokenizer and for the hashing stand-in."""
+    import sys
+
+    import numpy as np
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import synth_text as st
+    from tensor_truth_amd.tokenization import (HashTokenizer, PreTokenized, assemble_pairs, tokenizer_signature,
+                                               truncate_longest_first)
+
+    # the rule against a brute-force reading of "remove from the longer side until it fits; the shorter side keeps up to half"
+    for budget in (7, 8, 59, 60, 508):
+        for na in range(0, 40, 3):
+            for nb in range(0, 700, 37):
+                a, b = truncate_longest_first(na, nb, budget)
+                assert a <= na and b <= nb and (a + b == min(na + nb, budget) or na + nb <= budget)
+                if na + nb > budget and na <= budget // 2:
+                    assert a == na and b == budget - na
+    tk = st.unigram_tokenizer()
+    rng = np.random.default_rng(1)
+    for t in range(120):
+        nq, npw, ml = int(rng.integers(1, 300)), int(rng.integers(1, 400)), int(rng.choice([23, 24, 64, 129, 512]))
+        q, p = st.zipf_text(1000 + t, nq), st.zipf_text(5000 + t, npw)
+        body = np.asarray(tk.encode(p, None)[1:-1], dtype=np.int32)
+        assert assemble_pairs(tk, [(q, PreTokenized(body))], ml)[0].tolist() == tk.encode_pair(q, p, ml)[0], (nq, npw, ml)
+    for arch in ("xlmr", "bert"):
+        ht = HashTokenizer(arch, 30000)
+        for t in range(60):
+            nq, npw, ml = int(rng.integers(1, 200)), int(rng.integers(1, 300)), int(rng.choice([23, 24, 64, 129, 512]))
+            q = " ".join(f"w{int(j)}" for j in rng.integers(0, 999, size=nq))
+            p = " ".join(f"w{int(j)}" for j in rng.integers(0, 999, size=npw))
+            body = np.asarray(ht.encode(p, None)[1:-1], dtype=np.int32)
+            assert assemble_pairs(ht, [(q, PreTokenized(body))], ml)[0].tolist() == ht.encode_pair(q, p, ml)[0], (arch, nq, npw, ml)
+    assert tokenizer_signature(tk) == tokenizer_signature(st.unigram_tokenizer()) != tokenizer_signature(HashTokenizer("xlmr", 250002))
