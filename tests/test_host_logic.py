@@ -1390,3 +1390,45 @@ def test_pretokenized_pairs_equal_the_tokenizers_own_pair_encoding():
             body = np.asarray(ht.encode(p, None)[1:-1], dtype=np.int32)
             assert assemble_pairs(ht, [(q, PreTokenized(body))], ml)[0].tolist() == ht.encode_pair(q, p, ml)[0], (arch, nq, npw, ml)
     assert tokenizer_signature(tk) == tokenizer_signature(st.unigram_tokenizer()) != tokenizer_signature(HashTokenizer("xlmr", 250002))
+
+
+def test_posted_sends_do_not_block_on_a_busy_peer():
+    """ingest_workers._PipeConn.post / pump (round 5): the feeder hands a busy worker its next work unit -- larger than the pipe --
+    WITHOUT parking in write(): post() returns at once with bytes pending, pump() moves what the pipe takes, and the peer, once it
+    reads, receives the very objects, in order.  (A blocking send here cost a 6000-document build 44 of its 78 seconds.)"""
+    import threading
+    import time
+
+    import numpy as np
+
+    from tensor_truth_amd import ingest_workers as iw
+
+    r1, w1 = os.pipe()          # feeder -> peer
+    r2, w2 = os.pipe()          # peer -> feeder
+    feeder = iw._PipeConn(r2, w1, duplex_safe=True)
+    peer = iw._PipeConn(r1, w2)
+    big = [("split", 7, ["x" * 1000] * 3000), ("cut", 8, np.arange(300_000, dtype=np.float32))]
+    t0 = time.perf_counter()
+    for m in big:
+        feeder.post(m)
+    assert time.perf_counter() - t0 < 1.0 and feeder.pending()          # ~4 MB against a 64 KiB pipe: nothing blocked
+    got = []
+
+    def slow_peer():
+        time.sleep(0.3)                                                   # "busy with its current unit"
+        for _ in big:
+            got.append(peer.recv())
+        peer.send(("done", 1))
+
+    th = threading.Thread(target=slow_peer)
+    th.start()
+    deadline = time.time() + 30
+    while feeder.pending() and time.time() < deadline:
+        feeder.pump()
+        time.sleep(0.001)
+    assert not feeder.pending()
+    assert feeder.recv() == ("done", 1)
+    th.join(timeout=10)
+    assert got[0] == big[0] and got[1][:2] == ("cut", 8) and np.array_equal(got[1][2], big[1][2])
+    for fd in (r1, w1, r2, w2):
+        os.close(fd)
