@@ -57,7 +57,7 @@ class HipVectorIndex:
         self.n = 0
         self.leaf_ids: List[str] = []          # row -> node id
         # node id -> int32 body ids of the leaf's EMBED content as the embedder tokenised it (filled by add(token_ids=...): the
-        # worker-process ingest with keep_leaf_token_ids; not persisted -- a loaded index reranks from strings)
+        # worker-process ingest with keep_leaf_token_ids; persisted as leaf_tokens.<generation>.npz)
         self.leaf_token_ids: Optional[Dict[str, np.ndarray]] = None
         self.docstore: Dict[str, TextNode] = {}  # every node (leaves + parents), for auto-merging
         self.ref_docs: Dict[str, List[str]] = {}  # source document id -> ids of all its nodes (docstore ref_doc_info)
@@ -245,8 +245,15 @@ class HipVectorIndex:
                 nodes = {nid: _node_to_dict(nd) for nid, nd in self.docstore.items()}
                 ref_docs = {k: list(v) for k, v in self.ref_docs.items()}
                 n_rows = self.n
+                tok = None
+                if self.leaf_token_ids:        # row-aligned CSR of the kept leaf token ids (rows without ids: length 0)
+                    arrs = [self.leaf_token_ids.get(nid) for nid in leaf_ids]
+                    lens = np.fromiter((0 if a is None else len(a) for a in arrs), dtype=np.int32, count=len(arrs))
+                    flat = np.concatenate([a for a in arrs if a is not None and len(a)]) if int(lens.sum()) else np.zeros(0, np.int32)
+                    tok = (flat.astype(np.int32), lens)
             gen = _next_generation(persist_dir)
             corpus_name = f"corpus.{gen}.bf16"
+            tokens_name = f"leaf_tokens.{gen}.npz" if tok is not None else None
 
             def _atomic(name: str, write) -> None:
                 tmp = os.path.join(persist_dir, f".{name}.tmp.{os.getpid()}.{threading.get_ident()}")
@@ -254,6 +261,11 @@ class HipVectorIndex:
                 os.replace(tmp, os.path.join(persist_dir, name))
 
             _atomic(corpus_name, lambda t: mat_host.tofile(t))
+            if tok is not None:
+                def _write_tokens(t):
+                    with open(t, "wb") as f:
+                        np.savez(f, flat=tok[0], lens=tok[1])
+                _atomic(tokens_name, _write_tokens)
             # the reference's index_metadata.json (indexing/metadata.py:103-146) + what this store adds
             model = embedding_model or getattr(self.embed_model, "model_name", None)
             meta = {"embedding_model": model, "embedding_model_id": sanitize_model_id(model) if model else None,
@@ -270,9 +282,14 @@ class HipVectorIndex:
 
             _atomic(INDEX_METADATA_FILENAME, _dump(meta))
             _atomic("nodes.json", _dump({"dim": self.dim, "leaf_ids": leaf_ids, "nodes": nodes, "ref_docs": ref_docs,
-                                         "corpus_file": corpus_name, "generation": gen}))
+                                         "corpus_file": corpus_name, "generation": gen, "leaf_tokens_file": tokens_name}))
             for name in os.listdir(persist_dir):     # LOWER generations only: unreferenced once nodes.json has moved
                 g = _generation_of(name)
+                if g is None and name.startswith("leaf_tokens.") and name.endswith(".npz"):
+                    try:
+                        g = int(name[len("leaf_tokens."):-len(".npz")])
+                    except ValueError:
+                        g = None
                 if g is not None and g < gen:
                     try:
                         os.remove(os.path.join(persist_dir, name))
@@ -289,6 +306,15 @@ class HipVectorIndex:
         idx.leaf_ids = list(blob["leaf_ids"])
         idx.ref_docs = {k: list(v) for k, v in (blob.get("ref_docs") or {}).items()}
         idx.docstore = {nid: _node_from_dict(nid, d) for nid, d in blob["nodes"].items()}
+        tname = blob.get("leaf_tokens_file")
+        if tname and os.path.exists(os.path.join(persist_dir, tname)):
+            # the leaves' token ids kept at ingest (build_index(keep_leaf_token_ids=True)): usable by a reranker whose tokenizer is
+            # THIS embed_model's -- token_source() reports the signature of the tokenizer the caller loads the index with
+            with np.load(os.path.join(persist_dir, tname)) as z:
+                flat, lens = z["flat"], z["lens"]
+            if len(lens) == len(idx.leaf_ids):
+                ends = np.cumsum(lens)
+                idx.leaf_token_ids = {nid: flat[e - n:e] for nid, e, n in zip(idx.leaf_ids, ends, lens) if n > 0 and nid is not None}
         return idx
 
 

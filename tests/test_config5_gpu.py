@@ -511,6 +511,24 @@ def test_leaves_tokenised_once_at_ingest_rerank_from_stored_ids(dev, built_lib, 
     from_text = run(queries, 6)
     assert with_ids == from_text and lone == from_text[:3]
     assert all(len(r) == 5 for r in from_text)
+    # the ids survive persist / load (leaf_tokens.<generation>.npz beside the matrix), and a deleted leaf's ids go with it
+    import tempfile
+
+    from tensor_truth_amd.vector_index import HipVectorIndex
+
+    with tempfile.TemporaryDirectory() as pdir:
+        index.persist(pdir)
+        again = HipVectorIndex.load(pdir, embed_model=emb)
+        assert again.leaf_token_ids is not None and set(again.leaf_token_ids) == set(index.leaf_token_ids)
+        assert all(np.array_equal(again.leaf_token_ids[k], index.leaf_token_ids[k]) for k in list(index.leaf_token_ids)[::17])
+        assert again.token_source()[1] == index.token_source()[1]
+        victim = again.leaf_ids[3]
+        again.delete([victim])
+        assert victim not in again.leaf_token_ids
+        again.persist(pdir)
+        third = HipVectorIndex.load(pdir, embed_model=emb)
+        assert len(third.leaf_token_ids) == len(index.leaf_token_ids) - 1 and victim not in third.leaf_token_ids
+        assert sum(f.startswith("leaf_tokens.") for f in os.listdir(pdir)) == 1          # older generations removed
     # another tokenizer: refused, strings stay the path
     src, sig, instr = index.token_source()
     assert rr.attach_token_source(src, sig, instr) is True
