@@ -2044,6 +2044,13 @@ template <int EPI>
 int launch_skinny(const GemmParams& p, hipStream_t st) {
     {
         TtProfScope prof(TT_K_GEMM, st);
+#if TT_DIAG   // TT_GEMM_SKINNY_PF=32 / TT_GEMM_SKINNY_MT=2: shape experiments of round 5 (every K step of a K = 1024 projection in flight; two row tiles per wave)
+        static const int pf_env = TT_DIAG_ENV_INT("TT_GEMM_SKINNY_PF", 0);
+        static const int mt_env = TT_DIAG_ENV_INT("TT_GEMM_SKINNY_MT", 0);
+        if (pf_env == 32) hipLaunchKernelGGL((gemm_skinny_kernel<EPI, false, 1, 32>), dim3(p.N / 16, p.M / 16), dim3(64), 0, st, p);
+        else if (mt_env == 2 && p.M % 32 == 0) hipLaunchKernelGGL((gemm_skinny_kernel<EPI, false, 2, 16>), dim3(p.N / 16, p.M / 32), dim3(64), 0, st, p);
+        else
+#endif
         if (skinny_mt4()) hipLaunchKernelGGL((gemm_skinny_kernel<EPI, false, 4, 8>), dim3(p.N / 16, p.M / 64), dim3(64), 0, st, p);
         else hipLaunchKernelGGL((gemm_skinny_kernel<EPI, false>), dim3(p.N / 16, p.M / 16), dim3(64), 0, st, p);
     }
