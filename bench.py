@@ -758,7 +758,8 @@ def main():
                 sd = surface_leg(args, dev, shard_rows, emb_cfg, rr_cfg, world, rank, lo, data_group, default_precision=True,
                                  n_queries=max(args.surface_threads * 3, 96))
                 surface["default_precision"] = {k: sd[k] for k in ("queries_per_s", "queries", "threads", "single_caller_ms_per_query",
-                                                                   "scan_batches", "rerank_batches", "precision")}
+                                                                   "single_caller_ms_per_query_with_leaf_token_ids",
+                                                                   "lone_caller_breakdown", "scan_batches", "rerank_batches", "precision")}
         else:
             # Several ranks: the leg's collectives run over RCCL, which no box available to this build could exercise (two
             # ranks cannot share a GPU under RCCL; the gloo runs are the evidence).  The headline above is measured and must
@@ -1149,6 +1150,114 @@ def _run_threads(n_threads, work_items, fn):
     return dt, out
 
 
+PROF_KIDS = (("scan_filter", 1), ("scan_sample", 2), ("select", 3), ("gemm", 4), ("attention", 5), ("rowops", 6), ("scan_tail", 7))
+
+
+def read_prof_families(lib):
+    """tt_prof_read of every kernel family -> {family: (ms, launches)} (events of the CALLING thread since tt_prof_enable)."""
+    import ctypes
+
+    out = {}
+    for name, kid in PROF_KIDS:
+        ms, n = ctypes.c_double(0), ctypes.c_int(0)
+        lib.tt_prof_read(kid, ctypes.byref(ms), ctypes.byref(n))
+        out[name] = (ms.value, n.value)
+    return out
+
+
+def lone_caller_breakdown(dev, emb, index, retr, rr, queries, top_n):
+    """ONE un-batched caller (the reference's own usage: README.md:13, rag_engine.py:420-424, rag_service.py:594-622): where a
+    query's wall time goes.  Pass A: wall clock per call with host-side timers around the stages of retrieve() and
+    postprocess_nodes() (instance-level wrappers; launches are asynchronous, so a stage's host time is what the request thread
+    spends issuing it, and the two waits -- the scan result's copy to the host, the scores' event -- hold the GPU time the host did
+    not cover).  Pass B: the same calls with an event pair around every kernel launch (tt_prof_*: a lone caller's launches are all
+    made by the calling thread), read after retrieve() and after postprocess_nodes(): GPU milliseconds per kernel family and
+    phase.  Both passes: mean over the given queries."""
+    from tensor_truth_amd import _lib
+    from tensor_truth_amd.schema import QueryBundle
+
+    lib = _lib.load_library()
+    host = {}
+
+    def wrap(obj, name, key):
+        orig = getattr(obj, name)
+
+        def timed(*a, **k):
+            t = time.perf_counter()
+            try:
+                return orig(*a, **k)
+            finally:
+                host[key] = host.get(key, 0.0) + time.perf_counter() - t
+        had = name in getattr(obj, "__dict__", {})
+        setattr(obj, name, timed)
+        return obj, name, orig if had else None
+
+    hooks = [wrap(emb, "_tokenize", "tokenise_query"), wrap(emb, "embed_token_batches", "query_embed_issue"),
+             wrap(index, "search", "scan_issue"), wrap(retr, "nodes_from_hits", "build_nodes"),
+             wrap(rr, "_tokenize_pairs", "pair_tokenise_or_assemble"), wrap(rr, "_pack", "pair_pack"),
+             wrap(rr, "_score_packed", "rerank_issue"),
+             wrap(rr._front, "_finish", "rerank_wait")]      # (the coalescer holds the bound finish phase: wrapped where it is kept)
+    try:
+        n = len(queries)
+        wall = {"retrieve": 0.0, "postprocess": 0.0}
+        torch.cuda.synchronize(dev)
+        for q in queries:
+            t0 = time.perf_counter()
+            nodes = retr.retrieve(q)
+            t1 = time.perf_counter()
+            out = rr.postprocess_nodes(nodes, query_bundle=QueryBundle(query_str=q))
+            t2 = time.perf_counter()
+            assert len(out) == min(top_n, len(nodes))
+            wall["retrieve"] += t1 - t0
+            wall["postprocess"] += t2 - t1
+        host_ms = {k: v / n * 1e3 for k, v in host.items()}
+        wall_ms = {k: v / n * 1e3 for k, v in wall.items()}
+        # what is left of each call once its timed stages are taken out: the scan's result copy (= waiting for embedding + scan
+        # on the GPU), node/passages bookkeeping, sorting
+        host_ms["retrieve_wait_and_rest"] = wall_ms["retrieve"] - sum(host_ms.get(k, 0.0) for k in
+                                                                     ("tokenise_query", "query_embed_issue", "scan_issue", "build_nodes"))
+        host_ms["query_embed_issue"] = host_ms.get("query_embed_issue", 0.0)
+        # (_tokenize runs inside _embed_texts, embed_token_batches beside it; search() is called with the embedding as its argument,
+        # so its timer does not contain the embedding's)
+        host_ms["postprocess_rest"] = wall_ms["postprocess"] - sum(host_ms.get(k, 0.0) for k in
+                                                                   ("pair_tokenise_or_assemble", "pair_pack", "rerank_issue", "rerank_wait"))
+        gpu = {"retrieve": {}, "postprocess": {}}
+        for q in queries:
+            lib.tt_prof_enable(1)
+            nodes = retr.retrieve(q)
+            torch.cuda.synchronize(dev)
+            a = read_prof_families(lib)
+            lib.tt_prof_enable(1)
+            rr.postprocess_nodes(nodes, query_bundle=QueryBundle(query_str=q))
+            torch.cuda.synchronize(dev)
+            b = read_prof_families(lib)
+            lib.tt_prof_enable(0)
+            for ph, pr in (("retrieve", a), ("postprocess", b)):
+                for fam, (ms, cnt) in pr.items():
+                    if cnt:
+                        g = gpu[ph].setdefault(fam, [0.0, 0])
+                        g[0] += ms
+                        g[1] += cnt
+        gpu_ms = {ph: {fam: {"ms": v[0] / n, "launches": v[1] // n} for fam, v in d.items()} for ph, d in gpu.items()}
+        return {"queries": n, "wall_ms_per_query": wall_ms["retrieve"] + wall_ms["postprocess"], "wall_ms": wall_ms, "host_ms": host_ms,
+                "gpu_kernel_ms": gpu_ms,
+                "gpu_kernel_ms_total": {ph: sum(v["ms"] for v in d.values()) for ph, d in gpu_ms.items()},
+                "what": "one caller, one query at a time: wall_ms = the two plugin calls; host_ms = request-thread time per stage "
+                        "(issue = enqueueing asynchronous launches; *_wait = blocked on the GPU); gpu_kernel_ms = HIP-event time per "
+                        "kernel family, per phase, from a second pass with an event pair around every launch (retrieve: gemm / "
+                        "attention / rowops = the query embedding, scan_* / select = the scan; postprocess = the rerank forward)"}
+    finally:
+        lib.tt_prof_enable(0)
+        for obj, name, orig in hooks:
+            if orig is not None:
+                setattr(obj, name, orig)
+            else:
+                try:
+                    delattr(obj, name)
+                except AttributeError:
+                    pass
+
+
 _TEXTS = {}
 
 
@@ -1210,6 +1319,9 @@ def surface_leg(args, dev, shard_rows, emb_cfg, rr_cfg, world=1, rank=0, row_lo=
         # ... and a lone caller when the index kept its leaves' token ids at ingest (build_index(keep_leaf_token_ids=True)): here the
         # synthetic docstore's 4096 pool texts tokenised once -- the reranker then tokenises only the query string
         lat_ids = None
+        breakdown = None
+        if world == 1 and retr._tick is None and rr._front is not None:
+            breakdown = {"from_strings": lone_caller_breakdown(dev, emb, index, retr, rr, queries[18:26], topn)}
         if texts.tokenizer is not None and world == 1:
             from tensor_truth_amd.tokenization import tokenizer_signature
 
@@ -1223,6 +1335,8 @@ def surface_leg(args, dev, shard_rows, emb_cfg, rr_cfg, world=1, rank=0, row_lo=
                     one(q)
                 torch.cuda.synchronize()
                 lat_ids = (time.perf_counter() - t1) / 8
+                if breakdown is not None:
+                    breakdown["with_leaf_token_ids"] = lone_caller_breakdown(dev, emb, index, retr, rr, queries[26:34], topn)
                 rr.detach_token_source()
     finally:
         if world > 1:
@@ -1239,6 +1353,7 @@ def surface_leg(args, dev, shard_rows, emb_cfg, rr_cfg, world=1, rank=0, row_lo=
             "ranks": world, "scan_batches": n_scan, "rerank_batches": n_rr,
             "single_caller_ms_per_query": lat * 1e3,
             "single_caller_ms_per_query_with_leaf_token_ids": None if lat_ids is None else lat_ids * 1e3,
+            "lone_caller_breakdown": breakdown,
             "precision": getattr(rr, "precision", None) or ("reference (default)" if default_precision else "bf16"),
             "tokenizer": tokenizer,
             "tokenizer_detail": ("trained Unigram model, 250 002 pieces, XLM-R layout and pair template (tools/synth_text.py; Rust `tokenizers`, "
