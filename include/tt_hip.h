@@ -29,6 +29,12 @@
 extern "C" {
 #endif
 
+/* The library is built with -fvisibility=hidden: the declarations of this header -- and nothing else -- are its dynamic
+ * symbols (`nm -D libtt_hip.so`; tests/test_lib_abi.py). */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
+
 #define TT_OK 0
 #define TT_E_INVALID (-1)   /* bad argument (shape, alignment, null pointer)  */
 #define TT_E_UNSUPPORTED (-2) /* shape outside the compiled kernel set         */
@@ -496,6 +502,10 @@ int tt_attention_x3_f16(const void* qk_planes, int ld_qk, int q_col0, int k_col0
  * 7 scan tail rows (the < 256 rows behind the tiled filter pass of a 65+ query batch) */
 int tt_prof_enable(int on);
 int tt_prof_read(int which, double* total_ms_host, int* launches_host);
+
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 
 #ifdef __cplusplus
 }

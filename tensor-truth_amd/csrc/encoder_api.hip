@@ -428,7 +428,7 @@ int tt_gemm_fp8_ex(const void* a8, const float* a_scale, const void* w8, const f
 // diagnostic only (not in tt_hip.h): the varlen attention with s_memtime stamps of one workgroup (tools/att_stamps)
 #endif
 #if !TT_F16 && TT_DIAG   // bf16 instantiation of the DIAGNOSTIC library only (make DIAG=1): libtt_hip.so exports exactly include/tt_hip.h
-int tt_attention_debug_stamps(const void* qk, int ld_qk, int q_col0, int k_col0, const void* vt, int ldvt, void* out,
+__attribute__((visibility("default"))) int tt_attention_debug_stamps(const void* qk, int ld_qk, int q_col0, int k_col0, const void* vt, int ldvt, void* out,
                               int ld_out, const int32_t* seq_start, const int32_t* seq_len, int n_seq, int heads,
                               int head_dim, int max_len, void* stamps, void* stream) {
     AttnParams a{};
@@ -441,7 +441,7 @@ int tt_attention_debug_stamps(const void* qk, int ld_qk, int q_col0, int k_col0,
 }
 
 // diagnostic only (not in tt_hip.h): run the bias GEMM with a stamp buffer in GemmParams.vt
-int tt_gemm_debug_stamps(const void* a, const void* w, const float* bias, void* c, int m, int n, int k, void* stamps,
+__attribute__((visibility("default"))) int tt_gemm_debug_stamps(const void* a, const void* w, const float* bias, void* c, int m, int n, int k, void* stamps,
                          void* stream) {
     GemmParams g{};
     g.A = (const uint16_t*)a; g.lda = k; g.W = (const uint16_t*)w; g.bias = bias; g.C = (uint16_t*)c; g.ldc = n;

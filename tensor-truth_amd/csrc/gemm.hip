@@ -1916,6 +1916,78 @@ __global__ __launch_bounds__(64) void gemm_skinny_kernel(GemmParams p) {
     else gemm_epilogue_tile<EPI, 1, MT>(p, acc, m0, n0, lane);
 }
 
+// ---- relay form of the skinny kernel (round 6) ------------------------------------------------------------------------------
+// The one-wave kernel above is a chain of memory round trips: a wave keeps PF K-steps of loads in flight and every refill waits
+// for HBM again -- a K = 4096 projection is 128 (split planes: 384) steps = 6 (16) round trips of ~2.5 us while 255 of the
+// CU's wave slots idle (split-plane FFN-down: 43 us for 16 MB of weights).  Bit-identity with the tiled kernels pins the MFMA
+// CHAIN of an output tile (one accumulator, K ascending in steps of 32), not who issues it: here a workgroup of NW waves owns the
+// 16 x 16 output tile, wave w loads the fragments of K-steps [t CH, (t + 1) CH) for its turns t = w, w + NW, ... -- ALL waves'
+// loads are in flight from the first cycle -- and the accumulator is relayed through LDS (1 KiB) from turn to turn: wave t % NW
+// reads it, runs its CH (x 3) MFMAs, writes it back, one workgroup barrier per turn.  Same instruction, operands and order per
+// output element as gemm_skinny_kernel and the tiled kernels: the same bits (tests/test_configs_gpu.py, test_encoder_gpu.py).
+template <int EPI, bool X3 = false, int NW = 8, int CH = 8>
+__global__ __launch_bounds__(64 * NW) void gemm_relay_kernel(GemmParams p) {
+    __shared__ f32x4 relay[64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16;
+    const int frow = lane & 15, fchk = lane >> 4;
+    const uint16_t* wp = p.W + (size_t)(n0 + frow) * (X3 ? p.ldw : p.K) + fchk * 8;
+    const uint16_t* ap = p.A + (size_t)(m0 + frow) * p.lda + fchk * 8;
+    const int nks1 = p.K / 32;                      // K-steps of 32 elements
+    const int turns = (nks1 + CH - 1) / CH;
+    const size_t lo = (size_t)nks1 * 32;            // split planes: the lo plane sits K elements behind the hi plane in a row
+    ex8 wh[CH], xh[CH], wl[X3 ? CH : 1], xl[X3 ? CH : 1];
+    auto issue = [&](int t) {
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int k = t * CH + c;
+            if (k < nks1) {
+                wh[c] = *reinterpret_cast<const ex8*>(wp + (size_t)k * 32);
+                xh[c] = *reinterpret_cast<const ex8*>(ap + (size_t)k * 32);
+                if constexpr (X3) {
+                    wl[c] = *reinterpret_cast<const ex8*>(wp + lo + (size_t)k * 32);
+                    xl[c] = *reinterpret_cast<const ex8*>(ap + lo + (size_t)k * 32);
+                }
+            }
+        }
+    };
+    if (wave < turns) issue(wave);
+    f32x4 acc[1][1] = {{f32x4{0.f, 0.f, 0.f, 0.f}}};
+    for (int t = 0; t < turns; ++t) {
+        if ((t % NW) == wave) {
+            if (t > 0) acc[0][0] = relay[lane];
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                if (t * CH + c < nks1) {
+                    acc[0][0] = TT_MFMA_16x16x32(wh[c], xh[c], acc[0][0]);
+                    if constexpr (X3) {          // the tiled kernel's order per 32 K elements: hi.hi, x_hi.w_lo, x_lo.w_hi
+                        acc[0][0] = TT_MFMA_16x16x32(wl[c], xh[c], acc[0][0]);
+                        acc[0][0] = TT_MFMA_16x16x32(wh[c], xl[c], acc[0][0]);
+                    }
+                }
+            }
+            if (t + 1 < turns) relay[lane] = acc[0][0];
+            if (t + NW < turns) issue(t + NW);
+        }
+        if (t + 1 < turns) __syncthreads();
+    }
+    if (((turns - 1) % NW) == wave) {
+        if constexpr (X3) gemm_epilogue_tile_x3<EPI, 1, 1>(p, acc, m0, n0, lane);
+        else gemm_epilogue_tile<EPI, 1, 1>(p, acc, m0, n0, lane);
+    }
+}
+
+// (diagnostic library: TT_GEMM_RELAY=0 puts the one-wave kernel back -- the A/B switch)
+inline bool skinny_relay() {
+    static const bool on = TT_DIAG_ENV_INT("TT_GEMM_RELAY", 1) != 0;
+    return on;
+}
+inline bool skinny_relay_16() {
+    static const bool on = TT_DIAG_ENV_INT("TT_GEMM_RELAY", 1) == 2;
+    return on;
+}
+
 // TT_GEMM_SKINNY_MT=4: round 2's shape (four row tiles per wave, 8 steps in flight), the A/B switch
 inline bool skinny_mt4() {
     static const bool on = TT_DIAG_ENV_INT("TT_GEMM_SKINNY_MT", 0) == 4;
@@ -1943,6 +2015,7 @@ int launch_x3(const GemmParams& p, hipStream_t st) {
             {
                 TtProfScope prof(TT_K_GEMM, st);
                 if (skinny_mt4()) hipLaunchKernelGGL((gemm_skinny_kernel<EPI, true, 4, 8>), dim3(p.N / 16, p.M / 64), dim3(64), 0, st, q);
+                else if (skinny_relay()) hipLaunchKernelGGL((gemm_relay_kernel<EPI, true>), dim3(p.N / 16, p.M / 16), dim3(64 * 8), 0, st, q);
                 else hipLaunchKernelGGL((gemm_skinny_kernel<EPI, true>), dim3(p.N / 16, p.M / 16), dim3(64), 0, st, q);
             }
             TT_CHECK_LAUNCH();
@@ -2052,6 +2125,11 @@ int launch_skinny(const GemmParams& p, hipStream_t st) {
         else
 #endif
         if (skinny_mt4()) hipLaunchKernelGGL((gemm_skinny_kernel<EPI, false, 4, 8>), dim3(p.N / 16, p.M / 64), dim3(64), 0, st, p);
+        // (the relay form is for the split-plane stream, 3 K / 32 steps: on the 16-bit stream one wave's 24 steps in flight already cover
+        // K = 1024 in two round trips and the relay's barriers cost 5-10 % -- profiles/r06_relay_ab.log; TT_GEMM_RELAY=2 forces it here)
+#if TT_DIAG
+        else if (skinny_relay_16()) hipLaunchKernelGGL((gemm_relay_kernel<EPI, false>), dim3(p.N / 16, p.M / 16), dim3(64 * 8), 0, st, p);
+#endif
         else hipLaunchKernelGGL((gemm_skinny_kernel<EPI, false>), dim3(p.N / 16, p.M / 16), dim3(64), 0, st, p);
     }
     TT_CHECK_LAUNCH();

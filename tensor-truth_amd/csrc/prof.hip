@@ -5,11 +5,12 @@
 
 namespace {
 struct Rec { int id; hipEvent_t e0, e1; };
+struct EvPair { hipEvent_t first, second; };     // (a type of this translation unit: its vector instantiations are not dynamic symbols)
 struct ProfState {
     bool on = false;
     unsigned mask = ~0u;     // bit id set: kernel id is timed
     std::vector<Rec> recs;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
+    std::vector<EvPair> pool;
 };
 thread_local ProfState g_prof;
 constexpr size_t kMaxRecs = 1 << 16;
@@ -37,7 +38,7 @@ void tt_prof_end(hipStream_t st) {
 }
 
 extern "C" int tt_prof_enable(int on) {
-    for (auto& r : g_prof.recs) g_prof.pool.emplace_back(r.e0, r.e1);
+    for (auto& r : g_prof.recs) g_prof.pool.push_back(EvPair{r.e0, r.e1});
     g_prof.recs.clear();
     g_prof.on = on != 0;
     g_prof.mask = (on == 0 || on == 1) ? ~0u : (unsigned)on;   // on > 1: bit mask of kernel ids (1 << id)

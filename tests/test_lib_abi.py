@@ -40,6 +40,13 @@ def test_product_library_exports_exactly_the_header_and_reads_no_environment(bui
     out = subprocess.run(["nm", "-D", "--defined-only", built_lib], check=True, capture_output=True, text=True).stdout
     exported = sorted({ln.split()[-1] for ln in out.splitlines() if " T " in ln and ln.split()[-1].startswith("tt_")})
     assert exported == _declared_symbols(), sorted(set(exported) ^ set(_declared_symbols()))
+    # nothing ELSE either -- the library is built with -fvisibility=hidden and the header opens the C names; no mangled
+    # C++ internal (_Z14tt_gemm_launch..., _Z16tt_select_launch...) or template instantiation rides along as a dynamic symbol.
+    # (Left: the toolchain's own data symbols, __hip_cuid_* / __hip_fatbin*, which hipcc emits per translation unit.)
+    stray = sorted(ln.split()[-1] for ln in out.splitlines()
+                   if ln.split()[-1] not in exported and not ln.split()[-1].startswith(("__hip_", "_init", "_fini", "__bss", "_edata", "_end")))
+    assert not stray, f"dynamic symbols beside the header's: {stray[:8]}"
+    assert not [x for x in stray if "tt_" in x]
     data = open(built_lib, "rb").read()
     # (TT_EPI_* are the epilogue enumerators of tt_hip.h quoted in the text of a HIP error message, not switches)
     env_names = sorted({m.group(0).decode() for m in re.finditer(rb"TT_[A-Z0-9_]{3,}", data)} - {"TT_EPI_SCAN"})
