@@ -25,6 +25,9 @@ import time
 
 # multi-process GPU work on this pool needs dmabuf IPC (RCCL otherwise fails in hipIpcGetMemHandle); must be set before HIP starts
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# the application's decision (tensor_truth_amd never sets it on its own): the Rust tokenizer's thread pool, read once when it starts --
+# 16 threads do a rerank batch's pairs as fast as 256 and do not fight a retrieval batch's query tokenisation (README, section "Tuning")
+os.environ.setdefault("RAYON_NUM_THREADS", "16")
 
 
 def launch_plan(argv, environ):

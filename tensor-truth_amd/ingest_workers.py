@@ -24,6 +24,7 @@ from __future__ import annotations
 
 import atexit
 import contextlib
+import logging
 import os
 import pickle
 import select
@@ -31,10 +32,13 @@ import struct
 import subprocess
 import sys
 import threading
+import time
 from collections import deque
 from typing import Callable, Dict, List, Optional, Sequence
 
 import numpy as np
+
+logger = logging.getLogger(__name__)
 
 
 class _PipeConn:
@@ -575,13 +579,20 @@ class PairTokenizerPool:
     def close(self) -> None:
         self.pool.close()
 
-    def encode(self, pairs: Sequence, max_length: int):
-        """-> (list of int32 arrays, list of type-id arrays or None per pair), in order; None when the pool is busy (another thread's
-        batch is in it: the caller tokenises in process)."""
+    DEADLINE_S = 30.0      # a batch of pairs is tens of milliseconds of work: a pool that has not answered by then is hung
+
+    def encode(self, pairs: Sequence, max_length: int, deadline_s: Optional[float] = None):
+        """-> (list of int32 arrays, list of type-id arrays or None per pair), in order; None when the caller should tokenise in
+        process instead -- the pool is busy (another thread's batch is in it), a worker died or raised (EOFError on its pipe, its own
+        error), or the pool did not answer within ``deadline_s``: the in-process tokenizer returns the same ids, so a user's rerank
+        request never fails (or hangs) because of the pool.  A failed pool is killed; ``get_pair_pool`` starts a fresh one."""
         if not self.lock.acquire(blocking=False):
             return None
         try:
             pool, W = self.pool, len(self.pool.conns)
+            if W == 0:
+                return None
+            limit = time.monotonic() + (self.DEADLINE_S if deadline_s is None else deadline_s)
             n = len(pairs)
             per = (n + W - 1) // W
             jobs = []
@@ -594,10 +605,20 @@ class PairTokenizerPool:
                 jobs.append((w, self._seq))
             ids, types = [], []
             for w, key in jobs:
-                flat, lens, tflat = pool.wait(w, ("pairs", key))
+                k = ("pairs", key)
+                while k not in pool.buffers[w]:
+                    left = limit - time.monotonic()
+                    if left <= 0:
+                        raise TimeoutError(f"pair tokenizer pool: no answer from worker {w} within the deadline")
+                    pool.serve(min(left, 1.0))
+                flat, lens, tflat = pool.buffers[w].pop(k)
                 ids.extend(unflatten(flat, lens))
                 types.extend(unflatten(tflat, lens) if tflat is not None else [None] * len(lens))
             return ids, types
+        except Exception as exc:  # noqa: BLE001 - a dead / hung / failing worker: the caller falls back, the pool is replaced
+            logger.warning("pair tokenizer pool failed (%s: %s); tokenising in process", type(exc).__name__, exc)
+            self.pool.abort()
+            return None
         except BaseException:
             self.pool.abort()
             raise
@@ -619,8 +640,14 @@ def pair_workers_default() -> int:
     return 0 if cpus < 16 else min(16, cpus // 8)      # small hosts tokenise in process
 
 
-def get_pair_pool(tokenizer) -> Optional[PairTokenizerPool]:
-    """The process's pair-tokenisation pool for this tokenizer (None: disabled, or a tokenizer the workers cannot rebuild)."""
+_PAIR_POOLS_STARTING: set = set()
+
+
+def get_pair_pool(tokenizer, wait: bool = False) -> Optional[PairTokenizerPool]:
+    """The process's pair-tokenisation pool for this tokenizer; None: disabled, a tokenizer the workers cannot rebuild, the pool
+    could not be started -- or (``wait=False``, what a request thread passes) it is still being started by another thread: up to
+    16 interpreters each parsing a 17 MB tokenizer.json take seconds, which no request waits for (it tokenises in process meanwhile).
+    The pool is spawned OUTSIDE the registry lock; ``warm_pair_pool`` starts it in the background when a reranker is built."""
     W = pair_workers_default()
     if W <= 0:
         return None
@@ -630,9 +657,38 @@ def get_pair_pool(tokenizer) -> Optional[PairTokenizerPool]:
         return None
     with _POOLS_LOCK:
         pool = _PAIR_POOLS.get(key)
-        if pool is None or not pool.alive():
-            pool = _PAIR_POOLS[key] = PairTokenizerPool(tokenizer, W)
-        return pool
+        if pool is not None and pool.alive():
+            return pool
+        if key in _PAIR_POOLS_STARTING and not wait:
+            return None
+        mine = key not in _PAIR_POOLS_STARTING
+        if mine:
+            _PAIR_POOLS_STARTING.add(key)
+    if not mine:           # wait=True: another thread is starting it
+        while True:
+            time.sleep(0.02)
+            with _POOLS_LOCK:
+                if key not in _PAIR_POOLS_STARTING:
+                    pool = _PAIR_POOLS.get(key)
+                    return pool if pool is not None and pool.alive() else None
+    pool = None
+    try:
+        pool = PairTokenizerPool(tokenizer, W)
+    except Exception as exc:  # noqa: BLE001 - no workers: every caller tokenises in process
+        logger.warning("pair tokenizer pool could not be started (%s: %s)", type(exc).__name__, exc)
+    finally:
+        with _POOLS_LOCK:
+            _PAIR_POOLS_STARTING.discard(key)
+            if pool is not None:
+                _PAIR_POOLS[key] = pool
+    return pool
+
+
+def warm_pair_pool(tokenizer) -> None:
+    """Start the pair pool in a background thread (called when a reranker is constructed), so the first coalesced batch finds it."""
+    if pair_workers_default() <= 0:
+        return
+    threading.Thread(target=get_pair_pool, args=(tokenizer, True), name="tt-pair-pool-start", daemon=True).start()
 
 
 @atexit.register

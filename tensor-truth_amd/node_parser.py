@@ -33,9 +33,24 @@ def tokenizer_counter(tk) -> Callable[[str], int]:
     """A chunk-size counter that counts with a real sub-word tokenizer (``tk.encode(text)`` minus its two specials) -- what the
     reference's splitters do with llama-index's global tokenizer (tiktoken): chunk sizes are SUB-WORD token counts
     there, so a 256-token leaf is ~256 sub-word tokens, not 256 words.  Memoised like ``count_tokens``."""
-    @functools.lru_cache(maxsize=1 << 16)
+    # Memoised on a DIGEST of the text, for short pieces only: the hierarchy's levels re-count the same sentences (short strings,
+    # where the cache pays), while whole chunks and documents are counted once -- an lru_cache keyed on the strings themselves pinned
+    # up to 65 536 document-sized texts in memory.
+    cache: dict = {}
+    LIMIT, MAX_CHARS = 1 << 16, 2048
+
     def count(text: str) -> int:
-        return max(0, len(tk.encode(text)) - 2)
+        if len(text) > MAX_CHARS:
+            return max(0, len(tk.encode(text)) - 2)
+        key = hash(text)
+        hit = cache.get(key)
+        if hit is not None and hit[0] == len(text):
+            return hit[1]
+        n = max(0, len(tk.encode(text)) - 2)
+        if len(cache) >= LIMIT:
+            cache.clear()
+        cache[key] = (len(text), n)
+        return n
 
     return count
 

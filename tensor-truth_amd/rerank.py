@@ -61,6 +61,17 @@ class HipSentenceTransformerRerank:
         # two-phase: the host side of a batch (tokenise + pack) runs while the previous batch is on the GPU
         self.stats = {"pairs": 0, "tokens": 0}
         self._token_source = None
+        from .tokenization import HFTokenizer
+
+        if coalesce and isinstance(self._tokenizer, HFTokenizer):
+            # the worker processes of the coalesced batches' pair tokenisation start NOW, in the background: not inside the first
+            # request that brings 96 pairs (seconds of interpreter start-up + tokenizer parsing)
+            try:
+                from . import ingest_workers as iw
+
+                iw.warm_pair_pool(self._tokenizer)
+            except Exception as exc:  # noqa: BLE001
+                logger.warning("reranker: pair tokenizer pool not started (%s)", exc)
         # depth 3 (round 5): with a real sub-word tokenizer the host turn-around of a batch's callers (retrieve + tokenise + pack: ~100 ms
         # for 8 callers) is longer than ONE batch on the GPU, so with two unfinished batches the GPU waited for the third
         # (profiles/r05_surface_busy.log: 97.6 -> 102.3 q/s from 32 threads); TT_COALESCE_DEPTH overrides
@@ -118,10 +129,16 @@ class HipSentenceTransformerRerank:
         if isinstance(tk, HFTokenizer) and len(pairs) >= 96:
             # a coalesced batch's pairs go to single-threaded worker processes (ingest_workers.PairTokenizerPool): same ids, a
             # third of the time, and not under this process's GIL; a lone caller's 50 pairs stay here (3 ms)
-            from . import ingest_workers as iw
+            # Nothing about the pool can fail (or stall) a request: a pool that is still starting, busy, dead, hung past its deadline
+            # or raising hands back None and the pairs are tokenised right here -- identical ids either way.
+            try:
+                from . import ingest_workers as iw
 
-            pool = iw.get_pair_pool(tk)
-            got = pool.encode(list(pairs), self.max_length) if pool is not None else None
+                pool = iw.get_pair_pool(tk)
+                got = pool.encode(list(pairs), self.max_length) if pool is not None else None
+            except Exception as exc:  # noqa: BLE001
+                logger.warning("reranker: pair tokenizer pool unavailable (%s: %s); tokenising in process", type(exc).__name__, exc)
+                got = None
             if got is not None:
                 enc = list(zip(*got))
         if enc is not None:
@@ -181,15 +198,19 @@ class HipSentenceTransformerRerank:
         return self._predict_flat(pairs)
 
     # ---- passages tokenised once, at ingest -----------------------------------------------------------------
+    def accepts_token_source(self, signature: str, instruction: str = "") -> bool:
+        """Would ids made by the tokenizer ``signature`` (with ``instruction`` prepended to the text) be THIS model's ids?"""
+        from .tokenization import tokenizer_signature
+
+        return not self._use_types and not instruction and signature == tokenizer_signature(self._tokenizer)
+
     def attach_token_source(self, source, signature: str, instruction: str = "") -> bool:
         """``source(node_id) -> int32 body ids (no specials) or None``: the ids of a node's EMBED-mode content as the index's
         embedder tokenised them at ingest (``HipVectorIndex.leaf_token_ids``).  Accepted only when that tokenizer IS this model's
         (same signature: bge-m3 and bge-reranker-v2-m3 share XLM-R's vocabulary), no text instruction was prepended, and the model has one
         token type -- then ``postprocess_nodes`` hands known passages to the batch as ids and only queries are tokenised per call.
         Scores are bit-identical to the string path (tests/test_config5_gpu.py).  -> whether it was accepted."""
-        from .tokenization import tokenizer_signature
-
-        ok = (not self._use_types and not instruction and signature == tokenizer_signature(self._tokenizer))
+        ok = self.accepts_token_source(signature, instruction)
         self._token_source = source if ok else None
         if not ok:
             logger.info("reranker: token source refused (another tokenizer, a text instruction, or a model with segment ids)")
@@ -199,13 +220,15 @@ class HipSentenceTransformerRerank:
         self._token_source = None
 
     # ---- postprocessor surface ------------------------------------------------------------------------
-    def postprocess_nodes(self, nodes: List[NodeWithScore], query_bundle=None, query_str: Optional[str] = None):
+    def postprocess_nodes(self, nodes: List[NodeWithScore], query_bundle=None, query_str: Optional[str] = None, token_source=None):
+        """``token_source`` (keyword, optional): a per-CALL source of stored passage ids -- what ``RerankerWithTokenSource`` passes for
+        its service -- instead of the one attached to this (shared, ModelManager-cached) instance."""
         if query_bundle is None and query_str is None:
             raise ValueError("Missing query bundle in extra info.")
         q = query_str if query_bundle is None else query_bundle.query_str
         if len(nodes) == 0:
             return []
-        src = self._token_source
+        src = token_source if token_source is not None else self._token_source
         if src is None:
             passages = [n.node.get_content(metadata_mode=MetadataMode.EMBED) for n in nodes]
         else:
@@ -231,3 +254,22 @@ class HipSentenceTransformerRerank:
         if top_n is not None:
             order = order[:top_n]
         return [{"index": i, "relevance_score": float(scores[i])} for i in order]
+
+
+class RerankerWithTokenSource:
+    """One retrieval service's view of a shared reranker: the same model, tokenizer, coalescing front and statistics -- plus THIS
+    service's source of stored passage ids, handed over per call.  ``ModelManager.get_reranker`` returns one cached instance per
+    (model, device, top_n) (services/model_manager.py:143-186); attaching a service's token source to it would let the last service
+    built replace or detach every earlier service's (its lookups would then go through the other service's indexes)."""
+
+    def __init__(self, reranker: HipSentenceTransformerRerank, token_source):
+        self._reranker = reranker
+        self.token_source = token_source
+
+    def postprocess_nodes(self, nodes, query_bundle=None, query_str: Optional[str] = None):
+        return self._reranker.postprocess_nodes(nodes, query_bundle, query_str, token_source=self.token_source)
+
+    _postprocess_nodes = postprocess_nodes
+
+    def __getattr__(self, name):          # model, top_n, predict, rerank, stats ...: the shared instance's
+        return getattr(self._reranker, name)

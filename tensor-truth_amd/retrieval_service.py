@@ -108,9 +108,11 @@ def build_retrieval_service(indexes: List[Any], params: Optional[Dict[str, Any]]
     post: List[Any] = [rr]
     # leaves tokenised once, at ingest (build_index(keep_leaf_token_ids=True)): if the indexes kept their leaves' token ids and the
     # reranker's tokenizer is the embedder's, retrieved leaves reach the reranker as ids (auto-merged parents still as text)
-    if hasattr(rr, "attach_token_source"):
+    # The source stays with THIS service (a per-call argument through RerankerWithTokenSource): `rr` is ModelManager's shared cached
+    # instance, and a second service over other indexes must neither replace nor detach what this one looks its leaves up in.
+    if hasattr(rr, "accepts_token_source"):
         sources = [ts for ts in (ix.token_source() for ix in indexes if hasattr(ix, "token_source")) if ts is not None]
-        if sources and len({(sig, instr) for _, sig, instr in sources}) == 1:
+        if sources and len({(sig, instr) for _, sig, instr in sources}) == 1 and rr.accepts_token_source(sources[0][1], sources[0][2]):
             getters = [g for g, _, _ in sources]
 
             def lookup(node_id, _getters=getters):
@@ -120,9 +122,9 @@ def build_retrieval_service(indexes: List[Any], params: Optional[Dict[str, Any]]
                         return ids
                 return None
 
-            rr.attach_token_source(lookup if len(getters) > 1 else getters[0], sources[0][1], sources[0][2])
-        else:
-            rr.detach_token_source()
+            from .rerank import RerankerWithTokenSource
+
+            post[0] = RerankerWithTokenSource(rr, lookup if len(getters) > 1 else getters[0])
     hard = params.get("confidence_cutoff_hard", 0.0)
     if hard and hard > 0:
         post.append(SimilarityPostprocessor(similarity_cutoff=hard))

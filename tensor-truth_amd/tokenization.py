@@ -18,20 +18,37 @@ from typing import List, Optional, Sequence, Tuple
 _WORD = re.compile(r"\w+|[^\w\s]", re.UNICODE)
 
 
+_warned_threads = False
+
+
 def _cap_tokenizer_threads() -> None:
     """The Rust ``tokenizers`` library starts one rayon thread per host core the first time a batch is encoded.  On the 256-thread
     GPU host that buys nothing -- 400 rerank pairs x 292 tokens take 26.5 ms with 256 threads and 27.1 ms with 16
     (tools/probes/tokenizer_threads.py, profiles/r05_tokenizer_threads.log) -- and costs a lot as soon as two request threads encode
     at once (a rerank batch's pairs beside a retrieval batch's queries: 0.4 ms of query tokenisation became 5.5 ms in the surface
-    leg).  Unless the deployment says otherwise (``RAYON_NUM_THREADS``), the pool is capped at 16 threads; must run before the
-    library's first parallel call."""
-    if "RAYON_NUM_THREADS" not in os.environ:
-        try:
-            cpus = len(os.sched_getaffinity(0))
-        except AttributeError:
-            cpus = os.cpu_count() or 1
-        if cpus > 16:
-            os.environ["RAYON_NUM_THREADS"] = "16"
+    leg).  The size of that pool is the APPLICATION's decision: ``RAYON_NUM_THREADS`` is process-wide, every other rayon user
+    (polars ...) and every child process inherits it, and it is read once, when the pool starts.  So this package never sets it on
+    its own: ``TT_TOKENIZER_THREADS=N`` is the explicit opt-in (applied only while ``RAYON_NUM_THREADS`` is unset, before the library's
+    first parallel call); without it a many-core host gets one log line naming the setting.  The package's own worker processes
+    get their thread count in the environment they are started with (``ingest_workers``), never through this process's."""
+    global _warned_threads
+    if "RAYON_NUM_THREADS" in os.environ:
+        return
+    want = os.environ.get("TT_TOKENIZER_THREADS", "").strip()
+    if want:
+        os.environ["RAYON_NUM_THREADS"] = str(max(1, int(want)))
+        return
+    try:
+        cpus = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cpus = os.cpu_count() or 1
+    if cpus > 16 and not _warned_threads:
+        _warned_threads = True
+        import logging
+
+        logging.getLogger(__name__).info(
+            "tokenizers will start %d rayon threads; on many-core hosts RAYON_NUM_THREADS=16 (or TT_TOKENIZER_THREADS=16) in the "
+            "application's environment avoids contention between request threads", cpus)
 
 
 class PreTokenized:

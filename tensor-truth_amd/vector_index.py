@@ -59,6 +59,9 @@ class HipVectorIndex:
         # node id -> int32 body ids of the leaf's EMBED content as the embedder tokenised it (filled by add(token_ids=...): the
         # worker-process ingest with keep_leaf_token_ids; persisted as leaf_tokens.<generation>.npz)
         self.leaf_token_ids: Optional[Dict[str, np.ndarray]] = None
+        # (tokenizer signature, text instruction) the kept ids were produced with: set when the first ids are stored, persisted with
+        # them, and what token_source() reports -- never the values of whatever embed_model the index is later loaded next to
+        self.leaf_token_origin: Optional[tuple] = None
         self.docstore: Dict[str, TextNode] = {}  # every node (leaves + parents), for auto-merging
         self.ref_docs: Dict[str, List[str]] = {}  # source document id -> ids of all its nodes (docstore ref_doc_info)
         self._lock = threading.RLock()
@@ -116,23 +119,45 @@ class HipVectorIndex:
                 if self._row_of is not None:
                     self._row_of[nd.id_] = self.n + j
             if token_ids is not None:
+                origin = self._embedder_token_origin()
+                if self.leaf_token_ids and self.leaf_token_origin is not None and origin != self.leaf_token_origin:
+                    # ids of another tokenizer / instruction than the ones already kept: one table cannot describe both
+                    logger.warning("index: leaf token ids dropped (the embedder's tokenizer or text instruction changed between adds)")
+                    self.leaf_token_ids = None
                 if self.leaf_token_ids is None:
                     self.leaf_token_ids = {}
+                self.leaf_token_origin = origin
                 limit = getattr(self.embed_model, "max_length", None)
                 for nd, ids in zip(nodes, token_ids):
                     if limit is None or len(ids) < limit:
                         self.leaf_token_ids[nd.id_] = np.asarray(ids[1:-1], dtype=np.int32)       # body only: the reranker adds its own specials
+                    else:
+                        self.leaf_token_ids.pop(nd.id_, None)
+            elif self.leaf_token_ids:
+                # a node (re-)added WITHOUT ids (in-process build, insert_nodes): ids kept for an earlier version of this node id
+                # would make the reranker score text the node no longer has
+                for nd in nodes:
+                    self.leaf_token_ids.pop(nd.id_, None)
             self.n += len(nodes)
             self._version += 1
         return [nd.id_ for nd in nodes]
 
-    def token_source(self):
-        """-> (callable node id -> body ids or None, tokenizer signature, text instruction) for ``attach_token_source``, or None."""
-        if not self.leaf_token_ids or self.embed_model is None or not hasattr(self.embed_model, "_tokenizer"):
+    def _embedder_token_origin(self):
+        """(tokenizer signature, text instruction) of the index's embed_model, or None when it has no tokenizer to ask."""
+        em = self.embed_model
+        if em is None or not hasattr(em, "_tokenizer"):
             return None
         from .tokenization import tokenizer_signature
 
-        return self.leaf_token_ids.get, tokenizer_signature(self.embed_model._tokenizer), getattr(self.embed_model, "text_instruction", "") or ""
+        return tokenizer_signature(em._tokenizer), getattr(em, "text_instruction", "") or ""
+
+    def token_source(self):
+        """-> (callable node id -> body ids or None, tokenizer signature, text instruction) for ``attach_token_source``, or None.
+        Signature and instruction are the ones the ids were PRODUCED with (recorded at ``add``, persisted beside the ids) -- an index
+        loaded next to another embedder still reports its ingest-time tokenizer, and ids of unknown origin are never offered."""
+        if not self.leaf_token_ids or self.leaf_token_origin is None:
+            return None
+        return self.leaf_token_ids.get, self.leaf_token_origin[0], self.leaf_token_origin[1]
 
     def add_to_docstore(self, nodes: Iterable[TextNode]) -> None:
         """Parents of the hierarchy (``storage_context.docstore.add_documents``, builder.py:430)."""
@@ -251,8 +276,12 @@ class HipVectorIndex:
                     lens = np.fromiter((0 if a is None else len(a) for a in arrs), dtype=np.int32, count=len(arrs))
                     flat = np.concatenate([a for a in arrs if a is not None and len(a)]) if int(lens.sum()) else np.zeros(0, np.int32)
                     tok = (flat.astype(np.int32), lens)
+                tok_origin = self.leaf_token_origin
             gen = _next_generation(persist_dir)
             corpus_name = f"corpus.{gen}.bf16"
+            if tok is not None and tok_origin is None:
+                logger.warning("index: leaf token ids not persisted (the tokenizer they came from is unknown)")
+                tok = None
             tokens_name = f"leaf_tokens.{gen}.npz" if tok is not None else None
 
             def _atomic(name: str, write) -> None:
@@ -282,7 +311,10 @@ class HipVectorIndex:
 
             _atomic(INDEX_METADATA_FILENAME, _dump(meta))
             _atomic("nodes.json", _dump({"dim": self.dim, "leaf_ids": leaf_ids, "nodes": nodes, "ref_docs": ref_docs,
-                                         "corpus_file": corpus_name, "generation": gen, "leaf_tokens_file": tokens_name}))
+                                         "corpus_file": corpus_name, "generation": gen, "leaf_tokens_file": tokens_name,
+                                         # what the ids were tokenised with: load() offers them only to the same tokenizer / instruction
+                                         "leaf_tokens_tokenizer": tok_origin[0] if tokens_name else None,
+                                         "leaf_tokens_instruction": tok_origin[1] if tokens_name else None}))
             for name in os.listdir(persist_dir):     # LOWER generations only: unreferenced once nodes.json has moved
                 g = _generation_of(name)
                 if g is None and name.startswith("leaf_tokens.") and name.endswith(".npz"):
@@ -310,11 +342,22 @@ class HipVectorIndex:
         if tname and os.path.exists(os.path.join(persist_dir, tname)):
             # the leaves' token ids kept at ingest (build_index(keep_leaf_token_ids=True)): usable by a reranker whose tokenizer is
             # THIS embed_model's -- token_source() reports the signature of the tokenizer the caller loads the index with
-            with np.load(os.path.join(persist_dir, tname)) as z:
-                flat, lens = z["flat"], z["lens"]
-            if len(lens) == len(idx.leaf_ids):
-                ends = np.cumsum(lens)
-                idx.leaf_token_ids = {nid: flat[e - n:e] for nid, e, n in zip(idx.leaf_ids, ends, lens) if n > 0 and nid is not None}
+            sig, instr = blob.get("leaf_tokens_tokenizer"), blob.get("leaf_tokens_instruction")
+            mine = idx._embedder_token_origin()
+            if sig is None or instr is None:
+                logger.warning("index %s: leaf token ids ignored (persisted without the tokenizer signature they were made with)", persist_dir)
+            elif mine is not None and mine != (sig, instr):
+                # another tokenizer (a hash stand-in, another checkpoint) or another text instruction than at ingest: a reranker that
+                # matches THIS embedder would score foreign ids
+                logger.warning("index %s: leaf token ids ignored (tokenised with %s / instruction %r at ingest, loaded next to %s / %r)",
+                               persist_dir, sig, instr, mine[0], mine[1])
+            else:
+                with np.load(os.path.join(persist_dir, tname)) as z:
+                    flat, lens = z["flat"], z["lens"]
+                if len(lens) == len(idx.leaf_ids):
+                    ends = np.cumsum(lens)
+                    idx.leaf_token_ids = {nid: flat[e - n:e] for nid, e, n in zip(idx.leaf_ids, ends, lens) if n > 0 and nid is not None}
+                    idx.leaf_token_origin = (sig, instr)
         return idx
 
 

@@ -478,7 +478,9 @@ def test_leaves_tokenised_once_at_ingest_rerank_from_stored_ids(dev, built_lib, 
     params = {"reranker_top_n": 5, "similarity_top_k": 24, "confidence_cutoff": 0.0}
     svc = build_retrieval_service([index], params, device="cuda", manager=mgr)
     rr = mgr.get_reranker("BAAI/bge-reranker-v2-m3", top_n=5, device="cuda")
-    assert rr._token_source is not None
+    view = svc._node_postprocessors[0]
+    #  the source belongs to the SERVICE, handed over per call: ModelManager's cached reranker is not mutated
+    assert view.token_source is not None and rr._token_source is None and view._reranker is rr
     live = [x for x in index.leaf_ids if x is not None]
     queries = [" ".join(index.docstore[live[int(rng.integers(0, len(live)))]].text.replace(".", " ").split()[:10]) + f" q{i}" for i in range(24)]
 
@@ -507,7 +509,7 @@ def test_leaves_tokenised_once_at_ingest_rerank_from_stored_ids(dev, built_lib, 
     lone = run(queries[:3], 1)
     if hasattr(svc._retriever, "clear_cache"):
         svc._retriever.clear_cache()
-    rr.detach_token_source()
+    view.token_source = None
     from_text = run(queries, 6)
     assert with_ids == from_text and lone == from_text[:3]
     assert all(len(r) == 5 for r in from_text)

@@ -1351,6 +1351,115 @@ def test_pair_tokenizer_pool_returns_the_in_process_ids(monkeypatch):
     assert iw.get_pair_pool(tk) is None
 
 
+def test_pair_tokenizer_pool_failures_fall_back_instead_of_failing_the_request(monkeypatch):
+    """nothing about the pair pool may fail or hang a user's rerank request.  A worker that died (EOF on its pipe), a
+    pool past its deadline, a pool still being started: ``encode`` / ``get_pair_pool`` hand back None -- the caller tokenises in
+    process, identical ids -- the broken pool is killed and the next call gets a fresh one."""
+    import sys
+    import time
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import synth_text as st
+    from tensor_truth_amd import ingest_workers as iw
+
+    tk = st.unigram_tokenizer()
+    pairs = [(st.zipf_text(900 + i, 6), st.zipf_text(5000 + i, 40)) for i in range(100)]
+    monkeypatch.setenv("TT_PAIR_WORKERS", "2")
+    pool = iw.get_pair_pool(tk, wait=True)
+    assert pool is not None and pool.encode(pairs, 512) is not None
+    # a deadline that has already passed: None, and the pool is gone (not left with half-read frames)
+    assert pool.encode(pairs, 512, deadline_s=0.0) is None and not pool.alive()
+    fresh = iw.get_pair_pool(tk, wait=True)
+    assert fresh is not None and fresh is not pool and fresh.alive()
+    # a worker killed under the pool (OOM killer): EOFError inside -> None outside
+    fresh.pool.procs[0].kill()
+    fresh.pool.procs[0].wait(timeout=10)
+    assert fresh.encode(pairs, 512) is None
+    # while another thread is starting the pool, a request thread does not wait for it
+    import pickle
+    key = pickle.dumps((iw.tokenizer_spec(tk), 2))
+    with iw._POOLS_LOCK:
+        iw._PAIR_POOLS.pop(key, None)
+        iw._PAIR_POOLS_STARTING.add(key)
+    try:
+        t0 = time.perf_counter()
+        assert iw.get_pair_pool(tk) is None and time.perf_counter() - t0 < 0.5
+    finally:
+        with iw._POOLS_LOCK:
+            iw._PAIR_POOLS_STARTING.discard(key)
+    last = iw.get_pair_pool(tk, wait=True)
+    got = last.encode(pairs, 512)
+    want = tk.encode_pair_batch(pairs, 512)
+    assert got is not None and [a.tolist() for a in got[0]] == [w[0] for w in want]
+    monkeypatch.setenv("TT_PAIR_WORKERS", "0")
+
+
+def test_each_retrieval_service_keeps_its_own_token_source():
+    """``ModelManager.get_reranker`` returns ONE cached instance; a service's source of stored leaf ids travels with the
+    service (``RerankerWithTokenSource``: a per-call argument), so building a second service over other indexes neither replaces nor
+    detaches the first one's, and an index without ids gets the plain reranker."""
+    from tensor_truth_amd.rerank import RerankerWithTokenSource
+    from tensor_truth_amd.retrieval_service import build_retrieval_service
+    from tensor_truth_amd.schema import NodeWithScore, TextNode
+
+    calls = []
+
+    class FakeReranker:
+        top_n = 2
+        _token_source = None
+
+        def accepts_token_source(self, signature, instruction=""):
+            return signature == "sig-A" and not instruction
+
+        def postprocess_nodes(self, nodes, query_bundle=None, query_str=None, token_source=None):
+            calls.append(token_source)
+            return nodes[: self.top_n]
+
+    class FakeManager:
+        def __init__(self):
+            self.rr = FakeReranker()
+
+        def get_reranker(self, model=None, top_n=3, device="cuda"):
+            return self.rr
+
+    class FakeRetriever:
+        def __init__(self, name):
+            self.name = name
+
+        def retrieve(self, q):
+            return [NodeWithScore(node=TextNode(text=f"{self.name}{i}", id_=f"{self.name}{i}", metadata={}), score=1.0 - 0.1 * i) for i in range(3)]
+
+    class FakeIndex:
+        def __init__(self, name, sig):
+            self.name, self.sig, self.docstore = name, sig, {}
+            self.table = {f"{name}{i}": [i] for i in range(3)}
+
+        def as_retriever(self, similarity_top_k=10):
+            return FakeRetriever(self.name)
+
+        def token_source(self):
+            return None if self.sig is None else (self.table.get, self.sig, "")
+
+    mgr = FakeManager()
+    svc_a = build_retrieval_service([FakeIndex("a", "sig-A")], {"reranker_top_n": 2}, manager=mgr)
+    svc_b = build_retrieval_service([FakeIndex("b", "sig-A")], {"reranker_top_n": 2}, manager=mgr)
+    svc_c = build_retrieval_service([FakeIndex("c", None)], {"reranker_top_n": 2}, manager=mgr)            # no stored ids
+    svc_d = build_retrieval_service([FakeIndex("d", "sig-OTHER")], {"reranker_top_n": 2}, manager=mgr)     # another tokenizer's ids
+    va, vb = svc_a._node_postprocessors[0], svc_b._node_postprocessors[0]
+    assert isinstance(va, RerankerWithTokenSource) and isinstance(vb, RerankerWithTokenSource) and va._reranker is vb._reranker is mgr.rr
+    assert svc_c._node_postprocessors[0] is mgr.rr and svc_d._node_postprocessors[0] is mgr.rr
+    assert mgr.rr._token_source is None                                  # the shared instance was never touched
+    assert va.top_n == 2                                                 # everything else is the shared reranker's
+    svc_a.retrieve("q")
+    svc_b.retrieve("q")
+    svc_a.retrieve("q2")
+    svc_c.retrieve("q")
+    assert calls[0]("a1") == [1] and calls[0]("b1") is None              # service A looks up in ITS index only ...
+    assert calls[1]("b2") == [2] and calls[1]("a2") is None              # ... B in its own ...
+    assert calls[2]("a0") == [0]                                         # ... and A still does after B was built
+    assert calls[3] is None
+
+
 def test_pretokenized_pairs_equal_the_tokenizers_own_pair_encoding():
     """Round 5: leaves are tokenised once, at ingest (HipVectorIndex.leaf_token_ids); the reranker then assembles
     ``<s> q </s></s> passage </s>`` from the stored body ids instead of tokenising the passage again.  ``assemble_pairs`` must return

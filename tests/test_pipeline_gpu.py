@@ -737,3 +737,48 @@ def test_overlapping_persists_and_loads_never_pair_a_matrix_with_foreign_node_ta
     assert not errors, errors
     mats = [f for f in os.listdir(d) if f.startswith("corpus.") and f.endswith(".bf16")]
     assert len(mats) == 1
+
+
+def test_leaf_token_ids_travel_with_the_tokenizer_they_were_made_with(dev, built_lib, tmp_path):
+    """``leaf_tokens.<generation>.npz`` is only usable by the tokenizer (and text instruction) that produced it.  The index
+    records both when ids are stored, persists them in nodes.json, and ``load`` drops the ids -- with a log line -- when the embedder it
+    is loaded next to tokenises differently; ``token_source()`` reports the STORED origin, never the loader's; a node re-added
+    without ids loses its stale ones."""
+    import numpy as np
+
+    from tensor_truth_amd.schema import TextNode
+    from tensor_truth_amd.tokenization import HashTokenizer, tokenizer_signature
+    from tensor_truth_amd.vector_index import HipVectorIndex
+
+    class Emb:                                  # what the index reads of an embedder: tokenizer, instruction, length limit
+        def __init__(self, vocab, instruction=""):
+            self._tokenizer, self.text_instruction, self.max_length, self.model_name = HashTokenizer("xlmr", vocab), instruction, 64, "fake/emb"
+
+    em = Emb(5000)
+    nodes = [TextNode(text=f"alpha beta gamma {i}", id_=f"n{i}", metadata={}) for i in range(6)]
+    toks = [em._tokenizer.encode(n.text, 64) for n in nodes]
+    vecs = torch.randn(6, 128, generator=torch.Generator().manual_seed(5))
+    idx = HipVectorIndex(128, dev, em, "cosine")
+    idx.add(nodes, embeddings=vecs, token_ids=toks)
+    src, sig, instr = idx.token_source()
+    assert sig == tokenizer_signature(em._tokenizer) and instr == "" and src("n2").tolist() == toks[2][1:-1]
+    pdir = str(tmp_path / "ix")
+    idx.persist(pdir)
+    same = HipVectorIndex.load(pdir, dev, Emb(5000), "cosine")
+    assert same.token_source()[1] == sig and set(same.leaf_token_ids) == {f"n{i}" for i in range(6)}
+    bare = HipVectorIndex.load(pdir, dev, None, "cosine")                       # no embedder at load: the stored origin is reported
+    assert bare.token_source()[1:] == (sig, "") and np.array_equal(bare.leaf_token_ids["n4"], idx.leaf_token_ids["n4"])
+    other = HipVectorIndex.load(pdir, dev, Emb(7000), "cosine")                 # another tokenizer
+    assert other.leaf_token_ids is None and other.token_source() is None
+    prefixed = HipVectorIndex.load(pdir, dev, Emb(5000, "passage: "), "cosine")   # same tokenizer, but texts get an instruction prefix now
+    assert prefixed.leaf_token_ids is None and prefixed.token_source() is None
+    # a node re-added WITHOUT ids (insert_nodes, in-process build): its old ids must not survive
+    same.delete(["n3"])
+    same.add([TextNode(text="entirely different words", id_="n3", metadata={})], embeddings=vecs[:1])
+    assert "n3" not in same.leaf_token_ids and same.token_source()[0]("n3") is None and same.token_source()[0]("n2") is not None
+    # ids made with another tokenizer than the ones already kept: the table is dropped rather than mixed
+    mixed = HipVectorIndex(128, dev, em, "cosine")
+    mixed.add(nodes[:3], embeddings=vecs[:3], token_ids=toks[:3])
+    mixed.embed_model = Emb(7000)
+    mixed.add(nodes[3:], embeddings=vecs[3:], token_ids=toks[3:])
+    assert set(mixed.leaf_token_ids) == {"n3", "n4", "n5"} and mixed.token_source()[1] == tokenizer_signature(mixed.embed_model._tokenizer)
