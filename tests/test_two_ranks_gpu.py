@@ -224,3 +224,28 @@ def test_bench_self_launches_two_ranks_and_falls_back_from_rccl_by_agreement(bui
     assert cb.startswith("gloo (nccl pre-flight failed") and "Duplicate GPU" in cb, cb
     assert d["config"]["ranks_share_one_device"] is True
     assert "nccl data plane unusable" in r.stderr
+
+
+def test_bench_self_launches_eight_ranks_on_one_device(built_lib):
+    """the driver's N = 8 command -- `python bench.py --gpus 8` -- has never met an 8-GPU node, so a regression in
+    the launcher, the shard bounds, the 8-way gathered scan batch or the merge must be caught HERE: eight self-launched ranks share
+    GPU 0 over gloo (TT_BENCH_ONE_DEVICE=1), 800 k rows (100 k per shard), 2 layers, one JSON line with `ranks: 8`.  Checks start-up,
+    the sharded step and the line, not a rate."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TT_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "TT_BENCH_TRY_NCCL"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "1", "--layers", "2",
+                        "--corpus-rows", "800000", "--queries-per-gpu", "8", "--headline-only", "--no-cpu-baseline"],
+                       env=env, cwd=root, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1000:]
+    d = json.loads(lines[0])
+    assert d["ranks"] == 8 and d["n_gpus"] == 1 and d["value"] > 0 and d["scaling"] == "weak" and d["steps"] == 1
+    assert d["config"]["ranks_share_one_device"] is True and d["config"]["collective_backend"].startswith("gloo")
+    assert d["config"]["parallelism"].startswith("corpus row-sharded x8")
