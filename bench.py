@@ -215,6 +215,8 @@ def parse():
     ap.add_argument("--config5-doc-words", default="4000-8000", help="words per document, lo-hi (a 2048-token root fills)")
     ap.add_argument("--config5-queries", type=int, default=256)
     ap.add_argument("--config5-small-docs", type=int, default=2048, help="documents of the labelled small-geometry ingest (0 = skip)")
+    ap.add_argument("--no-reference-defaults-leg", action="store_true",
+                    help="skip the reference_defaults block (the reference's session defaults: K = 10 per index, top_n = 5, 1 and 3 modules)")
     ap.add_argument("--no-fp8-leg", action="store_true", help="skip the extra fp8-reranker timing (BASELINE config 5)")
     ap.add_argument("--no-reference-leg", action="store_true", help="skip the reference-precision (bf16x3) timing")
     ap.add_argument("--no-fp16-leg", action="store_true", help="skip the fp16-mode timing")
@@ -801,6 +803,12 @@ def main():
                     surface = {"error": "plugin-surface leg failed or timed out on another rank", "local_result": surface}
                 surface["surface_failed"] = True
                 hard_exit = True
+    reference_defaults = None
+    if not args.headline_only and not args.no_surface_leg and world == 1 and not args.no_reference_defaults_leg:
+        try:
+            reference_defaults = reference_defaults_leg(args, dev, shard_rows, emb_cfg, rr_cfg)
+        except Exception as exc:  # noqa: BLE001 - an optional block: the headline line is printed regardless
+            reference_defaults = {"error": f"{type(exc).__name__}: {exc}"[:300]}
     config5 = None
     if world == 1 and not args.headline_only and not args.no_config5_leg:
         config5 = config5_leg(args, dev, emb_cfg, rr_cfg)
@@ -913,6 +921,7 @@ def main():
             "scan_only": scan_only,
             "scan_only_shard": scan_shard,
             "plugin_surface": surface,
+            "reference_defaults": reference_defaults,
             "config5_composed": config5,
         },
         "roofline": {
@@ -1097,14 +1106,14 @@ class _Texts:
 class _RowIds:
     """row -> node id for a corpus whose ids derive from the row: no 10M-string table on the host."""
 
-    def __init__(self, n):
-        self.n = n
+    def __init__(self, n, base=0):
+        self.n, self.base = n, base
 
     def __len__(self):
         return self.n
 
     def __getitem__(self, r):
-        return f"r{r}"
+        return f"r{self.base + r}"
 
 
 class _SynthDocstore:
@@ -1368,6 +1377,96 @@ def surface_leg(args, dev, shard_rows, emb_cfg, rr_cfg, world=1, rank=0, row_lo=
                      f"strings in ({texts.q_words}-word queries, {texts.c_words}-word chunks: mean {args.query_len + 2} / "
                      f"{args.query_len + args.chunk_len + 4} tokens per query / pair), NodeWithScore out; "
                      "concurrent callers are coalesced into shared embed / scan / rerank batches")}
+
+
+def reference_defaults_leg(args, dev, shard_rows, emb_cfg, rr_cfg, n_lone=8, n_threads=8, n_threaded=64):
+    """The reference's OWN operating point on the clock: what an unchanged application issues.
+    ``services/session_service.py:76-90`` -- reranker_top_n = 5, confidence_cutoff = 0.35, confidence_cutoff_hard = 0.05 (the
+    SimilarityPostprocessor is active), balance_strategy = "top_k_per_index"; ``rag_engine.py:592-593`` -- similarity_top_k =
+    max(5, 2 * top_n) = 10 PER INDEX; ``rag_engine.py:420-424,463-507`` -- 1..N index modules behind one MultiIndexRetriever,
+    balanced; ``README.md:13`` -- one user, one un-batched call per query.  Built exactly as ``load_engine_for_modules`` builds it
+    (``build_retrieval_service``: AutoMergingRetriever(index.as_retriever(k)) per module -> MultiIndexRetriever -> [reranker,
+    SimilarityPostprocessor(0.05)]), models from ModelManager, strings in through the trained Unigram tokenizer, over 1 and 3
+    modules of the resident corpus (3 modules: one packed matrix, ONE segmented scan -- HipIndexGroup / tt_scan_topk_segmented),
+    a lone caller and 8 request threads (the reference's executor width, rag_engine.py:392), in bf16 (the reference's
+    ``torch_dtype: bfloat16`` option) and in the default precision (no dtype anywhere: fp32 semantics)."""
+    from tensor_truth_amd import model_manager as mm
+    from tensor_truth_amd.retrieval_service import build_retrieval_service
+    from tensor_truth_amd.vector_index import HipVectorIndex
+
+    params = {"reranker_top_n": 5, "confidence_cutoff": 0.35, "confidence_cutoff_hard": 0.05, "balance_strategy": "top_k_per_index"}
+    texts = surface_texts(args, "unigram-250k")
+    n_rows, D = shard_rows.shape
+    out = {"params": dict(params), "similarity_top_k_per_index": max(5, 2 * params["reranker_top_n"]), "corpus_rows": n_rows,
+           "request_threads": n_threads, "tokenizer": "unigram-250k",
+           "what": ("build_retrieval_service(indexes, the reference's session defaults): per module AutoMergingRetriever(index.as_retriever("
+                    "similarity_top_k = 10)) -> MultiIndexRetriever(top_k_per_index) -> [reranker top_n = 5, SimilarityPostprocessor(0.05)]; "
+                    "service.retrieve(query string) -> source nodes; pairs = 10 per module x (query + chunk) tokens; a lone caller's "
+                    "ms per query and the rate of 8 request threads, every query string distinct (the retriever's LRU never hits)")}
+    try:
+        for label, dt_kw in (("bf16", {"torch_dtype": "bfloat16"}), ("default_precision", {})):
+            if label == "default_precision" and args.no_reference_leg:
+                continue
+            mm.ModelManager.reset_instance()
+            mgr = mm.ModelManager.get_instance()
+            mgr.model_kwargs_overrides["BAAI/bge-m3"] = {"encoder_config": emb_cfg, "synthetic_seed": 1, "tokenizer": texts.tokenizer, **dt_kw}
+            mgr.model_kwargs_overrides["BAAI/bge-reranker-v2-m3"] = {"encoder_config": rr_cfg, "synthetic_seed": 2,
+                                                                     "tokenizer": texts.tokenizer, **dt_kw}
+            emb = mgr.get_embedder("BAAI/bge-m3", str(dev))
+            res = {}
+            for n_mod in (1, 3):
+                bounds = [n_rows * i // n_mod for i in range(n_mod + 1)]
+                docstore = _SynthDocstore(args.chunk_len, texts.chunk)
+                indexes = []
+                for lo, hi in zip(bounds[:-1], bounds[1:]):
+                    ix = HipVectorIndex(D, dev, emb)               # score_mode "chroma": exp(-(2 - 2 cos)), what the reference's store returns
+                    ix._mat, ix.n, ix.leaf_ids, ix.docstore = shard_rows[lo:hi], hi - lo, _RowIds(hi - lo, lo), docstore
+                    ix._mark_written()
+                    indexes.append(ix)
+                svc = build_retrieval_service(indexes, params, device=str(dev), manager=mgr)
+                rr = mgr.get_reranker(None, top_n=params["reranker_top_n"], device=str(dev))
+                key0 = 20_000_000_000 + (1_000_000 if label == "bf16" else 2_000_000) + 100_000 * n_mod
+                qs = [texts.query(key0 + i) for i in range(4 + n_lone + n_threads + n_threaded)]
+
+                def one(q, _svc=svc):
+                    r = _svc.retrieve(q)
+                    return len(r.source_nodes), r.confidence_level
+
+                for q in qs[:4]:
+                    one(q)
+                torch.cuda.synchronize(dev)
+                p0, k0 = rr.stats["pairs"], rr.stats["tokens"]
+                t0 = time.perf_counter()
+                got = [one(q) for q in qs[4:4 + n_lone]]
+                torch.cuda.synchronize(dev)
+                lone_ms = (time.perf_counter() - t0) / n_lone * 1e3
+                pairs, toks = rr.stats["pairs"] - p0, rr.stats["tokens"] - k0
+                from tensor_truth_amd import _lib as _tl
+
+                _tl.load_library().tt_prof_enable(1)        # one more lone query with an event pair around every launch (this thread's)
+                one(qs[3] + " again")
+                torch.cuda.synchronize(dev)
+                fam = {k: {"ms": v[0], "launches": v[1]} for k, v in read_prof_families(_tl.load_library()).items() if v[1]}
+                _tl.load_library().tt_prof_enable(0)
+                _run_threads(n_threads, qs[4 + n_lone:4 + n_lone + n_threads], one)
+                dt, got_t = _run_threads(n_threads, qs[4 + n_lone + n_threads:], one)
+                res[f"{n_mod}_index" + ("es" if n_mod > 1 else "")] = {
+                    "single_caller_ms_per_query": lone_ms, "queries_per_s_8_threads": n_threaded / dt,
+                    "rerank_pairs_per_query": pairs / n_lone, "mean_pair_tokens": toks / max(pairs, 1),
+                    "source_nodes_per_query": sum(g[0] for g in got) / n_lone,
+                    "lone_caller_gpu_kernel_ms": fam,
+                    "confidence_levels": sorted({g[1] for g in got + got_t}),
+                    "scan": "one pass over the module" if n_mod == 1 else f"{n_mod} modules packed into one matrix, one segmented pass"}
+                del svc, indexes
+            res["precision"] = getattr(rr, "precision", None)
+            out[label] = res
+    finally:
+        mm.ModelManager.reset_instance()
+        import gc
+
+        gc.collect()
+        torch.cuda.empty_cache()
+    return out
 
 
 def _c5_docs_reference_geometry(n_docs, words_lo, words_hi, rng):

@@ -1096,7 +1096,8 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
 
-    const int mt_n = p.M / BM3, nt_n = p.N / BN3;
+    // (split planes: N may end inside the last column tile -- a multiple of 64, so whole waves' 64-column strips are in or out)
+    const int mt_n = p.M / BM3, nt_n = (p.N + BN3 - 1) / BN3;
     int L = blockIdx.x;
     {
         const int nwg = gridDim.x;
@@ -1153,7 +1154,10 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
         // (split planes: source chunks 0-3 of a tile row are the hi plane's 64 bytes, 4-7 the lo plane's, K elements further)
         const uint32_t coff = X3 ? (chunk < 4 ? (uint32_t)chunk * 16u : (uint32_t)p.K * 2u + (uint32_t)(chunk - 4) * 16u) : (uint32_t)chunk * 16u;
         voffA[j] = (uint32_t)r * (uint32_t)p.lda * (uint32_t)ES + coff;
-        voffW[j] = (uint32_t)w_row_of(r) * (uint32_t)(p.ldw ? p.ldw : p.K) * (uint32_t)ES + coff;
+        // last column tile of an N that is not a multiple of 256 (split planes, N % 64 == 0: bge-small's 384 columns): the W rows of
+        // the 64-column strips beyond N are read from the tile's first row instead (finite garbage products, never stored)
+        const int wr = (X3 && n0 + (r >> 5) * 64 + 64 > p.N) ? 0 : w_row_of(r);
+        voffW[j] = (uint32_t)wr * (uint32_t)(p.ldw ? p.ldw : p.K) * (uint32_t)ES + coff;
     }
 
     unsigned long long* dbg0 = reinterpret_cast<unsigned long long*>(p.vt);
@@ -1207,7 +1211,12 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
     }
     // bias strip of this tile (256 floats = one 1-KiB copy), oldest operation of wave 0's queue
     if (wave == 0) {
-        glds16(p.bias + n0, lane * 16, (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem + kBiasOff);
+        uint32_t boff = lane * 16;
+        if constexpr (X3) {          // (a partial last column tile: stay inside the bias vector)
+            const uint32_t last = (uint32_t)((p.N - n0 < BN3 ? p.N - n0 : BN3) * 4 - 16);
+            boff = boff < last ? boff : last;
+        }
+        glds16(p.bias + n0, boff, (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem + kBiasOff);
     }
     if constexpr (FP8 && EPI != TT_EPI_VT) {   // (the V^T epilogue reads its scales from global memory)
         if (wave == 1) glds16(p.a_scale + m0, lane * 16, (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem + kScaleOff);
@@ -1458,6 +1467,9 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
     stage_res(3);               // every operand read is done: hi slots of buffer 1
 
     // ---- epilogue ---------------------------------------------------------------------------------
+    if constexpr (X3) {
+        if (n0 + wn * 64 >= p.N) return;       // this wave's 64-column strip lies beyond N (partial last column tile): nothing to store
+    }
     if constexpr (vblk) {
 #pragma unroll
         for (int qm = 0; qm < 2; ++qm)
@@ -2021,9 +2033,9 @@ int launch_x3(const GemmParams& p, hipStream_t st) {
             TT_CHECK_LAUNCH();
             return TT_OK;
         }
-        if (p.M % v3::BM3 || p.N % v3::BN3 || p.K % 64 || p.K < 128 || p.lda < 2 * p.K || ldw < 2 * p.K || p.lda % 8 || ldw % 8 || !p.A ||
+        if (p.M % v3::BM3 || p.N % 64 || p.K % 64 || p.K < 128 || p.lda < 2 * p.K || ldw < 2 * p.K || p.lda % 8 || ldw % 8 || !p.A ||
             !p.W || !p.bias) {
-            tt_set_error("gemm x3: M=%d N=%d K=%d lda=%d ldw=%d: M, N multiples of 256, K of 64, planes [.][>= 2K]", p.M, p.N, p.K, p.lda, ldw);
+            tt_set_error("gemm x3: M=%d N=%d K=%d lda=%d ldw=%d: M a multiple of 256, N and K of 64, planes [.][>= 2K]", p.M, p.N, p.K, p.lda, ldw);
             return TT_E_UNSUPPORTED;
         }
         if constexpr (EPI == TT_EPI_RESIDUAL) {
@@ -2033,7 +2045,7 @@ int launch_x3(const GemmParams& p, hipStream_t st) {
         } else {
             if (!p.C || p.ldc % 8 || p.c_lo_off % 8 || p.c_lo_off < p.N) { tt_set_error("gemm x3: planes output needs C, c_lo_off >= N"); return TT_E_INVALID; }
         }
-        const int mt_n = p.M / v3::BM3, nt_n = p.N / v3::BN3;
+        const int mt_n = p.M / v3::BM3, nt_n = (p.N + v3::BN3 - 1) / v3::BN3;      // (N % 64 == 0: the last column tile may be partial)
         const int SN = super_sn(nt_n), SM = 32 / SN;
         const int supers = ((mt_n + SM - 1) / SM) * ((nt_n + SN - 1) / SN);
         int blocks = supers * SM * SN;

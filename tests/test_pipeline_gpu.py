@@ -782,3 +782,92 @@ def test_leaf_token_ids_travel_with_the_tokenizer_they_were_made_with(dev, built
     mixed.embed_model = Emb(7000)
     mixed.add(nodes[3:], embeddings=vecs[3:], token_ids=toks[3:])
     assert set(mixed.leaf_token_ids) == {"n3", "n4", "n5"} and mixed.token_source()[1] == tokenizer_signature(mixed.embed_model._tokenizer)
+
+
+def test_reference_session_defaults_over_three_modules(dev, built_lib, monkeypatch):
+    """the call an unchanged application issues -- the reference's session defaults
+    (services/session_service.py:76-90: reranker_top_n = 5, confidence_cutoff_hard = 0.05, balance "top_k_per_index";
+    rag_engine.py:592-593: similarity_top_k = max(5, 2 top_n) = 10 PER index) over three index modules, built by
+    ``build_retrieval_service`` as ``load_engine_for_modules`` builds it.  Checked: ONE segmented scan for the three modules; every
+    module's 10 candidates are the CPU oracle's exact top-10 of that module (indices bit-exact on tie-free queries, Chroma-style
+    scores exp(-(2 - 2 cos)) within 1e-3 relative); the balance is the reference's arithmetic (rag_engine.py:463-507: limit =
+    max(1, total // n_indexes), first `limit` per index, sorted by score descending -- restated here independently); the service
+    returns the 5 best of those 30 by the reranker's own scores, none below the hard cutoff."""
+    import math
+
+    from tensor_truth_amd import model_manager as mm
+    from tensor_truth_amd import scan as tscan
+    from tensor_truth_amd.encoder import EncoderConfig
+    from tensor_truth_amd.retrieval_service import build_retrieval_service
+    from tensor_truth_amd.retrievers import similarity_top_k_for
+    from tensor_truth_amd.schema import TextNode
+    from tensor_truth_amd.vector_index import HipVectorIndex
+
+    dim, sizes = 256, [5000, 1200, 9000]
+    texts = _texts(64)
+
+    class FixedEmbed:                       # deterministic query vectors: the scan and the host logic are what is under test
+        model_name = "fixed"
+
+        def get_agg_embedding_from_queries(self, qs):
+            v = torch.randn(dim, generator=torch.Generator().manual_seed(1000 + len(qs[0])))
+            return (v / v.norm()).tolist()
+
+    emb = FixedEmbed()
+    mm.ModelManager.reset_instance()
+    mgr = mm.ModelManager.get_instance()
+    mgr.model_kwargs_overrides["test/xenc"] = {"encoder_config": EncoderConfig(**XENC), "synthetic_seed": 31}
+    corpora, indexes = [], []
+    for part, n in enumerate(sizes):
+        c = osc.synth_corpus(n, dim, seed=500 + part)
+        ix = HipVectorIndex(dim, embed_model=emb)                    # score_mode "chroma", the store the reference queries
+        ix.add([TextNode(text=texts[(7 * part + j) % 64] + f" m{part} leaf {j}", id_=f"m{part}_{j}", metadata={}) for j in range(n)],
+               embeddings=c.float())
+        corpora.append(c)
+        indexes.append(ix)
+    params = {"reranker_model": "test/xenc", "reranker_top_n": 5, "confidence_cutoff": 0.35, "confidence_cutoff_hard": 0.05,
+              "balance_strategy": "top_k_per_index"}
+    K = similarity_top_k_for(5)
+    assert K == 10
+    svc = build_retrieval_service(indexes, params, device="cuda", manager=mgr)
+    rr = mgr.get_reranker("test/xenc", top_n=5, device="cuda")
+    calls = {"seg": 0, "one": 0}
+    orig_seg, orig_one = tscan.scan_topk_segmented, tscan.scan_topk
+    monkeypatch.setattr(tscan, "scan_topk_segmented", lambda *a, **k: (calls.__setitem__("seg", calls["seg"] + 1), orig_seg(*a, **k))[1])
+    monkeypatch.setattr(tscan, "scan_topk", lambda *a, **k: (calls.__setitem__("one", calls["one"] + 1), orig_one(*a, **k))[1])
+    checked_modules = 0
+    for query in ("which kernel streams the corpus", "softmax", "a somewhat longer question about retrieval and ranking"):
+        calls.update(seg=0, one=0)
+        balanced = svc._retriever.retrieve(query)
+        assert calls == {"seg": 1, "one": 0}
+        qv = torch.tensor([emb.get_agg_embedding_from_queries([query])]).to(torch.bfloat16)
+        by_mod = {i: [n for n in balanced if n.node.metadata["_source_index"] == i] for i in range(3)}
+        # the reference's balance over 3 x 10 candidates: limit = max(1, 30 // 3) = 10 -> every module keeps its 10, sorted desc
+        assert all(len(v) == K for v in by_mod.values()) and len(balanced) == 3 * K
+        assert [n.score for n in balanced] == sorted((n.score for n in balanced), reverse=True)
+        for i, c in enumerate(corpora):
+            want_s, want_i, gap = osc.scan_topk(c, qv, K)
+            got = sorted(by_mod[i], key=lambda n: -n.score)
+            want_scores = [math.exp(-(2.0 - 2.0 * float(s))) for s in want_s[0]]
+            assert all(abs(g.score - w) <= 1e-3 * w for g, w in zip(got, want_scores))
+            if float(gap[0]) > 1e-6:
+                assert [int(g.node.id_.split("_")[1]) for g in got] == want_i[0].tolist()
+                checked_modules += 1
+        # the whole service: rerank the 30, keep 5, drop anything under the hard cutoff
+        res = svc.retrieve(query)
+        pairs = [(query, n.node.get_content()) for n in balanced]
+        scores = rr.predict(pairs)
+        order = sorted(range(len(pairs)), key=lambda j: -scores[j])[:5]
+        want_nodes = [(balanced[j].node.id_, scores[j]) for j in order if scores[j] >= 0.05]
+        assert [(n.node.id_, n.score) for n in res.source_nodes] == want_nodes
+        assert res.num_sources == len(want_nodes) and res.confidence_level in ("normal", "low", "none")
+        assert res.metrics["configuration"]["configured_top_n"] == 5
+    assert checked_modules >= 6
+    # unequal candidate counts: the reference's integer arithmetic (a module with 4 rows contributes 4; limit = 24 // 3 = 8)
+    tiny = HipVectorIndex(dim, embed_model=emb)
+    tiny.add([TextNode(text=f"tiny {j}", id_=f"t_{j}", metadata={}) for j in range(4)], embeddings=osc.synth_corpus(4, dim, seed=9).float())
+    svc2 = build_retrieval_service([indexes[0], tiny, indexes[2]], params, device="cuda", manager=mgr)
+    bal = svc2._retriever.retrieve("softmax")
+    counts = [sum(1 for n in bal if n.node.metadata["_source_index"] == i) for i in range(3)]
+    assert counts == [8, 4, 8] and [n.score for n in bal] == sorted((n.score for n in bal), reverse=True)
+    mm.ModelManager.reset_instance()
