@@ -124,9 +124,9 @@ def build_encoder(cfg, state, device, model_kwargs: Optional[Dict[str, Any]], wh
             w = EncoderWeightsF32(cfg, state, device)
             enc, desc = EncoderF32(w), "reference (fp32 weights, activations and MFMA)"
             if os.environ.get("TT_REFERENCE_IMPL", "").strip().lower() not in ("fp32", "float32", "f32"):
-                # the rate cliff of the default mode: the split-plane kernels are built for hidden sizes that are
-                # multiples of 256 with 64-wide heads (bge-m3, the bge rerankers); other shapes (bge-small 384, MiniLM 32-wide
-                # heads) run on the fp32 MFMA -- ~1/16 of the bf16 matrix rate instead of 1/3
+                # the rate cliff of the default mode: the split-plane kernels take hidden sizes that are multiples of 128
+                # with 64- or 32-wide heads (bge-m3, the bge rerankers; round 6: bge-small 384 and MiniLM's 32-wide heads too); any
+                # other shape runs on the fp32 MFMA -- ~1/16 of the bf16 matrix rate instead of 1/3
                 logger.warning("%s: hidden=%d heads=%d has no split-plane kernel: the reference precision falls back to the fp32 MFMA "
                                "path (about 1/16 of the bf16 rate; name torch_dtype=bfloat16 / float16 or TT_PRECISION for the "
                                "16-bit modes)", what, getattr(cfg, "hidden", -1), getattr(cfg, "heads", -1))
