@@ -1270,6 +1270,20 @@ def lone_caller_breakdown(dev, emb, index, retr, rr, queries, top_n):
                     pass
 
 
+def wait_pair_pool(rr):
+    """A reranker starts its pair-tokenisation worker processes in the background when it is built (ingest_workers.warm_pair_pool: a
+    first request never waits for them); the timed legs measure steady state, so they wait here until the pool is up."""
+    tk = getattr(rr, "_tokenizer", None)
+    try:
+        from tensor_truth_amd import ingest_workers as iw
+        from tensor_truth_amd.tokenization import HFTokenizer
+
+        if isinstance(tk, HFTokenizer):
+            iw.get_pair_pool(tk, wait=True)
+    except Exception:  # noqa: BLE001 - no pool: the legs run with in-process tokenisation
+        pass
+
+
 _TEXTS = {}
 
 
@@ -1300,6 +1314,7 @@ def surface_leg(args, dev, shard_rows, emb_cfg, rr_cfg, world=1, rank=0, row_lo=
                                   model_kwargs={"encoder_config": emb_cfg, "synthetic_seed": 1, **dt_kw})
     rr = HipSentenceTransformerRerank(model="BAAI/bge-reranker-v2-m3", top_n=topn, device=str(dev), batch_pairs=4096,
                                       model_kwargs={"encoder_config": rr_cfg, "synthetic_seed": 2, **dt_kw})
+    wait_pair_pool(rr)
     n = shard_rows.shape[0] if world == 1 else args.corpus_rows
     index = ShardedHipVectorIndex(shard_rows.shape[1], shard_rows, row_lo, n, _RowIds(n), _SynthDocstore(args.chunk_len, texts.chunk),
                                   embed_model=emb, score_mode="cosine", queries="partitioned" if world > 1 else "replicated", group=group)
@@ -1425,6 +1440,7 @@ def reference_defaults_leg(args, dev, shard_rows, emb_cfg, rr_cfg, n_lone=8, n_t
                     indexes.append(ix)
                 svc = build_retrieval_service(indexes, params, device=str(dev), manager=mgr)
                 rr = mgr.get_reranker(None, top_n=params["reranker_top_n"], device=str(dev))
+                wait_pair_pool(rr)
                 key0 = 20_000_000_000 + (1_000_000 if label == "bf16" else 2_000_000) + 100_000 * n_mod
                 qs = [texts.query(key0 + i) for i in range(4 + n_lone + n_threads + n_threaded)]
 
@@ -1542,6 +1558,7 @@ def config5_leg(args, dev, emb_cfg, rr_cfg):
     params = {"reranker_top_n": args.top_n, "similarity_top_k": args.top_k, "confidence_cutoff": 0.35}
     svc = build_retrieval_service([index], params, device="cuda", manager=mgr)
     rr = mgr.get_reranker("BAAI/bge-reranker-v2-m3", top_n=args.top_n, device="cuda")
+    wait_pair_pool(rr)
     cal = rng.integers(4, rr_cfg.vocab_size, size=(64, 128), dtype=np.int32)
     cal[:, 0], cal[:, -1] = 0, 2
     rr._encoder.calibrate_fp8(pack_token_matrix(cal, rr_cfg))     # static e4m3 scales of the FFN intermediate
@@ -1597,12 +1614,75 @@ def config5_leg(args, dev, emb_cfg, rr_cfg):
         return (time.perf_counter() - t1) / (len(qs) - 2) * 1e3
 
     lone_ids_ms = lone(lone_a)
-    src = index.token_source()
-    rr.detach_token_source()
+    # (the service holds its token source in its own view of the shared reranker: rerank.RerankerWithTokenSource)
+    view = svc._node_postprocessors[0]
+    saved_source = getattr(view, "token_source", None)
+    assert saved_source is not None, "the composed service was expected to serve its leaves from stored token ids"
+    view.token_source = None
     lone_txt_ms = lone(lone_b)
     dt_txt, _ = _run_threads(args.surface_threads, queries_txt, lambda q: svc.retrieve(q).num_sources)
-    if src is not None:
-        rr.attach_token_source(*src)
+    view.token_source = saved_source
+    # ---- the same workload with NO dtype named anywhere: embedder and reranker in the reference's own precision (fp32 semantics as
+    #      split-fp16 planes) -- same documents, same geometry, same service; its own query strings
+    default_precision = None
+    if not args.no_reference_leg:
+        del svc
+        mm.ModelManager.reset_instance()
+        mgr = mm.ModelManager.get_instance()
+        mgr.model_kwargs_overrides["BAAI/bge-m3"] = {"encoder_config": emb_cfg, "synthetic_seed": 1, "tokenizer": texts.tokenizer}
+        mgr.model_kwargs_overrides["BAAI/bge-reranker-v2-m3"] = {"encoder_config": rr_cfg, "synthetic_seed": 2, "tokenizer": texts.tokenizer}
+        emb_d = mgr.get_embedder("BAAI/bge-m3", "cuda")
+        build_index(docs[:64], emb_d, **ref_kw)
+        torch.cuda.synchronize()
+        sd0 = dict(emb_d.stats)
+        t0 = time.perf_counter()
+        index_d = build_index(docs, emb_d, **ref_kw)
+        torch.cuda.synchronize()
+        t_ing_d = time.perf_counter() - t0
+        tok_d, seqs_d = emb_d.stats["tokens"] - sd0["tokens"], emb_d.stats["sequences"] - sd0["sequences"]
+        flops_d = tok_d * ((L - 1) * 2 * (4 * H * H + 2 * H * F) + 4 * H * H) + seqs_d * 2 * (2 * H * H + 2 * H * F)
+        svc_d = build_retrieval_service([index_d], params, device="cuda", manager=mgr)
+        rr_d = mgr.get_reranker("BAAI/bge-reranker-v2-m3", top_n=args.top_n, device="cuda")
+        wait_pair_pool(rr_d)
+        live_d = [x for x in index_d.leaf_ids if x is not None]
+
+        def leaf_query_d(i):
+            words = index_d.docstore[live_d[int(rng.integers(0, len(live_d)))]].text.replace(".", " ").split()
+            pick = rng.choice(len(words), size=min(texts.q_words, len(words)), replace=False)
+            return " ".join(words[int(j)] for j in pick)
+
+        nqd = max(args.surface_threads * 2, nq // 2)
+        q_d, warm_d, lone_d = ([leaf_query_d(i) for i in range(n)] for n in (nqd, 1 + args.surface_threads, 8))
+        svc_d.retrieve(warm_d[0])
+        _run_threads(args.surface_threads, warm_d[1:], lambda q: svc_d.retrieve(q).num_sources)
+        rs0 = dict(rr_d.stats)
+        dt_d, res_d = _run_threads(args.surface_threads, q_d, lambda q: svc_d.retrieve(q).num_sources)
+        rs1 = dict(rr_d.stats)
+        for q in lone_d[:2]:
+            svc_d.retrieve(q)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for q in lone_d[2:]:
+            svc_d.retrieve(q)
+        torch.cuda.synchronize()
+        lone_d_ms = (time.perf_counter() - t1) / (len(lone_d) - 2) * 1e3
+        dpairs = max(rs1["pairs"] - rs0["pairs"], 1)
+        default_precision = {
+            "embedder_precision": getattr(emb_d, "precision", None), "reranker_precision": getattr(rr_d, "precision", None),
+            "docs": len(docs), "leaves": index_d.n, "ingest_s": t_ing_d, "docs_per_s": len(docs) / t_ing_d,
+            "tokens_embedded": tok_d, "tokens_embedded_per_s": tok_d / t_ing_d,
+            "roofline_ingest": {"bound": "mfma", "achieved": 3 * flops_d / t_ing_d / 1e12, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
+                                "frac": 3 * flops_d / t_ing_d / 1e12 / MFMA_BF16_PEAK_TF, "useful_TFLOPs": flops_d / t_ing_d / 1e12,
+                                "note": "split-fp16 planes: THREE fp16 MFMA products per product (hi.hi, hi.lo, lo.hi), so the matrix "
+                                        "cores do 3 x the GEMM flops of the bf16 pass; `achieved` counts that MFMA work over the wall time "
+                                        "of build_index from strings, `useful_TFLOPs` the products the model asks for"},
+            "queries": len(q_d), "queries_per_s": len(q_d) / dt_d, "mean_sources": float(np.mean(res_d)),
+            "single_caller_ms_per_query": lone_d_ms,
+            "rerank_pairs": {"pairs_per_query": (rs1["pairs"] - rs0["pairs"]) / len(q_d), "mean_pair_tokens": (rs1["tokens"] - rs0["tokens"]) / dpairs,
+                             "passages_from_stored_ids_frac": (rs1.get("pretokenized", 0) - rs0.get("pretokenized", 0)) / dpairs},
+            "what": "the primary pass again with the constructors exactly as the reference calls them (no dtype): embedder and reranker "
+                    "in the reference's fp32 semantics (f16x3), same documents, geometry, tokenizer, service and thread count"}
+        del svc_d, index_d
     # ---- secondary: rounds 2-4's small geometry, ingest only (hashing tokenizer, ~1.1 k-word documents)
     small = None
     if args.config5_small_docs > 0:
@@ -1651,6 +1731,8 @@ def config5_leg(args, dev, emb_cfg, rr_cfg):
                                         "the row kernels included; the kernel-level figure is roofline_embed"},
             "doc_generation_s": t_gen,
             "queries": len(queries), "queries_per_s": len(queries) / dt, "mean_sources": float(np.mean(res)), "reranker": "bf16",
+            "embedder_precision": "bf16 (fp32 accumulate): model_kwargs torch_dtype = bfloat16, the mode BASELINE's configurations name",
+            "default_precision": default_precision,
             "rerank_pairs": pair_stats,
             "leaf_token_ids": {"kept_at_ingest": index.leaf_token_ids is not None and len(index.leaf_token_ids),
                                "single_caller_ms_per_query": lone_ids_ms,
