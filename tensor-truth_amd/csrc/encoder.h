@@ -70,6 +70,19 @@ struct GemmParams {
     const uint8_t* a_scales;  // [M / 256][K / 128][1024]
     const uint8_t* w_scales;  // [N / 256][2 K / 128][1024]: the w_lo8 part's K / 128 chunks, then the w_x8 part's (exponents - 11)
     uint8_t* c_scales;        // GELU epilogue: the output's scales, tiled for a consumer with K = N
+#if TT_DIAG
+    // ---- LayerNorm-folding EXPERIMENT (round 6; diagnostic library only: tools/ln_fold_bench, profiles/r06_ln_folding_ab.log) ----
+    // 1 = consumer epilogue (bias / GELU; the A operand is the RAW pre-LayerNorm sum, W carries gamma):
+    //         out[m][n] = lnf_rows[m].rstd * acc + lnf_rows[m].nmr * lnf_c0[n] + bias[n]        (lnf_c0 = column sums of the folded W)
+    // 2 = producer epilogue (residual): the residual tile is the RAW pre-LayerNorm sum y of the previous block and LayerNorm(y) is
+    //     rebuilt on the fly, res = y * (rstd * gamma[n]) + (nmr * gamma[n] + beta[n])  (lnf_c0 = gamma, lnf_c1 = beta); the epilogue
+    //     also emits, per output row and 64-column strip, (sum, sum of squares) of the bf16-rounded outputs -> lnf_part[m][N / 64][2]
+    int lnf;
+    const float* lnf_rows;    // [M][2]: rstd, -mu * rstd of the rows of the folded LayerNorm's input
+    const float* lnf_c0;      // [N]
+    const float* lnf_c1;      // [N]
+    float* lnf_part;          // [M][N / 64][2]
+#endif
 };
 // Filter pass of the similarity scan for 65..256 queries per pass as a 256x256x64-tiled MFMA contraction (gemm.hip):
 // corpus [rows][dim] bf16 with rows a multiple of 256, queries256 [256][dim] bf16 (rows beyond the batch zero),

@@ -440,6 +440,17 @@ __attribute__((visibility("default"))) int tt_attention_debug_stamps(const void*
     return tt_attention_launch(a, (hipStream_t)stream);
 }
 
+// diagnostic only (not in tt_hip.h): the LayerNorm-folding experiment's epilogues (GemmParams.lnf; tools/ln_fold_bench)
+__attribute__((visibility("default"))) int tt_gemm_debug_lnfold(const void* a, const void* w, const float* bias, const void* residual,
+                                                                void* c, int m, int n, int k, int epilogue, int lnf, const float* rows,
+                                                                const float* c0, const float* c1, float* part, void* stream) {
+    GemmParams g{};
+    g.A = (const uint16_t*)a; g.lda = k; g.W = (const uint16_t*)w; g.bias = bias; g.residual = (const uint16_t*)residual; g.ldr = n;
+    g.C = (uint16_t*)c; g.ldc = n; g.M = m; g.N = n; g.K = k;
+    g.lnf = lnf; g.lnf_rows = rows; g.lnf_c0 = c0; g.lnf_c1 = c1; g.lnf_part = part;
+    return tt_gemm_launch(g, epilogue, (hipStream_t)stream);
+}
+
 // diagnostic only (not in tt_hip.h): run the bias GEMM with a stamp buffer in GemmParams.vt
 __attribute__((visibility("default"))) int tt_gemm_debug_stamps(const void* a, const void* w, const float* bias, void* c, int m, int n, int k, void* stamps,
                          void* stream) {

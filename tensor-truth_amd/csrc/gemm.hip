@@ -440,7 +440,7 @@ __device__ __forceinline__ float lds_read32_sync(uint32_t addr) {
 template <int EPI, bool STAGE, bool FP8, class Next>
 __device__ __forceinline__ void epilogue_all(const GemmParams& p, f32x4 (&acc)[2][2][2][4], const char* smem, int bias_off,
                                              int scale_off, int m0, int n0, int wm, int wn, int wave, int lane, bool has_next,
-                                             Next issue_next) {
+                                             Next issue_next, int lnf_col_off = 0, int lnf_row_off = 0) {
     const int g = lane >> 4;
     const bool odd = (g & 1) != 0;
     const int ncol = wn * 64 + (g & ~1) * 4;           // + qn*32 + nt*16: first of this lane's 8 columns
@@ -471,6 +471,26 @@ __device__ __forceinline__ void epilogue_all(const GemmParams& p, f32x4 (&acc)[2
             bias[i >> 2][(i >> 1) & 1][i & 1] = float4{__uint_as_float(b[i].x), __uint_as_float(b[i].y), __uint_as_float(b[i].z),
                                                        __uint_as_float(b[i].w)};
     }
+#if TT_DIAG
+    // LayerNorm-folding experiment (GemmParams.lnf): the column strip(s) and the tile's row statistics sit in LDS behind the bias
+    // strips (staged in the prologue like them); consumer form: the column sums of the folded weight, kept in registers like the bias
+    const int lnf = (FP8 || EPI == TT_EPI_TANH) ? 0 : p.lnf;
+    float4 lcs[2][2][2];
+    if (lnf == 1) {
+        const uint32_t caddr = lds0 + lnf_col_off + ncol * 4;
+        u32x4 b[8];
+        b[0] = lds_read128_async<0>(caddr);        b[1] = lds_read128_async<16>(caddr);
+        b[2] = lds_read128_async<64>(caddr);       b[3] = lds_read128_async<80>(caddr);
+        b[4] = lds_read128_async<128>(caddr);      b[5] = lds_read128_async<144>(caddr);
+        b[6] = lds_read128_async<192>(caddr);      b[7] = lds_read128_async<208>(caddr);
+        lds_wait(b[0], b[1], b[2], b[3]);
+        lds_wait(b[4], b[5], b[6], b[7]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            lcs[i >> 2][(i >> 1) & 1][i & 1] = float4{__uint_as_float(b[i].x), __uint_as_float(b[i].y), __uint_as_float(b[i].z),
+                                                      __uint_as_float(b[i].w)};
+    }
+#endif
     float4 wsc[2][2][2];
     float asc[2][2];   // [qm][pr]: this lane's output row of the block
     if constexpr (FP8) {
@@ -523,6 +543,15 @@ __device__ __forceinline__ void epilogue_all(const GemmParams& p, f32x4 (&acc)[2
                 lds_wait(res[0][0], res[0][1], res[1][0], res[1][1]);
                 if (has_next) issue_next(qm * 2 + pr);
             }
+#if TT_DIAG
+            float lrs = 1.f, lnm = 0.f, lsum = 0.f, lsq = 0.f;       // this lane's row of the block: rstd, -mu rstd; output partials
+            if (lnf) {
+                const uint32_t ra = lds0 + lnf_row_off + (uint32_t)(qm * 128 + mrow + (pr * 2 + (odd ? 1 : 0)) * 16) * 8u;
+                // (two 32-bit reads into registers of their own: read as one 64-bit pair, broadcasting the pair's HIGH dword into a packed-f32
+                // FMA is the op_sel form csrc/check_isa.py bans -- profiles/r03_pk_mfma_hazard.log)
+                asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %2 offset:4\n\ts_waitcnt lgkmcnt(0)" : "=&v"(lrs), "=&v"(lnm) : "v"(ra));
+            }
+#endif
 #pragma unroll
             for (int qn = 0; qn < 2; ++qn)
 #pragma unroll
@@ -537,6 +566,15 @@ __device__ __forceinline__ void epilogue_all(const GemmParams& p, f32x4 (&acc)[2
                         v[4 + k] = __uint_as_float(r[1]);
                     }
                     const float4 b0 = bias[qn][nt][0], b1 = bias[qn][nt][1];
+#if TT_DIAG
+                    if (lnf == 1) {          // consumer: rstd acc + (nmr cs + bias)
+                        const float4 c0 = lcs[qn][nt][0], c1 = lcs[qn][nt][1];
+                        v[0] = fmaf(v[0], lrs, fmaf(lnm, c0.x, b0.x)); v[1] = fmaf(v[1], lrs, fmaf(lnm, c0.y, b0.y));
+                        v[2] = fmaf(v[2], lrs, fmaf(lnm, c0.z, b0.z)); v[3] = fmaf(v[3], lrs, fmaf(lnm, c0.w, b0.w));
+                        v[4] = fmaf(v[4], lrs, fmaf(lnm, c1.x, b1.x)); v[5] = fmaf(v[5], lrs, fmaf(lnm, c1.y, b1.y));
+                        v[6] = fmaf(v[6], lrs, fmaf(lnm, c1.z, b1.z)); v[7] = fmaf(v[7], lrs, fmaf(lnm, c1.w, b1.w));
+                    } else
+#endif
                     if constexpr (FP8) {
                         const float sa = asc[qm][pr];
                         const float4 s0 = wsc[qn][nt][0], s1 = wsc[qn][nt][1];
@@ -559,22 +597,57 @@ __device__ __forceinline__ void epilogue_all(const GemmParams& p, f32x4 (&acc)[2
                         for (int k = 0; k < 8; ++k) v[k] = tanhf(v[k]);
                     } else if constexpr (EPI == TT_EPI_RESIDUAL) {
                         const u32x4 r = res[qn][nt];
+#if TT_DIAG
+                        if (lnf == 2) {      // producer: the residual tile is the raw pre-LayerNorm sum; LayerNorm rebuilt in fp32
+                            const uint32_t ga = lds0 + lnf_col_off + (uint32_t)(ncol + qn * 32 + nt * 16) * 4u;
+                            u32x4 g0 = lds_read128_async<0>(ga), g1 = lds_read128_async<16>(ga);
+                            u32x4 e0 = lds_read128_async<1024>(ga), e1 = lds_read128_async<1040>(ga);
+                            lds_wait(g0, g1, e0, e1);
+                            const float gm[8] = {__uint_as_float(g0.x), __uint_as_float(g0.y), __uint_as_float(g0.z), __uint_as_float(g0.w),
+                                                 __uint_as_float(g1.x), __uint_as_float(g1.y), __uint_as_float(g1.z), __uint_as_float(g1.w)};
+                            const float bt[8] = {__uint_as_float(e0.x), __uint_as_float(e0.y), __uint_as_float(e0.z), __uint_as_float(e0.w),
+                                                 __uint_as_float(e1.x), __uint_as_float(e1.y), __uint_as_float(e1.z), __uint_as_float(e1.w)};
+                            const float y[8] = {elo(r.x), ehi(r.x), elo(r.y), ehi(r.y), elo(r.z), ehi(r.z), elo(r.w), ehi(r.w)};
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) v[k] += fmaf(y[k], lrs * gm[k], fmaf(lnm, gm[k], bt[k]));
+                        } else
+#endif
+                        {
                         v[0] += elo(r.x); v[1] += ehi(r.x);
                         v[2] += elo(r.y); v[3] += ehi(r.y);
                         v[4] += elo(r.z); v[5] += ehi(r.z);
                         v[6] += elo(r.w); v[7] += ehi(r.w);
+                        }
                     }
                     const int m = m0 + qm * 128 + mrow + (pr * 2 + (odd ? 1 : 0)) * 16;
                     const int n = n0 + qn * 32 + nt * 16 + ncol;
                     uint4 o;
                     o.x = pack_e2(v[0], v[1]); o.y = pack_e2(v[2], v[3]);
                     o.z = pack_e2(v[4], v[5]); o.w = pack_e2(v[6], v[7]);
+#if TT_DIAG
+                    if (lnf == 2) {          // statistics of the values the consumer will read: the bf16-rounded outputs
+                        const float w8[8] = {elo(o.x), ehi(o.x), elo(o.y), ehi(o.y), elo(o.z), ehi(o.z), elo(o.w), ehi(o.w)};
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) { lsum += w8[k]; lsq = fmaf(w8[k], w8[k], lsq); }
+                    }
+#endif
                     if constexpr (STAGE) {
                         lds_write128_async(raddr[qn][nt] + kOffB[qm * 2 + pr], o);
                     } else {
                         *reinterpret_cast<uint4*>(p.C + (size_t)m * p.ldc + n) = o;
                     }
                 }
+#if TT_DIAG
+            if (lnf == 2) {
+                // the row's 64 columns of this wave sit in two lanes (g and g ^ 2: lanes 32 apart)
+                lsum += __shfl_xor(lsum, 32, 64);
+                lsq += __shfl_xor(lsq, 32, 64);
+                if ((g >> 1) == 0) {
+                    const int m = m0 + qm * 128 + mrow + (pr * 2 + (odd ? 1 : 0)) * 16;
+                    *reinterpret_cast<float2*>(p.lnf_part + ((size_t)m * (p.N >> 6) + (size_t)((n0 >> 6) + wn)) * 2) = float2{lsum, lsq};
+                }
+            }
+#endif
             if constexpr (STAGE) {
                 // the block's 32 rows x 128 B now sit row-major in this wave's two private pieces: read them back a
                 // row per 8 lanes and store whole 128-byte lines instead of 32-byte runs
@@ -1222,6 +1295,17 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
         if (wave == 1) glds16(p.a_scale + m0, lane * 16, (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem + kScaleOff);
         if (wave == 2) glds16(p.w_scale + n0, lane * 16, (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem + kScaleOff + 1024);
     }
+#if TT_DIAG
+    if constexpr (!FP8 && !X3 && !XC && (EPI == TT_EPI_BIAS || EPI == TT_EPI_GELU || EPI == TT_EPI_RESIDUAL)) {
+        if (p.lnf) {      // LayerNorm-folding experiment: column strip(s) + the tile's 256 row statistics, oldest operations of their waves
+            const uint32_t l0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+            if (wave == 1) glds16(p.lnf_c0 + n0, lane * 16, l0 + kScaleOff);
+            if (wave == 2 && p.lnf == 2) glds16(p.lnf_c1 + n0, lane * 16, l0 + kScaleOff + 1024);
+            if (wave == 3) glds16(p.lnf_rows + (size_t)m0 * 2, lane * 16, l0 + kScaleOff + 2048);
+            if (wave == 4) glds16(p.lnf_rows + (size_t)(m0 + 128) * 2, lane * 16, l0 + kScaleOff + 3072);
+        }
+    }
+#endif
     // ---- prologue: tile 0 complete, tile 1 without its A-hi (issued in L1(0)); same order as steady state
     stage_half<0, ES>(p, smem, 0, 0, 0, wave, voffA, m0, n0, TB);
     stage_half<1, ES>(p, smem, 0, 0, 0, wave, voffW, m0, n0, TB);
@@ -1502,7 +1586,7 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_v3(GemmParams p) {
             for (int qn = 0; qn < 2; ++qn)
                 gemm_epilogue_wide<EPI, 2, 4, true>(p, acc[qm][qn], m0 + qm * 128 + wm * 64, n0 + wn * 64 + qn * 32, lane);
     } else {
-        epilogue_all<EPI, true, FP8>(p, acc, smem, kBiasOff, kScaleOff, m0, n0, wm, wn, wave, lane, false, NoNext{});
+        epilogue_all<EPI, true, FP8>(p, acc, smem, kBiasOff, kScaleOff, m0, n0, wm, wn, wave, lane, false, NoNext{}, kScaleOff, kScaleOff + 2048);
     }
     if constexpr (SLOTS == 46) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1585,6 +1669,15 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_p(GemmParams p, int 
             if (wave == 1) glds16(p.a_scale + mm0, lane * 16, l0 + kScaleOff + par * 2048);
             if (wave == 2) glds16(p.w_scale + nn0, lane * 16, l0 + kScaleOff + par * 2048 + 1024);
         }
+#if TT_DIAG
+        if constexpr (!FP8 && (EPI == TT_EPI_BIAS || EPI == TT_EPI_GELU)) {
+            if (p.lnf == 1) {   // consumer form only: column sums at kScaleOff + par KiB, row statistics at kScaleOff + 2 KiB + par 2 KiB (launched with 2 KiB more LDS)
+                if (wave == 1) glds16(p.lnf_c0 + nn0, lane * 16, l0 + kScaleOff + par * 1024);
+                if (wave == 3) glds16(p.lnf_rows + (size_t)mm0 * 2, lane * 16, l0 + kScaleOff + 2048 + par * 2048);
+                if (wave == 5) glds16(p.lnf_rows + (size_t)(mm0 + 128) * 2, lane * 16, l0 + kScaleOff + 2048 + par * 2048 + 1024);
+            }
+        }
+#endif
     };
     // hi / lo halves of K-tile u of the current tile, or of K-tile u - nk of the next one (nk is even: same buffer)
     auto issue_hi = [&](int u) {
@@ -1753,7 +1846,7 @@ __global__ __launch_bounds__(kThreads3, 2) void gemm_kernel_p(GemmParams p, int 
             scan_filter_epilogue<2>(p, acc, smem, kBiasOff + bpar * 1024, m0, wm, wn, lane_e);
         else
             epilogue_all<EPI, false, FP8>(p, acc, smem, kBiasOff + bpar * 1024, kScaleOff + bpar * 2048, m0, n0, wm, wn, wave, lane_e,
-                                          false, NoNext{});
+                                          false, NoNext{}, kScaleOff + bpar * 1024, kScaleOff + 2048 + bpar * 2048);
         pstamp(101);                                  // epilogue done (stores issued)
         ++tile_no;
         if (!has_next) {
@@ -2171,13 +2264,14 @@ int launch(const GemmParams& p, hipStream_t st) {
         if constexpr (EPI == TT_EPI_GELU || EPI == TT_EPI_BIAS) {
             const int cus = tt_cu_count_cached() / 8 * 8;
             if (variant == 5 && (EPI == TT_EPI_GELU || (xp & 1)) && (p.K / BK) % 2 == 0 && p.K / BK >= 2 && blocks > cus && cus >= 8) {
-                TT_SET_MAX_LDS(v3::gemm_kernel_p<EPI>, v3::kLds3);
+                constexpr int kLdsP = v3::kLds3 + (TT_DIAG ? 2048 : 0);     // (diagnostic build: room for the LayerNorm-folding experiment's strips)
+                TT_SET_MAX_LDS(v3::gemm_kernel_p<EPI>, kLdsP);
                 {
                     TtProfScope prof(TT_K_GEMM, st);
                     GemmParams q = p;
                     q.sn = SN;
                     q.xp = xp;
-                    hipLaunchKernelGGL(v3::gemm_kernel_p<EPI>, dim3(cus), dim3(v3::kThreads3), v3::kLds3, st, q, blocks);
+                    hipLaunchKernelGGL(v3::gemm_kernel_p<EPI>, dim3(cus), dim3(v3::kThreads3), kLdsP, st, q, blocks);
                 }
                 TT_CHECK_LAUNCH();
                 return TT_OK;
