@@ -94,6 +94,25 @@ int tt_scan_topk_segmented(const void* corpus_bf16, int64_t n_rows, int dim,
                            float* out_scores, int32_t* out_idx,
                            void* workspace, size_t workspace_bytes, void* stream);
 
+/* fp8 shadow of the corpus: an EXACT prefilter for the scan of a lone caller (the reference's own usage: one un-batched
+ * retrieve() per query, src/tensortruth/rag_engine.py:420-424, README.md:13), where tt_scan_topk is one full read of the bf16
+ * matrix (20.5 GB at 10 M x 1024: 3 ms).  The shadow block holds, for a capacity of cap_rows rows, the rows as e4m3 bytes
+ * (x 256) and two floats per row -- the norm of what the rounding took and the norm of what it kept -- so that
+ * |q.c - q8.c8| <= ||q|| be + ||q - q8|| dn bounds every row's exact score from above (csrc/shadow.hip).
+ * tt_scan_topk_shadow: threshold = k-th best exact score of a row sample (as tt_scan_topk); one pass over the SHADOW lists
+ * the rows whose bound reaches it; those rows are re-scored from the bf16 matrix with tt_scan_topk's own arithmetic and the
+ * same exact selection.  Scores and indices are bit-identical to tt_scan_topk's.  n_queries <= 4; rows [0, n_rows) of the
+ * shadow must have been built from the same corpus rows (tt_scan_shadow_build, any sub-range at a time: appended rows only
+ * need their own range).  status_flag as in tt_scan_topk (a survivor list that overflowed: re-run tt_scan_topk). */
+size_t tt_scan_shadow_bytes(int64_t cap_rows, int dim);
+int tt_scan_shadow_build(const void* corpus_bf16, int dim, int64_t row_lo, int64_t row_hi,
+                         void* shadow, int64_t cap_rows, void* stream);
+size_t tt_scan_shadow_workspace_bytes(int64_t n_rows, int dim, int n_queries, int k);
+int tt_scan_topk_shadow(const void* corpus_bf16, const void* shadow, int64_t cap_rows, int64_t n_rows, int dim,
+                        const void* queries_bf16, int n_queries, int k, int32_t idx_base,
+                        float* out_scores, int32_t* out_idx,
+                        void* workspace, size_t workspace_bytes, int32_t* status_flag, void* stream);
+
 /* Merge per-shard partial top-k lists (the step after the RCCL all-gather of
  * SURVEY.md section 8e; also MultiIndexRetriever's concatenate+sort,
  * rag_engine.py:463-507, when indexes live in one matrix).

@@ -77,6 +77,11 @@ SIGNATURES = {
     "tt_scan_segmented_workspace_bytes": (c_size_t, [c_int64, c_int, c_int, c_int]),
     "tt_scan_topk_segmented": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p,
                                        c_void_p, c_void_p, c_size_t, c_void_p]),
+    "tt_scan_shadow_bytes": (c_size_t, [c_int64, c_int]),
+    "tt_scan_shadow_build": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_int64, c_void_p]),
+    "tt_scan_shadow_workspace_bytes": (c_size_t, [c_int64, c_int, c_int, c_int]),
+    "tt_scan_topk_shadow": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_int, c_int, c_int32, c_void_p, c_void_p,
+                                    c_void_p, c_size_t, c_void_p, c_void_p]),
     "tt_topk_merge": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "tt_encoder_workspace_bytes": (c_size_t, [c_void_p, c_int]),
     "tt_encoder_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,

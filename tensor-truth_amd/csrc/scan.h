@@ -28,6 +28,11 @@ struct ScanParams {
     int64_t group_stride;
     int64_t phys_rows;
     int prof_id;              // 0 = TT_K_SCAN_FILTER / TT_K_SCAN_SAMPLE by `out`; else the timing id of this launch
+    // mode 0 only (round 6, shadow.hip: exact re-scoring of the fp8 prefilter's survivors): launch row i is PHYSICAL row
+    // row_table[i] of `corpus` (a gather by index, same fragments and MFMA order as a contiguous scan: the same score bits);
+    // row_cnt (device) = the number of table entries, read by the kernel -- row_hi is then only the launch's upper bound
+    const int32_t* row_table;
+    const int32_t* row_cnt;
 };
 
 #define TT_SCAN_PRIV_SLOTS 16

@@ -180,6 +180,13 @@ __global__ __launch_bounds__(kThreads) void scan_kernel(ScanParams p) {
     const int qswz = ql & 15;
 
     // ---- row-group partition: block owns [g_lo, g_hi), waves interleave -------
+    if constexpr (MODE == 0) {
+        if (p.row_cnt) {          // gathered launch: the table's length lives on the device (no host round trip between the passes)
+            const int64_t n = *p.row_cnt;
+            p.row_hi = p.row_lo + (n < p.row_hi - p.row_lo ? n : p.row_hi - p.row_lo);
+            if (p.row_hi <= p.row_lo) return;
+        }
+    }
     const int64_t n_groups = (p.row_hi - p.row_lo + 31) / 32;
     const int64_t per_blk = n_groups / gridDim.x;
     const int64_t rem = n_groups % gridDim.x;
@@ -292,18 +299,25 @@ __global__ __launch_bounds__(kThreads) void scan_kernel(ScanParams p) {
     } else {
         constexpr int P = C::P0;
         uint4 ring[P];
-        auto issue = [&](uint4& dst, int64_t g, int ks) {
+        // physical row of this lane in group g: contiguous, or looked up in the gather table (entries beyond the table: its last row)
+        auto phys = [&](int64_t g) {
             int64_t row = p.row_lo + g * gstride * 32 + ql;
-            row = row < last_row ? row : last_row;
+            const int64_t last = p.row_table ? p.row_hi - 1 : last_row;
+            row = row < last ? row : last;
+            return p.row_table ? (int64_t)p.row_table[row] : row;
+        };
+        int64_t row_cur = grp < g_hi ? phys(grp) : 0, row_nxt = 0;
+        auto issue = [&](uint4& dst, int64_t row, int ks) {
             dst = ldg16c<(VAR & 1) == 0>(corpus + (size_t)row * D + ks * 16 + half * 8);
         };
         if (grp < g_hi) {
 #pragma unroll
-            for (int k = 0; k < P; ++k) issue(ring[k], grp, k);
+            for (int k = 0; k < P; ++k) issue(ring[k], row_cur, k);
         }
         while (grp < g_hi) {
             const int64_t nxt = grp + kWaves;
             const bool has_next = nxt < g_hi;
+            if (has_next) row_nxt = phys(nxt);
 #pragma unroll
             for (int ks = 0; ks < C::NKS; ++ks) {
                 const int s = ks % P;
@@ -320,14 +334,15 @@ __global__ __launch_bounds__(kThreads) void scan_kernel(ScanParams p) {
                     acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bfr[g], acc[g], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 if (ks + P < C::NKS) {
-                    issue(ring[s], grp, ks + P);
+                    issue(ring[s], row_cur, ks + P);
                 } else if (has_next) {
-                    issue(ring[s], nxt, ks + P - C::NKS);
+                    issue(ring[s], row_nxt, ks + P - C::NKS);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
             scan_epilogue<OUT>(p, acc, thr, qvalid, q0, ql, half, grp, pcnt, pbase);
             grp = nxt;
+            row_cur = row_nxt;
         }
     }
     if constexpr (OUT == 0) {

@@ -22,6 +22,7 @@
 #include "common.h"
 #include "scan.h"
 #include "encoder.h"   // tt_scan_gemm_launch
+#include "shadow.h"
 
 static thread_local char g_err[512] = "";
 
@@ -186,6 +187,67 @@ int scan_mode_from_env() {
     return 1;  // LDS-transpose load path (non-temporal corpus loads)
 }
 
+// ---- fp8 shadow prefilter: block layout and workspace plan (shadow.hip) ----
+struct ShadowLayout { size_t off_be, off_dn, total; };
+ShadowLayout shadow_layout(int64_t cap_rows, int dim) {
+    ShadowLayout l{};
+    const size_t r16 = (size_t)(cap_rows + 15) / 16 * 16;
+    size_t off = tt_align_up((size_t)cap_rows * dim, 256);
+    l.off_be = off; off += tt_align_up(r16 * sizeof(float), 256);
+    l.off_dn = off; off += tt_align_up(r16 * sizeof(float), 256);
+    l.total = off;
+    return l;
+}
+struct ShadowPlan {
+    int64_t n0, stride;        // threshold sample: rows, floats per query
+    int blocks, n_waves, capw, cap;
+    size_t off_sample, off_ss, off_si, off_thr, off_planes, off_qinfo, off_list, off_wcnt, off_table, off_tcnt, off_dense, total;
+};
+ShadowPlan shadow_plan(int64_t n_rows, int dim, int n_queries, int k, int cus) {
+    ShadowPlan pl{};
+    // The threshold decides how many rows survive the shadow pass: the bound is ~0.04 for unit rows at 1024 dimensions against a
+    // score spread of 1/32, so with the bf16 pass's 32 768-row sample (k-th best of it: 2.96 sigma at k = 50) 4.6 % of ALL rows would
+    // survive -- 460 k rows to re-score at 10 M.  A sample of rows / 32 (3 % more bytes) puts the threshold at 3.6 sigma: ~1 % survive.
+    int64_t n0 = kSampleRows;
+    if (n0 < (int64_t)128 * k) n0 = (int64_t)128 * k;
+    if (n0 < n_rows / 32) n0 = n_rows / 32 / 32 * 32;
+    pl.n0 = n0 < n_rows ? n0 : n_rows;
+    pl.stride = ((pl.n0 + 31) / 32 + 31) / 32 * 32;
+    pl.blocks = cus > 0 ? cus : 256;
+    const int64_t groups = (n_rows + 15) / 16;
+    if ((int64_t)pl.blocks * kShadowWavesPerBlock > groups) pl.blocks = (int)((groups + kShadowWavesPerBlock - 1) / kShadowWavesPerBlock);
+    if (pl.blocks < 1) pl.blocks = 1;
+    pl.n_waves = pl.blocks * kShadowWavesPerBlock;
+    // survivors: ~1 % of random unit rows at 10 M x 1024 (more on small shards, whose sample is small: 4 % at 1.3 M); sized for 6 % of the rows
+    int64_t cap = n_rows / 16;
+    if (cap < 65536) cap = 65536;
+    if (cap > (1 << 20)) cap = 1 << 20;
+    if (cap > (n_rows + 31) / 32 * 32) cap = (n_rows + 31) / 32 * 32;
+    pl.cap = (int)((cap + 31) / 32 * 32);
+    int64_t capw = 4 * (int64_t)pl.cap / pl.n_waves;
+    if (capw < 64) capw = 64;
+    pl.capw = (int)capw;
+    const int qpad = 64;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += tt_align_up(bytes, 256); return o; };
+    pl.off_sample = take((size_t)qpad * pl.stride * sizeof(float));
+    pl.off_ss = take((size_t)qpad * k * sizeof(float));
+    pl.off_si = take((size_t)qpad * k * sizeof(int32_t));
+    pl.off_thr = take((size_t)qpad * sizeof(float));
+    pl.off_planes = take((size_t)(dim / 128) * 4 * 1024);
+    pl.off_qinfo = take(32 * sizeof(float));
+    pl.off_list = take((size_t)n_queries * pl.n_waves * pl.capw * sizeof(int32_t));
+    pl.off_wcnt = take((size_t)n_queries * pl.n_waves * sizeof(int32_t));
+    pl.off_table = take((size_t)n_queries * pl.cap * sizeof(int32_t));
+    pl.off_tcnt = take((size_t)qpad * sizeof(int32_t));
+    pl.off_dense = take((size_t)pl.cap * sizeof(float));
+    pl.total = off;
+    return pl;
+}
+__global__ void add_idx_base_kernel(int32_t* idx, int n, int32_t base) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && idx[i] >= 0) idx[i] += base;
+}
 }  // namespace
 
 extern "C" {
@@ -465,6 +527,134 @@ int tt_scan_topk(const void* corpus_bf16, int64_t n_rows, int dim, const void* q
     s2.priv_cnt = mp.priv_cnt;
     s2.n_sub = pl.n_sub;
     return tt_select_launch(s2, n_queries, st);
+}
+
+// ---- fp8 shadow prefilter (shadow.hip; plan and layout helpers: the anonymous namespace above) ----
+size_t tt_scan_shadow_bytes(int64_t cap_rows, int dim) {
+    if (cap_rows <= 0 || dim <= 0 || dim % 128 || dim > 1024) return 0;
+    return shadow_layout(cap_rows, dim).total;
+}
+
+int tt_scan_shadow_build(const void* corpus_bf16, int dim, int64_t row_lo, int64_t row_hi, void* shadow, int64_t cap_rows, void* stream) {
+    TT_CHECK_ARG(dim > 0 && dim % 128 == 0 && dim <= 1024, "dim=%d must be a multiple of 128 and <= 1024", dim);
+    TT_CHECK_ARG(row_lo >= 0 && row_lo <= row_hi && row_hi <= cap_rows, "rows [%lld, %lld) outside the shadow's capacity %lld", (long long)row_lo,
+                 (long long)row_hi, (long long)cap_rows);
+    if (row_hi == row_lo) return TT_OK;
+    TT_CHECK_ARG(corpus_bf16 && shadow && ((uintptr_t)corpus_bf16 % 16) == 0 && ((uintptr_t)shadow % 256) == 0, "null or misaligned pointer");
+    const ShadowLayout l = shadow_layout(cap_rows, dim);
+    char* sb = (char*)shadow;
+    return tt_shadow_build_launch((const uint16_t*)corpus_bf16 + (size_t)row_lo * dim, row_hi - row_lo, dim, (uint8_t*)sb + (size_t)row_lo * dim,
+                                  (float*)(sb + l.off_be) + row_lo, (float*)(sb + l.off_dn) + row_lo, (hipStream_t)stream);
+}
+
+size_t tt_scan_shadow_workspace_bytes(int64_t n_rows, int dim, int n_queries, int k) {
+    if (n_rows <= 0 || n_queries <= 0 || n_queries > 4 || k < 1 || dim <= 0 || dim % 128) return 0;
+    int cus = tt_cu_count_cached();
+    if (cus <= 0) cus = 256;
+    return shadow_plan(n_rows, dim, n_queries, k, cus).total;
+}
+
+int tt_scan_topk_shadow(const void* corpus_bf16, const void* shadow, int64_t cap_rows, int64_t n_rows, int dim, const void* queries_bf16,
+                        int n_queries, int k, int32_t idx_base, float* out_scores, int32_t* out_idx, void* workspace, size_t workspace_bytes,
+                        int32_t* status_flag, void* stream) {
+    int rc = check_common(corpus_bf16, n_rows, dim, queries_bf16, n_queries, k, out_scores, out_idx);
+    if (rc) return rc;
+    if (n_queries == 0) return TT_OK;
+    TT_CHECK_ARG(n_queries <= 4, "n_queries=%d: the shadow prefilter serves lone callers (<= 4 queries per call)", n_queries);
+    TT_CHECK_ARG(shadow && ((uintptr_t)shadow % 256) == 0 && n_rows <= cap_rows, "shadow missing, misaligned or smaller than n_rows");
+    TT_CHECK_ARG(n_rows >= (int64_t)128 * k && n_rows > 8192, "n_rows=%lld: shards this small take tt_scan_topk's dense path", (long long)n_rows);
+    hipStream_t st = (hipStream_t)stream;
+    if (status_flag) TT_CHECK_HIP(hipMemsetAsync(status_flag, 0, sizeof(int32_t), st));
+    int cus = tt_cu_count_cached();
+    if (cus <= 0) cus = 256;
+    const ShadowPlan pl = shadow_plan(n_rows, dim, n_queries, k, cus);
+    if (!workspace || workspace_bytes < pl.total) {
+        tt_set_error("tt_scan_topk_shadow: workspace %zu < required %zu bytes", workspace_bytes, pl.total);
+        return TT_E_WORKSPACE;
+    }
+    TT_CHECK_ARG(((uintptr_t)workspace % 256) == 0, "workspace must be 256-byte aligned");
+    char* ws = (char*)workspace;
+    float* sample = (float*)(ws + pl.off_sample);
+    float* thr = (float*)(ws + pl.off_thr);
+    const int mode = scan_mode_from_env();
+    // 1. exact thresholds: the bf16 pass's own sample (group maxima of n0 rows spread evenly over the shard) and selection
+    ScanParams sp{};
+    sp.corpus = (const uint16_t*)corpus_bf16;
+    sp.queries = (const uint16_t*)queries_bf16;
+    sp.row_lo = 0;
+    sp.row_hi = pl.n0;
+    sp.n_queries = n_queries;
+    sp.dense = sample;
+    sp.dense_stride = pl.stride;
+    sp.group_stride = (n_rows / 32) / ((pl.n0 + 31) / 32);
+    sp.phys_rows = n_rows;
+    rc = tt_scan_launch(sp, dim, mode, 2, cus, st);
+    if (rc) return rc;
+    SelectParams s1{};
+    s1.scores = sample;
+    s1.stride = pl.stride;
+    s1.m_fixed = (int)((pl.n0 + 31) / 32);
+    s1.cap = INT_MAX;
+    s1.k = k;
+    s1.out_scores = (float*)(ws + pl.off_ss);
+    s1.out_idx = (int32_t*)(ws + pl.off_si);
+    s1.out_stride = k;
+    s1.thr_out = thr;
+    rc = tt_select_launch(s1, n_queries, st);
+    if (rc) return rc;
+    // 2. the queries as e4m3 planes; 3. one pass over the shadow: rows whose upper bound reaches thr; 4. one table per query
+    const ShadowLayout l = shadow_layout(cap_rows, dim);
+    const char* sb = (const char*)shadow;
+    uint16_t* planes = (uint16_t*)(ws + pl.off_planes);
+    float* qinfo = (float*)(ws + pl.off_qinfo);
+    int32_t* list = (int32_t*)(ws + pl.off_list);
+    int32_t* wcnt = (int32_t*)(ws + pl.off_wcnt);
+    int32_t* table = (int32_t*)(ws + pl.off_table);
+    int32_t* tcnt = (int32_t*)(ws + pl.off_tcnt);
+    rc = tt_shadow_query_launch((const uint16_t*)queries_bf16, n_queries, dim, planes, qinfo, st);
+    if (rc) return rc;
+    rc = tt_shadow_filter_launch((const uint8_t*)sb, (const float*)(sb + l.off_be), (const float*)(sb + l.off_dn), n_rows, dim, planes, qinfo, thr,
+                                 n_queries, pl.blocks, list, wcnt, pl.capw, status_flag, st);
+    if (rc) return rc;
+    rc = tt_shadow_compact_launch(list, wcnt, pl.n_waves, pl.capw, n_queries, table, pl.cap, tcnt, status_flag, st);
+    if (rc) return rc;
+    // 5. per query: the survivors' exact scores from the bf16 rows (the streaming kernel's fragments and MFMA order through a gather
+    //    table: the same bits as tt_scan_topk), then the exact selection over (score, row)
+    float* dense = (float*)(ws + pl.off_dense);
+    for (int q = 0; q < n_queries; ++q) {
+        ScanParams rp{};
+        rp.corpus = (const uint16_t*)corpus_bf16;
+        rp.queries = (const uint16_t*)queries_bf16 + (size_t)q * dim;
+        rp.row_lo = 0;
+        rp.row_hi = pl.cap;
+        rp.n_queries = 1;
+        rp.dense = dense;
+        rp.dense_stride = pl.cap;
+        rp.row_table = table + (size_t)q * pl.cap;
+        rp.row_cnt = tcnt + q;
+        rp.prof_id = TT_K_SCAN_TAIL;
+        rc = tt_scan_launch(rp, dim, 0, 1, cus, st);
+        if (rc) return rc;
+        SelectParams s2{};
+        s2.scores = dense;
+        s2.idx = table + (size_t)q * pl.cap;
+        s2.stride = pl.cap;
+        s2.cnt = tcnt + q;
+        s2.cap = pl.cap;
+        s2.k = k;
+        s2.out_scores = out_scores + (size_t)q * k;
+        s2.out_idx = out_idx + (size_t)q * k;
+        s2.out_stride = k;
+        s2.overflow_flag = status_flag;
+        rc = tt_select_launch(s2, 1, st);
+        if (rc) return rc;
+    }
+    if (idx_base != 0) {
+        const int n = n_queries * k;
+        hipLaunchKernelGGL(add_idx_base_kernel, dim3((n + 255) / 256), dim3(256), 0, st, out_idx, n, idx_base);
+        TT_CHECK_LAUNCH();
+    }
+    return TT_OK;
 }
 
 constexpr int64_t kPieceRows = 65536;   // longest row range one selection block walks (8 LDS rounds)

@@ -47,6 +47,53 @@ def _stream_ptr(device: torch.device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
 
+class ScanShadow:
+    """The fp8 shadow of a corpus matrix (``tt_scan_shadow_build``, csrc/shadow.hip): one e4m3 byte per element plus two floats
+    per row, an EXACT prefilter for the scan of a lone caller -- ``scan_topk(..., shadow=)`` then reads half the bytes and returns
+    bit-identical scores and indices.  ``rows`` = how many rows of the matrix the block currently mirrors (``extend`` adds the rows
+    appended since; a row rewritten in place -- a tombstone -- needs ``rebuild``)."""
+
+    MIN_ROWS = 1 << 20           # below this a bf16 pass is a few hundred microseconds: nothing to win
+    MAX_QUERIES = 4
+
+    def __init__(self, corpus: torch.Tensor, cap_rows: Optional[int] = None):
+        _require_cuda(corpus, "corpus")
+        if corpus.dtype != torch.bfloat16 or corpus.dim() != 2 or not corpus.is_contiguous():
+            raise TypeError("the shadow mirrors a contiguous [N, D] torch.bfloat16 matrix")
+        self.dim = int(corpus.shape[1])
+        self.cap_rows = int(cap_rows if cap_rows is not None else corpus.shape[0])
+        lib = _lib.load_library()
+        nbytes = lib.tt_scan_shadow_bytes(self.cap_rows, self.dim)
+        if nbytes == 0:
+            raise ValueError(f"no shadow for {self.cap_rows} rows x {self.dim}")
+        self._raw = torch.empty(nbytes + 256, dtype=torch.uint8, device=corpus.device)
+        self.ptr = (self._raw.data_ptr() + 255) // 256 * 256
+        self.rows = 0
+        self.base_ptr = corpus.data_ptr()
+        self.ready = torch.cuda.Event()       # recorded behind every build: a search on ANOTHER stream waits for it (scan_topk)
+        self.extend(corpus, int(corpus.shape[0]))
+
+    def extend(self, corpus: torch.Tensor, n_rows: int) -> None:
+        """Mirror rows [self.rows, n_rows) of ``corpus`` (rows appended since the last call)."""
+        if n_rows > self.cap_rows or corpus.shape[1] != self.dim:
+            raise ValueError("the shadow's capacity / width does not fit this matrix")
+        if n_rows <= self.rows:
+            return
+        lib = _lib.load_library()
+        with torch.cuda.device(corpus.device):
+            rc = lib.tt_scan_shadow_build(corpus.data_ptr(), self.dim, self.rows, n_rows, self.ptr, self.cap_rows, _stream_ptr(corpus.device))
+            _lib.check(rc, "tt_scan_shadow_build")
+            self.ready.record(torch.cuda.current_stream(corpus.device))
+        self.rows = n_rows
+
+    def rebuild(self, corpus: torch.Tensor, n_rows: int) -> None:
+        self.rows = 0
+        self.extend(corpus, n_rows)
+
+    def serves(self, n_rows: int, n_queries: int, k: int) -> bool:
+        return (self.rows >= n_rows >= max(self.MIN_ROWS, 128 * k) and 0 < n_queries <= self.MAX_QUERIES)
+
+
 def scan_topk(
     corpus: torch.Tensor,
     queries: torch.Tensor,
@@ -56,6 +103,7 @@ def scan_topk(
     check_overflow: bool = True,
     return_flag: bool = False,
     _packed: Optional[torch.Tensor] = None,
+    shadow: Optional[ScanShadow] = None,
 ):
     """corpus [N,D] bf16, queries [Q,D] bf16 (same HIP device) ->
     (scores [Q,k] fp32, idx [Q,k] int32), idx = idx_base + row, padding (-inf, -1).
@@ -96,7 +144,8 @@ def scan_topk(
                                         out_s.data_ptr(), out_i.data_ptr(), ws.data_ptr(), ws.numel(), st)
             _lib.check(rc, "tt_scan_topk_exact")
             return out_s, out_i
-        need = lib.tt_scan_workspace_bytes(n, d, q, k)
+        use_shadow = shadow is not None and shadow.dim == d and shadow.serves(n, q, k)
+        need = lib.tt_scan_shadow_workspace_bytes(n, d, q, k) if use_shadow else lib.tt_scan_workspace_bytes(n, d, q, k)
         ws = _ws.get(dev, need + 256)
         base = (ws.data_ptr() + 255) // 256 * 256
         if _packed is not None:
@@ -104,20 +153,28 @@ def scan_topk(
             flag.zero_()
         else:
             flag = torch.zeros(1, dtype=torch.int32, device=dev)
-        rc = lib.tt_scan_topk(corpus.data_ptr(), n, d, queries.data_ptr(), q, k, idx_base,
-                              out_s.data_ptr(), out_i.data_ptr(), base, ws.numel() - (base - ws.data_ptr()),
-                              flag.data_ptr(), st)
-        _lib.check(rc, "tt_scan_topk")
+        if use_shadow:
+            torch.cuda.current_stream(dev).wait_event(shadow.ready)     # (built / extended on whatever stream its first user ran on)
+            # a lone caller's scan: one pass over the fp8 shadow, the survivors re-scored from the bf16 rows -- the same bits out
+            rc = lib.tt_scan_topk_shadow(corpus.data_ptr(), shadow.ptr, shadow.cap_rows, n, d, queries.data_ptr(), q, k, idx_base,
+                                         out_s.data_ptr(), out_i.data_ptr(), base, ws.numel() - (base - ws.data_ptr()),
+                                         flag.data_ptr(), st)
+            _lib.check(rc, "tt_scan_topk_shadow")
+        else:
+            rc = lib.tt_scan_topk(corpus.data_ptr(), n, d, queries.data_ptr(), q, k, idx_base,
+                                  out_s.data_ptr(), out_i.data_ptr(), base, ws.numel() - (base - ws.data_ptr()),
+                                  flag.data_ptr(), st)
+            _lib.check(rc, "tt_scan_topk")
         if _packed is not None:
             return out_s, out_i
         if return_flag:
-            return out_s, out_i, int(flag.item()) != 0
+            return out_s, out_i, int(flag.item())
         if check_overflow and int(flag.item()) != 0:
             return scan_topk(corpus, queries, k, idx_base, exact_dense=True)
     return out_s, out_i
 
 
-def scan_topk_host(corpus: torch.Tensor, queries: torch.Tensor, k: int, idx_base: int = 0):
+def scan_topk_host(corpus: torch.Tensor, queries: torch.Tensor, k: int, idx_base: int = 0, shadow: Optional[ScanShadow] = None):
     """``scan_topk`` for callers that need the hits ON THE HOST (the retriever turns rows into nodes): scores, indices and the
     overflow status word live in one device buffer and come back in ONE copy -- the wait for the hits is the only host sync of a
     scan batch (``scan_topk`` itself reads the flag with its own ``.item()`` before the caller's ``.cpu()``: two syncs, 0.04 ms of
@@ -127,7 +184,7 @@ def scan_topk_host(corpus: torch.Tensor, queries: torch.Tensor, k: int, idx_base
     if q == 0:
         return torch.empty((0, k), dtype=torch.float32), torch.empty((0, k), dtype=torch.int32)
     packed = torch.empty(2 * q * k + 1, dtype=torch.int32, device=corpus.device)
-    scan_topk(corpus, queries, k, idx_base, _packed=packed)
+    scan_topk(corpus, queries, k, idx_base, _packed=packed, shadow=shadow)
     host = packed.cpu()                                   # the one sync (current stream only)
     if int(host[-1]) != 0:
         s, i = scan_topk(corpus, queries, k, idx_base, exact_dense=True)

@@ -82,9 +82,14 @@ class ShardedHipVectorIndex:
         if scan_fn is None or merge_fn is None:
             from . import scan as _scan
 
-            scan_fn = scan_fn or (lambda rows, q, k, base: _scan.scan_topk(rows, q, k, idx_base=base))
+            scan_fn = scan_fn or self._scan_shard
             merge_fn = merge_fn or _scan.topk_merge
         self._scan, self._merge = scan_fn, merge_fn
+        # fp8 shadow of every local shard (scan.ScanShadow): an exact prefilter for batches of <= 4 queries -- a lone caller's scan
+        # reads half the bytes, same bits out.  Built on first use (one pass over the shard, + 50 % of its HBM); TT_SCAN_SHADOW=0 turns it off.
+        self.fp8_shadow = os.environ.get("TT_SCAN_SHADOW", "1") != "0"
+        self._shadows: Dict[int, object] = {}
+        self._shadow_lock = threading.Lock()
         self._collective_lock = threading.Lock()
         self._tick_fronts = 0                      # live _TickFront threads (they own this index's collectives)
         self._written = None                       # (HipVectorRetriever._gpu_stream: event behind the last write to the rows)
@@ -179,6 +184,20 @@ class ShardedHipVectorIndex:
 
     def node_score(self, cos: float) -> float:
         return math.exp(-(2.0 - 2.0 * cos)) if self.score_mode == "chroma" else cos
+
+    def _scan_shard(self, rows: torch.Tensor, q16: torch.Tensor, k: int, base: int):
+        from . import scan as _scan
+
+        shadow = None
+        if self.fp8_shadow and 0 < q16.shape[0] <= _scan.ScanShadow.MAX_QUERIES and rows.shape[0] >= _scan.ScanShadow.MIN_ROWS:
+            key = rows.data_ptr()
+            shadow = self._shadows.get(key)
+            if shadow is None:
+                with self._shadow_lock:
+                    shadow = self._shadows.get(key)
+                    if shadow is None:
+                        shadow = self._shadows[key] = _scan.ScanShadow(rows)
+        return _scan.scan_topk(rows, q16, k, idx_base=base, shadow=shadow)
 
     def _local_topk(self, q16: torch.Tensor, k: int):
         """Partial top-k of this rank's rows (global ids): one scan per logical shard + a local merge."""

@@ -69,6 +69,11 @@ class HipVectorIndex:
         self._dead = 0                         # tombstoned rows (NaN-filled, leaf id None), see delete()
         self._row_of: Optional[Dict[str, int]] = None   # leaf id -> row, built on the first delete
         self._written: Optional[torch.cuda.Event] = None   # recorded behind the last device write to the matrix
+        # fp8 shadow of the matrix (scan.ScanShadow): an EXACT prefilter for batches of <= 4 queries over >= 1 M rows -- a lone caller's
+        # scan reads half the bytes and returns the same bits.  Built on first use, extended as rows are appended, dropped (and rebuilt
+        # on the next search) when rows are rewritten in place or the matrix is replaced.  + 50 % of the matrix's HBM; TT_SCAN_SHADOW=0: off
+        self.fp8_shadow = os.environ.get("TT_SCAN_SHADOW", "1") != "0"
+        self._shadow = None
 
     def _mark_written(self) -> None:
         """Searches may run on another stream than the one that wrote the matrix (the retrievers' own stream, below):
@@ -180,6 +185,7 @@ class HipVectorIndex:
                 idx = torch.tensor(rows, dtype=torch.long, device=self.device)
                 self._mat[: self.n].index_fill_(0, idx, float("nan"))
                 self._mark_written()
+                self._shadow = None            # rows rewritten in place: the fp8 shadow is rebuilt by the next lone caller's search
                 for r in rows:
                     self.leaf_ids[r] = None
                 self._dead += len(rows)
@@ -231,15 +237,31 @@ class HipVectorIndex:
         q = query_emb.to(self.device, dtype=torch.float32)
         return (q / q.norm(dim=1, keepdim=True).clamp_min(1e-12)).to(torch.bfloat16).contiguous()
 
+    def _shadow_for(self, mat: torch.Tensor, n_queries: int):
+        """The fp8 shadow that mirrors exactly the rows of ``mat`` (a snapshot's matrix view), or None: too few rows, too many
+        queries, switched off, or ``mat`` is no longer the index's current matrix (an older snapshot: it takes the bf16 pass)."""
+        if not self.fp8_shadow or not (0 < n_queries <= _scan.ScanShadow.MAX_QUERIES) or mat.shape[0] < _scan.ScanShadow.MIN_ROWS:
+            return None
+        with self._lock:
+            if mat.data_ptr() != self._mat.data_ptr() or mat.shape[0] > self.n:
+                return None
+            sh = self._shadow
+            if sh is None or sh.base_ptr != self._mat.data_ptr() or sh.cap_rows < self.n:
+                sh = self._shadow = _scan.ScanShadow(self._mat[: self.n], cap_rows=self._mat.shape[0])
+                sh.base_ptr = self._mat.data_ptr()
+            elif sh.rows < self.n:
+                sh.extend(self._mat, self.n)                     # rows appended since
+            return sh if sh.rows >= mat.shape[0] else None
+
     def search(self, query_emb: torch.Tensor, k: int, snapshot=None):
         """query_emb fp32/bf16 [Q, D] -> (scores [Q,k] fp32 cosine, rows [Q,k] int32)."""
         mat, _ = snapshot if snapshot is not None else self.snapshot()
-        return _scan.scan_topk(mat, self._unit_bf16(query_emb), k)
+        return _scan.scan_topk(mat, self._unit_bf16(query_emb), k, shadow=self._shadow_for(mat, query_emb.shape[0]))
 
     def search_host(self, query_emb: torch.Tensor, k: int, snapshot=None):
         """``search`` with the hits on the host (CPU tensors): one copy back, one sync per scan batch (``scan.scan_topk_host``)."""
         mat, _ = snapshot if snapshot is not None else self.snapshot()
-        return _scan.scan_topk_host(mat, self._unit_bf16(query_emb), k)
+        return _scan.scan_topk_host(mat, self._unit_bf16(query_emb), k, shadow=self._shadow_for(mat, query_emb.shape[0]))
 
     def node_score(self, cos: float) -> float:
         return math.exp(-(2.0 - 2.0 * cos)) if self.score_mode == "chroma" else cos

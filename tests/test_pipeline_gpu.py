@@ -871,3 +871,68 @@ def test_reference_session_defaults_over_three_modules(dev, built_lib, monkeypat
     counts = [sum(1 for n in bal if n.node.metadata["_source_index"] == i) for i in range(3)]
     assert counts == [8, 4, 8] and [n.score for n in bal] == sorted((n.score for n in bal), reverse=True)
     mm.ModelManager.reset_instance()
+
+
+def test_index_keeps_its_fp8_shadow_in_step_with_adds_and_deletes(dev, built_lib, monkeypatch):
+    """Round 6: ``HipVectorIndex`` serves batches of <= 4 queries through the fp8 shadow prefilter (scan.ScanShadow; exact, bit-identical
+    results).  The shadow must follow the matrix: built on the first lone search, EXTENDED when rows are appended, dropped when rows are
+    rewritten in place (tombstones) or the matrix is replaced (growth, compaction) -- at every step the index with the shadow returns
+    exactly what the same index returns with the shadow switched off."""
+    from tensor_truth_amd import scan as tscan
+    from tensor_truth_amd.schema import TextNode
+    from tensor_truth_amd.vector_index import HipVectorIndex
+
+    monkeypatch.setattr(tscan.ScanShadow, "MIN_ROWS", 20_000)      # (product: 1 M rows; the test keeps the node tables small)
+    dim, k = 256, 10
+    g = torch.Generator().manual_seed(41)
+    vecs = torch.randn(60_000, dim, generator=g)
+    q = torch.randn(3, dim, generator=g)
+    nodes = [TextNode(text=f"t{i}", id_=f"n{i}", metadata={}) for i in range(60_000)]
+    a, b = HipVectorIndex(dim, dev, None, "cosine"), HipVectorIndex(dim, dev, None, "cosine")
+    b.fp8_shadow = False
+    calls = {"shadow": 0}
+    orig = tscan.scan_topk
+
+    def counting(*args, **kw):
+        if kw.get("shadow") is not None and kw["shadow"].serves(args[0].shape[0], args[1].shape[0], args[2]):
+            calls["shadow"] += 1
+        return orig(*args, **kw)
+
+    monkeypatch.setattr(tscan, "scan_topk", counting)
+
+    def same(nq):
+        sa, ia = a.search(q[:nq], k)
+        sb, ib = b.search(q[:nq], k)
+        torch.cuda.synchronize()
+        assert torch.equal(ia, ib) and torch.equal(sa.view(torch.int32), sb.view(torch.int32))
+
+    for ix in (a, b):
+        ix.add(nodes[:30_000], embeddings=vecs[:30_000])
+    same(1)
+    assert calls["shadow"] == 1 and a._shadow is not None and a._shadow.rows == 30_000 and b._shadow is None
+    first = a._shadow
+    for ix in (a, b):
+        ix.add(nodes[30_000:31_000], embeddings=vecs[30_000:31_000])      # the matrix is re-allocated (capacity doubles): a new shadow
+    same(2)
+    assert a._shadow is not first and a._shadow.rows == 31_000 and a._shadow.cap_rows == a._mat.shape[0] >= 60_000
+    second = a._shadow
+    for ix in (a, b):
+        ix.add(nodes[31_000:], embeddings=vecs[31_000:])                  # fits the matrix's capacity: the shadow is EXTENDED
+    same(3)
+    assert a._shadow is second and a._shadow.rows == 60_000
+    same(4)
+    n_before = calls["shadow"]
+    sa, ia = a.search(torch.randn(5, dim, generator=g), k)                # 5 queries: the bf16 pass
+    assert calls["shadow"] == n_before
+    hit = int(a.search(q[:1], k)[1][0, 0])
+    for ix in (a, b):
+        ix.delete([f"n{hit}"])                                            # a tombstone: rows rewritten in place
+    assert a._shadow is None
+    same(1)
+    assert a._shadow is not None and int(a.search(q[:1], k)[1][0, 0]) != hit
+    for ix in (a, b):
+        ix.delete([f"n{i}" for i in range(0, 60_000, 3)])                 # a third of the rows: compaction replaces the matrix
+    same(2)
+    hs, hi = a.search_host(q[:1], k)
+    sb, ib = b.search(q[:1], k)
+    assert torch.equal(hi, ib.cpu()) and torch.equal(hs, sb.cpu())

@@ -500,3 +500,66 @@ def test_segmented_scan_argument_errors(dev, built_lib):
         tscan.scan_topk_segmented(corpus, q, 5, [0, 300])
     with pytest.raises(RuntimeError, match="n_segments"):
         tscan.scan_topk_segmented(corpus, q, 5, list(range(0, 67)))
+
+
+def test_fp8_shadow_prefilter_is_bit_identical_to_the_bf16_scan(dev, built_lib):
+    """Round 6: ``tt_scan_topk_shadow`` -- one pass over an e4m3 shadow of the corpus lists the rows whose rigorous upper bound reaches
+    the exact threshold, those rows are re-scored from the bf16 matrix with the streaming kernel's own arithmetic -- returns the SAME
+    scores and indices as ``tt_scan_topk``, bit for bit: random rows, planted neighbours, exact duplicates (ties broken by row),
+    NaN tombstones, rows that are not unit-norm, an index base, several widths, a shadow built in two pieces; a corpus of identical rows
+    overflows the survivor lists and comes back through the flagged fallback, still exact.  Indices also against the CPU oracle."""
+    from tensor_truth_amd import scan as tscan
+
+    g = torch.Generator(device=dev).manual_seed(99)
+
+    def corpus_of(n, d):
+        x = torch.randn((n, d), generator=g, device=dev)
+        return (x / x.norm(dim=1, keepdim=True)).to(torch.bfloat16)
+
+    n, d, k = 1_300_000, 1024, 50
+    c = corpus_of(n, d)
+    q = corpus_of(3, d).float()
+    q[1] = c[777_777].float() + 0.5 * q[1]                       # planted neighbour
+    q = (q / q.norm(dim=1, keepdim=True)).to(torch.bfloat16)
+    c[5] = c[1_200_000]                                           # exact duplicates: equal scores, the lower row first
+    c[900_001] = c[123]
+    c[40_000:40_064] = float("nan")                               # tombstones
+    c[1000:1100] *= 3.0                                           # not unit-norm: the bounds are per row, not assumed
+    c[2000:2100] *= 0.01
+    sh = tscan.ScanShadow(c[: n // 2].contiguous(), cap_rows=n)   # built in two pieces (rows appended later)
+    sh.extend(c, n)
+    assert sh.rows == n and sh.serves(n, 3, k) and not sh.serves(n, 5, k)
+    for nq in (1, 3):
+        want_s, want_i, flag0 = tscan.scan_topk(c, q[:nq], k, idx_base=7, return_flag=True)
+        got_s, got_i, flag1 = tscan.scan_topk(c, q[:nq], k, idx_base=7, return_flag=True, shadow=sh)
+        torch.cuda.synchronize()
+        assert not flag0 and not flag1, (flag0, flag1)
+        assert torch.equal(got_i, want_i) and torch.equal(got_s.view(torch.int32), want_s.view(torch.int32))
+    assert int(got_i[1, 0]) == 777_777 + 7
+    hs, hi = tscan.scan_topk_host(c, q[:1], k, shadow=sh)
+    assert torch.equal(hi, want_i[:1].cpu() - 7) and torch.equal(hs, want_s[:1].cpu())
+    # against the CPU oracle (tie-free queries: bit-exact indices)
+    clean = c.clone()
+    clean[40_000:40_064] = 0
+    o_s, o_i, gap = osc.scan_topk(clean.cpu(), q.cpu(), k)
+    tf = gap > 1e-6
+    assert tf.any() and torch.equal((got_i.cpu().to(torch.int64) - 7)[tf], o_i[tf])
+    del c, clean, sh
+    # other widths and k
+    for d2, k2 in ((384, 10), (128, 100), (768, 1)):
+        c2 = corpus_of(1_100_000, d2)
+        q2 = corpus_of(2, d2)
+        sh2 = tscan.ScanShadow(c2)
+        a = tscan.scan_topk(c2, q2, k2, return_flag=True)
+        b = tscan.scan_topk(c2, q2, k2, return_flag=True, shadow=sh2)
+        torch.cuda.synchronize()
+        assert not b[2] and torch.equal(a[1], b[1]) and torch.equal(a[0].view(torch.int32), b[0].view(torch.int32)), (d2, k2)
+        del c2, sh2
+    # every row identical: every row survives the prefilter, the lists overflow, the flag sends the call to the exact fallback
+    row = corpus_of(1, 256)
+    c3 = row.repeat(1_050_000, 1).contiguous()
+    sh3 = tscan.ScanShadow(c3)
+    s3, i3, flagged = tscan.scan_topk(c3, row, 20, return_flag=True, shadow=sh3)
+    assert flagged
+    s3, i3 = tscan.scan_topk(c3, row, 20, shadow=sh3)
+    assert i3[0].tolist() == list(range(20))
