@@ -1042,7 +1042,7 @@ int tt_attention_launch(const AttnParams& p, hipStream_t st) {
     AttnParams q = p;
     q.lazy = lazy;
     // default: the plain order.  Stand-alone the XCD-aware order is 2-9 % faster, inside the encoder (K / V fresh from the
-    // QKV GEMM) it measured 1.8 % slower -- see DESIGN.md section 4.4.
+    // QKV GEMM) it measured 1.8 % slower -- see DESIGN_HISTORY.md section 4.4.
     static const bool xcd = TT_DIAG_ENV_INT("TT_ATT_XCD", 0) == 1;
     q.n_qt = xcd ? n_qt : -n_qt;
     // TT_ATT_ROTATE=1: tail tiles deal their live row blocks to different waves (A/B switch, measured neutral; same bits either way)

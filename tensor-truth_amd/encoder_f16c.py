@@ -4,7 +4,7 @@ The reference builds its embedder and reranker without a dtype (``services/model
 ``app_utils/config_schema.py:66-76``: ``torch_dtype: None``), i.e. in fp32, and north_star's score tolerance (1e-3
 relative) is an fp32 tolerance.  ``encoder_x3`` (split planes, three products) meets it at a third of the bf16 matrix rate -- on
 ordinary AND hostile weights -- and is what the default mode runs; this path is the FAST VARIANT at half the rate
-(``TT_REFERENCE_IMPL=f16c``; 9e-5 relative on ordinary weights, 7e-3 on the stress fixture: DESIGN.md section 4.9): every GEMM operand is carried as "c-planes" -- ``hi = fp16(x)`` plus two OCP e4m3 planes (``x`` and ``x - hi``)
+(``TT_REFERENCE_IMPL=f16c``; 9e-5 relative on ordinary weights, 7e-3 on the stress fixture: DESIGN.md section 4.6): every GEMM operand is carried as "c-planes" -- ``hi = fp16(x)`` plus two OCP e4m3 planes (``x`` and ``x - hi``)
 with one E8M0 block exponent per 32 elements -- and a product runs as ``hi.hi`` on the fp16 matrix cores plus two
 block-scaled e4m3 cross terms at twice the rate (``a.w ~= a_hi.w_hi + e4m3(a).e4m3(w_lo) + e4m3(a_lo).e4m3(w)``; the cross
 terms are 2^-12 of the result, the dropped term 2^-24).  Attention on single fp16 products with fp32 softmax; the residual

@@ -1,4 +1,4 @@
-// Experiment (VERDICT r02 item 3 / DESIGN section 9 item 2): the encoder GEMM as FOUR waves of 128 x 128 per 256 x 256 tile
+// Experiment (VERDICT r02 item 3 / DESIGN_HISTORY.md section 4.3, round 3): the encoder GEMM as FOUR waves of 128 x 128 per 256 x 256 tile
 // -- one wave per SIMD, 256 accumulator registers in AGPRs -- against the product's 8-wave ping-pong kernel (gemm_kernel_v3),
 // A/B in one process on the four encoder shapes.
 //

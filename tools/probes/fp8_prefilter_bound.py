@@ -1,4 +1,4 @@
-"""How many rows would an fp8 shadow of the corpus pass on to an exact re-score?  (not built.)
+"""How many rows would an fp8 shadow of the corpus pass on to an exact re-score?  (Round 4 costing; BUILT in round 6: csrc/shadow.hip)
 Emulation with torch on the bench's synthetic corpus: rows and queries quantised to e4m3 with one scale per vector, the
 prefilter score s8 = <q8, c8> (exact in fp32 up to accumulation rounding), the RIGOROUS upper bound on the true bf16 score
     s <= s8 + |q - q8| . |c|  + |q8| . |c - c8|          (Cauchy-Schwarz on both error terms; all four norms known exactly)
