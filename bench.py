@@ -836,24 +836,24 @@ def main():
     scan_bytes = (hi - lo) * D * 2
     scan_gbs = scan_bytes * scan_n / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
 
-    # HBM traffic per launch: PMC counters cannot be read from inside this process; profiles/r05_pmc_traffic.json holds
+    # HBM traffic per launch: PMC counters cannot be read from inside this process; profiles/r06_pmc_traffic.json holds
     # them for exactly this default single-GPU command (tools/gpu_pmc_bench_r04.sh + tools/pmc_to_traffic.py: separate
     # --pmc passes, FETCH_SIZE doubled per the gfx950 rule).  The file records the hash of the kernel sources it was
     # measured on; a file from other sources is REFUSED (traffic null + the reason), so the number cannot go stale.
-    traffic = {"gemm": None, "scan_filter": None}
+    traffic = {"gemm": None, "scan_filter": None, "attention": None}
     traffic_note = None
     default_cfg = (world == 1 and args.corpus_rows == 10_000_000 and D == 1024 and Bq == 32 and K == 50
                    and args.chunk_len == 256 and args.query_len == 32 and L == 24)
-    tpath = os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", "r06_pmc_traffic.json")
     if not default_cfg:
         traffic_note = "not the default single-GPU configuration the PMC passes were collected on"
     elif not os.path.exists(tpath):
-        traffic_note = "profiles/r05_pmc_traffic.json not collected for this tree"
+        traffic_note = "profiles/r06_pmc_traffic.json not collected for this tree"
     else:
         with open(tpath) as f:
             tj = json.load(f)
         if tj.get("csrc_sha256") != csrc_sha256():
-            traffic_note = (f"profiles/r05_pmc_traffic.json was measured on kernel sources {str(tj.get('csrc_sha256'))[:12]}, "
+            traffic_note = (f"profiles/r06_pmc_traffic.json was measured on kernel sources {str(tj.get('csrc_sha256'))[:12]}, "
                             f"this tree is {csrc_sha256()[:12]}: refused")
         else:
             traffic = {k: tj[k]["hbm_bytes_per_launch"] for k in traffic if k in tj}
@@ -865,16 +865,16 @@ def main():
     # matrix-core utilisation (north_star: "evidenced by ... MFMA-utilisation counters"): SQ_VALU_MFMA_BUSY_CYCLES over kernel
     # cycles x SIMDs from a --pmc pass of this command on these kernel sources (tools/gpu_pmc_bench_r04.sh -> tools/pmc_to_mfma.py)
     mfma_busy, mfma_scan, mfma_note = None, None, None
-    mpath = os.path.join(ROOT, "profiles", "r05_pmc_mfma.json")
+    mpath = os.path.join(ROOT, "profiles", "r06_pmc_mfma.json")
     if not default_cfg:
         mfma_note = "not the default single-GPU configuration the PMC pass was collected on"
     elif not os.path.exists(mpath):
-        mfma_note = "profiles/r05_pmc_mfma.json not collected for this tree"
+        mfma_note = "profiles/r06_pmc_mfma.json not collected for this tree"
     else:
         with open(mpath) as f:
             mj = json.load(f)
         if mj.get("csrc_sha256") != csrc_sha256():
-            mfma_note = f"profiles/r05_pmc_mfma.json was measured on kernel sources {str(mj.get('csrc_sha256'))[:12]}: refused"
+            mfma_note = f"profiles/r06_pmc_mfma.json was measured on kernel sources {str(mj.get('csrc_sha256'))[:12]}: refused"
         else:
             mfma_busy = {k: v["mfma_busy"] for k, v in mj.items() if isinstance(v, dict) and "mfma_busy" in v}
             mfma_scan = mfma_busy.get("scan_tiled_filter_pass")
@@ -928,6 +928,10 @@ def main():
             "kernel": "gemm_kernel (encoder GEMMs, bf16 MFMA)",
             "bound": "mfma", "achieved": gemm_tf, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
             "frac": gemm_tf / MFMA_BF16_PEAK_TF, "traffic": traffic.get("gemm"), "traffic_note": traffic_note,
+            # the attention kernel's HBM bytes per launch of the rerank forward, same PMC passes (algorithmic: Q + K + V read once + O
+            # written once = 4 x token rows x 1024 x 2 bytes)
+            "traffic_attention": traffic.get("attention"),
+            "traffic_attention_algorithmic": 4.0 * tokens_step["rerank"] * rr_cfg.hidden * 2 if tokens_step.get("rerank") else None,
             "launches": gemm_n, "avg_launch_ms": gemm_ms / max(gemm_n, 1),
             "algorithmic_flops_per_launch": gemm_flops_step * args.steps / max(gemm_n, 1),
             "mfma_busy": mfma_busy, "mfma_busy_note": mfma_note,

@@ -36,6 +36,19 @@ def main(fetch_dir, write_dir, out):
         write = sum(float(r["Counter_Value"]) for r in wr) * 1024
         res[kind] = {"launches": len(fr), "fetch_bytes_per_launch": fetch / len(fr),
                      "write_bytes_per_launch": write / len(wr), "hbm_bytes_per_launch": (fetch + write) / len(fr)}
+    # attention (its "3.8 GB per launch = algorithmic" was arithmetic, not a counter): the varlen kernel's launches of the
+    # timed step's rerank forward -- the 23 largest by fetched bytes in the second half of the process's dispatches (the first half is warm-up;
+    # the query-embedding forward's 23 launches over 34-token sequences move a few MB each)
+    fa = [r for r in load(fetch_dir, "FETCH_SIZE") if "attention_kernel" in r["Kernel_Name"] and "cls" not in r["Kernel_Name"]]
+    wa = [r for r in load(write_dir, "WRITE_SIZE") if "attention_kernel" in r["Kernel_Name"] and "cls" not in r["Kernel_Name"]]
+    if fa and len(fa) == len(wa):
+        half = len(fa) // 2
+        idx = sorted(range(half, len(fa)), key=lambda i: -float(fa[i]["Counter_Value"]))[:23]
+        fetch = sum(float(fa[i]["Counter_Value"]) for i in idx) * 1024 * 2
+        write = sum(float(wa[i]["Counter_Value"]) for i in idx) * 1024
+        res["attention"] = {"launches": len(idx), "fetch_bytes_per_launch": fetch / len(idx), "write_bytes_per_launch": write / len(idx),
+                            "hbm_bytes_per_launch": (fetch + write) / len(idx),
+                            "algorithmic_bytes_per_launch_note": "Q + K + V read once + O written once = 4 x tokens x 1024 x 2 bytes (1600 x 296 rows: 3.88 GB)"}
     # the 256-query tiled filter pass of the scan-only leg (gemm_kernel_v3<TT_EPI_SCAN = 6, ...>): last of its launches
     is_scan = lambda r: "gemm_kernel_v3<6" in r["Kernel_Name"] or "gemm_kernel_p<6" in r["Kernel_Name"]   # noqa: E731 (one-tile / persistent form)
     fr = [r for r in load(fetch_dir, "FETCH_SIZE") if is_scan(r)]
