@@ -1255,8 +1255,20 @@ def lone_caller_breakdown(dev, emb, index, retr, rr, queries, top_n):
                         g[0] += ms
                         g[1] += cnt
         gpu_ms = {ph: {fam: {"ms": v[0] / n, "launches": v[1] // n} for fam, v in d.items()} for ph, d in gpu.items()}
+        # the scan's main pass against the HBM roofline: one query reads the fp8 shadow (rows x D bytes + 8 bytes of bounds per row) when the
+        # index serves lone callers through it, else the bf16 matrix (rows x D x 2)
+        scan_pass = None
+        sf = gpu_ms["retrieve"].get("scan_filter")
+        if sf and sf["launches"] == 1 and hasattr(index, "_shards"):
+            rows_, dim_ = sum(int(r.shape[0]) for r, _ in index._shards), index.dim
+            shadowed = bool(getattr(index, "_shadows", None))
+            nbytes = rows_ * dim_ + 8 * rows_ if shadowed else rows_ * dim_ * 2
+            scan_pass = {"form": "fp8 shadow prefilter (exact; survivors re-scored from the bf16 rows)" if shadowed else "bf16 streaming filter",
+                         "algorithmic_bytes": nbytes, "ms": sf["ms"], "GBps": nbytes / (sf["ms"] * 1e-3) / 1e9,
+                         "frac_of_hbm_peak": nbytes / (sf["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "whole_scan_ms": sum(v["ms"] for k, v in gpu_ms["retrieve"].items() if k.startswith("scan") or k == "select")}
         return {"queries": n, "wall_ms_per_query": wall_ms["retrieve"] + wall_ms["postprocess"], "wall_ms": wall_ms, "host_ms": host_ms,
-                "gpu_kernel_ms": gpu_ms,
+                "gpu_kernel_ms": gpu_ms, "scan_pass": scan_pass,
                 "gpu_kernel_ms_total": {ph: sum(v["ms"] for v in d.values()) for ph, d in gpu_ms.items()},
                 "what": "one caller, one query at a time: wall_ms = the two plugin calls; host_ms = request-thread time per stage "
                         "(issue = enqueueing asynchronous launches; *_wait = blocked on the GPU); gpu_kernel_ms = HIP-event time per "
