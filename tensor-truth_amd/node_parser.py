@@ -13,6 +13,7 @@ the structure (levels, links, overlap semantics, metadata inheritance) is what t
 from __future__ import annotations
 
 import functools
+import hashlib
 import re
 from typing import Callable, Iterable, List, Optional, Sequence
 
@@ -42,14 +43,14 @@ def tokenizer_counter(tk) -> Callable[[str], int]:
     def count(text: str) -> int:
         if len(text) > MAX_CHARS:
             return max(0, len(tk.encode(text)) - 2)
-        key = hash(text)
+        key = hashlib.blake2b(text.encode("utf-8", "surrogatepass"), digest_size=16).digest()     # (16 bytes per entry, not the text)
         hit = cache.get(key)
-        if hit is not None and hit[0] == len(text):
-            return hit[1]
+        if hit is not None:
+            return hit
         n = max(0, len(tk.encode(text)) - 2)
         if len(cache) >= LIMIT:
             cache.clear()
-        cache[key] = (len(text), n)
+        cache[key] = n
         return n
 
     return count
