@@ -246,6 +246,9 @@ class HipVectorIndex:
             if mat.data_ptr() != self._mat.data_ptr() or mat.shape[0] > self.n:
                 return None
             sh = self._shadow
+            if self._written is not None and (sh is None or sh.rows < self.n):
+                # the build below reads rows that may be newer than the snapshot (and than the event the searching stream waited for)
+                torch.cuda.current_stream(self.device).wait_event(self._written)
             if sh is None or sh.base_ptr != self._mat.data_ptr() or sh.cap_rows < self.n:
                 sh = self._shadow = _scan.ScanShadow(self._mat[: self.n], cap_rows=self._mat.shape[0])
                 sh.base_ptr = self._mat.data_ptr()
@@ -662,6 +665,10 @@ class HipIndexGroup:
         self._mat = None
         self._leaf_ids: List[list] = []
         self.offsets: List[int] = []
+        # fp8 shadows of the large modules (scan.ScanShadow, one per module, built on a lone caller's first search of this packing):
+        # <= 4 queries then take one exact-prefilter pass per module instead of the dense segmented pass -- same bits, half the bytes
+        self.fp8_shadow = os.environ.get("TT_SCAN_SHADOW", "1") != "0"
+        self._seg_shadows: Dict[int, object] = {}
 
     def _pack(self) -> None:
         for ix in self.indexes:
@@ -682,6 +689,7 @@ class HipIndexGroup:
             # its matrix copy-on-write and bumps its version, so the pair below stays consistent until the repack)
             self._mat, self.offsets, self._stamp = mat, offs, stamp
             self._leaf_ids = [ix.leaf_ids for ix in self.indexes]
+            self._seg_shadows = {}               # (they mirrored the previous packing)
         finally:
             for ix in self.indexes:
                 ix._lock.release()
@@ -692,8 +700,23 @@ class HipIndexGroup:
         outside the group lock on a snapshot (matrix, offsets, id lists) taken under it."""
         q = query_emb.to(self.device, dtype=torch.float32)
         q = (q / q.norm(dim=1, keepdim=True).clamp_min(1e-12)).to(torch.bfloat16).contiguous()
+        S = _scan.ScanShadow
         with self._lock:
             self._pack()
             mat, offs, ids = self._mat, list(self.offsets), list(self._leaf_ids)
-        s, r = _scan.scan_topk_segmented(mat, q, k, offs)
+            shadows = None
+            if self.fp8_shadow and 0 < q.shape[0] <= S.MAX_QUERIES and any(hi - lo >= max(S.MIN_ROWS, 128 * k) for lo, hi in zip(offs, offs[1:])):
+                for m, (lo, hi) in enumerate(zip(offs, offs[1:])):
+                    if hi - lo >= max(S.MIN_ROWS, 128 * k) and m not in self._seg_shadows:
+                        self._seg_shadows[m] = S(mat[lo:hi])
+                shadows = dict(self._seg_shadows)
+        if shadows is None:
+            s, r = _scan.scan_topk_segmented(mat, q, k, offs)
+        else:
+            # a lone caller over large modules: one pass per module -- through its shadow where it has one, the plain exact scan for
+            # the small ones.  Scores, module-local rows, ordering and padding are tt_scan_topk_segmented's (the same fragments and MFMA
+            # order score a row whichever pass reads it; tests/test_pipeline_gpu.py).
+            parts = [_scan.scan_topk(mat[lo:hi], q, k, shadow=shadows.get(m)) for m, (lo, hi) in enumerate(zip(offs, offs[1:]))]
+            s = torch.stack([p[0] for p in parts], dim=1)
+            r = torch.stack([p[1] for p in parts], dim=1)
         return (s, r, ids) if return_snapshot else (s, r)

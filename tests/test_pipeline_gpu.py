@@ -936,3 +936,61 @@ def test_index_keeps_its_fp8_shadow_in_step_with_adds_and_deletes(dev, built_lib
     hs, hi = a.search_host(q[:1], k)
     sb, ib = b.search(q[:1], k)
     assert torch.equal(hi, ib.cpu()) and torch.equal(hs, sb.cpu())
+
+
+def test_index_group_scans_large_modules_through_their_shadows(dev, built_lib, monkeypatch):
+    """Round 6: a lone caller (<= 4 queries) over a ``HipIndexGroup`` with large modules takes one pass per module -- through the module's
+    fp8 shadow where it has one, the plain exact scan for the small modules -- and returns exactly ``tt_scan_topk_segmented``'s scores,
+    module-local rows and padding (the reference's call: one query over the session's modules, rag_engine.py:420-424).  The shadows
+    belong to a packing: a mutated member repacks the group and the shadows are rebuilt."""
+    from tensor_truth_amd import scan as tscan
+    from tensor_truth_amd.schema import TextNode
+    from tensor_truth_amd.vector_index import HipIndexGroup, HipVectorIndex
+
+    monkeypatch.setattr(tscan.ScanShadow, "MIN_ROWS", 20_000)
+    dim, k = 256, 10
+    g = torch.Generator().manual_seed(43)
+    sizes = [30_000, 6, 25_000, 0]                                        # large, fewer rows than k, large, empty
+    members = []
+    for m, n in enumerate(sizes):
+        ix = HipVectorIndex(dim, dev, None, "cosine")
+        if n:
+            ix.add([TextNode(text=f"m{m} t{i}", id_=f"m{m}_n{i}", metadata={}) for i in range(n)], embeddings=torch.randn(n, dim, generator=g))
+        members.append(ix)
+    group = HipIndexGroup(members)
+    used = []
+    orig = tscan.scan_topk
+
+    def counting(*args, **kw):
+        sh = kw.get("shadow")
+        used.append(sh is not None and sh.serves(args[0].shape[0], args[1].shape[0], args[2]))
+        return orig(*args, **kw)
+
+    monkeypatch.setattr(tscan, "scan_topk", counting)
+
+    def same(nq):
+        q = torch.randn(nq, dim, generator=g)
+        s, r, ids = group.search(q, k, return_snapshot=True)
+        qn = (q.to(dev) / q.to(dev).norm(dim=1, keepdim=True).clamp_min(1e-12)).to(torch.bfloat16).contiguous()
+        ws, wr = tscan.scan_topk_segmented(group._mat, qn, k, list(group.offsets))
+        torch.cuda.synchronize()
+        assert s.shape == ws.shape == (nq, len(sizes), k) and r.dtype == wr.dtype
+        assert torch.equal(r, wr) and torch.equal(s.view(torch.int32), ws.view(torch.int32))
+        return s, r
+
+    s, r = same(1)
+    assert used == [True, False, True, False] and sorted(group._seg_shadows) == [0, 2]
+    assert int((r[0, 1] >= 0).sum()) == 6 and int((r[0, 3] >= 0).sum()) == 0 and bool(torch.isinf(s[0, 3]).all())
+    same(4)
+    first = group._seg_shadows[0]
+    del used[:]
+    same(5)                                                               # 5 queries: the dense segmented pass, no per-module calls
+    assert used == []
+    hit = int(r[0, 2, 0])
+    members[2].delete([f"m2_n{hit}"])                                     # a member changes: the group repacks, the shadows with it
+    s2, r2 = same(2)
+    assert group._seg_shadows[0] is not first and hit not in r2[:, 2].tolist()[0]
+    group.fp8_shadow = False
+    del used[:]
+    same(1)
+    assert used == []
