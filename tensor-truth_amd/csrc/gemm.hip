@@ -2021,6 +2021,222 @@ __global__ __launch_bounds__(64) void gemm_skinny_kernel(GemmParams p) {
     else gemm_epilogue_tile<EPI, 1, MT>(p, acc, m0, n0, lane);
 }
 
+// ---- staged 128x128 kernel (round 6): the one-round regime of a lone caller's rerank in the reference's precision ------------------
+// The reference's own call (K = 10 per index, top_n = 5: 10 pairs, M = 1-4 k rows) gives the 256x256 split-plane kernel 16-48 tiles
+// for the N = 1024 projections: a launch lasts one 256x256 tile's latency on a fifth of the chip (M = 3072: attention output 64 us,
+// FFN-down 190 us -- the same as at M = 7424), and the 128x128 kernel above has no split-plane form.  This is that form: a 128x128 tile
+// per workgroup of 4 waves, a FOUR-stage ring of 32-KiB K-steps in 128 KiB of LDS (one workgroup per CU -- there is at most one per CU
+// to run in this regime), the copies of three steps in flight behind the one being multiplied (counted vmcnt, one raw barrier per step),
+// fragments read with asm ds_reads one step ahead of the MFMAs (hipcc would put vmcnt(0) in front of ordinary reads).
+//   split planes: step = 32 K elements: [A hi][A lo][W hi][W lo], 128 rows x 64 B each; 16-B slot c of row r holds chunk
+//                 c ^ (3 if r & 8 else 0): ds_read_b128 serves the lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ... -- every
+//                 group holds all 16 fragment rows, rows 4-11 with the neighbouring chunk -- and the four rows that share a 64-byte quarter
+//                 of the 256-byte bank row (r, r + 4, r + 8, r + 12) then sit in four different slots (with c ^ ((r >> 2) & 3), the
+//                 swizzle for CONTIGUOUS 16-lane groups, every read was a 2-way conflict: SQ_LDS_BANK_CONFLICT 0 now); per step and
+//                 16x16 output tile the three products hi.hi, x_hi.w_lo, x_lo.w_hi in the tiled kernel's order
+//   16-bit:       step = 64 K elements: [A 128 x 128 B][W 128 x 128 B], the 128x128 kernel's swizzle and fragment order -- correct and
+//                 bit-identical, but NOT dispatched: it measured the same as the two-stage kernel (17 / 48 us at M = 3072)
+// Measured (profiles/r06_staged_ab.log, r06_staged_pmc.log): M = 3072 attention output 64 -> 32 us, FFN-down 190 -> 97 us; M = 1024
+// all four projections 1.7-2.0 x.  What bounds it is the LDS fill: 43 GB/s per CU (4 MiB per K = 4096 tile in 97 us), whatever the
+// ring depth, the request size (64- or 128-byte rows) or the fragment prefetch -- the matrix pipe is 41 % busy, TCP_PENDING_STALL 43 %
+// of the cycles, L2 hit rate 87 %.  The 256x256 kernel fills at the same per-CU rate with half the bytes per flop: from two rounds on
+// (more 128x128 tiles than CUs) the two tie or the big tile wins, so the dispatch takes this kernel only for ONE round.
+// One accumulator per output element, K ascending in steps of 32, the same MFMA and the same epilogue code as the other kernels:
+// the same bits, whichever kernel the row count selects (tests/test_x3_gpu.py::test_gemm_x3_rows_do_not_depend_on_the_kernel...).
+constexpr int kStagedStages = 4;
+constexpr int kStagedStageBytes = 32768;
+constexpr int kStagedLds = kStagedStages * kStagedStageBytes;   // 128 KiB
+
+__device__ __forceinline__ void lds_wait16(v3::u32x4 (&a)[16]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]),
+                                          "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]));
+}
+__device__ __forceinline__ ex8 as_ex8(v3::u32x4 v) { return __builtin_bit_cast(ex8, v); }
+
+template <int EPI, bool X3>
+__global__ __launch_bounds__(kGemmThreads, 1) void gemm_staged_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // block -> tile: the 128x128 kernel's map (XCD-contiguous ranges, then 8 x SN super-tiles)
+    const int mt_n = p.M / BM, nt_n = p.N / BN;
+    int L = blockIdx.x;
+    {
+        const int nwg = gridDim.x;
+        if ((nwg & 7) == 0) L = (L & 7) * (nwg >> 3) + (L >> 3);
+    }
+    const int SN = nt_n < 8 ? nt_n : 8;
+    const int SM = 8;
+    const int per_super = SM * SN;
+    const int supers_n = (nt_n + SN - 1) / SN;
+    const int s = L / per_super, w = L % per_super;
+    const int tm = (s / supers_n) * SM + w / SN;
+    const int tn = (s % supers_n) * SN + w % SN;
+    if (tm >= mt_n || tn >= nt_n) return;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    constexpr int KE = X3 ? 32 : 64;             // K elements per step
+    const int nk = p.K / KE;
+    const int ldw = X3 ? p.ldw : p.K;
+    // this wave's 8 copies per step: per-lane byte offsets from (operand + first tile row + step), constant for the whole kernel
+    uint32_t voff[8], ldst[8];
+    if constexpr (!X3) {
+        const int lrow = lane >> 3, slot = lane & 7;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = 32 * wave + 8 * j + lrow;
+            const int chunk = slot ^ ((row >> 1) & 7);
+            voff[j] = (uint32_t)row * (uint32_t)p.lda * 2u + chunk * 16;
+            voff[4 + j] = (uint32_t)row * (uint32_t)ldw * 2u + chunk * 16;
+            ldst[j] = (32 * wave + 8 * j) * 128;
+            ldst[4 + j] = 16384 + (32 * wave + 8 * j) * 128;
+        }
+    } else {
+        const int lrow = lane >> 2, slot = lane & 3;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int row = 32 * wave + 16 * j + lrow;
+            const int chunk = slot ^ (((row >> 3) & 1) * 3);
+            voff[j] = (uint32_t)row * (uint32_t)p.lda * 2u + chunk * 16;                 // A hi
+            voff[2 + j] = voff[j] + (uint32_t)p.K * 2u;                                    // A lo: K elements behind in the row
+            voff[4 + j] = (uint32_t)row * (uint32_t)ldw * 2u + chunk * 16;               // W hi
+            voff[6 + j] = voff[4 + j] + (uint32_t)p.K * 2u;                                // W lo
+#pragma unroll
+            for (int pl = 0; pl < 4; ++pl) ldst[2 * pl + j] = pl * 8192 + (32 * wave + 16 * j) * 64;
+        }
+    }
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    auto sgpr_ptr = [](const char* ptr) {
+        const unsigned long long b64 = reinterpret_cast<unsigned long long>(ptr);
+        const unsigned int blo = __builtin_amdgcn_readfirstlane((unsigned int)b64);
+        const unsigned int bhi = __builtin_amdgcn_readfirstlane((unsigned int)(b64 >> 32));
+        return reinterpret_cast<const char*>(((unsigned long long)bhi << 32) | blo);
+    };
+    const char* rowA = reinterpret_cast<const char*>(p.A) + (size_t)m0 * p.lda * 2;
+    const char* rowW = reinterpret_cast<const char*>(p.W) + (size_t)n0 * ldw * 2;
+    auto issue = [&](int kt) {
+        const uint32_t st = lds0 + (kt & (kStagedStages - 1)) * kStagedStageBytes;
+        const char* a = sgpr_ptr(rowA + (size_t)kt * KE * 2);
+        const char* wgt = sgpr_ptr(rowW + (size_t)kt * KE * 2);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v3::glds16(a, voff[c], st + ldst[c]);
+#pragma unroll
+        for (int c = 4; c < 8; ++c) v3::glds16(wgt, voff[c], st + ldst[c]);
+    };
+
+    f32x4 acc[4][4];  // [nt][mt]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // per-lane fragment addresses inside a stage: row (l & 15) of a 16-row tile (+ i * 16 rows as the immediate), chunk (l >> 4)
+    const int frow = lane & 15, fchk = lane >> 4;
+    uint32_t fa[2], fw[2];      // 16-bit: sub-step 0 / 1 of the A and W tiles; split planes: hi / lo plane of A and of W
+    if constexpr (!X3) {
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss) {
+            const int sw = ((4 * ss + fchk) ^ ((frow >> 1) & 7)) << 4;
+            fa[ss] = (wm * 64 + frow) * 128 + sw;
+            fw[ss] = 16384 + (wn * 64 + frow) * 128 + sw;
+        }
+    } else {
+        const int sw = (fchk ^ (((frow >> 3) & 1) * 3)) << 4;
+        fa[0] = (wm * 64 + frow) * 64 + sw;
+        fa[1] = 8192 + fa[0];
+        fw[0] = 16384 + (wn * 64 + frow) * 64 + sw;
+        fw[1] = 8192 + fw[0];
+    }
+    constexpr int RS = X3 ? 16 * 64 : 16 * 128;     // bytes from one 16-row tile to the next (the reads' immediate offset)
+#define TT_STAGED_RD4(dst, at, addr)                                                                  \
+    do {                                                                                              \
+        const uint32_t a_ = (addr);                                                                   \
+        dst[(at) + 0] = v3::lds_read128_async<0>(a_);      dst[(at) + 1] = v3::lds_read128_async<RS>(a_);     \
+        dst[(at) + 2] = v3::lds_read128_async<2 * RS>(a_); dst[(at) + 3] = v3::lds_read128_async<3 * RS>(a_); \
+    } while (0)
+
+    // fragments of a step: 16-bit {x[0..3], w[0..3]} of sub-step 0, then of sub-step 1; split planes {x_hi[0..3], w_hi[0..3], w_lo[0..3], x_lo[0..3]}
+    auto read_frags = [&](v3::u32x4 (&f)[16], int kt) {
+        const uint32_t st = lds0 + (kt & (kStagedStages - 1)) * kStagedStageBytes;
+        if constexpr (!X3) {
+            TT_STAGED_RD4(f, 0, st + fa[0]); TT_STAGED_RD4(f, 4, st + fw[0]);
+            TT_STAGED_RD4(f, 8, st + fa[1]); TT_STAGED_RD4(f, 12, st + fw[1]);
+        } else {
+            TT_STAGED_RD4(f, 0, st + fa[0]); TT_STAGED_RD4(f, 4, st + fw[0]);
+            TT_STAGED_RD4(f, 8, st + fw[1]); TT_STAGED_RD4(f, 12, st + fa[1]);
+        }
+    };
+    auto multiply = [&](const v3::u32x4 (&f)[16]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = TT_MFMA_16x16x32(as_ex8(f[4 + i]), as_ex8(f[j]), acc[i][j]);            // (split planes: hi.hi)
+        if constexpr (!X3) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = TT_MFMA_16x16x32(as_ex8(f[12 + i]), as_ex8(f[8 + j]), acc[i][j]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = TT_MFMA_16x16x32(as_ex8(f[8 + i]), as_ex8(f[j]), acc[i][j]);        // x_hi.w_lo
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = TT_MFMA_16x16x32(as_ex8(f[4 + i]), as_ex8(f[12 + j]), acc[i][j]);   // x_lo.w_hi
+        }
+    };
+    auto wait_groups = [](int g) {                  // at most g of this wave's 8-copy groups still in flight
+        if (g >= 3) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+        else if (g == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if (g == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    // One step: (1) this wave's copies of step kt + 1 have landed, (2) its fragment reads of step kt (issued a step ago) have
+    // returned, (3) barrier: both hold for every wave -- stage kt % 4 is free and stage (kt + 1) % 4 is complete, (4) the copies of
+    // step kt + 4 go into the freed stage (three steps of lead), (5) the fragment reads of step kt + 1 are issued and (6) return
+    // while the matrix pipe runs step kt: without (5) before (6) the four waves, in lockstep behind the barrier, alternate between
+    // an LDS phase (64 KiB of fragment reads: 512 cycles) and an MFMA phase (512-768 cycles) -- measured 1.0 us per step instead of 0.4.
+    auto step = [&](v3::u32x4 (&cur)[16], v3::u32x4 (&nxt)[16], int kt) {
+        if (kt + 1 < nk) wait_groups(nk - 2 - kt < 2 ? nk - 2 - kt : 2);
+        lds_wait16(cur);
+        __builtin_amdgcn_s_barrier();
+        if (kt + kStagedStages < nk) issue(kt + kStagedStages);
+        if (kt + 1 < nk) read_frags(nxt, kt + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        multiply(cur);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+#pragma unroll
+    for (int kt = 0; kt < kStagedStages; ++kt)
+        if (kt < nk) issue(kt);
+    wait_groups(nk - 1 < 3 ? nk - 1 : 3);
+    __builtin_amdgcn_s_barrier();
+    v3::u32x4 fA[16], fB[16];
+    read_frags(fA, 0);
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+        step(fA, fB, kt);
+        step(fB, fA, kt + 1);
+    }
+    if (kt < nk) step(fA, fB, kt);
+#undef TT_STAGED_RD4
+    if constexpr (X3) gemm_epilogue_tile_x3<EPI, 4, 4>(p, acc, m0 + wm * 64, n0 + wn * 64, lane);
+    else gemm_epilogue<EPI>(p, acc, m0 + wm * 64, n0 + wn * 64, lane);
+}
+
+// (diagnostic library: TT_GEMM_STAGED=0 puts the 256x256 split-plane kernel back; TT_GEMM_STAGED_MAX = the 128x128-tile count up to
+// which the staged kernel takes a split-plane GEMM, default the CU count)
+inline bool staged_enabled() {
+    static const bool on = TT_DIAG_ENV_INT("TT_GEMM_STAGED", 1) != 0;
+    return on;
+}
+
 // ---- relay form of the skinny kernel (round 6) ------------------------------------------------------------------------------
 // The one-wave kernel above is a chain of memory round trips: a wave keeps PF K-steps of loads in flight and every refill waits
 // for HBM again -- a K = 4096 projection is 128 (split planes: 384) steps = 6 (16) round trips of ~2.5 us while 255 of the
@@ -2137,6 +2353,25 @@ int launch_x3(const GemmParams& p, hipStream_t st) {
             if (!p.vt || !p.vt_lo || p.ldvt % 8) { tt_set_error("gemm x3: V^T epilogue needs vt / vt_lo"); return TT_E_INVALID; }
         } else {
             if (!p.C || p.ldc % 8 || p.c_lo_off % 8 || p.c_lo_off < p.N) { tt_set_error("gemm x3: planes output needs C, c_lo_off >= N"); return TT_E_INVALID; }
+        }
+        // a lone caller's rerank (the reference's 10 pairs: M = 1-4 k rows): when the 128x128 tiles fit the chip in ONE round (<= one per
+        // CU) the staged kernel is a 128x128 tile's latency instead of a 256x256 tile's on a quarter of the CUs -- measured 1.8 x
+        // (profiles/r06_staged_ab.log); in two rounds it ties with the 256x256 kernel, beyond that it loses (twice the LDS fill per flop)
+        static const int staged_max = TT_DIAG_ENV_INT("TT_GEMM_STAGED_MAX", 0);
+        const int mt1 = p.M / BM, nt1 = p.N / BN;
+        if (staged_enabled() && p.N % BN == 0 && (long long)mt1 * nt1 <= (staged_max ? staged_max : tt_cu_count_cached())) {
+            const int SN1 = nt1 < 8 ? nt1 : 8, SM1 = 8;
+            int blocks1 = ((mt1 + SM1 - 1) / SM1) * ((nt1 + SN1 - 1) / SN1) * SM1 * SN1;
+            blocks1 = (blocks1 + 7) / 8 * 8;
+            TT_SET_MAX_LDS((gemm_staged_kernel<EPI, true>), kStagedLds);
+            {
+                TtProfScope prof(TT_K_GEMM, st);
+                GemmParams q = p;
+                q.ldw = ldw;
+                hipLaunchKernelGGL((gemm_staged_kernel<EPI, true>), dim3(blocks1), dim3(kGemmThreads), kStagedLds, st, q);
+            }
+            TT_CHECK_LAUNCH();
+            return TT_OK;
         }
         const int mt_n = p.M / v3::BM3, nt_n = (p.N + v3::BN3 - 1) / v3::BN3;      // (N % 64 == 0: the last column tile may be partial)
         const int SN = super_sn(nt_n), SM = 32 / SN;

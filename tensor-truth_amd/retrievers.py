@@ -134,8 +134,8 @@ class MultiIndexRetriever:
         if k < 1:
             return [[] for _ in bases]
         q = torch.tensor([bundle.embedding], dtype=torch.float32)
-        scores, rows, snap_ids = group.search(q, k, return_snapshot=True)
-        scores, rows = scores[0].cpu().tolist(), rows[0].cpu().tolist()
+        scores, rows, snap_ids = group.search_host(q, k)
+        scores, rows = scores[0].tolist(), rows[0].tolist()
         out = []
         for i, (r, b) in enumerate(zip(self.retrievers, bases)):
             kk = min(b.similarity_top_k, indexes[i].num_live)

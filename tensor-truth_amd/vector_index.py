@@ -694,29 +694,68 @@ class HipIndexGroup:
             for ix in self.indexes:
                 ix._lock.release()
 
+    def _snapshot_for(self, q: torch.Tensor, k: int):
+        """Under the group lock: pack if a member changed, then (matrix, offsets, id lists, per-module shadows or None).  Shadows are
+        used -- and built, on the first such call of a packing -- when the batch is a lone caller's (<= 4 queries) and at least one
+        module is large enough for the prefilter to pay."""
+        S = _scan.ScanShadow
+        with self._lock:
+            self._pack()
+            mat, offs, ids = self._mat, list(self.offsets), list(self._leaf_ids)
+            shadows = None
+            big = [m for m, (lo, hi) in enumerate(zip(offs, offs[1:])) if hi - lo >= max(S.MIN_ROWS, 128 * k)]
+            if self.fp8_shadow and 0 < q.shape[0] <= S.MAX_QUERIES and big:
+                for m in big:
+                    if m not in self._seg_shadows:
+                        self._seg_shadows[m] = S(mat[offs[m]:offs[m + 1]])
+                shadows = dict(self._seg_shadows)
+        return mat, offs, ids, shadows
+
+    @staticmethod
+    def _scan_modules(mat, offs, q, k, shadows) -> torch.Tensor:
+        """A lone caller over large modules: one pass per module -- through its shadow where it has one, the plain exact scan for the
+        small ones -- issued back to back with NO host sync in between; every module's scores, rows and status word land in one
+        int32 buffer [S, 2 Q k + 1] (scan_topk's packed layout).  Scores, module-local rows, ordering and padding are
+        tt_scan_topk_segmented's: the same fragments and MFMA order score a row whichever pass reads it (tests/test_pipeline_gpu.py)."""
+        nq, n_seg = q.shape[0], len(offs) - 1
+        packed = torch.empty((n_seg, 2 * nq * k + 1), dtype=torch.int32, device=mat.device)
+        for m, (lo, hi) in enumerate(zip(offs, offs[1:])):
+            _scan.scan_topk(mat[lo:hi], q, k, _packed=packed[m], shadow=shadows.get(m))
+        return packed
+
+    @staticmethod
+    def _unpack_modules(packed: torch.Tensor, mat, offs, q, k):
+        """[S, 2 Q k + 1] (anywhere) -> (scores [Q, S, k] fp32, rows [Q, S, k] int32); a module whose candidate lists overflowed
+        (status word != 0) is scanned again through the dense exact path, as scan_topk does."""
+        nq, n_seg = q.shape[0], len(offs) - 1
+        s = packed[:, : nq * k].view(torch.float32).view(n_seg, nq, k).permute(1, 0, 2).contiguous()
+        r = packed[:, nq * k: 2 * nq * k].view(n_seg, nq, k).permute(1, 0, 2).contiguous()
+        for m in torch.nonzero(packed[:, -1].cpu()).flatten().tolist():
+            es, er = _scan.scan_topk(mat[offs[m]:offs[m + 1]], q, k, exact_dense=True)
+            s[:, m], r[:, m] = es.to(s.device), er.to(r.device)
+        return s, r
+
     def search(self, query_emb: torch.Tensor, k: int, return_snapshot: bool = False):
         """query_emb [Q, D] -> (cosine scores [Q, S, k] fp32, module-local rows [Q, S, k] int32); with
         ``return_snapshot`` also the per-module row -> id lists of the matrix that was scanned.  The scan runs
         outside the group lock on a snapshot (matrix, offsets, id lists) taken under it."""
         q = query_emb.to(self.device, dtype=torch.float32)
         q = (q / q.norm(dim=1, keepdim=True).clamp_min(1e-12)).to(torch.bfloat16).contiguous()
-        S = _scan.ScanShadow
-        with self._lock:
-            self._pack()
-            mat, offs, ids = self._mat, list(self.offsets), list(self._leaf_ids)
-            shadows = None
-            if self.fp8_shadow and 0 < q.shape[0] <= S.MAX_QUERIES and any(hi - lo >= max(S.MIN_ROWS, 128 * k) for lo, hi in zip(offs, offs[1:])):
-                for m, (lo, hi) in enumerate(zip(offs, offs[1:])):
-                    if hi - lo >= max(S.MIN_ROWS, 128 * k) and m not in self._seg_shadows:
-                        self._seg_shadows[m] = S(mat[lo:hi])
-                shadows = dict(self._seg_shadows)
+        mat, offs, ids, shadows = self._snapshot_for(q, k)
         if shadows is None:
             s, r = _scan.scan_topk_segmented(mat, q, k, offs)
         else:
-            # a lone caller over large modules: one pass per module -- through its shadow where it has one, the plain exact scan for
-            # the small ones.  Scores, module-local rows, ordering and padding are tt_scan_topk_segmented's (the same fragments and MFMA
-            # order score a row whichever pass reads it; tests/test_pipeline_gpu.py).
-            parts = [_scan.scan_topk(mat[lo:hi], q, k, shadow=shadows.get(m)) for m, (lo, hi) in enumerate(zip(offs, offs[1:]))]
-            s = torch.stack([p[0] for p in parts], dim=1)
-            r = torch.stack([p[1] for p in parts], dim=1)
+            s, r = self._unpack_modules(self._scan_modules(mat, offs, q, k, shadows), mat, offs, q, k)
         return (s, r, ids) if return_snapshot else (s, r)
+
+    def search_host(self, query_emb: torch.Tensor, k: int):
+        """``search`` with the hits on the host (the retriever turns rows into nodes): -> (scores [Q, S, k], rows [Q, S, k], id lists),
+        CPU tensors.  The per-module passes come back in ONE copy, which is the only host sync of the call."""
+        q = query_emb.to(self.device, dtype=torch.float32)
+        q = (q / q.norm(dim=1, keepdim=True).clamp_min(1e-12)).to(torch.bfloat16).contiguous()
+        mat, offs, ids, shadows = self._snapshot_for(q, k)
+        if shadows is None:
+            s, r = _scan.scan_topk_segmented(mat, q, k, offs)
+            return s.cpu(), r.cpu(), ids
+        s, r = self._unpack_modules(self._scan_modules(mat, offs, q, k, shadows).cpu(), mat, offs, q, k)
+        return s, r, ids

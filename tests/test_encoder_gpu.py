@@ -67,7 +67,8 @@ def test_gemm_epilogues(dev, built_lib, m, n, k, epi):
 def test_skinny_gemm_is_bit_identical_to_the_tiled_kernels(dev, built_lib, n, k, epi):
     """Up to 256 rows the projections run as weight-streaming skinny GEMMs (one wave per 16 columns, no LDS); same MFMA,
     same K order, same epilogue code as the tiled kernels -> the same bits for the same rows, whatever else is in the
-    batch.  64 rows alone (skinny) vs the same rows inside 512- and 2048-row GEMMs (128x128 and 256x256 tiles)."""
+    batch.  64 rows alone (skinny) vs the same rows inside 512- and 2048-row GEMMs (the 128x128 kernel: fewer than 128 tiles of
+    256x256) -- and ``test_rows_do_not_depend_on_the_kernel_that_computed_them`` below with the 256x256 kernel as well."""
     from tensor_truth_amd import _lib
 
     lib = _lib.load_library()
@@ -87,6 +88,42 @@ def test_skinny_gemm_is_bit_identical_to_the_tiled_kernels(dev, built_lib, n, k,
     torch.cuda.synchronize()
     assert torch.equal(outs[0], outs[1][:64]) and torch.equal(outs[0], outs[2][:64]) and torch.equal(outs[0], outs[3][:64])
     assert torch.equal(outs[1], outs[3][:192])
+
+
+@pytest.mark.parametrize("epi", [0, 1, 2])
+@pytest.mark.parametrize("n,k", [(1024, 1024), (1024, 4096), (3072, 1024)])
+def test_rows_do_not_depend_on_the_kernel_that_computed_them(dev, built_lib, n, k, epi):
+    """Which GEMM kernel runs is decided by the row count of the batch a text rides in: <= 256 rows the skinny kernel, fewer than
+    128 tiles of 256x256 the 128x128 kernel (a lone caller's rerank), from there the 256x256 ping-pong kernel (a row count that is not
+    a multiple of 256: the 128x128 kernel again, on a large grid).  One accumulator per output element, K ascending, the same MFMA and
+    epilogue code in all of them: the first rows of every launch carry the same bits."""
+    from tensor_truth_amd import _lib
+
+    lib = _lib.load_library()
+    g = torch.Generator().manual_seed(7 * n + k + epi)
+    rows = {1024: (64, 512, 3072, 8192, 8320), 3072: (64, 512, 2816, 8320)}[n]     # skinny, 128x128 (x2), 256x256, 128x128 on a large grid
+    big = max(rows)
+    a = _bf(torch.randn(big, k, generator=g)).to(dev)
+    w = _bf(torch.randn(n, k, generator=g) * 0.05).to(dev)
+    bias = (torch.randn(n, generator=g) * 0.1).to(dev)
+    res = _bf(torch.randn(big, n, generator=g)).to(dev)
+    outs = []
+    for m in rows:
+        c = torch.empty(m, n, dtype=torch.bfloat16, device=dev)
+        rc = lib.tt_gemm_bf16(a.data_ptr(), w.data_ptr(), bias.data_ptr(), res.data_ptr() if epi == 2 else None,
+                              c.data_ptr(), m, n, k, epi, _stream())
+        _lib.check(rc, "tt_gemm_bf16")
+        outs.append(c)
+    torch.cuda.synchronize()
+    for m, c in zip(rows[:-1], outs[:-1]):
+        assert torch.equal(c.view(torch.int16), outs[-1][:m].view(torch.int16)), m
+    ref = a[:512].float() @ w.float().T + bias                      # (and they are the right bits: the product itself)
+    if epi == 1:
+        ref = oe.gelu_erf(ref.cpu()).to(dev)
+    elif epi == 2:
+        ref = ref + res[:512].float()
+    err = (outs[1].float() - ref).abs()
+    assert (err <= 2 ** -7 * ref.abs() + 2e-3).all()
 
 
 def test_gemm_rejects_bad_shapes(dev, built_lib):

@@ -976,10 +976,12 @@ def test_index_group_scans_large_modules_through_their_shadows(dev, built_lib, m
         torch.cuda.synchronize()
         assert s.shape == ws.shape == (nq, len(sizes), k) and r.dtype == wr.dtype
         assert torch.equal(r, wr) and torch.equal(s.view(torch.int32), ws.view(torch.int32))
+        hs, hr, hids = group.search_host(q, k)                            # what MultiIndexRetriever calls: one copy back
+        assert not hs.is_cuda and torch.equal(hr, wr.cpu()) and torch.equal(hs.view(torch.int32), ws.cpu().view(torch.int32)) and hids == ids
         return s, r
 
     s, r = same(1)
-    assert used == [True, False, True, False] and sorted(group._seg_shadows) == [0, 2]
+    assert used == [True, False, True, False] * 2 and sorted(group._seg_shadows) == [0, 2]
     assert int((r[0, 1] >= 0).sum()) == 6 and int((r[0, 3] >= 0).sum()) == 0 and bool(torch.isinf(s[0, 3]).all())
     same(4)
     first = group._seg_shadows[0]

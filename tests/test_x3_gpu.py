@@ -93,6 +93,46 @@ def test_gemm_x3_building_block(dev, built_lib, m, n, k):
             _lib.check(lib.tt_gemm_x3(dap.data_ptr(), dwp.data_ptr(), db.data_ptr(), None, cp.data_ptr(), None, m, n + 8, k, 0, st), "x")
 
 
+@pytest.mark.parametrize("planes", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("n,k", [(1024, 1024), (1024, 4096), (2048, 1024)])
+def test_gemm_x3_rows_do_not_depend_on_the_kernel_that_computed_them(dev, built_lib, n, k, planes):
+    """Split planes, three kernels by row count: <= 256 rows the relay kernel, up to one 128x128 tile per CU the staged 128x128
+    kernel (round 6: the reference's own call, 10 pairs = 1-4 k rows, was one 256x256 tile's latency on a fifth of the chip), above
+    that the 256x256 ping-pong kernel.  Per 32 K elements the products hi.hi, x_hi.w_lo, x_lo.w_hi into ONE accumulator, K ascending, the
+    same epilogue operations: the first rows of every launch carry the same bits (planes out, GELU planes out, fp32 residual out)."""
+    from tensor_truth_amd import _lib
+
+    lib = _lib.load_library()
+    g = torch.Generator().manual_seed(n + k)
+    rows = (64, 256, 768, 256 * 128 * 128 // n, 128 * 256 * 256 // n)      # relay, relay, staged, staged (256 tiles of 128x128), 256x256 (128 tiles)
+    big = rows[-1]
+    from tensor_truth_amd.encoder_x3 import split_planes
+
+    ap = split_planes(torch.randn(big, k, generator=g), planes).to(dev)
+    wp = split_planes(torch.randn(n, k, generator=g) * 0.04, planes).to(dev)
+    bias, res = torch.randn(n, generator=g).to(dev), torch.randn(big, n, generator=g).to(dev)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    gemm = lib.tt_gemm_x3 if planes == torch.bfloat16 else lib.tt_gemm_x3_f16
+    for epi in (0, 1, 2):
+        outs = []
+        for m in rows:
+            cp = torch.full((m, 2 * n), float("nan"), dtype=planes, device=dev)
+            c32 = torch.full((m, n), float("nan"), device=dev)
+            rc = gemm(ap.data_ptr(), wp.data_ptr(), bias.data_ptr(), res.data_ptr() if epi == 2 else None,
+                                cp.data_ptr() if epi != 2 else None, c32.data_ptr() if epi == 2 else None, m, n, k, epi, st)
+            _lib.check(rc, "tt_gemm_x3")
+            outs.append(c32.view(torch.int32) if epi == 2 else cp.view(torch.int16))
+        torch.cuda.synchronize()
+        for m, c in zip(rows[:-1], outs[:-1]):
+            assert torch.equal(c, outs[-1][:m]), (epi, m)
+        if epi == 2:          # (and they are the right bits: against fp64 on the planes' own values)
+            a64 = (ap[:768, :k].double() + ap[:768, k:].double()).cpu()
+            w64 = (wp[:, :k].double() + wp[:, k:].double()).cpu()
+            want = a64 @ w64.T + bias.cpu().double() + res[:768].cpu().double()
+            got = outs[2].view(torch.float32).cpu().double()
+            assert ((got - want).abs().max() / want.abs().max()).item() <= 2e-5
+
+
 def test_gemm_x3_is_row_permutation_equivariant_bit_for_bit(dev, built_lib):
     from tensor_truth_amd import _lib
 
