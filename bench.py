@@ -1418,7 +1418,8 @@ def reference_defaults_leg(args, dev, shard_rows, emb_cfg, rr_cfg, n_lone=8, n_t
     balanced; ``README.md:13`` -- one user, one un-batched call per query.  Built exactly as ``load_engine_for_modules`` builds it
     (``build_retrieval_service``: AutoMergingRetriever(index.as_retriever(k)) per module -> MultiIndexRetriever -> [reranker,
     SimilarityPostprocessor(0.05)]), models from ModelManager, strings in through the trained Unigram tokenizer, over 1 and 3
-    modules of the resident corpus (3 modules: one packed matrix, ONE segmented scan -- HipIndexGroup / tt_scan_topk_segmented),
+    modules of the resident corpus (3 modules: one packed matrix -- HipIndexGroup; a lone caller's scan is one fp8-shadow pass per module,
+    a coalesced batch of more than 4 queries ONE segmented pass, tt_scan_topk_segmented: the same bits either way),
     a lone caller and 8 request threads (the reference's executor width, rag_engine.py:392), in bf16 (the reference's
     ``torch_dtype: bfloat16`` option) and in the default precision (no dtype anywhere: fp32 semantics)."""
     from tensor_truth_amd import model_manager as mm
@@ -1488,7 +1489,7 @@ def reference_defaults_leg(args, dev, shard_rows, emb_cfg, rr_cfg, n_lone=8, n_t
                     "source_nodes_per_query": sum(g[0] for g in got) / n_lone,
                     "lone_caller_gpu_kernel_ms": fam,
                     "confidence_levels": sorted({g[1] for g in got + got_t}),
-                    "scan": "one pass over the module" if n_mod == 1 else f"{n_mod} modules packed into one matrix, one segmented pass"}
+                    "scan": "one pass over the module" if n_mod == 1 else f"{n_mod} modules packed into one matrix: a lone caller one fp8-shadow pass per module, larger batches one segmented pass"}
                 del svc, indexes
             res["precision"] = getattr(rr, "precision", None)
             out[label] = res
