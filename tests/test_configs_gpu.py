@@ -210,6 +210,37 @@ def test_full_size_rerank_is_batch_invariant(dev, built_lib):
     assert torch.equal(s_few, s_all[5:8])
 
 
+@pytest.mark.parametrize("precision", ["bf16", "reference"])
+def test_the_references_session_sized_reranks_are_batch_invariant(dev, built_lib, precision):
+    """The reference's own operating points (session defaults: 10 candidates per index module, ``rag_engine.py:592-593``) at full
+    depth: 10 / 30 pairs x 292 tokens = 12 / 35 row tiles.  Those sizes take other kernels than a large batch does -- in the
+    default precision the staged 128x128 split-plane kernel for the N = 1024 projections of 10 pairs, in bf16 the 128x128 kernel --
+    and must score every pair with the bits it gets inside a 120-pair batch (all 24 layers: QKV with its transposed V third,
+    residual and GELU epilogues, both plane outputs)."""
+    import numpy as np
+
+    from tensor_truth_amd.encoder import BGE_RERANKER_V2_M3, Encoder, EncoderWeights, pack_token_matrix, synthetic_state_device
+
+    cfg = BGE_RERANKER_V2_M3
+    state = synthetic_state_device(cfg, dev, seed=2)
+    if precision == "bf16":
+        enc = Encoder(EncoderWeights(cfg, state, dev))
+    else:
+        from tensor_truth_amd.encoder_x3 import EncoderWeightsX3, EncoderX3
+
+        enc = EncoderX3(EncoderWeightsX3(cfg, state, dev, dtype=torch.float16))
+    rng = np.random.default_rng(13)
+    pairs = rng.integers(4, cfg.vocab_size, size=(120, 292), dtype=np.int32)
+    pairs[:, 0], pairs[:, -1] = 0, 2
+    pairs[:, 34:36] = 2
+    s_all = enc.rerank_packed(pack_token_matrix(pairs, cfg)).cpu()
+    assert torch.isfinite(s_all).all() and ((s_all > 0) & (s_all < 1)).all()
+    assert pack_token_matrix(pairs[:30], cfg).n_rows == 8960 and pack_token_matrix(pairs[:10], cfg).n_rows == 3072
+    for lo, hi in ((0, 30), (30, 40), (47, 77)):
+        s_few = enc.rerank_packed(pack_token_matrix(pairs[lo:hi], cfg)).cpu()
+        assert torch.equal(s_few.view(torch.int32), s_all[lo:hi].view(torch.int32)), (precision, lo, hi)
+
+
 def test_query_embedding_alone_equals_query_embedding_in_a_batch(dev, built_lib):
     """One query on its own (64 token rows: every projection of the 24 layers is a skinny weight-streaming GEMM) gets
     bit for bit the embedding it gets inside a batch of 200 queries (8000 rows: tiled kernels)."""
