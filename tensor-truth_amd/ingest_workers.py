@@ -269,7 +269,6 @@ class _Host:
         return self._hierarchy(srcs)
 
     def _hierarchy(self, sources):
-        from .node_parser import get_leaf_nodes
         from .schema import MetadataMode
 
         nodes = self.hier.get_nodes_from_documents(sources)

@@ -10,7 +10,7 @@ from concurrent.futures import ThreadPoolExecutor, as_completed
 from functools import lru_cache
 from typing import Dict, List, Optional
 
-from .schema import NodeWithScore, QueryBundle, TextNode, as_query_bundle
+from .schema import NodeWithScore, QueryBundle, as_query_bundle
 
 
 def similarity_top_k_for(reranker_top_n: int) -> int:

@@ -11,8 +11,6 @@ between breakpoints.
 from __future__ import annotations
 
 import os
-
-import re
 from typing import List, Optional, Sequence
 
 import numpy as np

@@ -15,7 +15,7 @@ there, because the product merge kernel needs a GPU).
 """
 from __future__ import annotations
 
-from typing import Callable, Optional, Tuple
+from typing import Callable, Tuple
 
 import torch
 import torch.distributed as dist

@@ -27,7 +27,6 @@ from __future__ import annotations
 import math
 import os
 import threading
-import time
 from typing import Callable, Dict, List, Optional, Sequence, Tuple  # noqa: F401
 
 import torch

@@ -24,7 +24,7 @@ import torch
 from . import _lib
 from . import scan as _scan
 from .coalesce import Coalescer
-from .schema import MetadataMode, NodeWithScore, QueryBundle, TextNode, as_query_bundle
+from .schema import MetadataMode, NodeWithScore, TextNode, as_query_bundle
 
 logger = logging.getLogger(__name__)
 
