@@ -166,11 +166,3 @@ class EncoderF32:
 
     def rerank(self, seqs, max_len: Optional[int] = 512, want_logits: bool = False):
         return self.rerank_packed(pack_tokens(seqs, self.cfg, None, max_len), want_logits)
-
-
-def wants_float32(model_kwargs) -> bool:
-    """``model_kwargs["torch_dtype"]`` as the reference passes it (a string from its config or a torch dtype)."""
-    td = (model_kwargs or {}).get("torch_dtype")
-    if td is None:
-        return False
-    return str(td).replace("torch.", "") in ("float32", "fp32", "float")
