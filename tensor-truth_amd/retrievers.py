@@ -56,6 +56,11 @@ class MultiIndexRetriever:
         self.single_pass = single_pass
         self._group = None
         self._group_lock = threading.Lock()
+        # concurrent callers (the reference's request threads, rag_engine.py:392) share ONE pass over the packed matrix: a lone caller
+        # runs at once, alone (per-module fp8-shadow passes); what queues up behind a running scan goes out as one batch
+        from .coalesce import Coalescer
+
+        self._scan_front = Coalescer(self._group_scan_many, max_batch=64)
         if enable_cache:
             self._retrieve_cached = lru_cache(maxsize=cache_size)(self._retrieve_impl)
         else:
@@ -133,14 +138,32 @@ class MultiIndexRetriever:
         k = max(min(b.similarity_top_k, ix.num_live) for b, ix in zip(bases, indexes))
         if k < 1:
             return [[] for _ in bases]
-        q = torch.tensor([bundle.embedding], dtype=torch.float32)
-        scores, rows, snap_ids = group.search_host(q, k)
-        scores, rows = scores[0].tolist(), rows[0].tolist()
+        scores, rows, snap_ids = self._scan_front.submit((group, bundle.embedding, k))
         out = []
         for i, (r, b) in enumerate(zip(self.retrievers, bases)):
             kk = min(b.similarity_top_k, indexes[i].num_live)
             nodes = b.nodes_from_hits(scores[i][:kk], rows[i][:kk], snap_ids[i])
             out.append(r.merge(nodes) if r is not b and hasattr(r, "merge") else nodes)
+        return out
+
+    @staticmethod
+    def _group_scan_many(items):
+        """[(group, query embedding, k)] -> [(scores [S][k'], rows [S][k'], id lists)]: one ``HipIndexGroup.search_host`` per group
+        (there is one) with k' = the largest k asked for -- an exact top-k list is a prefix of every longer one (score descending,
+        row ascending among equals), and every caller slices its own k per module."""
+        import torch
+
+        out = [None] * len(items)
+        by_group = {}
+        for i, (group, _, _) in enumerate(items):
+            by_group.setdefault(id(group), (group, []))[1].append(i)
+        for group, members in by_group.values():
+            k = max(items[i][2] for i in members)
+            q = torch.tensor([items[i][1] for i in members], dtype=torch.float32)
+            scores, rows, ids = group.search_host(q, k)
+            scores, rows = scores.tolist(), rows.tolist()
+            for j, i in enumerate(members):
+                out[i] = (scores[j], rows[j], ids)
         return out
 
     def _balance_top_k_per_index(self, nodes: List[NodeWithScore]) -> List[NodeWithScore]:

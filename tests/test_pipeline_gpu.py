@@ -354,6 +354,9 @@ def test_retrieve_and_rerank_from_eight_threads(dev, built_lib):
         [t.join() for t in threads]
         assert not errs, errs
         assert got == serial and all(len(r) == 4 for r in got)
+        # one pass over the packed modules per BATCH of concurrent callers (round 6): every query went through the scan front
+        front = mir._scan_front
+        assert (front.items, front.batches <= front.items) == ((32, True) if single_pass else (0, True))
 
 
 def test_deleted_rows_are_tombstones_that_never_rank(dev, built_lib, tmp_path):
