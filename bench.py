@@ -750,21 +750,31 @@ def main():
     hard_exit = comm_hung        # (a pre-flight thread still sits in an RCCL call: leave without destroying the groups)
     if not args.headline_only and not args.no_surface_leg and (world == 1 or args.surface_leg):
         if world == 1:
-            surface = surface_leg(args, dev, shard_rows, emb_cfg, rr_cfg, world, rank, lo, data_group)
-            # rounds 1-4's stand-in beside it (one hashed id per word: no sub-word cost), and what pair tokenisation costs one host thread
-            sh = surface_leg(args, dev, shard_rows, emb_cfg, rr_cfg, world, rank, lo, data_group, tokenizer="hash",
-                             n_queries=max(args.surface_threads * 4, 128))
-            surface["hash_tokenizer_variant"] = {k: sh[k] for k in ("queries_per_s", "queries", "single_caller_ms_per_query", "tokenizer_detail")}
-            surface["host_tokenize"] = {"unigram-250k": surface_texts(args, "unigram-250k").host_rate(),
-                                        "hash": surface_texts(args, "hash").host_rate()}
-            # ... and what an UNCHANGED reference call gets through the same surface: constructors without a dtype (the reference's
-            # own default, fp32 semantics) -- fewer queries, the models run at about a third of the bf16 rate
-            if not args.no_reference_leg:
-                sd = surface_leg(args, dev, shard_rows, emb_cfg, rr_cfg, world, rank, lo, data_group, default_precision=True,
-                                 n_queries=max(args.surface_threads * 3, 96))
-                surface["default_precision"] = {k: sd[k] for k in ("queries_per_s", "queries", "threads", "single_caller_ms_per_query",
-                                                                   "single_caller_ms_per_query_with_leaf_token_ids",
-                                                                   "lone_caller_breakdown", "scan_batches", "rerank_batches", "precision")}
+            # (optional blocks: one that throws is reported under its own key, the headline line is printed regardless)
+            def _optional(fn):
+                try:
+                    return fn()
+                except Exception as exc:  # noqa: BLE001
+                    return {"error": f"{type(exc).__name__}: {exc}"[:300]}
+
+            surface = _optional(lambda: surface_leg(args, dev, shard_rows, emb_cfg, rr_cfg, world, rank, lo, data_group))
+            if "error" not in surface:
+                # rounds 1-4's stand-in beside it (one hashed id per word: no sub-word cost), and what pair tokenisation costs one host thread
+                sh = _optional(lambda: surface_leg(args, dev, shard_rows, emb_cfg, rr_cfg, world, rank, lo, data_group, tokenizer="hash",
+                                                   n_queries=max(args.surface_threads * 4, 128)))
+                surface["hash_tokenizer_variant"] = sh if "error" in sh else {k: sh[k] for k in ("queries_per_s", "queries", "single_caller_ms_per_query",
+                                                                                                  "tokenizer_detail")}
+                surface["host_tokenize"] = _optional(lambda: {"unigram-250k": surface_texts(args, "unigram-250k").host_rate(),
+                                                              "hash": surface_texts(args, "hash").host_rate()})
+                # ... and what an UNCHANGED reference call gets through the same surface: constructors without a dtype (the reference's
+                # own default, fp32 semantics) -- fewer queries, the models run at about a third of the bf16 rate
+                if not args.no_reference_leg:
+                    sd = _optional(lambda: surface_leg(args, dev, shard_rows, emb_cfg, rr_cfg, world, rank, lo, data_group, default_precision=True,
+                                                       n_queries=max(args.surface_threads * 3, 96)))
+                    surface["default_precision"] = sd if "error" in sd else {
+                        k: sd[k] for k in ("queries_per_s", "queries", "threads", "single_caller_ms_per_query",
+                                           "single_caller_ms_per_query_with_leaf_token_ids", "lone_caller_breakdown", "scan_batches",
+                                           "rerank_batches", "precision")}
         else:
             # Several ranks: the leg's collectives run over RCCL, which no box available to this build could exercise (two
             # ranks cannot share a GPU under RCCL; the gloo runs are the evidence).  The headline above is measured and must
@@ -811,7 +821,10 @@ def main():
             reference_defaults = {"error": f"{type(exc).__name__}: {exc}"[:300]}
     config5 = None
     if world == 1 and not args.headline_only and not args.no_config5_leg:
-        config5 = config5_leg(args, dev, emb_cfg, rr_cfg)
+        try:
+            config5 = config5_leg(args, dev, emb_cfg, rr_cfg)
+        except Exception as exc:  # noqa: BLE001 - an optional block, as above
+            config5 = {"error": f"{type(exc).__name__}: {exc}"[:300]}
 
     # ---- roofline of the dominant kernel (GEMM, MFMA-bound) and of the scan (HBM-bound) -------
     H, F, L = emb_cfg.hidden, emb_cfg.ffn, emb_cfg.layers
