@@ -2021,45 +2021,48 @@ __global__ __launch_bounds__(64) void gemm_skinny_kernel(GemmParams p) {
     else gemm_epilogue_tile<EPI, 1, MT>(p, acc, m0, n0, lane);
 }
 
-// ---- staged 128x128 kernel (round 6): the one-round regime of a lone caller's rerank in the reference's precision ------------------
-// The reference's own call (K = 10 per index, top_n = 5: 10 pairs, M = 1-4 k rows) gives the 256x256 split-plane kernel 16-48 tiles
-// for the N = 1024 projections: a launch lasts one 256x256 tile's latency on a fifth of the chip (M = 3072: attention output 64 us,
+// ---- staged 128x128 kernel (round 6): the one- and two-round regime of a lone caller's rerank -----------------------------------------
+// The reference's own call (K = 10 per index, top_n = 5: 10-20 pairs, M = 1-8 k rows) gives the 256x256 split-plane kernel 16-120 tiles
+// for the N = 1024 projections: a launch lasts one 256x256 tile's latency on a fraction of the chip (M = 3072: attention output 64 us,
 // FFN-down 190 us -- the same as at M = 7424), and the 128x128 kernel above has no split-plane form.  This is that form: a 128x128 tile
-// per workgroup of 4 waves, a FOUR-stage ring of 32-KiB K-steps in 128 KiB of LDS (one workgroup per CU -- there is at most one per CU
-// to run in this regime), the copies of three steps in flight behind the one being multiplied (counted vmcnt, one raw barrier per step),
-// fragments read with asm ds_reads one step ahead of the MFMAs (hipcc would put vmcnt(0) in front of ordinary reads).
+// per workgroup of 8 waves (64 x 32 each, two per SIMD), a FOUR-stage ring of 32-KiB K-steps in 128 KiB of LDS (one workgroup per CU),
+// the copies of three steps in flight behind the one being multiplied (counted vmcnt, one raw barrier per step), fragments read with asm
+// ds_reads one step ahead of the MFMAs (hipcc would put vmcnt(0) in front of ordinary reads), the step's LDS-DMA issues BETWEEN its MFMAs.
 //   split planes: step = 32 K elements: [A hi][A lo][W hi][W lo], 128 rows x 64 B each; 16-B slot c of row r holds chunk
 //                 c ^ (3 if r & 8 else 0): ds_read_b128 serves the lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ... -- every
 //                 group holds all 16 fragment rows, rows 4-11 with the neighbouring chunk -- and the four rows that share a 64-byte quarter
 //                 of the 256-byte bank row (r, r + 4, r + 8, r + 12) then sit in four different slots (with c ^ ((r >> 2) & 3), the
 //                 swizzle for CONTIGUOUS 16-lane groups, every read was a 2-way conflict: SQ_LDS_BANK_CONFLICT 0 now); per step and
 //                 16x16 output tile the three products hi.hi, x_hi.w_lo, x_lo.w_hi in the tiled kernel's order
-//   16-bit:       step = 64 K elements: [A 128 x 128 B][W 128 x 128 B], the 128x128 kernel's swizzle and fragment order -- correct and
-//                 bit-identical, but NOT dispatched: it measured the same as the two-stage kernel (17 / 48 us at M = 3072)
-// Measured (profiles/r06_staged_ab.log, r06_staged_pmc.log): M = 3072 attention output 64 -> 32 us, FFN-down 190 -> 97 us; M = 1024
-// all four projections 1.7-2.0 x.  What bounds it is the LDS fill: 43 GB/s per CU (4 MiB per K = 4096 tile in 97 us), whatever the
-// ring depth, the request size (64- or 128-byte rows) or the fragment prefetch -- the matrix pipe is 41 % busy, TCP_PENDING_STALL 43 %
-// of the cycles, L2 hit rate 87 %.  The 256x256 kernel fills at the same per-CU rate with half the bytes per flop: from two rounds on
-// (more 128x128 tiles than CUs) the two tie or the big tile wins, so the dispatch takes this kernel only for ONE round.
+//   16-bit:       step = 64 K elements: [A 128 x 128 B][W 128 x 128 B], the 128x128 kernel's swizzle and fragment order
+// Measured (profiles/r06_staged_ab.log, r06_staged_pmc.log, r06_fill_rate.log): split planes, M = 3072: attention output 63 -> 28 us,
+// FFN-down 190 -> 88 us; M = 1024: all four projections 2.0-2.5 x; two rounds (M = 5-8 k) 1.1-1.2 x.  16-bit, one round: 17 -> 15 and
+// 49 -> 42 us.  A step takes 0.66-0.69 us in either form -- the MFMAs are 0.21 (0.32) us of it, the matrix pipe 41 % busy.  A CU with
+// nothing else to do takes in a 32-KiB step per 0.43 us when every CU loads (fill_rate.cpp: 77 GB/s per CU over 192 CUs = 14.7 TB/s,
+// 104 GB/s over 64 CUs; with ONE step in flight 45 GB/s -- the two-stage kernel's rate); first version, the 8 issues of a step in a
+// block in front of its MFMAs: 0.78 us per step; between the MFMAs: 0.66; 4 or 8 waves: the same.  The 256x256 kernel needs half the
+// fill per flop, so beyond two rounds it wins.
 // One accumulator per output element, K ascending in steps of 32, the same MFMA and the same epilogue code as the other kernels:
-// the same bits, whichever kernel the row count selects (tests/test_x3_gpu.py::test_gemm_x3_rows_do_not_depend_on_the_kernel...).
+// the same bits, whichever kernel the row count selects (tests/test_x3_gpu.py::test_gemm_x3_rows_do_not_depend_on_the_kernel...,
+// tests/test_encoder_gpu.py::test_rows_do_not_depend_on_the_kernel_that_computed_them).
 constexpr int kStagedStages = 4;
 constexpr int kStagedStageBytes = 32768;
 constexpr int kStagedLds = kStagedStages * kStagedStageBytes;   // 128 KiB
+constexpr int kStagedThreads = 512;                             // 8 waves: 2 (rows of 64) x 4 (columns of 32), two per SIMD
 
-__device__ __forceinline__ void lds_wait16(v3::u32x4 (&a)[16]) {
+__device__ __forceinline__ void lds_wait12(v3::u32x4 (&a)[12]) {
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]),
-                                          "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]));
+                                          "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]));
 }
 __device__ __forceinline__ ex8 as_ex8(v3::u32x4 v) { return __builtin_bit_cast(ex8, v); }
 
 template <int EPI, bool X3>
-__global__ __launch_bounds__(kGemmThreads, 1) void gemm_staged_kernel(GemmParams p) {
+__global__ __launch_bounds__(kStagedThreads, 1) void gemm_staged_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave >> 2, wn = wave & 3;          // the wave's 64 x 32 piece of the tile: rows wm * 64, columns wn * 32
 
     // block -> tile: the 128x128 kernel's map (XCD-contiguous ranges, then 8 x SN super-tiles)
     const int mt_n = p.M / BM, nt_n = p.N / BN;
@@ -2081,32 +2084,30 @@ __global__ __launch_bounds__(kGemmThreads, 1) void gemm_staged_kernel(GemmParams
     constexpr int KE = X3 ? 32 : 64;             // K elements per step
     const int nk = p.K / KE;
     const int ldw = X3 ? p.ldw : p.K;
-    // this wave's 8 copies per step: per-lane byte offsets from (operand + first tile row + step), constant for the whole kernel
-    uint32_t voff[8], ldst[8];
+    // this wave's 4 copies per step (1 KiB each): per-lane byte offsets from (operand + first tile row + step), constant for the whole
+    // kernel.  16-bit: rows 16 w + [0, 16) of A and of W, 8 rows of 128 B per copy.  Split planes: rows 16 w + [0, 16) of each of the
+    // four planes, one copy of 16 rows x 64 B per plane.  Copies 0, 1 read A, copies 2, 3 read W.
+    uint32_t voff[4], ldst[4];
     if constexpr (!X3) {
         const int lrow = lane >> 3, slot = lane & 7;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int row = 32 * wave + 8 * j + lrow;
+        for (int j = 0; j < 2; ++j) {
+            const int row = 16 * wave + 8 * j + lrow;
             const int chunk = slot ^ ((row >> 1) & 7);
             voff[j] = (uint32_t)row * (uint32_t)p.lda * 2u + chunk * 16;
-            voff[4 + j] = (uint32_t)row * (uint32_t)ldw * 2u + chunk * 16;
-            ldst[j] = (32 * wave + 8 * j) * 128;
-            ldst[4 + j] = 16384 + (32 * wave + 8 * j) * 128;
+            voff[2 + j] = (uint32_t)row * (uint32_t)ldw * 2u + chunk * 16;
+            ldst[j] = (16 * wave + 8 * j) * 128;
+            ldst[2 + j] = 16384 + ldst[j];
         }
     } else {
-        const int lrow = lane >> 2, slot = lane & 3;
+        const int row = 16 * wave + (lane >> 2), slot = lane & 3;
+        const int chunk = slot ^ (((row >> 3) & 1) * 3);
+        voff[0] = (uint32_t)row * (uint32_t)p.lda * 2u + chunk * 16;                    // A hi
+        voff[1] = voff[0] + (uint32_t)p.K * 2u;                                          // A lo: K elements behind in the row
+        voff[2] = (uint32_t)row * (uint32_t)ldw * 2u + chunk * 16;                      // W hi
+        voff[3] = voff[2] + (uint32_t)p.K * 2u;                                          // W lo
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int row = 32 * wave + 16 * j + lrow;
-            const int chunk = slot ^ (((row >> 3) & 1) * 3);
-            voff[j] = (uint32_t)row * (uint32_t)p.lda * 2u + chunk * 16;                 // A hi
-            voff[2 + j] = voff[j] + (uint32_t)p.K * 2u;                                    // A lo: K elements behind in the row
-            voff[4 + j] = (uint32_t)row * (uint32_t)ldw * 2u + chunk * 16;               // W hi
-            voff[6 + j] = voff[4 + j] + (uint32_t)p.K * 2u;                                // W lo
-#pragma unroll
-            for (int pl = 0; pl < 4; ++pl) ldst[2 * pl + j] = pl * 8192 + (32 * wave + 16 * j) * 64;
-        }
+        for (int pl = 0; pl < 4; ++pl) ldst[pl] = pl * 8192 + 16 * wave * 64;
     }
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     auto sgpr_ptr = [](const char* ptr) {
@@ -2121,15 +2122,15 @@ __global__ __launch_bounds__(kGemmThreads, 1) void gemm_staged_kernel(GemmParams
         const uint32_t st = lds0 + (kt & (kStagedStages - 1)) * kStagedStageBytes;
         const char* a = sgpr_ptr(rowA + (size_t)kt * KE * 2);
         const char* wgt = sgpr_ptr(rowW + (size_t)kt * KE * 2);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) v3::glds16(a, voff[c], st + ldst[c]);
-#pragma unroll
-        for (int c = 4; c < 8; ++c) v3::glds16(wgt, voff[c], st + ldst[c]);
+        v3::glds16(a, voff[0], st + ldst[0]);
+        v3::glds16(a, voff[1], st + ldst[1]);
+        v3::glds16(wgt, voff[2], st + ldst[2]);
+        v3::glds16(wgt, voff[3], st + ldst[3]);
     };
 
-    f32x4 acc[4][4];  // [nt][mt]
+    f32x4 acc[2][4];  // [nt][mt]
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -2141,13 +2142,13 @@ __global__ __launch_bounds__(kGemmThreads, 1) void gemm_staged_kernel(GemmParams
         for (int ss = 0; ss < 2; ++ss) {
             const int sw = ((4 * ss + fchk) ^ ((frow >> 1) & 7)) << 4;
             fa[ss] = (wm * 64 + frow) * 128 + sw;
-            fw[ss] = 16384 + (wn * 64 + frow) * 128 + sw;
+            fw[ss] = 16384 + (wn * 32 + frow) * 128 + sw;
         }
     } else {
         const int sw = (fchk ^ (((frow >> 3) & 1) * 3)) << 4;
         fa[0] = (wm * 64 + frow) * 64 + sw;
         fa[1] = 8192 + fa[0];
-        fw[0] = 16384 + (wn * 64 + frow) * 64 + sw;
+        fw[0] = 16384 + (wn * 32 + frow) * 64 + sw;
         fw[1] = 8192 + fw[0];
     }
     constexpr int RS = X3 ? 16 * 64 : 16 * 128;     // bytes from one 16-row tile to the next (the reads' immediate offset)
@@ -2157,58 +2158,72 @@ __global__ __launch_bounds__(kGemmThreads, 1) void gemm_staged_kernel(GemmParams
         dst[(at) + 0] = v3::lds_read128_async<0>(a_);      dst[(at) + 1] = v3::lds_read128_async<RS>(a_);     \
         dst[(at) + 2] = v3::lds_read128_async<2 * RS>(a_); dst[(at) + 3] = v3::lds_read128_async<3 * RS>(a_); \
     } while (0)
-
-    // fragments of a step: 16-bit {x[0..3], w[0..3]} of sub-step 0, then of sub-step 1; split planes {x_hi[0..3], w_hi[0..3], w_lo[0..3], x_lo[0..3]}
-    auto read_frags = [&](v3::u32x4 (&f)[16], int kt) {
+#define TT_STAGED_RD2(dst, at, addr)                                                                  \
+    do {                                                                                              \
+        const uint32_t a_ = (addr);                                                                   \
+        dst[(at) + 0] = v3::lds_read128_async<0>(a_);      dst[(at) + 1] = v3::lds_read128_async<RS>(a_);     \
+    } while (0)
+    // fragments of a step, 12 registers: 16-bit {x[0..3], w[0..1]} of sub-step 0, then of sub-step 1;
+    //                                    split planes {x_hi[0..3], w_hi[0..1], w_lo[0..1], x_lo[0..3]}
+    auto read_frags = [&](v3::u32x4 (&f)[12], int kt) {
         const uint32_t st = lds0 + (kt & (kStagedStages - 1)) * kStagedStageBytes;
         if constexpr (!X3) {
-            TT_STAGED_RD4(f, 0, st + fa[0]); TT_STAGED_RD4(f, 4, st + fw[0]);
-            TT_STAGED_RD4(f, 8, st + fa[1]); TT_STAGED_RD4(f, 12, st + fw[1]);
+            TT_STAGED_RD4(f, 0, st + fa[0]); TT_STAGED_RD2(f, 4, st + fw[0]);
+            TT_STAGED_RD4(f, 6, st + fa[1]); TT_STAGED_RD2(f, 10, st + fw[1]);
         } else {
-            TT_STAGED_RD4(f, 0, st + fa[0]); TT_STAGED_RD4(f, 4, st + fw[0]);
-            TT_STAGED_RD4(f, 8, st + fw[1]); TT_STAGED_RD4(f, 12, st + fa[1]);
+            TT_STAGED_RD4(f, 0, st + fa[0]); TT_STAGED_RD2(f, 4, st + fw[0]);
+            TT_STAGED_RD2(f, 6, st + fw[1]); TT_STAGED_RD4(f, 8, st + fa[1]);
         }
     };
-    auto multiply = [&](const v3::u32x4 (&f)[16]) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = TT_MFMA_16x16x32(as_ex8(f[4 + i]), as_ex8(f[j]), acc[i][j]);            // (split planes: hi.hi)
-        if constexpr (!X3) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = TT_MFMA_16x16x32(as_ex8(f[12 + i]), as_ex8(f[8 + j]), acc[i][j]);
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = TT_MFMA_16x16x32(as_ex8(f[8 + i]), as_ex8(f[j]), acc[i][j]);        // x_hi.w_lo
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = TT_MFMA_16x16x32(as_ex8(f[4 + i]), as_ex8(f[12 + j]), acc[i][j]);   // x_lo.w_hi
-        }
+    // the step's MFMAs in their fixed order -- (split planes) hi.hi, x_hi.w_lo, x_lo.w_hi over the wave's 8 output tiles, (16-bit)
+    // sub-step 0, sub-step 1 -- cut into 4 equal groups; between(g) runs after group g (the step's 4 LDS-DMA issues, one per gap)
+    auto multiply = [&](const v3::u32x4 (&f)[12], auto&& between) {
+        constexpr int NMM = X3 ? 24 : 16, PER = NMM / 4;
+        v3::static_for<NMM>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            constexpr int ph = t / 8, i = (t % 8) / 4, j = t % 4;
+            if constexpr (!X3) acc[i][j] = TT_MFMA_16x16x32(as_ex8(f[(ph ? 10 : 4) + i]), as_ex8(f[(ph ? 6 : 0) + j]), acc[i][j]);
+            else if constexpr (ph == 0) acc[i][j] = TT_MFMA_16x16x32(as_ex8(f[4 + i]), as_ex8(f[j]), acc[i][j]);             // hi.hi
+            else if constexpr (ph == 1) acc[i][j] = TT_MFMA_16x16x32(as_ex8(f[6 + i]), as_ex8(f[j]), acc[i][j]);             // x_hi.w_lo
+            else acc[i][j] = TT_MFMA_16x16x32(as_ex8(f[4 + i]), as_ex8(f[8 + j]), acc[i][j]);                                // x_lo.w_hi
+            if constexpr (t % PER == PER - 1) {
+                __builtin_amdgcn_sched_barrier(0);
+                between(std::integral_constant<int, t / PER>{});
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        });
     };
-    auto wait_groups = [](int g) {                  // at most g of this wave's 8-copy groups still in flight
-        if (g >= 3) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-        else if (g == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        else if (g == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    auto wait_groups = [](int g) {                  // at most g of this wave's 4-copy groups still in flight
+        if (g >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if (g == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (g == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
     // One step: (1) this wave's copies of step kt + 1 have landed, (2) its fragment reads of step kt (issued a step ago) have
-    // returned, (3) barrier: both hold for every wave -- stage kt % 4 is free and stage (kt + 1) % 4 is complete, (4) the copies of
-    // step kt + 4 go into the freed stage (three steps of lead), (5) the fragment reads of step kt + 1 are issued and (6) return
-    // while the matrix pipe runs step kt: without (5) before (6) the four waves, in lockstep behind the barrier, alternate between
-    // an LDS phase (64 KiB of fragment reads: 512 cycles) and an MFMA phase (512-768 cycles) -- measured 1.0 us per step instead of 0.4.
-    auto step = [&](v3::u32x4 (&cur)[16], v3::u32x4 (&nxt)[16], int kt) {
+    // returned, (3) barrier: both hold for every wave -- stage kt % 4 is free and stage (kt + 1) % 4 is complete, (4) the fragment
+    // reads of step kt + 1 are issued and return while the matrix pipe runs step kt, (5) the copies of step kt + 4 go into the freed
+    // stage (three steps of lead), ONE BETWEEN EVERY FEW MFMAs: an LDS-DMA issue holds the wave's in-order instruction stream until
+    // the texture addresser takes it (100-150 cycles each; tools/probes/fill_rate.cpp: a CU takes in 32 KiB per 0.43 us with nothing
+    // else in the loop), and issued in a block in front of the MFMAs that time ADDS to theirs (4 waves, 8 issues each, in a block:
+    // 0.78 us per step; between the MFMAs: 0.66).  Two waves per SIMD: while one waits in an issue the other feeds the matrix pipe.
+    auto step = [&](v3::u32x4 (&cur)[12], v3::u32x4 (&nxt)[12], int kt) {
         if (kt + 1 < nk) wait_groups(nk - 2 - kt < 2 ? nk - 2 - kt : 2);
-        lds_wait16(cur);
+        lds_wait12(cur);
         __builtin_amdgcn_s_barrier();
-        if (kt + kStagedStages < nk) issue(kt + kStagedStages);
         if (kt + 1 < nk) read_frags(nxt, kt + 1);
         __builtin_amdgcn_sched_barrier(0);
-        multiply(cur);
+        if (kt + kStagedStages < nk) {
+            const int nx = kt + kStagedStages;
+            const uint32_t st = lds0 + (nx & (kStagedStages - 1)) * kStagedStageBytes;
+            const char* a = sgpr_ptr(rowA + (size_t)nx * KE * 2);
+            const char* wgt = sgpr_ptr(rowW + (size_t)nx * KE * 2);
+            multiply(cur, [&](auto gc) {
+                constexpr int g = decltype(gc)::value;
+                v3::glds16(g < 2 ? a : wgt, voff[g], st + ldst[g]);
+            });
+        } else {
+            multiply(cur, [](auto) {});
+        }
         __builtin_amdgcn_sched_barrier(0);
     };
 
@@ -2217,7 +2232,7 @@ __global__ __launch_bounds__(kGemmThreads, 1) void gemm_staged_kernel(GemmParams
         if (kt < nk) issue(kt);
     wait_groups(nk - 1 < 3 ? nk - 1 : 3);
     __builtin_amdgcn_s_barrier();
-    v3::u32x4 fA[16], fB[16];
+    v3::u32x4 fA[12], fB[12];
     read_frags(fA, 0);
     int kt = 0;
     for (; kt + 1 < nk; kt += 2) {
@@ -2226,8 +2241,9 @@ __global__ __launch_bounds__(kGemmThreads, 1) void gemm_staged_kernel(GemmParams
     }
     if (kt < nk) step(fA, fB, kt);
 #undef TT_STAGED_RD4
-    if constexpr (X3) gemm_epilogue_tile_x3<EPI, 4, 4>(p, acc, m0 + wm * 64, n0 + wn * 64, lane);
-    else gemm_epilogue<EPI>(p, acc, m0 + wm * 64, n0 + wn * 64, lane);
+#undef TT_STAGED_RD2
+    if constexpr (X3) gemm_epilogue_tile_x3<EPI, 2, 4>(p, acc, m0 + wm * 64, n0 + wn * 32, lane);
+    else gemm_epilogue_tile<EPI, 2, 4>(p, acc, m0 + wm * 64, n0 + wn * 32, lane);
 }
 
 // (diagnostic library: TT_GEMM_STAGED=0 puts the 256x256 split-plane kernel back; TT_GEMM_STAGED_MAX = the 128x128-tile count up to
@@ -2354,12 +2370,12 @@ int launch_x3(const GemmParams& p, hipStream_t st) {
         } else {
             if (!p.C || p.ldc % 8 || p.c_lo_off % 8 || p.c_lo_off < p.N) { tt_set_error("gemm x3: planes output needs C, c_lo_off >= N"); return TT_E_INVALID; }
         }
-        // a lone caller's rerank (the reference's 10 pairs: M = 1-4 k rows): when the 128x128 tiles fit the chip in ONE round (<= one per
-        // CU) the staged kernel is a 128x128 tile's latency instead of a 256x256 tile's on a quarter of the CUs -- measured 1.8 x
-        // (profiles/r06_staged_ab.log); in two rounds it ties with the 256x256 kernel, beyond that it loses (twice the LDS fill per flop)
+        // a lone caller's rerank (the reference's 10-20 pairs: M = 1-8 k rows): up to TWO rounds of 128x128 tiles the staged kernel beats
+        // the 256x256 kernel's one round on a fraction of the CUs -- one round 2.1-2.4 x (M = 3072: 63 -> 28 us, 190 -> 88 us), two rounds
+        // 1.1-1.2 x (M = 7424: 68 -> 57, 206 -> 182 us); beyond that the big tile's half fill per flop wins (profiles/r06_staged_ab.log)
         static const int staged_max = TT_DIAG_ENV_INT("TT_GEMM_STAGED_MAX", 0);
         const int mt1 = p.M / BM, nt1 = p.N / BN;
-        if (staged_enabled() && p.N % BN == 0 && (long long)mt1 * nt1 <= (staged_max ? staged_max : tt_cu_count_cached())) {
+        if (staged_enabled() && p.N % BN == 0 && (long long)mt1 * nt1 <= (staged_max ? staged_max : 2 * tt_cu_count_cached())) {
             const int SN1 = nt1 < 8 ? nt1 : 8, SM1 = 8;
             int blocks1 = ((mt1 + SM1 - 1) / SM1) * ((nt1 + SN1 - 1) / SN1) * SM1 * SN1;
             blocks1 = (blocks1 + 7) / 8 * 8;
@@ -2368,7 +2384,7 @@ int launch_x3(const GemmParams& p, hipStream_t st) {
                 TtProfScope prof(TT_K_GEMM, st);
                 GemmParams q = p;
                 q.ldw = ldw;
-                hipLaunchKernelGGL((gemm_staged_kernel<EPI, true>), dim3(blocks1), dim3(kGemmThreads), kStagedLds, st, q);
+                hipLaunchKernelGGL((gemm_staged_kernel<EPI, true>), dim3(blocks1), dim3(kStagedThreads), kStagedLds, st, q);
             }
             TT_CHECK_LAUNCH();
             return TT_OK;
@@ -2562,6 +2578,18 @@ int launch(const GemmParams& p, hipStream_t st) {
     const int supers = ((mt_n + SM - 1) / SM) * ((nt_n + SN - 1) / SN);
     int blocks = supers * SM * SN;
     blocks = (blocks + 7) / 8 * 8;
+    // ONE round of 128x128 tiles (a lone caller's 10-pair rerank): the staged kernel (four-stage ring, LDS-DMA issues between the MFMAs)
+    // -- M = 3072: attention output 17 -> 15 us, FFN-down 49 -> 42 us; in two rounds the two-stage kernel's two workgroups per CU win
+    static const int staged16 = TT_DIAG_ENV_INT("TT_GEMM_STAGED16", 1);
+    if (staged16 && staged_enabled() && (long long)mt_n * nt_n <= (staged16 > 1 ? staged16 : tt_cu_count_cached()) && p.K % 64 == 0) {
+        TT_SET_MAX_LDS((gemm_staged_kernel<EPI, false>), kStagedLds);
+        {
+            TtProfScope prof(TT_K_GEMM, st);
+            hipLaunchKernelGGL((gemm_staged_kernel<EPI, false>), dim3(blocks), dim3(kStagedThreads), kStagedLds, st, p);
+        }
+        TT_CHECK_LAUNCH();
+        return TT_OK;
+    }
     auto kern = gemm_kernel<EPI>;
     TT_SET_MAX_LDS(kern, kGemmLds);
     {

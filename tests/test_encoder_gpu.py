@@ -67,8 +67,8 @@ def test_gemm_epilogues(dev, built_lib, m, n, k, epi):
 def test_skinny_gemm_is_bit_identical_to_the_tiled_kernels(dev, built_lib, n, k, epi):
     """Up to 256 rows the projections run as weight-streaming skinny GEMMs (one wave per 16 columns, no LDS); same MFMA,
     same K order, same epilogue code as the tiled kernels -> the same bits for the same rows, whatever else is in the
-    batch.  64 rows alone (skinny) vs the same rows inside 512- and 2048-row GEMMs (the 128x128 kernel: fewer than 128 tiles of
-    256x256) -- and ``test_rows_do_not_depend_on_the_kernel_that_computed_them`` below with the 256x256 kernel as well."""
+    batch.  64 rows alone (skinny) vs the same rows inside 512- and 2048-row GEMMs (the staged 128x128 kernel: up to one tile per
+    CU) -- and ``test_rows_do_not_depend_on_the_kernel_that_computed_them`` below with the two-stage and 256x256 kernels as well."""
     from tensor_truth_amd import _lib
 
     lib = _lib.load_library()
@@ -93,15 +93,16 @@ def test_skinny_gemm_is_bit_identical_to_the_tiled_kernels(dev, built_lib, n, k,
 @pytest.mark.parametrize("epi", [0, 1, 2])
 @pytest.mark.parametrize("n,k", [(1024, 1024), (1024, 4096), (3072, 1024)])
 def test_rows_do_not_depend_on_the_kernel_that_computed_them(dev, built_lib, n, k, epi):
-    """Which GEMM kernel runs is decided by the row count of the batch a text rides in: <= 256 rows the skinny kernel, fewer than
-    128 tiles of 256x256 the 128x128 kernel (a lone caller's rerank), from there the 256x256 ping-pong kernel (a row count that is not
-    a multiple of 256: the 128x128 kernel again, on a large grid).  One accumulator per output element, K ascending, the same MFMA and
-    epilogue code in all of them: the first rows of every launch carry the same bits."""
+    """Which GEMM kernel runs is decided by the row count of the batch a text rides in: <= 256 rows the skinny kernel, up to one
+    128x128 tile per CU the staged 128x128 kernel (round 6: a lone caller's 10-pair rerank), fewer than 128 tiles of 256x256 the
+    two-stage 128x128 kernel, from there the 256x256 ping-pong kernel (a row count that is not a multiple of 256: the two-stage
+    kernel again, on a large grid).  One accumulator per output element, K ascending, the same MFMA and epilogue code in all of
+    them: the first rows of every launch carry the same bits."""
     from tensor_truth_amd import _lib
 
     lib = _lib.load_library()
     g = torch.Generator().manual_seed(7 * n + k + epi)
-    rows = {1024: (64, 512, 3072, 8192, 8320), 3072: (64, 512, 2816, 8320)}[n]     # skinny, 128x128 (x2), 256x256, 128x128 on a large grid
+    rows = {1024: (64, 512, 3072, 5120, 8192, 8320), 3072: (64, 512, 2816, 8320)}[n]   # skinny, staged (x2 / x1), [two-stage,] 256x256, two-stage on a large grid
     big = max(rows)
     a = _bf(torch.randn(big, k, generator=g)).to(dev)
     w = _bf(torch.randn(n, k, generator=g) * 0.05).to(dev)

@@ -96,15 +96,15 @@ def test_gemm_x3_building_block(dev, built_lib, m, n, k):
 @pytest.mark.parametrize("planes", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("n,k", [(1024, 1024), (1024, 4096), (2048, 1024)])
 def test_gemm_x3_rows_do_not_depend_on_the_kernel_that_computed_them(dev, built_lib, n, k, planes):
-    """Split planes, three kernels by row count: <= 256 rows the relay kernel, up to one 128x128 tile per CU the staged 128x128
-    kernel (round 6: the reference's own call, 10 pairs = 1-4 k rows, was one 256x256 tile's latency on a fifth of the chip), above
-    that the 256x256 ping-pong kernel.  Per 32 K elements the products hi.hi, x_hi.w_lo, x_lo.w_hi into ONE accumulator, K ascending, the
+    """Split planes, three kernels by row count: <= 256 rows the relay kernel, up to two 128x128 tiles per CU the staged 128x128
+    kernel (round 6: the reference's own call, 10-20 pairs = 1-8 k rows, was one 256x256 tile's latency on a fraction of the chip),
+    above that the 256x256 ping-pong kernel.  Per 32 K elements the products hi.hi, x_hi.w_lo, x_lo.w_hi into ONE accumulator, K ascending, the
     same epilogue operations: the first rows of every launch carry the same bits (planes out, GELU planes out, fp32 residual out)."""
     from tensor_truth_amd import _lib
 
     lib = _lib.load_library()
     g = torch.Generator().manual_seed(n + k)
-    rows = (64, 256, 768, 256 * 128 * 128 // n, 128 * 256 * 256 // n)      # relay, relay, staged, staged (256 tiles of 128x128), 256x256 (128 tiles)
+    rows = (64, 256, 768, 256 * 128 * 128 // n, 512 * 128 * 128 // n, 16384)   # relay, relay, staged: part of a round, one round, two rounds; 256x256
     big = rows[-1]
     from tensor_truth_amd.encoder_x3 import split_planes
 
