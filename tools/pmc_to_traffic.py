@@ -22,9 +22,10 @@ def load(dirname, counter):
 
 def main(fetch_dir, write_dir, out):
     res = {}
-    for kind, match in (("gemm", "gemm_kernel"), ("scan_filter", "scan_kernel<1024, 1, 0")):
-        fr = [r for r in load(fetch_dir, "FETCH_SIZE") if match in r["Kernel_Name"]]
-        wr = [r for r in load(write_dir, "WRITE_SIZE") if match in r["Kernel_Name"]]
+    # (the tiled GEMM kernels: gemm_kernel / gemm_kernel_v3 / gemm_kernel_p and, since round 6, gemm_staged_kernel for one-round grids)
+    for kind, match in (("gemm", ("gemm_kernel", "gemm_staged_kernel")), ("scan_filter", ("scan_kernel<1024, 1, 0",))):
+        fr = [r for r in load(fetch_dir, "FETCH_SIZE") if any(m in r["Kernel_Name"] for m in match)]
+        wr = [r for r in load(write_dir, "WRITE_SIZE") if any(m in r["Kernel_Name"] for m in match)]
         if kind == "gemm":
             # rerank forward: 24 layers x 5 launches (QKV as two) + the head GEMM; query-embedding forward (small grid,
             # 128x128 kernel, fused QKV): 24 x 4

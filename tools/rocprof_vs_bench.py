@@ -21,7 +21,7 @@ def main():
     with open(stats_csv) as f:
         for r in csv.DictReader(f):
             name, calls, tot = r["Name"], int(r["Calls"]), int(r["TotalDurationNs"])
-            if "gemm_kernel" in name or "gemm_skinny" in name:
+            if "gemm_kernel" in name or "gemm_skinny" in name or "gemm_staged" in name or "gemm_relay" in name:
                 gemm_calls += calls
                 gemm_ns += tot
                 rows.append((name.split("::")[-1][:60], calls, tot / calls / 1e6))
