@@ -33,7 +33,9 @@ def _bf(x):
 @pytest.mark.parametrize("m,n,k", [(128, 128, 64), (256, 384, 384), (384, 1152, 384), (128, 1536, 384),
                                    (512, 1024, 1024), (256, 4096, 1024), (256, 1024, 4096),
                                    (64, 1024, 1024), (192, 3072, 1024), (64, 1024, 4096), (64, 1152, 384),   # skinny
-                                   (384, 128, 64), (640, 1024, 4096), (1024, 384, 1536)])                    # 128x128 tiles
+                                   (384, 128, 64), (640, 1024, 4096), (1024, 384, 1536),                     # 128x128 tiles
+                                   # round 6, the staged kernel's four-stage ring around its depth: 1, 2, 3, 5 and 6 K-steps of 64
+                                   (256, 256, 128), (128, 256, 192), (256, 128, 320), (384, 384, 384)])
 @pytest.mark.parametrize("epi", [0, 1, 2, 3])
 def test_gemm_epilogues(dev, built_lib, m, n, k, epi):
     from tensor_truth_amd import _lib

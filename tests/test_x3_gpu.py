@@ -56,7 +56,9 @@ def test_split_planes_kernel_equals_the_torch_formula(dev, built_lib):
 @pytest.mark.parametrize("m,n,k", [(256, 256, 128), (512, 768, 256), (256, 1024, 1024), (768, 256, 4096), (1024, 4096, 1024),
                                    (64, 1024, 1024), (192, 4096, 1024), (128, 1024, 4096),       # <= 256 rows: the skinny kernel
                                    # round 6: N = 64 j, the last column tile partial (bge-small: 384 / 1152 / 1536 columns, K = 384 / 1536)
-                                   (256, 384, 384), (512, 1536, 384), (768, 384, 1536), (256, 64, 128), (512, 448, 256), (64, 384, 1536)])
+                                   (256, 384, 384), (512, 1536, 384), (768, 384, 1536), (256, 64, 128), (512, 448, 256), (64, 384, 1536),
+                                   # round 6, the staged kernel's four-stage ring around its depth: 4, 6 and 10 K-steps of 32 (K is a multiple of 64)
+                                   (512, 128, 128), (256, 256, 192), (512, 384, 320)])
 def test_gemm_x3_building_block(dev, built_lib, m, n, k):
     """tt_gemm_x3 against fp64 on the operands' own (hi + lo) values: error of an fp32-accumulated product, two orders
     below what one bf16 rounding of an operand costs (2^-9 relative)."""
