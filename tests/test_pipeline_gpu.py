@@ -999,3 +999,44 @@ def test_index_group_scans_large_modules_through_their_shadows(dev, built_lib, m
     del used[:]
     same(1)
     assert used == []
+
+
+def test_index_group_module_whose_survivor_lists_overflow_comes_back_exact(dev, built_lib, monkeypatch):
+    """A module of identical rows: every row reaches the shadow pass's threshold, the survivor lists overflow, the module's status word
+    is raised -- and ``HipIndexGroup`` scans that module again through the dense exact path (``_unpack_modules``), leaving the other
+    modules' shadow results as they are: still ``tt_scan_topk_segmented``'s bits, on the device and through the one-copy host form."""
+    from tensor_truth_amd import scan as tscan
+    from tensor_truth_amd.schema import TextNode
+    from tensor_truth_amd.vector_index import HipIndexGroup, HipVectorIndex
+
+    monkeypatch.setattr(tscan.ScanShadow, "MIN_ROWS", 20_000)
+    dim, k = 256, 10
+    g = torch.Generator().manual_seed(47)
+    one = torch.randn(1, dim, generator=g)
+    embs = [torch.randn(24_000, dim, generator=g), one.repeat(80_000, 1), torch.randn(300, dim, generator=g)]   # (list capacity >= 65 536 rows)
+    members = []
+    for m, e in enumerate(embs):
+        ix = HipVectorIndex(dim, dev, None, "cosine")
+        ix.add([TextNode(text=f"m{m} t{i}", id_=f"m{m}_n{i}", metadata={}) for i in range(e.shape[0])], embeddings=e)
+        members.append(ix)
+    group = HipIndexGroup(members)
+    reruns = []
+    orig = tscan.scan_topk
+
+    def counting(*args, **kw):
+        if kw.get("exact_dense"):
+            reruns.append(args[0].shape[0])
+        return orig(*args, **kw)
+
+    monkeypatch.setattr(tscan, "scan_topk", counting)
+    q = torch.cat([one + 0.3 * torch.randn(1, dim, generator=g), torch.randn(1, dim, generator=g)])
+    qn = (q.to(dev) / q.to(dev).norm(dim=1, keepdim=True)).to(torch.bfloat16).contiguous()
+    s, r = group.search(q, k)
+    ws, wr = tscan.scan_topk_segmented(group._mat, qn, k, list(group.offsets))
+    torch.cuda.synchronize()
+    assert reruns == [80_000]                                             # the flagged module, once
+    assert torch.equal(r, wr) and torch.equal(s.view(torch.int32), ws.view(torch.int32))
+    assert r[0, 1].tolist() == list(range(k))                             # equal scores: rows in ascending order
+    del reruns[:]
+    hs, hr, _ = group.search_host(q, k)
+    assert reruns == [80_000] and torch.equal(hr, wr.cpu()) and torch.equal(hs.view(torch.int32), ws.cpu().view(torch.int32))
