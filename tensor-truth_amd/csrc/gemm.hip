@@ -2036,12 +2036,14 @@ __global__ __launch_bounds__(64) void gemm_skinny_kernel(GemmParams p) {
 //                 16x16 output tile the three products hi.hi, x_hi.w_lo, x_lo.w_hi in the tiled kernel's order
 //   16-bit:       step = 64 K elements: [A 128 x 128 B][W 128 x 128 B], the 128x128 kernel's swizzle and fragment order
 // Measured (profiles/r06_staged_ab.log, r06_staged_pmc.log, r06_fill_rate.log): split planes, M = 3072: attention output 63 -> 28 us,
-// FFN-down 190 -> 88 us; M = 1024: all four projections 2.0-2.5 x; two rounds (M = 5-8 k) 1.1-1.2 x.  16-bit, one round: 17 -> 15 and
-// 49 -> 42 us.  A step takes 0.66-0.69 us in either form -- the MFMAs are 0.21 (0.32) us of it, the matrix pipe 41 % busy.  A CU with
-// nothing else to do takes in a 32-KiB step per 0.43 us when every CU loads (fill_rate.cpp: 77 GB/s per CU over 192 CUs = 14.7 TB/s,
-// 104 GB/s over 64 CUs; with ONE step in flight 45 GB/s -- the two-stage kernel's rate); first version, the 8 issues of a step in a
-// block in front of its MFMAs: 0.78 us per step; between the MFMAs: 0.66; 4 or 8 waves: the same.  The 256x256 kernel needs half the
-// fill per flop, so beyond two rounds it wins.
+// FFN-down 190 -> 84 us; M = 1024: all four projections 2.0-2.5 x; two rounds (M = 5-8 k) 1.1-1.2 x.  16-bit, one round: 17 -> 15 and
+// 49 -> 42 us.  Where a step's 0.64 us go (an ablation build, EXPERIMENTS.md round 6; split-plane FFN-down, 128 steps): with L2-hot
+// operands nothing changes -- it is not memory; MFMAs + barriers alone 0.5 us per step (768 matrix-pipe cycles per SIMD: the 0.6-0.65 of
+// the matrix peak the 256x256 kernel also reaches), copies + barriers alone 0.55 us, the empty loop (waits + barrier) 0.15 us: the step
+// is max(MFMAs, copies) + the barrier, within 1.3 x of its matrix-pipe time.  (A CU with nothing else to do takes in a 32-KiB step per
+// 0.43 us when every CU loads -- fill_rate.cpp: 77 GB/s per CU over 192 CUs, 104 over 64; ONE step in flight 45 GB/s, the two-stage
+// kernel's rate.)  First version, 4 waves, the 8 issues of a step in a block in front of its MFMAs: 0.78 us per step; between the MFMAs
+// 0.66; 8 waves 0.64 wherever the issues sit.  The 256x256 kernel needs half the fill per flop: beyond two rounds it wins.
 // One accumulator per output element, K ascending in steps of 32, the same MFMA and the same epilogue code as the other kernels:
 // the same bits, whichever kernel the row count selects (tests/test_x3_gpu.py::test_gemm_x3_rows_do_not_depend_on_the_kernel...,
 // tests/test_encoder_gpu.py::test_rows_do_not_depend_on_the_kernel_that_computed_them).
@@ -2178,7 +2180,7 @@ __global__ __launch_bounds__(kStagedThreads, 1) void gemm_staged_kernel(GemmPara
     // the step's MFMAs in their fixed order -- (split planes) hi.hi, x_hi.w_lo, x_lo.w_hi over the wave's 8 output tiles, (16-bit)
     // sub-step 0, sub-step 1 -- cut into 4 equal groups; between(g) runs after group g (the step's 4 LDS-DMA issues, one per gap)
     auto multiply = [&](const v3::u32x4 (&f)[12], auto&& between) {
-        constexpr int NMM = X3 ? 24 : 16, PER = NMM / 4;
+        constexpr int NMM = X3 ? 24 : 16;
         v3::static_for<NMM>([&](auto tc) {
             constexpr int t = decltype(tc)::value;
             constexpr int ph = t / 8, i = (t % 8) / 4, j = t % 4;
@@ -2186,9 +2188,12 @@ __global__ __launch_bounds__(kStagedThreads, 1) void gemm_staged_kernel(GemmPara
             else if constexpr (ph == 0) acc[i][j] = TT_MFMA_16x16x32(as_ex8(f[4 + i]), as_ex8(f[j]), acc[i][j]);             // hi.hi
             else if constexpr (ph == 1) acc[i][j] = TT_MFMA_16x16x32(as_ex8(f[6 + i]), as_ex8(f[j]), acc[i][j]);             // x_hi.w_lo
             else acc[i][j] = TT_MFMA_16x16x32(as_ex8(f[4 + i]), as_ex8(f[8 + j]), acc[i][j]);                                // x_lo.w_hi
-            if constexpr (t % PER == PER - 1) {
+            // copy 0 of the step goes out right behind the barrier (step(), below), copies 1-3 after each third of the MFMAs -- the last
+            // one at the very end: the texture addresser should not run dry while the waves pass the barrier and read their fragments
+            constexpr int g = (3 * (t + 1)) / NMM;                       // thirds completed after this MFMA
+            if constexpr (g >= 1 && (3 * t) / NMM < g) {
                 __builtin_amdgcn_sched_barrier(0);
-                between(std::integral_constant<int, t / PER>{});
+                between(std::integral_constant<int, g>{});
                 __builtin_amdgcn_sched_barrier(0);
             }
         });
@@ -2202,26 +2207,29 @@ __global__ __launch_bounds__(kStagedThreads, 1) void gemm_staged_kernel(GemmPara
     // One step: (1) this wave's copies of step kt + 1 have landed, (2) its fragment reads of step kt (issued a step ago) have
     // returned, (3) barrier: both hold for every wave -- stage kt % 4 is free and stage (kt + 1) % 4 is complete, (4) the fragment
     // reads of step kt + 1 are issued and return while the matrix pipe runs step kt, (5) the copies of step kt + 4 go into the freed
-    // stage (three steps of lead), ONE BETWEEN EVERY FEW MFMAs: an LDS-DMA issue holds the wave's in-order instruction stream until
-    // the texture addresser takes it (100-150 cycles each; tools/probes/fill_rate.cpp: a CU takes in 32 KiB per 0.43 us with nothing
-    // else in the loop), and issued in a block in front of the MFMAs that time ADDS to theirs (4 waves, 8 issues each, in a block:
-    // 0.78 us per step; between the MFMAs: 0.66).  Two waves per SIMD: while one waits in an issue the other feeds the matrix pipe.
+    // stage (three steps of lead): the first right behind the barrier, the others after each third of the MFMAs.  An LDS-DMA issue holds
+    // the wave's in-order instruction stream until the texture addresser takes it (100-150 cycles each); issued in a block in front of
+    // the MFMAs that time ADDS to theirs when a SIMD has one wave (4 waves: 0.78 us per step, between the MFMAs 0.66).  Two waves per
+    // SIMD: while one waits in an issue the other feeds the matrix pipe (0.64, wherever the issues sit).
     auto step = [&](v3::u32x4 (&cur)[12], v3::u32x4 (&nxt)[12], int kt) {
         if (kt + 1 < nk) wait_groups(nk - 2 - kt < 2 ? nk - 2 - kt : 2);
         lds_wait12(cur);
         __builtin_amdgcn_s_barrier();
-        if (kt + 1 < nk) read_frags(nxt, kt + 1);
-        __builtin_amdgcn_sched_barrier(0);
         if (kt + kStagedStages < nk) {
             const int nx = kt + kStagedStages;
             const uint32_t st = lds0 + (nx & (kStagedStages - 1)) * kStagedStageBytes;
             const char* a = sgpr_ptr(rowA + (size_t)nx * KE * 2);
             const char* wgt = sgpr_ptr(rowW + (size_t)nx * KE * 2);
+            v3::glds16(a, voff[0], st + ldst[0]);
+            if (kt + 1 < nk) read_frags(nxt, kt + 1);
+            __builtin_amdgcn_sched_barrier(0);
             multiply(cur, [&](auto gc) {
                 constexpr int g = decltype(gc)::value;
                 v3::glds16(g < 2 ? a : wgt, voff[g], st + ldst[g]);
             });
         } else {
+            if (kt + 1 < nk) read_frags(nxt, kt + 1);
+            __builtin_amdgcn_sched_barrier(0);
             multiply(cur, [](auto) {});
         }
         __builtin_amdgcn_sched_barrier(0);
