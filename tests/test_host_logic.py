@@ -95,6 +95,33 @@ def test_multi_index_no_balance_single_and_failure(capsys):
     assert len(res) == 1 and "Retriever failed" in capsys.readouterr().out
 
 
+def test_group_scan_front_batches_callers_and_hands_each_its_own_rows():
+    """``MultiIndexRetriever._group_scan_many``: concurrent callers of the packed-module scan go out as ONE ``search_host`` per group
+    with the largest k asked for; every caller gets its own query's rows (a longer exact top-k list contains every shorter one as its
+    prefix, so callers slice their own k) and the id lists of the snapshot that was scanned."""
+    import torch
+
+    class FakeGroup:
+        def __init__(self, tag):
+            self.tag, self.calls = tag, []
+
+        def search_host(self, q, k):
+            self.calls.append((tuple(q.shape), k))
+            b = q.shape[0]
+            scores = q[:, :1].reshape(b, 1, 1) - torch.arange(k, dtype=torch.float32).reshape(1, 1, k).repeat(b, 2, 1)
+            rows = torch.arange(k, dtype=torch.int32).reshape(1, 1, k).repeat(b, 2, 1) + (q[:, 1].to(torch.int32) * 100).reshape(b, 1, 1)
+            return scores, rows, [f"{self.tag}-ids0", f"{self.tag}-ids1"]
+
+    ga, gb = FakeGroup("a"), FakeGroup("b")
+    items = [(ga, [0.5, 1.0, 9.0], 3), (gb, [0.25, 7.0, 9.0], 2), (ga, [0.75, 2.0, 9.0], 5)]
+    out = rt.MultiIndexRetriever._group_scan_many(items)
+    assert ga.calls == [((2, 3), 5)] and gb.calls == [((1, 3), 2)]                       # one pass per group, the largest k
+    (s0, r0, i0), (s1, r1, i1), (s2, r2, i2) = out
+    assert i0 == i2 == ["a-ids0", "a-ids1"] and i1 == ["b-ids0", "b-ids1"]
+    assert r0[0][:3] == [100, 101, 102] and r2[1] == [200, 201, 202, 203, 204] and r1[0] == [700, 701]
+    assert s0[0][:3] == [0.5, -0.5, -1.5] and s2[0][0] == 0.75 and s1[1] == [0.25, -0.75]
+
+
 def test_multi_index_cache_and_clear():
     r = MagicMock()
     r.retrieve.return_value = [_nws(0.5)]
