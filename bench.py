@@ -1308,7 +1308,7 @@ def wait_pair_pool(rr):
         from tensor_truth_amd.tokenization import HFTokenizer
 
         if isinstance(tk, HFTokenizer):
-            iw.get_pair_pool(tk, wait=True)
+            iw.get_pair_pool(tk, wait=True, max_length=getattr(rr, "max_length", 512))
     except Exception:  # noqa: BLE001 - no pool: the legs run with in-process tokenisation
         pass
 
@@ -1472,7 +1472,7 @@ def reference_defaults_leg(args, dev, shard_rows, emb_cfg, rr_cfg, n_lone=8, n_t
                 rr = mgr.get_reranker(None, top_n=params["reranker_top_n"], device=str(dev))
                 wait_pair_pool(rr)
                 key0 = 20_000_000_000 + (1_000_000 if label == "bf16" else 2_000_000) + 100_000 * n_mod
-                qs = [texts.query(key0 + i) for i in range(4 + n_lone + n_threads + n_threaded)]
+                qs = [texts.query(key0 + i) for i in range(4 + n_lone + 2 * n_threaded)]
 
                 def one(q, _svc=svc):
                     r = _svc.retrieve(q)
@@ -1494,8 +1494,10 @@ def reference_defaults_leg(args, dev, shard_rows, emb_cfg, rr_cfg, n_lone=8, n_t
                 torch.cuda.synchronize(dev)
                 fam = {k: {"ms": v[0], "launches": v[1]} for k, v in read_prof_families(_tl.load_library()).items() if v[1]}
                 _tl.load_library().tt_prof_enable(0)
-                _run_threads(n_threads, qs[4 + n_lone:4 + n_lone + n_threads], one)
-                dt, got_t = _run_threads(n_threads, qs[4 + n_lone + n_threads:], one)
+                # (an untimed burst of the same size first: the coalesced batch sizes of the timed burst meet buffers that exist --
+                # tools/probes/threads_variance.py: the first 64-query burst of a process runs at 55-60 % of the following ones)
+                _run_threads(n_threads, qs[4 + n_lone:4 + n_lone + n_threaded], one)
+                dt, got_t = _run_threads(n_threads, qs[4 + n_lone + n_threaded:], one)
                 res[f"{n_mod}_index" + ("es" if n_mod > 1 else "")] = {
                     "single_caller_ms_per_query": lone_ms, "queries_per_s_8_threads": n_threaded / dt,
                     "rerank_pairs_per_query": pairs / n_lone, "mean_pair_tokens": toks / max(pairs, 1),

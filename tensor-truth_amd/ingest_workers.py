@@ -642,7 +642,7 @@ def pair_workers_default() -> int:
 _PAIR_POOLS_STARTING: set = set()
 
 
-def get_pair_pool(tokenizer, wait: bool = False) -> Optional[PairTokenizerPool]:
+def get_pair_pool(tokenizer, wait: bool = False, max_length: int = 512) -> Optional[PairTokenizerPool]:
     """The process's pair-tokenisation pool for this tokenizer; None: disabled, a tokenizer the workers cannot rebuild, the pool
     could not be started -- or (``wait=False``, what a request thread passes) it is still being started by another thread: up to
     16 interpreters each parsing a 17 MB tokenizer.json take seconds, which no request waits for (it tokenises in process meanwhile).
@@ -673,8 +673,16 @@ def get_pair_pool(tokenizer, wait: bool = False) -> Optional[PairTokenizerPool]:
     pool = None
     try:
         pool = PairTokenizerPool(tokenizer, W)
+        # one job through every worker BEFORE the pool is published, at the reranker's own max_length: a worker builds its truncating
+        # pair tokenizer (a second parse of the 17 MB tokenizer.json, keyed on the length) on its first pair -- ~0.5 s, measured as a
+        # 488-580 ms prepare phase of the first coalesced batch that reached a fresh pool (tools/probes/threads_variance.py).  Paid
+        # here, in the starting thread; request threads tokenise in process until the pool is in the registry.
+        if pool.encode([("warm up", "a short passage for the pair tokenizer to see once")] * (2 * W), max_length, deadline_s=120.0) is None:
+            pool.close()
+            pool = None
     except Exception as exc:  # noqa: BLE001 - no workers: every caller tokenises in process
         logger.warning("pair tokenizer pool could not be started (%s: %s)", type(exc).__name__, exc)
+        pool = None
     finally:
         with _POOLS_LOCK:
             _PAIR_POOLS_STARTING.discard(key)
@@ -683,11 +691,19 @@ def get_pair_pool(tokenizer, wait: bool = False) -> Optional[PairTokenizerPool]:
     return pool
 
 
-def warm_pair_pool(tokenizer) -> None:
-    """Start the pair pool in a background thread (called when a reranker is constructed), so the first coalesced batch finds it."""
-    if pair_workers_default() <= 0:
-        return
-    threading.Thread(target=get_pair_pool, args=(tokenizer, True), name="tt-pair-pool-start", daemon=True).start()
+def warm_pair_pool(tokenizer, max_length: int = 512) -> None:
+    """Start the pair pool in a background thread (called when a reranker is constructed, with its max_length), so the first coalesced
+    batch finds it started AND warm."""
+    def _warm():
+        try:       # the request process's own truncating pair tokenizer first (a lone caller's first rerank would build it: ~0.5 s)
+            if hasattr(tokenizer, "encode_pair_batch"):
+                tokenizer.encode_pair_batch([("warm up", "a short passage for the pair tokenizer to see once")], max_length)
+        except Exception as exc:  # noqa: BLE001 - a warm-up: the first request builds it instead
+            logger.warning("pair tokenizer warm-up failed (%s: %s)", type(exc).__name__, exc)
+        if pair_workers_default() > 0:
+            get_pair_pool(tokenizer, True, max_length)
+
+    threading.Thread(target=_warm, name="tt-pair-pool-start", daemon=True).start()
 
 
 @atexit.register

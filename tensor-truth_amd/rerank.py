@@ -69,7 +69,7 @@ class HipSentenceTransformerRerank:
             try:
                 from . import ingest_workers as iw
 
-                iw.warm_pair_pool(self._tokenizer)
+                iw.warm_pair_pool(self._tokenizer, self.max_length)
             except Exception as exc:  # noqa: BLE001
                 logger.warning("reranker: pair tokenizer pool not started (%s)", exc)
         # depth 3 (round 5): with a real sub-word tokenizer the host turn-around of a batch's callers (retrieve + tokenise + pack: ~100 ms

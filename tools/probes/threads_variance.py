@@ -36,15 +36,58 @@ for lo, hi in zip(bounds[:-1], bounds[1:]):
 svc = build_retrieval_service(indexes, params, device=str(dev), manager=mgr)
 rr = mgr.get_reranker(None, top_n=5, device=str(dev))
 B.wait_pair_pool(rr)
-one = lambda q: len(svc.retrieve(q).source_nodes)  # noqa: E731
+lat = []
+phase_max = {}
+
+
+def _timed(obj, attr, label):
+    fn = getattr(obj, attr, None)
+    if fn is None:
+        return
+
+    def wrapper(*a, **k):
+        t0 = time.perf_counter()
+        try:
+            return fn(*a, **k)
+        finally:
+            dt = time.perf_counter() - t0
+            if dt > phase_max.get(label, (0.0, 0))[0]:
+                phase_max[label] = (dt, len(a[0]) if a and hasattr(a[0], "__len__") else -1)
+
+    setattr(obj, attr, wrapper)
+
+
+from tensor_truth_amd import ingest_workers as _iw  # noqa: E402
+
+_timed(rr, "_tokenize_pairs", "rerank.tokenize_pairs")
+_timed(_iw.PairTokenizerPool, "encode", "pool.encode")
+_timed(rr._front, "_run", "rerank.prepare")
+_timed(rr._front, "_execute", "rerank.execute")
+_timed(rr._front, "_finish", "rerank.finish")
+_timed(svc._retriever._scan_front, "_run", "group.scan")
+_timed(emb, "get_agg_embedding_from_queries", "query.embed")
+
+
+def one(q):
+    t0 = time.perf_counter()
+    n = len(svc.retrieve(q).source_nodes)
+    lat.append(time.perf_counter() - t0)
+    return n
+
+
 for i in range(4):
     one(texts.query(9_000_000_000 + i))
 out = []
 for burst in range(6):
     qs = [texts.query(9_100_000_000 + 1000 * burst + i) for i in range(64)]
     torch.cuda.synchronize(dev)
+    del lat[:]
+    phase_max.clear()
     dt, _ = B._run_threads(8, qs, one)
+    slow = sorted(lat)[-3:]
     front = svc._retriever._scan_front
     out.append({"burst": burst, "queries_per_s": 64 / dt, "scan_batches": front.batches, "scan_items": front.items,
-                "rerank_batches": rr._front.batches if rr._front else None})
+                "rerank_batches": rr._front.batches if rr._front else None, "slowest_calls_ms": [round(x * 1e3, 1) for x in slow],
+                "median_call_ms": round(sorted(lat)[len(lat) // 2] * 1e3, 1),
+                "slowest_phase_ms": {k: (round(v[0] * 1e3, 1), v[1]) for k, v in phase_max.items()}})
 print(json.dumps(out))
