@@ -642,34 +642,8 @@ def pair_workers_default() -> int:
 _PAIR_POOLS_STARTING: set = set()
 
 
-def get_pair_pool(tokenizer, wait: bool = False, max_length: int = 512) -> Optional[PairTokenizerPool]:
-    """The process's pair-tokenisation pool for this tokenizer; None: disabled, a tokenizer the workers cannot rebuild, the pool
-    could not be started -- or (``wait=False``, what a request thread passes) it is still being started by another thread: up to
-    16 interpreters each parsing a 17 MB tokenizer.json take seconds, which no request waits for (it tokenises in process meanwhile).
-    The pool is spawned OUTSIDE the registry lock; ``warm_pair_pool`` starts it in the background when a reranker is built."""
-    W = pair_workers_default()
-    if W <= 0:
-        return None
-    try:
-        key = pickle.dumps((tokenizer_spec(tokenizer), W))
-    except TypeError:
-        return None
-    with _POOLS_LOCK:
-        pool = _PAIR_POOLS.get(key)
-        if pool is not None and pool.alive():
-            return pool
-        if key in _PAIR_POOLS_STARTING and not wait:
-            return None
-        mine = key not in _PAIR_POOLS_STARTING
-        if mine:
-            _PAIR_POOLS_STARTING.add(key)
-    if not mine:           # wait=True: another thread is starting it
-        while True:
-            time.sleep(0.02)
-            with _POOLS_LOCK:
-                if key not in _PAIR_POOLS_STARTING:
-                    pool = _PAIR_POOLS.get(key)
-                    return pool if pool is not None and pool.alive() else None
+def _start_pair_pool(tokenizer, key: bytes, W: int, max_length: int) -> Optional[PairTokenizerPool]:
+    """Spawn, warm and publish the pool for ``key`` (the caller has put ``key`` into _PAIR_POOLS_STARTING); runs OUTSIDE the registry lock."""
     pool = None
     try:
         pool = PairTokenizerPool(tokenizer, W)
@@ -689,6 +663,40 @@ def get_pair_pool(tokenizer, wait: bool = False, max_length: int = 512) -> Optio
             if pool is not None:
                 _PAIR_POOLS[key] = pool
     return pool
+
+
+def get_pair_pool(tokenizer, wait: bool = False, max_length: int = 512) -> Optional[PairTokenizerPool]:
+    """The process's pair-tokenisation pool for this tokenizer; None: disabled, a tokenizer the workers cannot rebuild, the pool
+    could not be started -- or (``wait=False``, what a request thread passes) it is not up yet: up to 16 interpreters each parsing a
+    17 MB tokenizer.json take seconds, which no request waits for -- it tokenises in process meanwhile, and if nobody is starting the
+    pool (the first one died, or no reranker warmed it) a background thread is set to.  ``wait=True`` (``warm_pair_pool``, the bench's
+    steady-state legs) starts it in the calling thread or waits for whoever does."""
+    W = pair_workers_default()
+    if W <= 0:
+        return None
+    try:
+        key = pickle.dumps((tokenizer_spec(tokenizer), W))
+    except TypeError:
+        return None
+    with _POOLS_LOCK:
+        pool = _PAIR_POOLS.get(key)
+        if pool is not None and pool.alive():
+            return pool
+        mine = key not in _PAIR_POOLS_STARTING
+        if mine:
+            _PAIR_POOLS_STARTING.add(key)
+    if not wait:
+        if mine:
+            threading.Thread(target=_start_pair_pool, args=(tokenizer, key, W, max_length), name="tt-pair-pool-start", daemon=True).start()
+        return None
+    if not mine:           # another thread is starting it
+        while True:
+            time.sleep(0.02)
+            with _POOLS_LOCK:
+                if key not in _PAIR_POOLS_STARTING:
+                    pool = _PAIR_POOLS.get(key)
+                    return pool if pool is not None and pool.alive() else None
+    return _start_pair_pool(tokenizer, key, W, max_length)
 
 
 def warm_pair_pool(tokenizer, max_length: int = 512) -> None:

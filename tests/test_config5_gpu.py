@@ -417,6 +417,7 @@ def test_reference_geometry_with_subword_tokenizer_workers_and_pair_pool(dev, bu
         return out
 
     monkeypatch.setenv("TT_PAIR_WORKERS", "3")
+    assert iw.get_pair_pool(tk, wait=True, max_length=rr.max_length) is not None      # (request threads tokenise in process until it is up)
     pairs0 = rr.stats["pairs"]
     pooled = run_all()
     pool = iw.get_pair_pool(tk)

@@ -1366,7 +1366,8 @@ def test_pair_tokenizer_pool_returns_the_in_process_ids(monkeypatch):
     pairs = [(st.zipf_text(900 + i, 5 + i % 20), st.zipf_text(5000 + i, 30 + (i * 37) % 400)) for i in range(131)]
     want = tk.encode_pair_batch(pairs, 512)
     monkeypatch.setenv("TT_PAIR_WORKERS", "3")
-    pool = iw.get_pair_pool(tk)
+    assert iw.get_pair_pool(tk) is None                       # a request thread never starts the pool itself: it sets a background start off
+    pool = iw.get_pair_pool(tk, wait=True)                     # ... which this call waits for (the pool comes back warm: one job per worker)
     assert pool is not None and pool is iw.get_pair_pool(tk)
     ids, types = pool.encode(pairs, 512)
     assert len(ids) == len(want) and max(len(x) for x in ids) == 512
@@ -1414,7 +1415,12 @@ def test_pair_tokenizer_pool_failures_fall_back_instead_of_failing_the_request(m
     finally:
         with iw._POOLS_LOCK:
             iw._PAIR_POOLS_STARTING.discard(key)
-    last = iw.get_pair_pool(tk, wait=True)
+    # no pool and nobody starting one (the last one died): the request thread gets None AT ONCE and a background start is under way
+    t0 = time.perf_counter()
+    assert iw.get_pair_pool(tk) is None and time.perf_counter() - t0 < 0.5
+    with iw._POOLS_LOCK:
+        assert key in iw._PAIR_POOLS_STARTING or key in iw._PAIR_POOLS
+    last = iw.get_pair_pool(tk, wait=True)                     # waits for that start
     got = last.encode(pairs, 512)
     want = tk.encode_pair_batch(pairs, 512)
     assert got is not None and [a.tolist() for a in got[0]] == [w[0] for w in want]
